@@ -1,0 +1,352 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the ACTUAL reference (stockeh/swift).
+
+Runs only in the build container, where ``/root/reference`` is mounted.  The
+reference's Python never travels to the GPU box; these small input/output
+vectors do.  Usage:  python tools/make_golden.py [--only NAME]
+
+Import recipe: the reference needs ``omegaconf``,
+``hydra`` and ``ezpz`` (absent here) only for type annotations, a logger and a
+``_target_`` importer, and ``h5py`` only for file reading; four import-time
+stub modules stand in for them.  No reference source is copied: the modules are
+imported from where they lie and driven with seeded inputs.
+
+Weights come from ``swift_amd.utils.detinit`` (Philox + Box-Muller, not a torch
+RNG stream) and are loaded into the reference modules with ``load_state_dict``,
+so fixtures for big configurations hold only (seed, outputs).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import logging
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/src"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def install_stubs():
+    sys.path.insert(0, REF)
+    om = types.ModuleType("omegaconf")
+    om.ListConfig = type("ListConfig", (list,), {})
+    om.DictConfig = type("DictConfig", (dict,), {})
+    om.OmegaConf = type("OmegaConf", (), {})
+    sys.modules["omegaconf"] = om
+    ez = types.ModuleType("ezpz")
+    ez.get_logger = logging.getLogger
+    sys.modules["ezpz"] = ez
+    hy, hu = types.ModuleType("hydra"), types.ModuleType("hydra.utils")
+
+    def instantiate(cfg, *a, **kw):
+        cfg = dict(cfg)
+        tgt = cfg.pop("_target_")
+        kw.pop("_convert_", None)
+        kw.pop("_recursive_", None)
+        mod, name = tgt.rsplit(".", 1)
+        return getattr(importlib.import_module(mod), name)(*a, **{**cfg, **kw})
+
+    hu.instantiate = instantiate
+    hy.utils = hu
+    sys.modules["hydra"], sys.modules["hydra.utils"] = hy, hu
+    sys.modules["h5py"] = types.ModuleType("h5py")  # data/era5.py imports it; never called here
+
+
+install_stubs()
+from swift.data.era5 import ERA5Dataset  # noqa: E402
+from swift.generating.factory import sampler_factory  # noqa: E402
+from swift.models.precond import PassPrecond  # noqa: E402
+from swift.models.swinv2 import SwinV2, timestep_embedding  # noqa: E402
+from swift.training.loss import (  # noqa: E402
+    CRPSLoss,
+    SCMLoss,
+    TrigFlowLoss,
+    _calculate_latitude_weights,
+    _calculate_variable_weights,
+)
+
+from swift_amd.utils.detinit import det_normal, state_fingerprint, swinv2_state  # noqa: E402
+
+TINY = dict(img=(32, 64), n_vars=4, n_forc=3, window=(4, 4), shift=(2, 2), patch=(2, 2), dim=96, heads=4, depth=3)
+SMALLB = dict(img=(64, 64), n_vars=69, n_forc=3, window=(16, 16), shift=(8, 8), patch=(2, 2), dim=1056, heads=12, depth=2)
+SWIFTB = dict(img=(128, 256), n_vars=69, n_forc=3, window=(16, 16), shift=(8, 8), patch=(2, 2), dim=1056, heads=12, depth=12)
+
+
+def model_cfg(c, logvar=False):
+    return dict(_target_="swift.models.swinv2.SwinV2", window_size=list(c["window"]), shift_size=list(c["shift"]),
+                patch_size=list(c["patch"]), depth=c["depth"], dim=c["dim"], heads=c["heads"], logvar=logvar,
+                timestep_weight=1.0)
+
+
+def build_ref_net(c, seed, logvar=False, sigma_data=1.0):
+    nv, nf = c["n_vars"], c["n_forc"]
+    net = PassPrecond(model_cfg(c, logvar), img_resolution=list(c["img"]), img_channels=nv,
+                      condition_channels=nv + nf, auxiliary_dim=1, sigma_min=0, sigma_max=float("inf"),
+                      sigma_data=sigma_data)
+    grid = (c["img"][0] // c["patch"][0], c["img"][1] // c["patch"][1])
+    state = swinv2_state(grid=grid, in_channels=2 * nv + nf, out_channels=nv, patch_size=c["patch"], depth=c["depth"],
+                         dim=c["dim"], heads=c["heads"], auxiliary_dim=1, logvar=logvar, seed=seed)
+    missing = net.load_state_dict(state, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return net.eval(), state
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+class FakeDDP(torch.nn.Module):
+    """loss.py reaches through ``net.module`` (training/loss.py:213,217)."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.module = m
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+class FakeERA5(ERA5Dataset):
+    """The real standardisation methods of data/era5.py on synthetic statistics (no h5 files)."""
+
+    def __init__(self, c, seed, forc_bank):
+        torch.utils.data.Dataset.__init__(self)
+        nv, nf = c["n_vars"], c["n_forc"]
+        self.variables = [f"v{i}" for i in range(nv)]
+        self.forcings = [f"f{i}" for i in range(nf)]
+        self.intervals = [6, 12, 24]
+        self.residual = True
+        self.x_means = det_normal((nv + nf, 1, 1), seed, "x_mean", std=2.0).numpy()
+        self.x_stds = (det_normal((nv + nf, 1, 1), seed, "x_std", std=0.3).abs() + 0.5).numpy()
+        self.t_stds = {d: (det_normal((nv, 1, 1), seed, f"t_std{d}", std=0.05).abs() + 0.1).numpy() for d in (6, 12, 24)}
+        self.t_means = {d: np.zeros_like(self.t_stds[d]) for d in (6, 12, 24)}
+        self._shape = (nv, *c["img"])
+        self._bank = forc_bank  # [T, nf, H, W] physical forcings
+
+    def get_forcings(self, idx):
+        return self._bank[int(idx)].clone()
+
+
+# --------------------------------------------------------------------------- fixtures
+
+
+@torch.no_grad()
+def fx_swinv2_tiny():
+    c, seed = TINY, 1
+    net, state = build_ref_net(c, seed, logvar=True)
+    B, nv, nf = 2, c["n_vars"], c["n_forc"]
+    x = det_normal((B, 2 * nv + nf, *c["img"]), seed, "x")
+    t = torch.tensor([0.3, 1.2])
+    aux = torch.tensor([[0.6], [1.2]])
+    y = net.model(x, t, auxiliary=aux)
+    yn = net.model(x, t, auxiliary=aux, jvp=True)
+    y2, lv = net.model(x, t, auxiliary=aux, return_logvar=True)
+    assert torch.equal(y, y2)
+    # through PassPrecond with split (x, condition) and scalar auxiliary (precond.py:21-31,133-148)
+    yp = net(x[:, :nv], t, x[:, nv:], 0.6)
+    temb = timestep_embedding(torch.tensor([0.0, 1.0, math.pi / 2]), c["dim"])
+    ar = torch.arange(2 * 4 * 4, dtype=torch.float32).reshape(1, 2, 4, 4)
+    pe = net.model.patch_embed
+    from einops import rearrange
+    pat = rearrange(ar, "b c (h p1) (w p2) -> b (h w) (p1 p2 c)", p1=pe.patch_size[0], p2=pe.patch_size[1])
+    save("swinv2_tiny", seed=seed, fingerprint=state_fingerprint(state), x=x, t=t, aux=aux, y_flash=y, y_naive=yn,
+         logvar=lv, y_precond_scalar_aux=yp, temb=temb, patchify_arange=pat)
+
+
+@torch.no_grad()
+def fx_swinv2_smallb():
+    c, seed = SMALLB, 2
+    net, state = build_ref_net(c, seed)
+    B, nv, nf = 2, c["n_vars"], c["n_forc"]
+    x = det_normal((B, 2 * nv + nf, *c["img"]), seed, "x")
+    t = torch.tensor([math.pi / 2, 0.7])
+    aux = torch.tensor([[0.6], [2.4]])
+    y = net.model(x, t, auxiliary=aux)
+    yn = net.model(x, t, auxiliary=aux, jvp=True)
+    save("swinv2_smallb", seed=seed, fingerprint=state_fingerprint(state), t=t, aux=aux, y_flash=y,
+         y_naive_stats=np.array([float(yn.mean()), float(yn.std()), float((yn - y).norm() / y.norm())]))
+
+
+@torch.no_grad()
+def fx_attention_hd88():
+    """One reference Attention module (to_qkv -> cosine attention -> wo -> ModulatedNorm) at Swift-B width."""
+    seed = 3
+    from swift.models.swinv2 import Attention
+    att = Attention(1056, 12, 88, flash=True).eval()
+    st = swinv2_state(grid=(16, 16), in_channels=4, out_channels=4, patch_size=(1, 1), depth=1, dim=1056, heads=12,
+                      seed=seed, prefix="")
+    att.load_state_dict({k[len("transformer.layers.0.0."):]: v for k, v in st.items()
+                         if k.startswith("transformer.layers.0.0.")})
+    x = det_normal((2, 256, 1056), seed, "x")
+    tl = det_normal((2, 1056), seed, "t", std=0.5)
+    y = att(x, tl)
+    yn = att(x, tl, jvp=True)
+    save("attention_hd88", seed=seed, y=y, naive_rel=float((yn - y).norm() / y.norm()))
+
+
+@torch.no_grad()
+def fx_samplers_tiny():
+    c, seed = TINY, 4
+    net, state = build_ref_net(c, seed)
+    B, nv, nf = 2, c["n_vars"], c["n_forc"]
+    cond = det_normal((B, nv + nf, *c["img"]), seed, "cond")
+    lat = det_normal((B, nv, *c["img"]), seed, "lat")
+    ren = [det_normal((B, nv, *c["img"]), seed, f"ren{i}") for i in range(4)]
+    from swift.generating.diffusion import DiffusionSampler
+    S = DiffusionSampler(net)
+
+    def feeder():
+        it = iter(ren)
+        return lambda like: next(it).to(like)
+
+    kw = dict(sigma_min=0.02, sigma_max=200.0, auxiliary=0.6)
+    out = {}
+    for n in (1, 2, 3):
+        out[f"scm{n}"] = S.scm_solver(lat.clone(), condition=cond, randn_like=feeder(), num_steps=n, **kw)
+    out["scm_mid"] = S.scm_solver(lat.clone(), condition=cond, randn_like=feeder(), num_steps=2,
+                                  intermediates=[0.9, 0.4], **kw)
+    out["dpm2s3"] = S.dpm_solver_2s(lat.clone(), condition=cond, num_steps=3, **kw)
+    # factory path with a torch generator (generating/factory.py:47-60): record what it drew
+    g = torch.Generator().manual_seed(7)
+    smp = sampler_factory("scm", net, num_steps=1, **kw)
+    out["factory_scm1"] = smp(cond, generator=g)
+    g = torch.Generator().manual_seed(7)
+    out["factory_latents"] = torch.randn((B, nv, *c["img"]), generator=g)
+    save("samplers_tiny", seed=seed, fingerprint=state_fingerprint(state), cond=cond, lat=lat,
+         **{f"ren{i}": r for i, r in enumerate(ren)}, **out)
+
+
+@torch.no_grad()
+def fx_rollout_tiny():
+    """generate.py:85-131 driven by hand with the reference's sampler and ERA5Dataset methods."""
+    c, seed, steps, interval = TINY, 5, 3, 6
+    net, state = build_ref_net(c, seed)
+    B, nv, nf = 2, c["n_vars"], c["n_forc"]
+    bank = det_normal((B + steps + 2, nf, *c["img"]), seed, "forc", std=1.5, mean=0.5)
+    ds = FakeERA5(c, seed, bank)
+    idx = torch.tensor([0, 2])
+    X = det_normal((B, nv, *c["img"]), seed, "X0")
+    sampler = sampler_factory("scm", net, num_steps=1, sigma_min=0.02, sigma_max=200.0, auxiliary=interval / 10.0)
+    gen = torch.Generator().manual_seed(11)
+    traj = [ds.unstandardize_x(X)]
+    X0 = X.clone()
+    for i in range(steps):
+        Xc = torch.cat([X, ds.standardize_x(torch.stack([ds.get_forcings(j + int(i * interval // 6)) for j in idx], 0))], 1)
+        Y = sampler(Xc, generator=gen)
+        X_un = ds.unstandardize_x(Xc)[:, :nv]
+        Y_un = ds.unstandardize_t(Y, delta=int(interval))
+        X = X_un + Y_un
+        traj.append(X)
+        X = ds.standardize_x(X)
+    gen = torch.Generator().manual_seed(11)
+    lats = [torch.randn((B, nv, *c["img"]), generator=gen) for _ in range(steps)]
+    save("rollout_tiny", seed=seed, fingerprint=state_fingerprint(state), X0=X0, idx=idx, bank=bank,
+         x_mean=ds.x_means, x_std=ds.x_stds, t_std6=ds.t_stds[6], traj=torch.stack(traj, 1),
+         latents=torch.stack(lats, 0))
+
+
+def fx_losses_tiny():
+    c, seed = TINY, 6
+    net, state = build_ref_net(c, seed, logvar=True)
+    net.train().requires_grad_(True)
+    B, nv, nf = 2, c["n_vars"], c["n_forc"]
+    bank = det_normal((B + 8, nf, *c["img"]), seed, "forc")
+    ds = FakeERA5(c, seed, bank)
+    # variables must be real names for the weight tables (training/loss.py:35-55)
+    ds.variables = ["2m_temperature", "10m_u_component_of_wind", "geopotential_500", "temperature_850"]
+    target = det_normal((B, nv, *c["img"]), seed, "target")
+    cond = det_normal((B, nv + nf, *c["img"]), seed, "cond")
+    aux = torch.tensor([0.6, 0.6])
+    ddp = FakeDDP(net)
+    gsel = ["model.head.head.0.weight", "model.transformer.layers.1.0.to_qkv.weight", "model.pos_embed",
+            "model.transformer.layers.0.1.norm.modulation.weight", "model.transformer.layers.2.0.scale",
+            "model.logvar_embed.weight"]
+    out = {}
+
+    def grads():
+        named = dict(net.named_parameters())
+        g = np.array([float(named[k].grad.norm()) if named[k].grad is not None else -1.0 for k in gsel])
+        net.zero_grad(set_to_none=True)
+        return g
+
+    noise = dict(dist="loguniform", sigma_min=0.02, sigma_max=200.0)
+    # TrigFlow: draws u = rand([B,1,1,1]) then z = randn_like(x)  (loss.py:66-71,133-136)
+    torch.manual_seed(21)
+    L = TrigFlowLoss(ds, dict(noise), sigma_data=1.0)
+    val = L(ddp, target, condition=cond, auxiliary=aux)
+    val.backward()
+    out["trigflow"], out["trigflow_g"] = float(val), grads()
+    torch.manual_seed(21)
+    out["trigflow_u"], out["trigflow_z"] = torch.rand([B, 1, 1, 1]), torch.randn_like(target)
+    # sCM (loss.py:196-260)
+    torch.manual_seed(22)
+    L = SCMLoss(ds, dict(noise), sigma_data=1.0, tangent_warmup_kimg=3)
+    val = L(ddp, target, step=1200, condition=cond, auxiliary=aux)
+    val.backward()
+    out["scm"], out["scm_g"] = float(val), grads()
+    torch.manual_seed(22)
+    out["scm_u"], out["scm_z"] = torch.rand([B, 1, 1, 1]), torch.randn_like(target)
+    # CRPS multistep, steps=3, ensemble 2 (loss.py:373-445); noise order: member-major, step-minor
+    steps = 3
+    torch.manual_seed(23)
+    L = CRPSLoss(ds, sigma_data=1.0, ensemble_size=2, alpha=0.95)
+    val = L(ddp, target, condition=cond, auxiliary=aux, idx=[0, 3], steps=steps)
+    val.backward()
+    out["crps"], out["crps_g"] = float(val), grads()
+    torch.manual_seed(23)
+    out["crps_lat"] = torch.stack([torch.stack([torch.randn_like(target) for _ in range(steps)]) for _ in range(2)])
+    save("losses_tiny", seed=seed, fingerprint=state_fingerprint(state), target=target, cond=cond, aux=aux, bank=bank,
+         x_mean=ds.x_means, x_std=ds.x_stds, t_std6=ds.t_stds[6], grad_keys=np.array(gsel), w_lat=L.w_lat, w_var=L.w_var,
+         **out)
+
+
+@torch.no_grad()
+def fx_swiftb_step():
+    """BASELINE config 1: Swift-B, 1 member x 1 IC x 1 six-hour step, fp32 CPU."""
+    c, seed = SWIFTB, 1234
+    net, state = build_ref_net(c, seed)
+    nv, nf = c["n_vars"], c["n_forc"]
+    cond = det_normal((1, nv + nf, *c["img"]), seed, "cond")
+    lat = det_normal((1, nv, *c["img"]), seed, "lat")
+    from swift.generating.diffusion import DiffusionSampler
+    import time
+    t0 = time.time()
+    y = DiffusionSampler(net).scm_solver(lat, condition=cond, num_steps=1, sigma_min=0.02, sigma_max=200.0, auxiliary=0.6)
+    print(f"reference Swift-B scm step on CPU: {time.time() - t0:.2f} s ({torch.get_num_threads()} threads)")
+    save("swiftb_step", seed=seed, fingerprint=state_fingerprint(state), y_sub=y[0, ::4, ::8, ::8],
+         stats=np.array([float(y.mean()), float(y.std()), float(y.abs().max()), float(y.double().norm())]))
+
+
+def fx_weights_aux():
+    import yaml
+    with open("/root/reference/src/swift/configs/data/era5-flare-1.4.yaml") as f:
+        d = yaml.safe_load(f)
+    variables = d["dataset"]["variables"]
+    save("weights_aux", variables=np.array(variables), w_lat128=_calculate_latitude_weights(128),
+         w_var69=_calculate_variable_weights(variables), w_lat32=_calculate_latitude_weights(32))
+
+
+ALL = dict(swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
+           samplers_tiny=fx_samplers_tiny, rollout_tiny=fx_rollout_tiny, losses_tiny=fx_losses_tiny,
+           swiftb_step=fx_swiftb_step, weights_aux=fx_weights_aux)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    for k, fn in ALL.items():
+        if a.only is None or a.only == k:
+            print("==", k)
+            fn()
