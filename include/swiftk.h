@@ -1,0 +1,224 @@
+/*
+ * swiftk.h -- C ABI of the MI355X (gfx950) kernels behind swift_amd.
+ *
+ * The reference (stockeh/swift) is pure Python/PyTorch and has no FFI of its
+ * own; its "operator boundary" is the Python call
+ *     AbstractNetwork.forward(x, t, auxiliary, jvp, return_logvar)
+ *                                   (reference: src/swift/models/abstract.py:26-35,
+ *                                    src/swift/models/swinv2.py:305-330)
+ * reached through PassPrecond.forward (src/swift/models/precond.py:133-148).
+ * This header is what a maintainer of the reference would bind with ctypes to
+ * replace the ATen ops on that path (INTEGRATION.md shows the stub).  Each
+ * entry point below cites the reference code it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     the name ends in _host;
+ *   - the caller owns all buffers (PyTorch allocations, tensor.data_ptr());
+ *     nothing here allocates, synchronises or throws;
+ *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return 0 on success, a negative SWIFTK_E* code on a rejected argument,
+ *     or a positive hipError_t if the launch itself failed;
+ *   - dtype: SWIFTK_F32 = 0 (IEEE fp32 operands, fp32 MFMA), SWIFTK_BF16 = 1
+ *     (bf16 operands, fp32 accumulate).  Normalisation, softmax statistics and
+ *     the residual stream are fp32 in both modes.
+ */
+#ifndef SWIFTK_H
+#define SWIFTK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWIFTK_F32 0
+#define SWIFTK_BF16 1
+
+#define SWIFTK_EINVAL (-1)   /* bad argument (null pointer, negative size) */
+#define SWIFTK_ESHAPE (-2)   /* shape not supported by the gfx950 kernels   */
+#define SWIFTK_EALIGN (-3)   /* pointer / leading dimension mis-aligned     */
+#define SWIFTK_EWORKSPACE (-4) /* workspace too small                        */
+
+/* GEMM epilogues */
+#define SWIFTK_EPI_NONE 0      /* C = A W^T                                              */
+#define SWIFTK_EPI_BIAS_POS 1  /* C = A W^T + bias[n] + pos[(m % pos_rows)][n]           */
+#define SWIFTK_EPI_SWIGLU 2    /* C[m][j] = silu(acc[m][2j]) * acc[m][2j+1]  (W rows interleaved gate/up) */
+
+int swiftk_version(void);
+
+/* Round `k` up to the K granularity of the GEMM for `dtype` (64 bf16 / 32 fp32 elements = 128 B). */
+int64_t swiftk_gemm_k_pad(int dtype, int64_t k);
+
+/*
+ * C[M,N] = epilogue(A[M,K] * W[N,K]^T): nn.Linear with its weight as stored.
+ * Replaces F.linear at src/swift/models/swinv2.py:119 (to_qkv), :137 (wo),
+ * :99-100 (w1 + SwiGLU, w2), :230 (patch embedding) and :240 (head).
+ *   A  [M, lda]  dtype, row major, K multiple of swiftk_gemm_k_pad granularity
+ *                (pad columns must be finite; W's pad columns must be zero)
+ *   W  [N, ldw]  dtype
+ *   C  [M, ldc]  out_dtype (SWIFTK_F32 or same as dtype); SWIGLU writes N/2 columns
+ *   ep0 = bias[N] fp32, ep1 = pos[pos_rows, N] fp32 (BIAS_POS only)
+ */
+int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                int64_t K, int dtype, int out_dtype, int epilogue, const float* ep0, const float* ep1, int64_t pos_rows,
+                void* stream);
+
+/*
+ * Shifted-window cosine attention, fused: window gather (+cyclic roll), L2
+ * normalisation of q and k, per-head logit scale exp(min(s, ln 100)), softmax
+ * over the 256 keys of the window, P V, scatter back to token order.
+ * Replaces src/swift/models/swinv2.py:189-208 (roll / window_partition /
+ * window_reverse / roll) and :120-136 (Attention core).
+ *   qkv   [B, gh*gw, ldq] dtype, per token and head h the channels
+ *         [h*3*hd, h*3*hd + 3*hd) hold q | k | v (swinv2.py:120-121)
+ *   out   [B, gh*gw, ldo] dtype, channels h*hd + d
+ *   scale [heads] fp32 (the nn.Parameter, un-exponentiated)
+ * Supported: 16x16 windows, head_dim % 8 == 0 and <= 96.
+ */
+int swiftk_window_attention(const void* qkv, int64_t ldq, void* out, int64_t ldo, const float* scale, int B, int gh, int gw,
+                            int heads, int head_dim, int shift_h, int shift_w, int dtype, void* stream);
+
+/*
+ * x += LayerNorm(y; gamma, beta, eps) * (1 + scale_b) + shift_b, fused with the
+ * residual add; also writes a `dtype` copy of the new x as the next GEMM operand.
+ * Replaces src/swift/models/swinv2.py:83-86 (ModulatedNorm) + :211-212 (residual).
+ *   y     [M, ldy] dtype                 x   [M, d] fp32 (in/out)
+ *   xcopy [M, ldc] dtype (may be NULL)   mod [B, ldmod] fp32: scale at [0,d), shift at [d,2d)
+ *   rows_per_sample: M / B
+ */
+int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, void* xcopy, int64_t ldc, const float* gamma,
+                            const float* beta, const float* mod, int64_t ldmod, int64_t M, int d, int64_t rows_per_sample,
+                            float eps, int dtype, void* stream);
+
+/*
+ * Channel-concat + patchify of up to three NCHW fp32 sources into the GEMM
+ * operand of the patch embedding: A[b*gh*gw + gy*gw + gx][(i1*p2 + i2)*C + c]
+ * = scale_s * src_s[b][c - c0_s][gy*p1 + i1][gx*p2 + i2]; pad columns zeroed.
+ * Replaces src/swift/models/precond.py:139-141 (cat) and swinv2.py:224-229.
+ */
+int swiftk_patchify(const float* src0, int c0, float s0, const float* src1, int c1, float s1, const float* src2, int c2,
+                    float s2, void* A, int64_t lda, int B, int H, int W, int p1, int p2, int dtype, void* stream);
+
+/*
+ * out[b][c][y][x] = alpha[b] * xt[b][c][y][x] + beta[b] * tok[b][gy*gw+gx][(c*p1+i1)*p2+i2]
+ * (xt may be NULL -> alpha ignored).  Replaces swinv2.py:241-243 (un-patchify)
+ * fused with the sampler update cos(t) x_t - sin(t) sigma_d F (diffusion.py:459).
+ *   tok [B, gh*gw, ldt] fp32
+ */
+int swiftk_unpatchify_affine(const float* tok, int64_t ldt, const float* xt, const float* alpha, const float* beta,
+                             float* out, int B, int C, int H, int W, int p1, int p2, void* stream);
+
+/*
+ * Sinusoidal timestep embedding + auxiliary embedding:
+ *   emb[b][i] = sin(t_b w f_i) (i < d/2) | cos(t_b w f_{i-d/2})  + aux_w[i][:] . aux[b][:] sqrt(aux_dim) + aux_b[i]
+ * Replaces swinv2.py:44-60 and :318-320.  freqs [d/2] fp32 is supplied by the host.
+ */
+int swiftk_timestep_embed(const float* t, const float* aux, const float* freqs, const float* aux_w, const float* aux_b,
+                          float* emb, int B, int d, int aux_dim, float timestep_weight, void* stream);
+
+/*
+ * Small-batch fp32 linear: out[b][n] = act(x[b][:] . W[n][:] + bias[n]), B <= 64.
+ * act: 0 none, 1 SiLU.  Replaces swinv2.py:74 (LatentEmbedding), :85
+ * (all modulation Linears, concatenated along n), :327 (logvar).
+ */
+int swiftk_linear_small(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* out,
+                        int64_t ldo, int B, int N, int K, int act, void* stream);
+
+/*
+ * Residual rollout update in physical units, fused with re-standardisation:
+ *   phys[b][c] = xstd[b][c]*sx[c] + mx[c] + y[b][c]*st[c];  xstd[b][c] = (phys[b][c] - mx[c]) / sx[c]
+ * Replaces generate.py:120-131 with data/era5.py:110-166.
+ */
+int swiftk_rollout_update(float* xstd, const float* y, float* phys, const float* mx, const float* sx, const float* st,
+                          int B, int C, int64_t hw, void* stream);
+
+/*
+ * out = a*x + b*y (fp32, out may alias x or y): the samplers' state arithmetic between network
+ * evaluations -- re-noising sin(t) sigma_d eps + cos(t) x (diffusion.py:454-455) and the Heun
+ * average (diffusion.py:411).
+ */
+int swiftk_axpby(float* out, float a, const float* x, float b, const float* y, int64_t n, void* stream);
+
+/*
+ * Measurement hooks (bench.py's roofline leg; not on the reference's path).  After
+ * swiftk_profile_gemm(epilogue, N) every swiftk_gemm launch with that epilogue (and that N, if
+ * N != 0) is bracketed by a HIP event pair recorded on its launch stream; swiftk_profile_collect
+ * synchronises on them, returns the summed kernel time and the launch count, and re-arms.
+ * swiftk_profile_gemm(-1, 0) switches the hooks off.  At most 4096 launches per collection.
+ */
+int swiftk_profile_gemm(int epilogue, int64_t N);
+int swiftk_profile_collect(double* total_ms_host, int64_t* launches_host);
+
+/* fp32 -> dtype copy with row padding: dst[r][c] = src[r][c] for c < cols, 0 for cols <= c < ldd. */
+int swiftk_cast_pad(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype,
+                    void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Whole-network forward (the operator boundary itself).
+ * ------------------------------------------------------------------------ */
+
+typedef struct swiftk_layer {
+    const void* qkv_w;   /* [3*heads*hd, kd] dtype                     (to_qkv.weight)            */
+    const void* wo_w;    /* [d, kd]          dtype                     (wo.weight)                */
+    const void* w1_w;    /* [2*mlp, kd]      dtype, rows interleaved gate_j, up_j (w1.weight)      */
+    const void* w2_w;    /* [d, kmlp]        dtype                     (w2.weight)                */
+    const float* scale;  /* [heads]                                    (Attention.scale)          */
+    const float* ln1_g;  /* [d] attn norm.norm.weight */
+    const float* ln1_b;
+    const float* ln2_g;  /* [d] ff norm.norm.weight   */
+    const float* ln2_b;
+} swiftk_layer;
+
+typedef struct swiftk_model {
+    int32_t dtype;                 /* SWIFTK_F32 | SWIFTK_BF16 */
+    int32_t H, W, p1, p2;          /* image and patch size      */
+    int32_t in_ch, out_ch;         /* 141, 69                   */
+    int32_t depth, dim, heads;     /* 12, 1056, 12              */
+    int32_t mlp;                   /* int(8/3 dim) = 2816       */
+    int32_t wh, ww, sh, sw;        /* window 16x16, shift 8x8   */
+    int32_t aux_dim;
+    int32_t has_logvar;
+    float timestep_weight;
+    int64_t kd;                    /* swiftk_gemm_k_pad(dtype, dim)            */
+    int64_t kmlp;                  /* swiftk_gemm_k_pad(dtype, mlp)            */
+    int64_t kpe;                   /* swiftk_gemm_k_pad(dtype, in_ch*p1*p2)    */
+    const void* pe_w;              /* [d, kpe] dtype   (patch_embed.emb.weight) */
+    const float* pe_b;             /* [d]                                       */
+    const float* pos;              /* [gh*gw, d]       (pos_embed)              */
+    const float* freqs;            /* [d/2]                                     */
+    const float* aux_w;            /* [d, aux_dim]     (auxiliary_embed)        */
+    const float* aux_b;
+    const float* l1_w;             /* [d, d] fp32      (latent_embed.l1)        */
+    const float* l1_b;
+    const float* l2_w;
+    const float* l2_b;
+    const float* mod_w;            /* [depth*2*2d, d] fp32: layer i attn at rows (2i)*2d, ff at (2i+1)*2d */
+    const float* mod_b;            /* [depth*2*2d]                              */
+    const float* logvar_w;         /* [1, d] or NULL                            */
+    const float* logvar_b;
+    const void* head_w;            /* [out_ch*p1*p2, kd] dtype (head.head.0.weight) */
+    const swiftk_layer* layers_host; /* HOST array of `depth` entries           */
+} swiftk_model;
+
+/* Bytes of scratch swiftk_swinv2_forward needs for batch B (0 on a bad model). */
+int64_t swiftk_workspace_bytes(const swiftk_model* m, int B);
+
+/*
+ * out = alpha * xt + beta * SwinV2(cat[src0*s0, src1*s1, src2*s2], t, aux)
+ * i.e. swinv2.py:305-330 with precond.py:139-148's concat folded into the
+ * patch gather and (optionally) diffusion.py:459's update folded into the
+ * un-patchify.  Pass xt = NULL for the bare network output.
+ *   src_k NCHW fp32, channels c0 + c1 + c2 == in_ch (unused sources NULL / 0)
+ *   t [B], aux [B, aux_dim] (or NULL), alpha/beta [B] fp32 (NULL -> 0 / 1)
+ *   out [B, out_ch, H, W] fp32;  logvar [B] fp32 or NULL
+ */
+int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, int c0, float s0, const float* src1, int c1, float s1,
+                          const float* src2, int c2, float s2, const float* t, const float* aux, const float* xt,
+                          const float* alpha, const float* beta, float* out, float* logvar, int B, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWIFTK_H */

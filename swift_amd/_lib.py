@@ -1,0 +1,88 @@
+"""ctypes binding of ``csrc/libswiftk.so`` (the C ABI declared in ``include/swiftk.h``).
+
+There is deliberately no fallback: if the shared library is missing or a kernel
+rejects its arguments, the caller gets an exception -- the product path never
+silently computes on the CPU or through ATen.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libswiftk.so")
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_BIAS_POS, EPI_SWIGLU = 0, 1, 2
+
+_ERR = {-1: "SWIFTK_EINVAL (bad argument)", -2: "SWIFTK_ESHAPE (unsupported shape)",
+        -3: "SWIFTK_EALIGN (misaligned pointer / leading dimension)", -4: "SWIFTK_EWORKSPACE (workspace too small)"}
+
+
+class SwiftkError(RuntimeError):
+    pass
+
+
+class Layer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("qkv_w", "wo_w", "w1_w", "w2_w", "scale", "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+
+
+class Model(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ("dtype", "H", "W", "p1", "p2", "in_ch", "out_ch", "depth", "dim", "heads", "mlp",
+                                  "wh", "ww", "sh", "sw", "aux_dim", "has_logvar")]
+        + [("timestep_weight", C.c_float)]
+        + [(n, C.c_int64) for n in ("kd", "kmlp", "kpe")]
+        + [(n, C.c_void_p) for n in ("pe_w", "pe_b", "pos", "freqs", "aux_w", "aux_b", "l1_w", "l1_b", "l2_w", "l2_b",
+                                     "mod_w", "mod_b", "logvar_w", "logvar_b", "head_w")]
+        + [("layers_host", C.POINTER(Layer))]
+    )
+
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGS = {
+    "swiftk_version": ([], C.c_int),
+    "swiftk_gemm_k_pad": ([_i, _l], _l),
+    "swiftk_gemm": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _i, _i, _i, _p, _p, _l, _p], _i),
+    "swiftk_window_attention": ([_p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "swiftk_modnorm_residual": ([_p, _l, _p, _p, _l, _p, _p, _p, _l, _l, _i, _l, _f, _i, _p], _i),
+    "swiftk_patchify": ([_p, _i, _f, _p, _i, _f, _p, _i, _f, _p, _l, _i, _i, _i, _i, _i, _i, _p], _i),
+    "swiftk_unpatchify_affine": ([_p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "swiftk_timestep_embed": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p], _i),
+    "swiftk_linear_small": ([_p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _p], _i),
+    "swiftk_rollout_update": ([_p, _p, _p, _p, _p, _p, _i, _i, _l, _p], _i),
+    "swiftk_cast_pad": ([_p, _l, _p, _l, _l, _l, _i, _p], _i),
+    "swiftk_axpby": ([_p, _f, _p, _f, _p, _l, _p], _i),
+    "swiftk_profile_gemm": ([_i, _l], _i),
+    "swiftk_profile_collect": ([C.POINTER(C.c_double), C.POINTER(C.c_int64)], _i),
+    "swiftk_workspace_bytes": ([C.POINTER(Model), _i], _l),
+    "swiftk_swinv2_forward": ([C.POINTER(Model), _p, _i, _f, _p, _i, _f, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p,
+                               _l, _p], _i),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SwiftkError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C swift_amd/csrc)")
+        h = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(h, name)
+            fn.argtypes, fn.restype = args, res
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = _ERR.get(rc, f"hipError_t {rc}" if rc > 0 else f"error {rc}")
+        raise SwiftkError(f"{what} failed: {msg}")

@@ -1,0 +1,249 @@
+"""Minimal Hydra-compatible configuration layer.
+
+The reference drives everything through Hydra (``@hydra.main`` + ``hydra.utils.instantiate``,
+train.py:135, generate.py:197); neither hydra nor omegaconf is installed here, so this module
+provides the three things the hot path needs, with the same key names:
+
+  * ``instantiate(cfg, *args, **kwargs)`` -- the ``_target_`` plugin boundary
+    (``_recursive_`` / ``_convert_`` accepted and ignored: values are plain Python objects already).
+    Targets under ``swift.`` (the reference's package) resolve to this package, so a saved
+    ``.hydra/config.yaml`` of a reference run works unchanged;
+  * ``compose(config_dir, overrides)`` -- defaults-list composition of the yaml tree under
+    ``swift_amd/configs`` (group selection ``a=b`` / ``a/b=c``, ``override /x: y`` entries,
+    ``# @package _global_`` files, dotted value overrides ``a.b.c=v``, ``${oc.env:X}`` and ``${key}``);
+  * ``Cfg`` -- a dict with attribute access (``cfg.model.dim``), the only OmegaConf feature used.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import re
+from typing import Any, Optional
+
+import yaml
+
+TARGET_ALIASES = (("swift.", "swift_amd."),)
+
+
+class Cfg(dict):
+    """dict with attribute access; nested dicts are wrapped on the way in."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+        for key, v in dict(*a, **k).items():
+            self[key] = v
+
+    @staticmethod
+    def wrap(v):
+        if isinstance(v, dict) and not isinstance(v, Cfg):
+            return Cfg(v)
+        if isinstance(v, (list, tuple)):
+            return [Cfg.wrap(x) for x in v]
+        return v
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, Cfg.wrap(v))
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def to_plain(self):
+        def conv(v):
+            if isinstance(v, dict):
+                return {k: conv(x) for k, x in v.items()}
+            if isinstance(v, list):
+                return [conv(x) for x in v]
+            return v
+        return conv(self)
+
+
+def resolve_target(path: str):
+    for old, new in TARGET_ALIASES:
+        if path.startswith(old):
+            path = new + path[len(old):]
+            break
+    mod, name = path.rsplit(".", 1)
+    return getattr(importlib.import_module(mod), name)
+
+
+def _plain(v):
+    if isinstance(v, dict):
+        return {k: _plain(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_plain(x) for x in v]
+    return v
+
+
+def instantiate(cfg, *args, **kwargs):
+    """``hydra.utils.instantiate`` for the ``_target_`` convention (precond.py:123-131, train.py:212-220)."""
+    cfg = dict(cfg)
+    target = cfg.pop("_target_")
+    recursive = kwargs.pop("_recursive_", True)
+    kwargs.pop("_convert_", None)
+    params = {}
+    for k, v in {**cfg, **kwargs}.items():
+        if recursive and isinstance(v, dict) and "_target_" in v:
+            v = instantiate(v)
+        elif k != "model_config":
+            v = _plain(v)
+        params[k] = v
+    return resolve_target(target)(*args, **params)
+
+
+# ----------------------------------------------------------------------------- composition
+
+_PKG_RE = re.compile(r"^#\s*@package\s+(\S+)", re.M)
+
+
+def _load_yaml(path):
+    with open(path) as f:
+        text = f.read()
+    pkg = _PKG_RE.search(text)
+    return (yaml.safe_load(text) or {}), (pkg.group(1) if pkg else None)
+
+
+def _merge(dst: dict, src: dict):
+    for k, v in src.items():
+        if isinstance(v, dict) and isinstance(dst.get(k), dict):
+            _merge(dst[k], v)
+        else:
+            dst[k] = v
+    return dst
+
+
+def _place(root: dict, package: Optional[str], group: str, content: dict):
+    if package == "_global_":
+        return _merge(root, content)
+    path = (package if package else group).strip("/").split("/")
+    node = root
+    for p in path:
+        if p:
+            node = node.setdefault(p, {})
+    return _merge(node, content)
+
+
+def _compose_file(config_dir, group, name, root, choices, package_override=None):
+    path = os.path.join(config_dir, group.strip("/"), f"{name}.yaml")
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    body, pkg = _load_yaml(path)
+    pkg = package_override or pkg
+    defaults = body.pop("defaults", [])
+    # where does this file's own content land?
+    here = "" if pkg == "_global_" else (pkg.replace(".", "/") if pkg else group.strip("/"))
+    self_done = False
+    for d in defaults:
+        if d == "_self_":
+            _place(root, pkg, group, body)
+            self_done = True
+            continue
+        if isinstance(d, str):
+            d = {d: None}
+        (k, v), = d.items()
+        if k.startswith("override "):
+            continue  # recorded by _collect_overrides before composition
+        if v is None and "/" not in k and not os.path.isdir(os.path.join(config_dir, group.strip("/"), k)):
+            # plain file in the same group
+            _compose_file(config_dir, group, k, root, choices)
+            continue
+        sub = k if k.startswith("/") else (group.strip("/") + "/" + k if group.strip("/") else k)
+        sub = sub.strip("/")
+        choice = choices.get(sub, v)
+        if choice is None or choice == "null":
+            continue
+        # relative groups nest under the parent's package (loss/noise -> loss.noise)
+        _compose_file(config_dir, sub, choice, root, choices)
+    if not self_done:
+        _place(root, pkg, group, body)
+
+
+def _collect_overrides(config_dir, group, name, choices):
+    path = os.path.join(config_dir, group.strip("/"), f"{name}.yaml")
+    if not os.path.exists(path):
+        return
+    body, _ = _load_yaml(path)
+    for d in body.get("defaults", []):
+        if isinstance(d, dict):
+            (k, v), = d.items()
+            if k.startswith("override "):
+                choices.setdefault(k[len("override "):].strip().strip("/"), v)
+            elif v is not None:
+                sub = (k if k.startswith("/") else (group.strip("/") + "/" + k if group.strip("/") else k)).strip("/")
+                _collect_overrides(config_dir, sub, choices.get(sub, v), choices)
+
+
+def _parse_value(s: str):
+    try:
+        return yaml.safe_load(s)
+    except yaml.YAMLError:
+        return s
+
+
+def _interp(root: dict):
+    pat = re.compile(r"\$\{([^}]+)\}")
+
+    def lookup(key):
+        if key.startswith("oc.env:"):
+            name, _, default = key[len("oc.env:"):].partition(",")
+            return os.environ.get(name, default)
+        node = root
+        for p in key.split("."):
+            node = node[p]
+        return node
+
+    def walk(v):
+        if isinstance(v, dict):
+            return {k: walk(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [walk(x) for x in v]
+        if isinstance(v, str) and "${" in v:
+            m = pat.fullmatch(v)
+            if m:
+                return lookup(m.group(1))
+            return pat.sub(lambda mm: str(lookup(mm.group(1))), v)
+        return v
+
+    return walk(root)
+
+
+def compose(config_dir: str, config_name: str = "train", overrides=()) -> Cfg:
+    """Compose ``config_name`` with Hydra-style command-line overrides."""
+    choices, values = {}, []
+    for o in overrides:
+        k, _, v = o.partition("=")
+        k = k.lstrip("+")
+        if os.path.isdir(os.path.join(config_dir, k)):
+            choices[k] = v
+        else:
+            values.append((k, v))
+    # overrides declared inside selected files (e.g. "override /optimizer: muon") apply unless the CLI chose
+    _collect_overrides(config_dir, "", config_name, choices)
+    for g, n in list(choices.items()):
+        if n not in (None, "null"):
+            _collect_overrides(config_dir, g, n, choices)
+    root: dict = {}
+    _compose_file(config_dir, "", config_name, root, choices)
+    for k, v in values:
+        node = root
+        parts = k.split(".")
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        node[parts[-1]] = _parse_value(v)
+    root.pop("hydra", None) if False else None
+    return Cfg(_interp(root))
+
+
+def load_saved(path: str) -> Cfg:
+    """Load a composed ``.hydra/config.yaml`` (what generate.py:161 and train.py:57 read back)."""
+    with open(path) as f:
+        return Cfg(yaml.safe_load(f))
+
+
+def to_yaml(cfg) -> str:
+    return yaml.safe_dump(_plain(cfg), sort_keys=False)

@@ -1,0 +1,59 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of swift_amd.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/swiftk.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef uint16_t bf16_t;  // storage type of a bf16 element
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+#define SWIFTK_CHECK_LAUNCH()                         \
+    do {                                              \
+        hipError_t e__ = hipGetLastError();           \
+        if (e__ != hipSuccess) return (int)e__;       \
+    } while (0)
+
+// fp32 -> bf16, round to nearest even; a plain cast lowers to v_cvt_pk_bf16_f32 and keeps NaN a NaN.
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T>
+struct elem;
+template <>
+struct elem<float> {
+    static constexpr int dtype = SWIFTK_F32;
+    __device__ static float to_f(float v) { return v; }
+    __device__ static float from_f(float v) { return v; }
+};
+template <>
+struct elem<bf16_t> {
+    static constexpr int dtype = SWIFTK_BF16;
+    __device__ static float to_f(bf16_t v) { return bf2f(v); }
+    __device__ static bf16_t from_f(float v) { return f2bf(v); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }

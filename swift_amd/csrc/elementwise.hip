@@ -1,0 +1,370 @@
+// HBM-bound pieces of the SwinV2 forecast path for gfx950: modulated LayerNorm + residual,
+// patchify / un-patchify with the concat and the sampler update folded in, the tiny
+// time-embedding MLP, the rollout state update and operand casts.
+#include "common.h"
+
+namespace {
+
+// --------------------------------------------------------------------------------- modnorm + residual
+// One wave per token row; the row (d <= 2048) lives in registers between the two reduction passes.
+// Bytes per element: read y (2|4) + x (4), write x (4) + copy (2|0).
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void modnorm_kernel(const T* __restrict__ y, int64_t ldy, float* __restrict__ x,
+                                                      T* __restrict__ xc, int64_t ldc, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ mod,
+                                                      int64_t ldmod, int64_t M, int d, int64_t rps, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nv = d >> 2;  // float4 groups per row
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave; row < M; row += nwaves) {
+        float v[MAXV][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                if constexpr (sizeof(T) == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(y + row * ldy + 4 * c);
+                    v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
+                } else {
+                    const uint2 t = *reinterpret_cast<const uint2*>(y + row * ldy + 4 * c);
+                    v[i][0] = __uint_as_float(t.x << 16); v[i][1] = __uint_as_float(t.x & 0xffff0000u);
+                    v[i][2] = __uint_as_float(t.y << 16); v[i][3] = __uint_as_float(t.y & 0xffff0000u);
+                }
+                sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            }
+        }
+        const float mean = wave_sum(sum) / (float)d;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[i][e] -= mean;
+                    sq += v[i][e] * v[i][e];
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)d + eps);
+        const float* mrow = mod + (row / rps) * ldmod;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c);
+                const float4 bt = *reinterpret_cast<const float4*>(beta + 4 * c);
+                const float4 sc = *reinterpret_cast<const float4*>(mrow + 4 * c);
+                const float4 sh = *reinterpret_cast<const float4*>(mrow + d + 4 * c);
+                float4 xr = *reinterpret_cast<const float4*>(x + row * d + 4 * c);
+                xr.x += (v[i][0] * rstd * g.x + bt.x) * (1.0f + sc.x) + sh.x;
+                xr.y += (v[i][1] * rstd * g.y + bt.y) * (1.0f + sc.y) + sh.y;
+                xr.z += (v[i][2] * rstd * g.z + bt.z) * (1.0f + sc.z) + sh.z;
+                xr.w += (v[i][3] * rstd * g.w + bt.w) * (1.0f + sc.w) + sh.w;
+                *reinterpret_cast<float4*>(x + row * d + 4 * c) = xr;
+                if (xc) {
+                    if constexpr (sizeof(T) == 4)
+                        *reinterpret_cast<float4*>(xc + row * ldc + 4 * c) = xr;
+                    else
+                        *reinterpret_cast<uint2*>(xc + row * ldc + 4 * c) =
+                            make_uint2(pack_bf16(xr.x, xr.y), pack_bf16(xr.z, xr.w));
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------- patchify
+// Thread per output element so that the GEMM operand is written fully coalesced; the strided reads hit L2
+// (each 128-B input line is shared by 16 tokens x p2).
+struct PatchArgs {
+    const float* src[3];
+    int c0[3];  // first channel of each source in the concatenated order
+    int cn[3];
+    float sc[3];
+    int B, H, W, p1, p2, C, gh, gw;
+    int64_t lda;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(PatchArgs a, T* __restrict__ A) {
+    const int64_t total = (int64_t)a.B * a.gh * a.gw * a.lda;
+    const int F = a.p1 * a.p2 * a.C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int f = (int)(i % a.lda);
+        const int64_t tokg = i / a.lda;
+        float val = 0.f;
+        if (f < F) {
+            const int c = f % a.C, pp = f / a.C;
+            const int i1 = pp / a.p2, i2 = pp - i1 * a.p2;
+            const int gx = (int)(tokg % a.gw);
+            const int64_t t2 = tokg / a.gw;
+            const int gy = (int)(t2 % a.gh);
+            const int64_t b = t2 / a.gh;
+            const int s = c >= a.c0[2] ? 2 : (c >= a.c0[1] ? 1 : 0);
+            const int64_t off = ((b * a.cn[s] + (c - a.c0[s])) * a.H + (gy * a.p1 + i1)) * a.W + gx * a.p2 + i2;
+            val = a.src[s][off] * a.sc[s];
+        }
+        A[i] = elem<T>::from_f(val);
+    }
+}
+
+// --------------------------------------------------------------------------------- un-patchify (+ sampler affine)
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ tok, int64_t ldt,
+                                                         const float* __restrict__ xt, const float* __restrict__ alpha,
+                                                         const float* __restrict__ beta, float* __restrict__ out, int B,
+                                                         int C, int H, int W, int p1, int p2) {
+    const int64_t total = (int64_t)B * C * H * W;
+    const int gw = W / p2, gh = H / p1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int xw = (int)(i % W);
+        int64_t r = i / W;
+        const int yh = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % C);
+        const int64_t b = r / C;
+        const int gy = yh / p1, i1 = yh - gy * p1, gx = xw / p2, i2 = xw - gx * p2;
+        const float f = tok[(b * gh * gw + (int64_t)gy * gw + gx) * ldt + (c * p1 + i1) * p2 + i2];
+        const float bb = beta ? beta[b] : 1.0f;
+        float o = bb * f;
+        if (xt) o = (alpha ? alpha[b] : 0.0f) * xt[i] + o;
+        out[i] = o;
+    }
+}
+
+// --------------------------------------------------------------------------------- time embedding
+__global__ void temb_kernel(const float* __restrict__ t, const float* __restrict__ aux, const float* __restrict__ freqs,
+                            const float* __restrict__ aux_w, const float* __restrict__ aux_b, float* __restrict__ emb,
+                            int B, int d, int aux_dim, float tw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * d) return;
+    const int b = i / d, k = i - b * d, half = d >> 1;
+    float v = 0.f;
+    if (k < 2 * half) {
+        const float arg = (t[b] * tw) * freqs[k < half ? k : k - half];
+        v = k < half ? sinf(arg) : cosf(arg);
+    }
+    if (aux && aux_w) {
+        const float s = sqrtf((float)aux_dim);
+        float acc = 0.f;
+        for (int j = 0; j < aux_dim; ++j) acc += (aux[b * aux_dim + j] * s) * aux_w[k * aux_dim + j];
+        v += acc + aux_b[k];
+    }
+    emb[i] = v;
+}
+
+// --------------------------------------------------------------------------------- small-batch linear
+// One wave per output feature n, lanes stride over K in float4; x rows are tiny and stay in L1/L2.
+template <int BB>
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           const float* __restrict__ W, int64_t ldw,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int64_t ldo, int B, int N, int K, int act) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int k4 = K >> 2;
+    for (int b0 = 0; b0 < B; b0 += BB) {
+        float acc[BB];
+#pragma unroll
+        for (int j = 0; j < BB; ++j) acc[j] = 0.f;
+        for (int c = lane; c < k4; c += 64) {
+            const float4 w = *reinterpret_cast<const float4*>(W + (int64_t)n * ldw + 4 * c);
+#pragma unroll
+            for (int j = 0; j < BB; ++j) {
+                if (b0 + j < B) {
+                    const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)(b0 + j) * ldx + 4 * c);
+                    acc[j] += (w.x * xv.x + w.y * xv.y) + (w.z * xv.z + w.w * xv.w);
+                }
+            }
+        }
+        for (int k = (k4 << 2) + lane; k < K; k += 64)  // K % 4 tail
+#pragma unroll
+            for (int j = 0; j < BB; ++j)
+                if (b0 + j < B) acc[j] += W[(int64_t)n * ldw + k] * x[(int64_t)(b0 + j) * ldx + k];
+#pragma unroll
+        for (int j = 0; j < BB; ++j) {
+            const float s = wave_sum(acc[j]);
+            if (lane == 0 && b0 + j < B) {
+                float v = s + (bias ? bias[n] : 0.f);
+                if (act == 1) v = v / (1.0f + expf(-v));
+                out[(int64_t)(b0 + j) * ldo + n] = v;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------- rollout update
+__global__ __launch_bounds__(256) void rollout_update_kernel(float* __restrict__ xstd, const float* __restrict__ y,
+                                                             float* __restrict__ phys, const float* __restrict__ mx,
+                                                             const float* __restrict__ sx, const float* __restrict__ st,
+                                                             int C, int64_t hw4, int64_t total4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i / hw4) % C);
+        const float m = mx[c], s = sx[c], t = st[c];
+        const float4 xv = reinterpret_cast<const float4*>(xstd)[i];
+        const float4 yv = reinterpret_cast<const float4*>(y)[i];
+        float4 p, q;
+        p.x = (xv.x * s + m) + yv.x * t; p.y = (xv.y * s + m) + yv.y * t;
+        p.z = (xv.z * s + m) + yv.z * t; p.w = (xv.w * s + m) + yv.w * t;
+        q.x = (p.x - m) / s; q.y = (p.y - m) / s; q.z = (p.z - m) / s; q.w = (p.w - m) / s;
+        if (phys) reinterpret_cast<float4*>(phys)[i] = p;
+        reinterpret_cast<float4*>(xstd)[i] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ out, float a, const float* __restrict__ x, float b,
+                                                    const float* __restrict__ y, int64_t n4, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        const float4 yv = reinterpret_cast<const float4*>(y)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(a * xv.x + b * yv.x, a * xv.y + b * yv.y, a * xv.z + b * yv.z,
+                                                        a * xv.w + b * yv.w);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 256) out[i] = a * x[i] + b * y[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, int64_t lds, T* __restrict__ dst,
+                                                       int64_t ldd, int64_t rows, int64_t cols) {
+    const int64_t total = rows * ldd;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ldd, c = i - r * ldd;
+        dst[i] = elem<T>::from_f(c < cols ? src[r * lds + c] : 0.f);
+    }
+}
+
+inline int grid_for(int64_t work_items, int per_block = 256, int cap = 256 * 16) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+extern "C" int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, void* xcopy, int64_t ldc, const float* gamma,
+                                       const float* beta, const float* mod, int64_t ldmod, int64_t M, int d,
+                                       int64_t rows_per_sample, float eps, int dtype, void* stream) {
+    if (!y || !x || !gamma || !beta || !mod || M <= 0 || d <= 0 || rows_per_sample <= 0) return SWIFTK_EINVAL;
+    if (d % 4 || d > 2048) return SWIFTK_ESHAPE;
+    const int es = dtype == SWIFTK_BF16 ? 2 : 4;
+    if (((uintptr_t)y % (4 * es)) || (ldy * es) % (4 * es) || ((uintptr_t)x & 15) || ((uintptr_t)gamma & 15) ||
+        ((uintptr_t)beta & 15) || ((uintptr_t)mod & 15) || (ldmod % 4) || (xcopy && (((uintptr_t)xcopy % (4 * es)) || (ldc * es) % (4 * es))))
+        return SWIFTK_EALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(M, 4, 256 * 32);
+    if (dtype == SWIFTK_BF16)
+        hipLaunchKernelGGL((modnorm_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(y), ldy, x,
+                           static_cast<bf16_t*>(xcopy), ldc, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps);
+    else if (dtype == SWIFTK_F32)
+        hipLaunchKernelGGL((modnorm_kernel<float, 8>), dim3(grid), dim3(256), 0, st, static_cast<const float*>(y), ldy, x,
+                           static_cast<float*>(xcopy), ldc, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps);
+    else
+        return SWIFTK_EINVAL;
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_patchify(const float* src0, int c0, float s0, const float* src1, int c1, float s1, const float* src2,
+                               int c2, float s2, void* A, int64_t lda, int B, int H, int W, int p1, int p2, int dtype,
+                               void* stream) {
+    if (!A || !src0 || c0 <= 0 || c1 < 0 || c2 < 0 || B <= 0 || p1 <= 0 || p2 <= 0) return SWIFTK_EINVAL;
+    if ((c1 > 0 && !src1) || (c2 > 0 && !src2)) return SWIFTK_EINVAL;
+    if (H % p1 || W % p2) return SWIFTK_ESHAPE;
+    PatchArgs a;
+    a.src[0] = src0; a.src[1] = src1 ? src1 : src0; a.src[2] = src2 ? src2 : src0;
+    a.cn[0] = c0; a.cn[1] = c1; a.cn[2] = c2;
+    a.c0[0] = 0; a.c0[1] = c0; a.c0[2] = c0 + c1;
+    if (c1 == 0) a.c0[1] = 1 << 30;
+    if (c2 == 0) a.c0[2] = 1 << 30;
+    a.sc[0] = s0; a.sc[1] = s1; a.sc[2] = s2;
+    a.B = B; a.H = H; a.W = W; a.p1 = p1; a.p2 = p2; a.C = c0 + c1 + c2; a.gh = H / p1; a.gw = W / p2;
+    a.lda = lda;
+    if (lda < (int64_t)p1 * p2 * a.C) return SWIFTK_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((int64_t)B * a.gh * a.gw * lda);
+    if (dtype == SWIFTK_BF16)
+        hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a, static_cast<bf16_t*>(A));
+    else if (dtype == SWIFTK_F32)
+        hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), 0, st, a, static_cast<float*>(A));
+    else
+        return SWIFTK_EINVAL;
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_unpatchify_affine(const float* tok, int64_t ldt, const float* xt, const float* alpha,
+                                        const float* beta, float* out, int B, int C, int H, int W, int p1, int p2,
+                                        void* stream) {
+    if (!tok || !out || B <= 0 || C <= 0 || p1 <= 0 || p2 <= 0) return SWIFTK_EINVAL;
+    if (H % p1 || W % p2 || ldt < (int64_t)C * p1 * p2) return SWIFTK_ESHAPE;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for((int64_t)B * C * H * W)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), tok, ldt, xt, alpha, beta, out, B, C, H, W, p1, p2);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_timestep_embed(const float* t, const float* aux, const float* freqs, const float* aux_w,
+                                     const float* aux_b, float* emb, int B, int d, int aux_dim, float timestep_weight,
+                                     void* stream) {
+    if (!t || !freqs || !emb || B <= 0 || d <= 0) return SWIFTK_EINVAL;
+    if (aux && aux_w && (!aux_b || aux_dim <= 0)) return SWIFTK_EINVAL;
+    hipLaunchKernelGGL(temb_kernel, dim3((B * d + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), t, aux, freqs,
+                       aux_w, aux_b, emb, B, d, aux_dim, timestep_weight);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_linear_small(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* out,
+                                   int64_t ldo, int B, int N, int K, int act, void* stream) {
+    if (!x || !W || !out || B <= 0 || N <= 0 || K <= 0) return SWIFTK_EINVAL;
+    if (B > 64) return SWIFTK_ESHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)W & 15) || (ldx % 4) || (ldw % 4)) return SWIFTK_EALIGN;
+    hipLaunchKernelGGL(linear_small_kernel<8>, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, W,
+                       ldw, bias, out, ldo, B, N, K, act);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_rollout_update(float* xstd, const float* y, float* phys, const float* mx, const float* sx,
+                                     const float* st, int B, int C, int64_t hw, void* stream) {
+    if (!xstd || !y || !mx || !sx || !st || B <= 0 || C <= 0 || hw <= 0) return SWIFTK_EINVAL;
+    if (hw % 4) return SWIFTK_ESHAPE;
+    if (((uintptr_t)xstd & 15) || ((uintptr_t)y & 15) || (phys && ((uintptr_t)phys & 15))) return SWIFTK_EALIGN;
+    const int64_t total4 = (int64_t)B * C * hw / 4;
+    hipLaunchKernelGGL(rollout_update_kernel, dim3(grid_for(total4)), dim3(256), 0, static_cast<hipStream_t>(stream), xstd, y,
+                       phys, mx, sx, st, C, hw / 4, total4);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_cast_pad(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols,
+                               int dtype, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || ldd < cols || lds < cols) return SWIFTK_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(rows * ldd);
+    if (dtype == SWIFTK_BF16)
+        hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, src, lds, static_cast<bf16_t*>(dst), ldd,
+                           rows, cols);
+    else if (dtype == SWIFTK_F32)
+        hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(grid), dim3(256), 0, st, src, lds, static_cast<float*>(dst), ldd, rows,
+                           cols);
+    else
+        return SWIFTK_EINVAL;
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_axpby(float* out, float a, const float* x, float b, const float* y, int64_t n, void* stream) {
+    if (!out || !x || !y || n <= 0) return SWIFTK_EINVAL;
+    if (((uintptr_t)out & 15) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return SWIFTK_EALIGN;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, static_cast<hipStream_t>(stream), out, a, x, b, y,
+                       n / 4, n);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_version(void) { return 1; }

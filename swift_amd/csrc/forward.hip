@@ -1,0 +1,145 @@
+// swiftk_swinv2_forward: the whole SwinV2 denoiser as one C call (launch sequence on one HIP stream).
+// Host-side orchestration only; every arithmetic step is one of the kernels in gemm/attention/elementwise.hip.
+// Mirrors reference src/swift/models/swinv2.py:305-330 (+ precond.py:139-148, diffusion.py:459 folded in).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void zero_cols_kernel(char* p, int64_t ld_b, int64_t col0_b, int64_t ncol_b, int64_t rows) {
+    // zero bytes [col0_b, col0_b + ncol_b) of every row (4-byte granularity)
+    const int64_t per = ncol_b >> 2, total = rows * per;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / per, c = i - r * per;
+        *reinterpret_cast<uint32_t*>(p + r * ld_b + col0_b + 4 * c) = 0u;
+    }
+}
+
+struct Layout {
+    int64_t emb, h1, lat, mod, ape, x, xt, qkv, att, y, hmid, tok, total;
+};
+
+inline int64_t al(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+bool model_ok(const swiftk_model* m) {
+    if (!m || !m->layers_host) return false;
+    if (m->dtype != SWIFTK_F32 && m->dtype != SWIFTK_BF16) return false;
+    if (m->depth <= 0 || m->dim <= 0 || m->heads <= 0 || m->dim % m->heads) return false;
+    if (m->H % m->p1 || m->W % m->p2) return false;
+    if (m->wh != 16 || m->ww != 16) return false;
+    if ((m->H / m->p1) % 16 || (m->W / m->p2) % 16) return false;
+    if (m->dim % 4 || m->mlp % 2 || (m->out_ch * m->p1 * m->p2) % 4) return false;
+    return true;
+}
+
+Layout make_layout(const swiftk_model* m, int B) {
+    const int64_t es = m->dtype == SWIFTK_BF16 ? 2 : 4;
+    const int64_t ntok = (int64_t)(m->H / m->p1) * (m->W / m->p2), M = ntok * B, d = m->dim;
+    Layout L;
+    int64_t o = 0;
+    L.emb = o; o += al(B * d * 4);
+    L.h1 = o; o += al(B * d * 4);
+    L.lat = o; o += al(B * d * 4);
+    L.mod = o; o += al((int64_t)B * m->depth * 4 * d * 4);
+    L.ape = o; o += al(M * m->kpe * es);
+    L.x = o; o += al(M * d * 4);
+    L.xt = o; o += al(M * m->kd * es);
+    L.qkv = o; o += al(M * 3 * d * es);
+    L.att = o; o += al(M * m->kd * es);
+    L.y = o; o += al(M * d * es);
+    L.hmid = o; o += al(M * m->kmlp * es);
+    L.tok = o; o += al(M * (int64_t)m->out_ch * m->p1 * m->p2 * 4);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+#define RUN(expr)                  \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+extern "C" int64_t swiftk_workspace_bytes(const swiftk_model* m, int B) {
+    if (!model_ok(m) || B <= 0) return 0;
+    return make_layout(m, B).total;
+}
+
+extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, int c0, float s0, const float* src1, int c1,
+                                     float s1, const float* src2, int c2, float s2, const float* t, const float* aux,
+                                     const float* xt, const float* alpha, const float* beta, float* out, float* logvar,
+                                     int B, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!model_ok(m)) return SWIFTK_ESHAPE;
+    if (!src0 || !t || !out || !workspace || B <= 0) return SWIFTK_EINVAL;
+    if (c0 + c1 + c2 != m->in_ch) return SWIFTK_ESHAPE;
+    if (B > 64) return SWIFTK_ESHAPE;
+    if ((uintptr_t)workspace & 255) return SWIFTK_EALIGN;
+    const Layout L = make_layout(m, B);
+    if (workspace_bytes < L.total) return SWIFTK_EWORKSPACE;
+    char* ws = static_cast<char*>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int dt = m->dtype;
+    const int64_t es = dt == SWIFTK_BF16 ? 2 : 4;
+    const int gh = m->H / m->p1, gw = m->W / m->p2, d = m->dim, hd = m->dim / m->heads;
+    const int64_t ntok = (int64_t)gh * gw, M = ntok * B;
+    const int64_t ldmod = (int64_t)m->depth * 4 * d;
+    float* emb = reinterpret_cast<float*>(ws + L.emb);
+    float* h1 = reinterpret_cast<float*>(ws + L.h1);
+    float* lat = reinterpret_cast<float*>(ws + L.lat);
+    float* mod = reinterpret_cast<float*>(ws + L.mod);
+    float* x = reinterpret_cast<float*>(ws + L.x);
+    float* tok = reinterpret_cast<float*>(ws + L.tok);
+    void *ape = ws + L.ape, *xT = ws + L.xt, *qkv = ws + L.qkv, *att = ws + L.att, *y = ws + L.y, *hmid = ws + L.hmid;
+
+    // time / auxiliary embedding -> latent -> all 2*depth modulation vectors in one pass (swinv2.py:316-321, :85)
+    RUN(swiftk_timestep_embed(t, m->aux_dim > 0 ? aux : nullptr, m->freqs, m->aux_w, m->aux_b, emb, B, d, m->aux_dim,
+                              m->timestep_weight, stream));
+    RUN(swiftk_linear_small(emb, d, m->l1_w, d, m->l1_b, h1, d, B, d, d, 1, stream));
+    RUN(swiftk_linear_small(h1, d, m->l2_w, d, m->l2_b, lat, d, B, d, d, 1, stream));
+    RUN(swiftk_linear_small(lat, d, m->mod_w, d, m->mod_b, mod, ldmod, B, (int)ldmod, d, 0, stream));
+    if (logvar) {
+        if (!m->logvar_w) return SWIFTK_EINVAL;
+        RUN(swiftk_linear_small(lat, d, m->logvar_w, d, m->logvar_b, logvar, 1, B, 1, d, 0, stream));
+    }
+
+    // patch embedding (+bias +pos_embed) into the fp32 residual stream, plus its GEMM-operand copy
+    RUN(swiftk_patchify(src0, c0, s0, src1, c1, s1, src2, c2, s2, ape, m->kpe, B, m->H, m->W, m->p1, m->p2, dt, stream));
+    RUN(swiftk_gemm(ape, m->kpe, m->pe_w, m->kpe, x, d, M, d, m->kpe, dt, SWIFTK_F32, SWIFTK_EPI_BIAS_POS, m->pe_b, m->pos,
+                    ntok, stream));
+    RUN(swiftk_cast_pad(x, d, xT, m->kd, M, d, dt, stream));
+    if (m->kd > d) {  // K-padding columns of the attention output must be finite (they meet zero weight columns)
+        hipLaunchKernelGGL(zero_cols_kernel, dim3(1024), dim3(256), 0, st, static_cast<char*>(att), m->kd * es, d * es,
+                           (m->kd - d) * es, M);
+        SWIFTK_CHECK_LAUNCH();
+    }
+    if (m->kmlp > m->mlp) {
+        hipLaunchKernelGGL(zero_cols_kernel, dim3(1024), dim3(256), 0, st, static_cast<char*>(hmid), m->kmlp * es,
+                           (int64_t)m->mlp * es, (m->kmlp - m->mlp) * es, M);
+        SWIFTK_CHECK_LAUNCH();
+    }
+
+    const bool do_shift = (m->sh != 0) || (m->sw != 0);
+    for (int i = 0; i < m->depth; ++i) {
+        const swiftk_layer& ly = m->layers_host[i];
+        const bool shifted = do_shift && (i & 1);
+        RUN(swiftk_gemm(xT, m->kd, ly.qkv_w, m->kd, qkv, 3 * d, M, 3 * d, m->kd, dt, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0,
+                        stream));
+        RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
+                                    shifted ? m->sw : 0, dt, stream));
+        RUN(swiftk_gemm(att, m->kd, ly.wo_w, m->kd, y, d, M, d, m->kd, dt, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, stream));
+        RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok,
+                                    1e-6f, dt, stream));
+        RUN(swiftk_gemm(xT, m->kd, ly.w1_w, m->kd, hmid, m->kmlp, M, 2 * m->mlp, m->kd, dt, dt, SWIFTK_EPI_SWIGLU, nullptr,
+                        nullptr, 0, stream));
+        RUN(swiftk_gemm(hmid, m->kmlp, ly.w2_w, m->kmlp, y, d, M, d, m->kmlp, dt, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0,
+                        stream));
+        RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d,
+                                    ntok, 1e-6f, dt, stream));
+    }
+
+    const int po = m->out_ch * m->p1 * m->p2;
+    RUN(swiftk_gemm(xT, m->kd, m->head_w, m->kd, tok, po, M, po, m->kd, dt, SWIFTK_F32, SWIFTK_EPI_NONE, nullptr, nullptr, 0,
+                    stream));
+    RUN(swiftk_unpatchify_affine(tok, po, xt, alpha, beta, out, B, m->out_ch, m->H, m->W, m->p1, m->p2, stream));
+    return 0;
+}

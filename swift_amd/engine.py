@@ -1,0 +1,143 @@
+"""Device-side state of one SwinV2 module for one compute dtype: GEMM-ready weights, the
+``swiftk_model`` descriptor and the scratch workspace, plus the call into ``swiftk_swinv2_forward``.
+
+Weight layout in HBM (built once per parameter version, all on the device):
+  * GEMM operands (``patch_embed``, ``to_qkv``, ``wo``, ``w1``, ``w2``, ``head``) in the compute
+    dtype, K padded with zero columns to the 128-byte k-tile of the MFMA kernels
+    (1056 -> 1088 for bf16); ``w1`` rows interleaved (gate_j, up_j) so SwiGLU fuses into the
+    GEMM epilogue;
+  * everything that is not GEMM-bound stays fp32: LayerNorm affine, logit scales, pos_embed,
+    the time-embedding MLP and the 2*depth modulation Linears, concatenated into one
+    [depth*4*d, d] matrix so all modulation vectors come from a single launch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import ops
+from ._lib import Layer, Model, SwiftkError, check, lib
+
+
+class SwinEngine:
+    def __init__(self, module, dtype: torch.dtype):
+        self.module = module
+        self.dtype = dtype
+        self._stamp = None
+        self._keep = []
+        self._ws = None
+        self.model: Optional[Model] = None
+
+    # ------------------------------------------------------------------ weights
+    def _param_stamp(self):
+        return tuple((p.data_ptr(), p._version) for p in self.module.parameters())
+
+    def refresh(self) -> None:
+        stamp = self._param_stamp()
+        if stamp == self._stamp:
+            return
+        m = self.module
+        dev = m.pos_embed.device
+        if dev.type != "cuda":
+            raise SwiftkError("SwinV2 parameters must live on the GPU (module.to('cuda')); there is no CPU path")
+        dt = self.dtype
+        d, heads, depth, mlp = m.dim, m.heads, m.depth, m.mlp_dim
+        p1, p2 = m.patch_size
+        kd, kmlp, kpe = ops.k_pad(dt, d), ops.k_pad(dt, mlp), ops.k_pad(dt, m.in_channels * p1 * p2)
+        keep = []
+
+        def f32(t):
+            t = t.detach().contiguous().float()
+            keep.append(t)
+            return t.data_ptr()
+
+        def gemm_w(t, k):
+            t = ops.pad_cols(t.detach(), k, dt)
+            keep.append(t)
+            return t.data_ptr()
+
+        layers = (Layer * depth)()
+        mods_w, mods_b = [], []
+        for i, (att, ff) in enumerate(m.transformer.layers):
+            w1 = ff.w1.weight.detach()
+            w1i = w1.view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)  # rows: gate_0, up_0, gate_1, up_1, ...
+            layers[i].qkv_w = gemm_w(att.to_qkv.weight, kd)
+            layers[i].wo_w = gemm_w(att.wo.weight, kd)
+            layers[i].w1_w = gemm_w(w1i, kd)
+            layers[i].w2_w = gemm_w(ff.w2.weight, kmlp)
+            layers[i].scale = f32(att.scale.reshape(-1))
+            layers[i].ln1_g, layers[i].ln1_b = f32(att.norm.norm.weight), f32(att.norm.norm.bias)
+            layers[i].ln2_g, layers[i].ln2_b = f32(ff.norm.norm.weight), f32(ff.norm.norm.bias)
+            mods_w += [att.norm.modulation.weight.detach(), ff.norm.modulation.weight.detach()]
+            mods_b += [att.norm.modulation.bias.detach(), ff.norm.modulation.bias.detach()]
+
+        half = d // 2
+        freqs = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32) / half).to(dev)  # swinv2.py:48-50
+
+        mo = Model()
+        mo.dtype = ops.dtype_code(dt)
+        mo.H, mo.W = m.image_size
+        mo.p1, mo.p2 = p1, p2
+        mo.in_ch, mo.out_ch = m.in_channels, m.out_channels
+        mo.depth, mo.dim, mo.heads, mo.mlp = depth, d, heads, mlp
+        mo.wh, mo.ww = m.window_size
+        mo.sh, mo.sw = m.shift_size
+        mo.aux_dim = m.auxiliary_dim
+        mo.has_logvar = int(m.logvar_embed is not None)
+        mo.timestep_weight = float(m.timestep_weight)
+        mo.kd, mo.kmlp, mo.kpe = kd, kmlp, kpe
+        mo.pe_w = gemm_w(m.patch_embed.emb.weight, kpe)
+        mo.pe_b = f32(m.patch_embed.emb.bias)
+        mo.pos = f32(m.pos_embed.reshape(-1, d))
+        mo.freqs = f32(freqs)
+        if m.auxiliary_embed is not None:
+            mo.aux_w, mo.aux_b = f32(m.auxiliary_embed.weight), f32(m.auxiliary_embed.bias)
+        mo.l1_w, mo.l1_b = f32(m.latent_embed.l1.weight), f32(m.latent_embed.l1.bias)
+        mo.l2_w, mo.l2_b = f32(m.latent_embed.l2.weight), f32(m.latent_embed.l2.bias)
+        mo.mod_w, mo.mod_b = f32(torch.cat(mods_w, 0)), f32(torch.cat(mods_b, 0))
+        if m.logvar_embed is not None:
+            mo.logvar_w, mo.logvar_b = f32(m.logvar_embed.weight), f32(m.logvar_embed.bias)
+        mo.head_w = gemm_w(m.head.head[0].weight, kd)
+        mo.layers_host = C.cast(layers, C.POINTER(Layer))
+        keep.append(layers)
+        self.model, self._keep, self._stamp = mo, keep, stamp
+
+    # ------------------------------------------------------------------ forward
+    def workspace(self, B: int) -> torch.Tensor:
+        need = int(lib().swiftk_workspace_bytes(C.byref(self.model), B))
+        if need <= 0:
+            raise SwiftkError("model configuration not supported by the gfx950 kernels "
+                              "(need 16x16 windows, grid divisible by 16, dim % 4 == 0)")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.module.pos_embed.device)
+        return self._ws
+
+    def forward(self, srcs: Sequence[torch.Tensor], scales: Sequence[float], t: torch.Tensor,
+                aux: Optional[torch.Tensor], xt: Optional[torch.Tensor] = None, alpha: Optional[torch.Tensor] = None,
+                beta: Optional[torch.Tensor] = None, want_logvar: bool = False):
+        """out = alpha*xt + beta*SwinV2(cat_k srcs[k]*scales[k], t, aux)   (all fp32 NCHW on the device)."""
+        self.refresh()
+        m = self.module
+        B = srcs[0].shape[0]
+        srcs = [s.contiguous().float() for s in srcs]
+        for s in srcs:
+            if not s.is_cuda:
+                raise SwiftkError("inputs must be device tensors; there is no CPU path")
+        t = t.contiguous().float()
+        aux = None if aux is None else aux.contiguous().float()
+        ws = self.workspace(B)
+        out = torch.empty(B, m.out_channels, *m.image_size, dtype=torch.float32, device=t.device)
+        logvar = torch.empty(B, dtype=torch.float32, device=t.device) if want_logvar else None
+        ps = [(s.data_ptr(), s.shape[1], float(c)) for s, c in zip(srcs, scales)] + [(None, 0, 1.0)] * (3 - len(srcs))
+        keep = (srcs, t, aux, xt, alpha, beta)  # noqa: F841  (alive until the launch sequence is enqueued)
+        rc = lib().swiftk_swinv2_forward(
+            C.byref(self.model), ps[0][0], ps[0][1], ps[0][2], ps[1][0], ps[1][1], ps[1][2], ps[2][0], ps[2][1], ps[2][2],
+            t.data_ptr(), None if aux is None else aux.data_ptr(), None if xt is None else xt.data_ptr(),
+            None if alpha is None else alpha.data_ptr(), None if beta is None else beta.data_ptr(), out.data_ptr(),
+            None if logvar is None else logvar.data_ptr(), B, ws.data_ptr(), ws.numel(),
+            torch.cuda.current_stream().cuda_stream)
+        check(rc, "swiftk_swinv2_forward")
+        return (out, logvar) if want_logvar else out

@@ -1,0 +1,162 @@
+"""Tensor-level wrappers over the C ABI (``include/swiftk.h``).
+
+PyTorch is plumbing here: it owns device memory and the stream; every wrapper
+passes raw ``data_ptr()``s to the HIP kernels and returns immediately (the
+launch is asynchronous on torch's current stream).  CPU tensors are rejected --
+there is no fallback implementation.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BF16, EPI_BIAS_POS, EPI_NONE, EPI_SWIGLU, F32, SwiftkError, check, lib
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise SwiftkError("swift_amd kernels need device (HIP) tensors; there is no CPU fallback")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise SwiftkError(f"unsupported dtype {dt}") from None
+
+
+def k_pad(dtype: torch.dtype, k: int) -> int:
+    return int(lib().swiftk_gemm_k_pad(dtype_code(dtype), k))
+
+
+def pad_cols(w: torch.Tensor, k: int, dtype: torch.dtype) -> torch.Tensor:
+    """[rows, cols] fp32 -> [rows, k] ``dtype`` with zero padding (GEMM operand layout), on the device."""
+    _dev(w)
+    w = w.contiguous().float()
+    out = torch.empty(w.shape[0], k, dtype=dtype, device=w.device)
+    check(lib().swiftk_cast_pad(w.data_ptr(), w.shape[1], out.data_ptr(), k, w.shape[0], w.shape[1], dtype_code(dtype),
+                                _stream()), "swiftk_cast_pad")
+    return out
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *, n_out: Optional[int] = None,
+         out_dtype: Optional[torch.dtype] = None, epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None,
+         pos: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N] = epilogue(a[M, K] @ w[N, K]^T); a, w row-major 2-D (row stride may exceed K)."""
+    _dev(a, w, out, bias, pos)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
+    odt = out_dtype or a.dtype
+    ncol = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty(M, n_out or ncol, dtype=odt, device=a.device)
+    check(lib().swiftk_gemm(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+                            dtype_code(a.dtype), dtype_code(out.dtype), epilogue, _ptr(bias), _ptr(pos),
+                            0 if pos is None else pos.shape[0], _stream()), "swiftk_gemm")
+    return out
+
+
+def window_attention(qkv: torch.Tensor, scale: torch.Tensor, grid: Tuple[int, int], heads: int,
+                     shift: Tuple[int, int] = (0, 0), out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qkv [B, gh*gw, >=3*heads*hd] -> out [B, gh*gw, heads*hd] (token order, un-rolled)."""
+    _dev(qkv, scale, out)
+    B, n, _ = qkv.shape
+    gh, gw = grid
+    assert n == gh * gw and qkv.stride(2) == 1
+    hd = qkv.shape[2] // (3 * heads)
+    if out is None:
+        out = torch.empty(B, n, heads * hd, dtype=qkv.dtype, device=qkv.device)
+    check(lib().swiftk_window_attention(qkv.data_ptr(), qkv.stride(1), out.data_ptr(), out.stride(1),
+                                        scale.contiguous().data_ptr(), B, gh, gw, heads, hd, shift[0], shift[1],
+                                        dtype_code(qkv.dtype), _stream()), "swiftk_window_attention")
+    return out
+
+
+def modnorm_residual(y: torch.Tensor, x: torch.Tensor, gamma, beta, mod: torch.Tensor, rows_per_sample: int,
+                     xcopy: Optional[torch.Tensor] = None, eps: float = 1e-6) -> None:
+    """x[M,d] (fp32, in place) += LN(y) * (1 + mod[:, :d]) + mod[:, d:2d]; optional operand copy of the new x."""
+    _dev(y, x, gamma, beta, mod, xcopy)
+    M, d = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float32 and mod.stride(1) == 1
+    check(lib().swiftk_modnorm_residual(y.data_ptr(), y.stride(0), x.data_ptr(), _ptr(xcopy),
+                                        0 if xcopy is None else xcopy.stride(0), gamma.data_ptr(), beta.data_ptr(),
+                                        mod.data_ptr(), mod.stride(0), M, d, rows_per_sample, eps, dtype_code(y.dtype),
+                                        _stream()), "swiftk_modnorm_residual")
+
+
+def patchify(srcs: Sequence[torch.Tensor], scales: Sequence[float], patch: Tuple[int, int], lda: int,
+             dtype: torch.dtype) -> torch.Tensor:
+    """Concat (channel dim) + patchify of up to three NCHW fp32 tensors -> [B*gh*gw, lda] ``dtype``."""
+    _dev(*srcs)
+    assert 1 <= len(srcs) <= 3
+    B, _, H, W = srcs[0].shape
+    srcs = [s.contiguous() for s in srcs]
+    ps = [(s.data_ptr(), s.shape[1], float(c)) for s, c in zip(srcs, scales)] + [(None, 0, 1.0)] * (3 - len(srcs))
+    out = torch.empty(B * (H // patch[0]) * (W // patch[1]), lda, dtype=dtype, device=srcs[0].device)
+    check(lib().swiftk_patchify(ps[0][0], ps[0][1], ps[0][2], ps[1][0], ps[1][1], ps[1][2], ps[2][0], ps[2][1], ps[2][2],
+                                out.data_ptr(), lda, B, H, W, patch[0], patch[1], dtype_code(dtype), _stream()),
+          "swiftk_patchify")
+    return out
+
+
+def unpatchify_affine(tok: torch.Tensor, out_shape, patch, xt=None, alpha=None, beta=None) -> torch.Tensor:
+    _dev(tok, xt, alpha, beta)
+    B, C, H, W = out_shape
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=tok.device)
+    check(lib().swiftk_unpatchify_affine(tok.data_ptr(), tok.stride(-2), _ptr(xt), _ptr(alpha), _ptr(beta), out.data_ptr(),
+                                         B, C, H, W, patch[0], patch[1], _stream()), "swiftk_unpatchify_affine")
+    return out
+
+
+def timestep_embed(t, aux, freqs, aux_w, aux_b, d: int, timestep_weight: float = 1.0) -> torch.Tensor:
+    _dev(t, aux, freqs, aux_w, aux_b)
+    B = t.shape[0]
+    out = torch.empty(B, d, dtype=torch.float32, device=t.device)
+    ad = 0 if aux is None else aux.shape[1]
+    check(lib().swiftk_timestep_embed(t.data_ptr(), _ptr(aux), freqs.data_ptr(), _ptr(aux_w), _ptr(aux_b), out.data_ptr(), B,
+                                      d, ad, timestep_weight, _stream()), "swiftk_timestep_embed")
+    return out
+
+
+def linear_small(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0) -> torch.Tensor:
+    _dev(x, w, bias)
+    B, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    check(lib().swiftk_linear_small(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _ptr(bias), out.data_ptr(), N, B, N,
+                                    K, act, _stream()), "swiftk_linear_small")
+    return out
+
+
+def rollout_update(xstd: torch.Tensor, y: torch.Tensor, mx, sx, st, phys: Optional[torch.Tensor] = None) -> None:
+    """In place: phys = xstd*sx + mx + y*st ; xstd = (phys - mx)/sx  (per channel)."""
+    _dev(xstd, y, mx, sx, st, phys)
+    B, Cc, H, W = xstd.shape
+    assert xstd.is_contiguous() and y.is_contiguous() and (phys is None or phys.is_contiguous())
+    check(lib().swiftk_rollout_update(xstd.data_ptr(), y.data_ptr(), _ptr(phys), mx.data_ptr(), sx.data_ptr(), st.data_ptr(),
+                                      B, Cc, H * W, _stream()), "swiftk_rollout_update")
+
+
+def axpby(a: float, x: torch.Tensor, b: float, y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = a*x + b*y on fp32 device tensors of equal shape (out may alias x or y)."""
+    _dev(x, y, out)
+    assert x.is_contiguous() and y.is_contiguous() and x.shape == y.shape and x.dtype == y.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().swiftk_axpby(out.data_ptr(), float(a), x.data_ptr(), float(b), y.data_ptr(), x.numel(), _stream()),
+          "swiftk_axpby")
+    return out

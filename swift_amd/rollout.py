@@ -1,0 +1,91 @@
+"""Device-resident autoregressive ensemble rollout (the hot loop of reference generate.py:85-131).
+
+What changes relative to the reference loop, and why it is the same computation:
+  * the state never leaves HBM: no per-step ``.cpu()`` (generate.py:129) -- the physical
+    trajectory is written by the update kernel straight into a device buffer and copied out
+    once per batch;
+  * forcings are staged (standardised) on the device up front instead of an h5 read per sample
+    per step (generate.py:101-112);
+  * ``cat[X, forcings]`` and ``cat[x_t, condition]`` are never built: state, forcings and the
+    noisy latent go to the patch-gather kernel as three sources;
+  * unstandardise-x + unstandardise-t + add + re-standardise (generate.py:120-131) is one kernel;
+  * the work unit is a (member, IC) pair, not a member: any contiguous block of the flattened
+    member x IC space can run as one batch, which is what lets 12 members fill 8 GPUs.
+Noise: each unit gets its own generator seeded from (member, IC index) so results do not depend
+on how units are sharded or batched (the reference seeds per member and consumes the stream in
+batch order, generate.py:83 -- that coupling is deliberately not reproduced; parity tests inject
+latents explicitly).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence
+
+import torch
+
+from . import ops
+from .generating.factory import sampler_factory
+
+
+def unit_seed(member: int, ic: int) -> int:
+    return (int(member) * 1_000_003 + int(ic) * 7919 + 12345) & 0x7FFFFFFF
+
+
+class RolloutEngine:
+    def __init__(self, net, dataset, interval: int = 6, solver: str = "scm", denoise_dtype: torch.dtype = torch.float32,
+                 **solver_kwargs):
+        self.net, self.dataset, self.interval = net, dataset, int(interval)
+        kw = dict(num_steps=1, sigma_min=0.02, sigma_max=200.0, auxiliary=interval / 10.0)  # generate.py:255-260
+        kw.update(solver_kwargs)
+        self.sampler = sampler_factory(solver, net, denoise_dtype=denoise_dtype, **kw)
+        self.residual = getattr(dataset, "residual", False)
+        if not self.residual:
+            raise NotImplementedError("non-residual datasets (generate.py:133-137) are not on the forecast path built here")
+        self._stats = None
+
+    def stats(self, device):
+        if self._stats is None or self._stats[0].device != device:
+            self._stats = self.dataset.rollout_stats(self.interval, device)
+        return self._stats
+
+    def stage_forcings(self, ic_indices: Sequence[int], steps: int, device) -> torch.Tensor:
+        """Standardised forcings [steps, B, n_forc, H, W] on the device (file index j + i*interval//6)."""
+        rows = []
+        for i in range(steps):
+            f = torch.stack([self.dataset.get_forcings(int(j) + int(i * self.interval // 6)) for j in ic_indices], 0)
+            rows.append(self.dataset.standardize_x(f))
+        return torch.stack(rows, 0).to(device, non_blocking=True)
+
+    @torch.no_grad()
+    def run(self, X0: torch.Tensor, forcings: torch.Tensor, steps: int, *, seeds: Optional[Sequence[int]] = None,
+            latents: Optional[Callable[[int], torch.Tensor]] = None, out: Optional[torch.Tensor] = None,
+            keep_trajectory: bool = True) -> torch.Tensor:
+        """Roll ``steps`` lead steps from the standardised state X0 [B, n_vars, H, W] (device, fp32).
+
+        ``forcings`` [steps, B, n_forc, H, W] standardised, on the device.  ``latents(i)`` overrides the
+        noise of step i (tests); otherwise unit b draws from ``torch.Generator`` seeded ``seeds[b]``.
+        Returns the physical trajectory as a [B, steps+1, n_vars, H, W] view of a step-major buffer
+        ``out`` [steps+1, B, ...] (or the final physical state if ``keep_trajectory`` is False).
+        """
+        dev = X0.device
+        B, nv, H, W = X0.shape
+        mx, sx, st = self.stats(dev)
+        X = X0.contiguous().float().clone()
+        if keep_trajectory:
+            if out is None:  # step-major so that every lead step is one contiguous [B, C, H, W] block
+                out = torch.empty(steps + 1, B, nv, H, W, dtype=torch.float32, device=dev)
+            out[0] = self.dataset.unstandardize_x(X.clone())
+        gens = None
+        if latents is None:
+            seeds = list(seeds) if seeds is not None else list(range(B))
+            gens = [torch.Generator(device=dev).manual_seed(int(s)) for s in seeds]
+        phys = torch.empty_like(X)
+        for i in range(steps):
+            if latents is not None:
+                z = latents(i)
+            else:
+                z = torch.empty(B, nv, H, W, dtype=torch.float32, device=dev)
+                for b, g in enumerate(gens):
+                    z[b].normal_(generator=g)
+            Y = self.sampler((X, forcings[i]), latents=z)
+            ops.rollout_update(X, Y, mx, sx, st, phys=out[i + 1] if keep_trajectory else phys)
+        return out.transpose(0, 1) if keep_trajectory else phys

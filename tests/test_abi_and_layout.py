@@ -1,0 +1,76 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/swiftk.h declares (no compute
+calls without a GPU), the product never imports the oracle, and the product refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "swiftk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(swiftk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from swift_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 15
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(h, n), f"{n} declared in include/swiftk.h but not exported by libswiftk.so"
+    assert set(names) == set(_lib.EXPORTS), set(names) ^ set(_lib.EXPORTS)
+    assert _lib.lib().swiftk_version() == 1
+    assert _lib.lib().swiftk_gemm_k_pad(_lib.BF16, 1056) == 1088 and _lib.lib().swiftk_gemm_k_pad(_lib.F32, 1056) == 1056
+
+
+def test_host_side_argument_validation_needs_no_gpu():
+    """Error conventions of the C ABI: negative SWIFTK_E* codes, never a crash."""
+    from swift_amd import _lib
+    L = _lib.lib()
+    assert L.swiftk_gemm(None, 0, None, 0, None, 0, 1, 1, 1, 0, 0, 0, None, None, 0, None) == -1
+    assert L.swiftk_gemm(16, 40, 16, 40, 16, 4, 4, 4, 40, _lib.BF16, _lib.BF16, 0, None, None, 0, None) == -2  # K % 64
+    assert L.swiftk_gemm(8, 64, 16, 64, 16, 4, 4, 4, 64, _lib.BF16, _lib.BF16, 0, None, None, 0, None) == -3  # alignment
+    assert L.swiftk_window_attention(16, 3168, 16, 1056, 16, 1, 24, 16, 12, 88, 0, 0, 0, None) == -2
+    assert L.swiftk_workspace_bytes(None, 1) == 0
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base in ("swift_amd",):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".hip", ".h", ".cpp")):
+                    src = open(os.path.join(dp, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "oracle/" in src:
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_no_cpu_fallback():
+    from swift_amd._lib import SwiftkError
+    from swift_amd.models.swinv2 import SwinV2
+    m = SwinV2([32, 32], 5, 2, [16, 16], [8, 8], [2, 2], depth=1, dim=96, heads=4, auxiliary_dim=1)
+    with pytest.raises(SwiftkError):
+        m(torch.zeros(1, 5, 32, 32), torch.zeros(1))
+
+
+def test_state_dict_surface_matches_reference_names():
+    from swift_amd.models.precond import PassPrecond
+    from swift_amd.utils.detinit import swinv2_state
+    cfg = dict(_target_="swift.models.swinv2.SwinV2", window_size=[16, 16], shift_size=[8, 8], patch_size=[2, 2],
+               depth=2, dim=96, heads=4, logvar=True)
+    net = PassPrecond(cfg, [32, 64], 4, 7, auxiliary_dim=1)
+    ref = swinv2_state(grid=(16, 32), in_channels=11, out_channels=4, patch_size=(2, 2), depth=2, dim=96, heads=4,
+                       logvar=True)
+    assert list(net.state_dict().keys()) == list(ref.keys()) or set(net.state_dict()) == set(ref)
+    assert all(net.state_dict()[k].shape == v.shape for k, v in ref.items())
+    # reference init semantics (swinv2.py:295-303): modulation and head start at zero, scale at ln 10
+    sd = net.state_dict()
+    assert float(sd["model.head.head.0.weight"].abs().max()) == 0.0
+    assert float(sd["model.transformer.layers.0.0.norm.modulation.weight"].abs().max()) == 0.0
+    assert torch.allclose(sd["model.transformer.layers.1.0.scale"], torch.log(torch.tensor(10.0)))

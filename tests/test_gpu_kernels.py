@@ -1,0 +1,222 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against the CPU oracle on the same inputs.
+
+Tolerances (relative L2 unless noted):
+  fp32 kernels   1e-5 per op (fp32 MFMA is an exact fp32 FMA chain; only summation order differs)
+  bf16 kernels   operands rounded to bf16 (2^-9 relative), fp32 accumulation: 6e-3 per GEMM-like op
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-5
+BF16_TOL = 6e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda", 0)
+
+
+def rnd(shape, seed, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * std
+
+
+def to_dt(x, dt, dev):
+    return x.to(dev).to(dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(300, 704, 192), (2048, 3168, 1088), (512, 276, 1088), (77, 36, 64)])
+def test_gemm_plain(dev, dt, shape):
+    from swift_amd import ops
+    M, N, K = shape
+    K = ops.k_pad(dt, K)
+    a, w = rnd((M, K), 1), rnd((N, K), 2, 0.05)
+    ad, wd = to_dt(a, dt, dev), to_dt(w, dt, dev)
+    c = ops.gemm(ad, wd)
+    ref = ad.float().cpu().double() @ wd.float().cpu().double().T  # same rounded operands, exact accumulate
+    assert c.dtype == dt
+    assert rel_l2(c.float().cpu(), ref) < (F32_TOL if dt == torch.float32 else 4e-3)
+    c32 = ops.gemm(ad, wd, out_dtype=torch.float32)
+    assert rel_l2(c32.cpu(), ref) < F32_TOL
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_strided_rows_and_identity(dev, dt):
+    """A = I picks rows of an ASYMMETRIC W: catches transposed / permuted fragment maps exactly."""
+    from swift_amd import ops
+    K = 128
+    a = torch.zeros(256, 192)
+    a[:, :K] = torch.eye(256)[:, :K]
+    a[:, K:] = float("nan")  # beyond lda-visible K: must never be read
+    w = (torch.arange(352 * K, dtype=torch.float32).reshape(352, K) % 251) - 125.0
+    ad, wd = to_dt(a, dt, dev), to_dt(w, dt, dev)
+    c = ops.gemm(ad[:, :K], wd, out_dtype=torch.float32)
+    ref = torch.zeros(256, 352)
+    ref[:K] = w.T
+    assert torch.equal(c.cpu(), ref)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_bias_pos(dev, dt):
+    from swift_amd import ops
+    M, N, K = 1024, 1056, ops.k_pad(dt, 564)
+    a, w = rnd((M, K), 3), rnd((N, K), 4, 0.05)
+    bias, pos = rnd((N,), 5), rnd((256, N), 6)
+    ad, wd = to_dt(a, dt, dev), to_dt(w, dt, dev)
+    c = ops.gemm(ad, wd, out_dtype=torch.float32, epilogue=ops.EPI_BIAS_POS, bias=bias.to(dev), pos=pos.to(dev))
+    ref = ad.float().cpu().double() @ wd.float().cpu().double().T + bias.double() + pos.double().repeat(4, 1)
+    assert rel_l2(c.cpu(), ref) < F32_TOL
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_swiglu(dev, dt):
+    from swift_amd import ops
+    M, H, K = 512, 2816, ops.k_pad(dt, 1056)
+    a, w1 = rnd((M, K), 7), rnd((2 * H, K), 8, 0.03)
+    wi = w1.view(2, H, K).permute(1, 0, 2).reshape(2 * H, K)  # gate_j, up_j interleaved
+    ad, wd = to_dt(a, dt, dev), to_dt(wi, dt, dev)
+    c = ops.gemm(ad, wd, epilogue=ops.EPI_SWIGLU)
+    assert c.shape == (M, H)
+    h = ad.float().cpu().double() @ to_dt(w1, dt, dev).float().cpu().double().T
+    ref = torch.nn.functional.silu(h[:, :H]) * h[:, H:]
+    assert rel_l2(c.float().cpu(), ref) < (F32_TOL if dt == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shift", [(0, 0), (8, 8), (3, 5)])
+def test_window_attention(dev, dt, shift):
+    from oracle.swinv2 import cosine_window_attention, window_token_index
+    from swift_amd import ops
+    B, grid, heads, hd = 2, (32, 48), 12, 88
+    n = grid[0] * grid[1]
+    qkv = rnd((B, n, 3 * heads * hd), 9)
+    scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 10.0]))
+    qd = to_dt(qkv, dt, dev)
+    out = ops.window_attention(qd, scale.to(dev), grid, heads, shift)
+    idx = window_token_index(grid, (16, 16), shift)
+    src = qd.float().cpu()
+    ow = cosine_window_attention(src[:, idx.reshape(-1)].reshape(B * idx.shape[0], 256, -1), scale.view(1, heads, 1, 1),
+                                 heads, naive=True)
+    ref = torch.empty(B, n, heads * hd)
+    ref[:, idx.reshape(-1)] = ow.reshape(B, n, -1)
+    assert rel_l2(out.float().cpu(), ref) < (2e-5 if dt == torch.float32 else 1.2e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_window_attention_sharp_rows(dev, dt):
+    """Logits up to +-100 (scale clamp) with near-duplicate keys: exercises the row-max subtraction."""
+    from oracle.swinv2 import cosine_window_attention
+    from swift_amd import ops
+    heads, hd = 12, 88
+    qkv = rnd((1, 256, 3 * heads * hd), 10)
+    v = qkv.view(1, 256, heads, 3, hd)
+    v[:, :, :, 1] = v[:, :, :, 0] * 3.0 + 0.01 * rnd((1, 256, heads, hd), 11)  # k ~ parallel to q -> cos ~ 1
+    scale = torch.full((heads,), 9.0)  # clamped to ln(100)
+    qd = to_dt(qkv, dt, dev)
+    out = ops.window_attention(qd, scale.to(dev), (16, 16), heads)
+    ref = cosine_window_attention(qd.float().cpu(), scale.view(1, heads, 1, 1), heads, naive=True)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out.float().cpu(), ref) < (5e-5 if dt == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_modnorm_residual(dev, dt):
+    from swift_amd import ops
+    B, rps, d = 3, 200, 1056
+    M = B * rps
+    y, x = rnd((M, d), 12, 2.0) + 0.5, rnd((M, d), 13)
+    gamma, beta, mod = 1 + 0.1 * rnd((d,), 14), 0.1 * rnd((d,), 15), 0.3 * rnd((B, 5 * 2 * d), 16)
+    yd = to_dt(y, dt, dev)
+    xd = x.to(dev).clone()
+    ld = ops.k_pad(dt, d)
+    xc = torch.full((M, ld), 7.0, dtype=dt, device=dev)
+    msl = mod.to(dev)[:, 4 * d: 6 * d]  # a strided slice, like layer 2 of the concatenated modulation
+    ops.modnorm_residual(yd, xd, gamma.to(dev), beta.to(dev), msl, rps, xcopy=xc)
+    yn = torch.nn.functional.layer_norm(yd.float().cpu(), (d,), gamma, beta, 1e-6)
+    m = mod[:, 4 * d: 6 * d].repeat_interleave(rps, 0)
+    ref = x + yn * (1 + m[:, :d]) + m[:, d:]
+    assert rel_l2(xd.cpu(), ref) < F32_TOL
+    assert rel_l2(xc[:, :d].float().cpu(), ref) < (F32_TOL if dt == torch.float32 else 3e-3)
+    assert (xc[:, d:].float() == 7.0).all()  # pad columns untouched
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_patchify_three_sources(dev, dt):
+    from oracle.swinv2 import patchify
+    from swift_amd import ops
+    B, H, W = 2, 32, 64
+    a, b, c = rnd((B, 5, H, W), 17), rnd((B, 4, H, W), 18), rnd((B, 3, H, W), 19)
+    lda = ops.k_pad(dt, 12 * 4)
+    out = ops.patchify([a.to(dev), b.to(dev), c.to(dev)], [0.5, 1.0, 2.0], (2, 2), lda, dt)
+    ref = patchify(torch.cat([a * 0.5, b, c * 2.0], 1), (2, 2)).reshape(-1, 48)
+    assert rel_l2(out[:, :48].float().cpu(), ref) < (1e-7 if dt == torch.float32 else 3e-3)
+    assert (out[:, 48:].float() == 0).all()
+
+
+def test_unpatchify_affine(dev):
+    from oracle.swinv2 import unpatchify
+    from swift_amd import ops
+    B, C, H, W = 2, 5, 32, 64
+    tok = rnd((B, 16 * 32, 20), 20)
+    xt, al, be = rnd((B, C, H, W), 21), torch.tensor([0.3, -1.0]), torch.tensor([2.0, 0.5])
+    out = ops.unpatchify_affine(tok.to(dev), (B, C, H, W), (2, 2), xt.to(dev), al.to(dev), be.to(dev))
+    ref = al.view(B, 1, 1, 1) * xt + be.view(B, 1, 1, 1) * unpatchify(tok, (2, 2), (16, 32))
+    assert rel_l2(out.cpu(), ref) < 1e-7
+    out = ops.unpatchify_affine(tok.to(dev), (B, C, H, W), (2, 2))
+    assert torch.equal(out.cpu(), unpatchify(tok, (2, 2), (16, 32)))
+
+
+def test_timestep_embed_and_small_linear(dev):
+    from oracle.swinv2 import timestep_embedding
+    from swift_amd import ops
+    d, B = 1056, 5
+    t = torch.tensor([0.0, 1.0, math.pi / 2, 0.37, 1.5])
+    aux = torch.tensor([[0.6], [1.2], [2.4], [0.6], [0.0]])
+    aw, ab = rnd((d, 1), 22, 0.02), rnd((d,), 23, 0.02)
+    half = d // 2
+    freqs = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32) / half)
+    e = ops.timestep_embed(t.to(dev), aux.to(dev), freqs.to(dev), aw.to(dev), ab.to(dev), d, 1.0)
+    ref = timestep_embedding(t, d) + torch.nn.functional.linear(aux, aw, ab)
+    assert rel_l2(e.cpu(), ref) < 2e-6
+    w, b = rnd((2112, d), 24, 0.03), rnd((2112,), 25)
+    x = rnd((B, d), 26)
+    o = ops.linear_small(x.to(dev), w.to(dev), b.to(dev), act=1)
+    assert rel_l2(o.cpu(), torch.nn.functional.silu(x.double() @ w.double().T + b.double())) < 2e-6
+    o = ops.linear_small(x.to(dev), w.to(dev), None, act=0)
+    assert rel_l2(o.cpu(), x.double() @ w.double().T) < 2e-6
+
+
+def test_rollout_update_and_axpby(dev):
+    from swift_amd import ops
+    B, C, H, W = 2, 7, 16, 32
+    x, y = rnd((B, C, H, W), 27), rnd((B, C, H, W), 28)
+    mx, sx, st = rnd((C,), 29, 3.0), rnd((C,), 30).abs() + 0.5, rnd((C,), 31).abs() + 0.1
+    xd, phys = x.to(dev).clone(), torch.empty(B, C, H, W, device=dev)
+    ops.rollout_update(xd, y.to(dev), mx.to(dev), sx.to(dev), st.to(dev), phys=phys)
+    v = lambda s: s.view(1, C, 1, 1)
+    p = (x * v(sx) + v(mx)) + y * v(st)
+    assert rel_l2(phys.cpu(), p) < 1e-7
+    assert rel_l2(xd.cpu(), (p - v(mx)) / v(sx)) < 1e-6
+    o = ops.axpby(0.25, x.to(dev), -1.5, y.to(dev))
+    assert rel_l2(o.cpu(), 0.25 * x - 1.5 * y) < 1e-7
+
+
+def test_rejects_cpu_tensors_and_bad_shapes(dev):
+    from swift_amd import ops
+    from swift_amd._lib import SwiftkError
+    with pytest.raises(SwiftkError):
+        ops.gemm(torch.zeros(4, 64), torch.zeros(4, 64))
+    with pytest.raises(SwiftkError):  # K not a multiple of the k-tile
+        ops.gemm(torch.zeros(4, 40, device=dev), torch.zeros(4, 40, device=dev))
+    with pytest.raises(SwiftkError):  # grid not divisible by the 16x16 window
+        ops.window_attention(torch.zeros(1, 24 * 16, 3168, device=dev), torch.zeros(12, device=dev), (24, 16), 12)
