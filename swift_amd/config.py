@@ -117,30 +117,36 @@ def _merge(dst: dict, src: dict):
     return dst
 
 
-def _place(root: dict, package: Optional[str], group: str, content: dict):
-    if package == "_global_":
-        return _merge(root, content)
-    path = (package if package else group).strip("/").split("/")
+def _place(root: dict, pkg_path: str, content: dict):
     node = root
-    for p in path:
+    for p in pkg_path.strip("/").split("/"):
         if p:
             node = node.setdefault(p, {})
     return _merge(node, content)
 
 
-def _compose_file(config_dir, group, name, root, choices, package_override=None):
+def _compose_file(config_dir, group, name, root, choices, pkg_path=None):
+    """Merge ``group/name.yaml`` into ``root``.
+
+    Packages follow Hydra: a file lands at its group path unless a ``# @package`` header says otherwise, and
+    every defaults entry of a file is packaged *relative to that file's package* -- so ``/loss: crps`` inside
+    ``finetune/multistep.yaml`` ends up at ``finetune.loss`` (reference train.py:75-77 then hoists those keys).
+    """
     path = os.path.join(config_dir, group.strip("/"), f"{name}.yaml")
     if not os.path.exists(path):
         raise FileNotFoundError(path)
-    body, pkg = _load_yaml(path)
-    pkg = package_override or pkg
+    body, header = _load_yaml(path)
+    if header == "_global_":
+        here = ""
+    elif header:
+        here = header.replace(".", "/")
+    else:
+        here = group.strip("/") if pkg_path is None else pkg_path
     defaults = body.pop("defaults", [])
-    # where does this file's own content land?
-    here = "" if pkg == "_global_" else (pkg.replace(".", "/") if pkg else group.strip("/"))
     self_done = False
     for d in defaults:
         if d == "_self_":
-            _place(root, pkg, group, body)
+            _place(root, here, body)
             self_done = True
             continue
         if isinstance(d, str):
@@ -149,18 +155,16 @@ def _compose_file(config_dir, group, name, root, choices, package_override=None)
         if k.startswith("override "):
             continue  # recorded by _collect_overrides before composition
         if v is None and "/" not in k and not os.path.isdir(os.path.join(config_dir, group.strip("/"), k)):
-            # plain file in the same group
-            _compose_file(config_dir, group, k, root, choices)
+            _compose_file(config_dir, group, k, root, choices, pkg_path=here)  # plain file of the same group
             continue
-        sub = k if k.startswith("/") else (group.strip("/") + "/" + k if group.strip("/") else k)
-        sub = sub.strip("/")
+        sub = (k if k.startswith("/") else (group.strip("/") + "/" + k if group.strip("/") else k)).strip("/")
         choice = choices.get(sub, v)
         if choice is None or choice == "null":
             continue
-        # relative groups nest under the parent's package (loss/noise -> loss.noise)
-        _compose_file(config_dir, sub, choice, root, choices)
+        child_pkg = (here + "/" if here else "") + k.strip("/")
+        _compose_file(config_dir, sub, choice, root, choices, pkg_path=child_pkg)
     if not self_done:
-        _place(root, pkg, group, body)
+        _place(root, here, body)
 
 
 def _collect_overrides(config_dir, group, name, choices):

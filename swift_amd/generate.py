@@ -1,0 +1,164 @@
+"""Ensemble autoregressive rollout driver -- ``python -m swift_amd.generate`` (mirrors reference
+src/swift/generate.py: same flags, same run-directory layout, same npy output layout).
+
+    python -m swift_amd.generate --input RUN --checkpoint NAME --members 12 --steps 60 --samples 64 --interval 6 --dump numpy
+
+reads ``RUN/.hydra/config.yaml`` (the saved composed config, generate.py:161) and
+``RUN/checkpoints/checkpoint-NNNNNN.pt`` (``state["ema"]``, generate.py:225-226) and writes
+``RUN/output/<ckpt>/output-{n}i-{steps}s-{members}m-{interval}h.npy`` with shape
+(samples, members, steps+1, C, H, W) float32 (utils/io.py:237-259).
+
+MI355X-first differences: the flattened member x IC space is sharded in
+contiguous blocks over ranks (the reference shards members only, generate.py:79-81, which caps
+12 members at 6x on 8 GPUs); rank 0 loads the checkpoint and broadcasts the weights over RCCL;
+each rank rolls its units on the device (``RolloutEngine``) and writes its own slices of the
+shared memmap; a barrier closes the job.  Additive flags: ``--solver``, ``--num-steps``,
+``--dtype``, ``--synthetic`` (random-init weights + synthetic fields when no run directory exists).
+zarr output needs the ``zarr`` package, which this image lacks: ``--dump zarr`` raises.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+from glob import glob
+
+import numpy as np
+import torch
+import torch.distributed as tdist
+
+from . import dist
+from .config import Cfg, instantiate, load_saved
+from .rollout import RolloutEngine, unit_seed
+
+parser = argparse.ArgumentParser()
+parser.add_argument("--input", type=str, required=True, help="Input directory")
+parser.add_argument("--checkpoint", type=str, default=None, help="Checkpoint name (default: latest)")
+parser.add_argument("--members", type=int, default=1, help="Number of ensemble members")
+parser.add_argument("--steps", type=int, default=8, help="Number of prediction steps")
+parser.add_argument("--batch", type=int, default=32, help="(member, IC) units per device batch")
+parser.add_argument("--samples", type=int, default=-1, help="Number of samples use")
+parser.add_argument("--interval", type=int, default=6, choices=[6, 12, 24], help="Interval in hours")
+parser.add_argument("--dump", type=str, default="zarr", choices=["zarr", "numpy"], help="Output format")
+# additive
+parser.add_argument("--solver", type=str, default="scm", choices=["scm", "2s"])
+parser.add_argument("--num-steps", type=int, default=1, help="solver steps per forecast step")
+parser.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16"], help="GEMM operand type")
+parser.add_argument("--synthetic", action="store_true", help="random-init weights + synthetic data (no run dir needed)")
+
+
+def get_ckpt_num(fpath: str) -> int:
+    """utils/helpers.py:11-14."""
+    return int(fpath.split(".pt")[-2].split("-")[-1])
+
+
+def create_empty_numpy(ofile, dataset_len, n_channels, img_resolution, members, steps):
+    """utils/io.py:237-259."""
+    np.lib.format.open_memmap(ofile, dtype=np.float32, mode="w+",
+                              shape=(dataset_len, members, steps + 1, n_channels, *img_resolution))
+
+
+def synthetic_cfg() -> Cfg:
+    from .config import compose
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
+    return compose(here, "train", ["data=era5-synthetic-1.4"])
+
+
+def select_indices(n_dataset: int, samples: int, steps: int, interval: int):
+    if samples == -1:
+        return list(range(n_dataset))
+    return np.linspace(0, n_dataset - 1 - (steps * interval // 6), num=samples, dtype=int).tolist()  # generate.py:179-184
+
+
+def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, steps: int, ofile: str, device, args):
+    """generate.py:48-154 with (member, IC) units instead of members as the sharded work item."""
+    if args.dump != "numpy":
+        raise NotImplementedError("zarr output needs the zarr package; use --dump numpy")
+    store = np.lib.format.open_memmap(ofile, mode="r+")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_ic = len(indices)
+    mine = dist.shard_units(members * n_ic, rank, world)  # unit u = member * n_ic + ic
+    nv = len(dataset.variables)
+    done = 0
+    for s in range(mine.start, mine.stop, args.batch):
+        units = [(u // n_ic, u % n_ic) for u in range(s, min(s + args.batch, mine.stop))]
+        ics = [indices[ic] for _, ic in units]
+        X0 = torch.stack([dataset[int(j)][0][0][:nv] for j in ics], 0).to(device, non_blocking=True)
+        forc = engine.stage_forcings(ics, steps, device)
+        traj = engine.run(X0, forc, steps, seeds=[unit_seed(m, indices[ic]) for m, ic in units])
+        host = traj.cpu().numpy()  # one D2H per batch instead of one per step (generate.py:129)
+        for k, (m, ic) in enumerate(units):
+            store[ic, m] = host[k]
+        store.flush()
+        done += len(units)
+        dist.log0(f"rank 0: {done}/{len(mine)} units")
+
+
+def main(args):
+    if args.synthetic and not os.path.exists(os.path.join(args.input, ".hydra", "config.yaml")):
+        cfg = synthetic_cfg()
+    else:
+        cfg = load_saved(os.path.join(args.input, ".hydra", "config.yaml"))
+    dist.setup_torch(backend=cfg.system.torch.backend)
+    np.random.seed(cfg.seed % (1 << 31))
+    torch.manual_seed(np.random.randint(1 << 31))
+    device = dist.get_torch_device()
+
+    dist.log0("Loading dataset...")
+    dataset = instantiate(cfg.data.dataset, split="test", _convert_="object")
+    indices = select_indices(len(dataset), args.samples, args.steps, args.interval)
+
+    dist.log0("Constructing network...")
+    net = instantiate(cfg.precond, model_config=cfg.model, img_resolution=dataset.img_resolution,
+                      img_channels=dataset.n_target_channels, condition_channels=dataset.n_condition_channels,
+                      sigma_max=float("inf"), _recursive_=False, _convert_="object")
+    ckpt_basename = "synthetic"
+    if not args.synthetic:
+        if args.checkpoint is not None:
+            name = args.checkpoint if args.checkpoint.endswith(".pt") else args.checkpoint + ".pt"
+            ckpt = os.path.join(args.input, "checkpoints", name)
+            if not os.path.exists(ckpt):
+                raise ValueError(f"Specified checkpoint {ckpt} does not exist")
+            ckpt_basename = os.path.basename(name)[:-3]
+        else:
+            paths = sorted(glob(os.path.join(args.input, "checkpoints", "checkpoint*.pt")), key=get_ckpt_num)
+            assert paths, FileNotFoundError(f"No checkpoints in {os.path.join(args.input, 'checkpoints')}")
+            ckpt, ckpt_basename = paths[-1], "latest"
+        if dist.get_rank() == 0:
+            dist.log0(f"Loading checkpoint: {ckpt}")
+            net.load_state_dict(torch.load(ckpt, map_location="cpu", weights_only=True)["ema"])
+    elif dist.get_rank() == 0:
+        from .utils.detinit import swinv2_state
+        m = net.model
+        net.load_state_dict(swinv2_state(grid=m.grid_size, in_channels=m.in_channels, out_channels=m.out_channels,
+                                         patch_size=m.patch_size, depth=m.depth, dim=m.dim, heads=m.heads,
+                                         auxiliary_dim=m.auxiliary_dim, logvar=m.logvar_embed is not None, seed=cfg.seed))
+    net = net.to(device).eval()
+    if dist.get_world_size() > 1:  # one-time weight broadcast over RCCL / xGMI
+        for p in net.parameters():
+            tdist.broadcast(p.data, src=0)
+
+    odir = os.path.join(args.input, "output", ckpt_basename)
+    dist.run_on_rank0(os.makedirs, odir, exist_ok=True)
+    filename = f"output-{len(indices)}i-{args.steps}s-{args.members}m-{args.interval}h"
+    ofile = os.path.join(odir, f"{filename}.npy")
+    dist.run_on_rank0(create_empty_numpy, ofile, len(indices), dataset.n_target_channels, dataset.img_resolution,
+                      args.members, args.steps)
+
+    solver_kwargs = dict(num_steps=args.num_steps, sigma_min=0.02, sigma_max=200.0, auxiliary=args.interval / 10.0)
+    engine = RolloutEngine(net, dataset, interval=args.interval, solver=args.solver,
+                           denoise_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, **solver_kwargs)
+    dist.log0("Rolling out samples...")
+    t0 = time.time()
+    rollout_and_save(engine, dataset, indices, args.members, args.steps, ofile, device, args)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.log0(f"Done! Took {time.time() - t0:.3f} seconds.")
+    if tdist.is_initialized():
+        tdist.destroy_process_group()
+    dist.log0(f"Output saved to: {ofile}")
+    return ofile
+
+
+if __name__ == "__main__":
+    main(parser.parse_args())

@@ -3,7 +3,10 @@ reference and (b) the CPU oracle run live on the same inputs.
 
 Tolerances (relative L2):
   fp32 engine  1e-4  -- the bar BASELINE.json's north_star states ("within 1e-4 relative L2 of the reference")
-  bf16 engine  3e-2  -- bf16 GEMM operands (2^-9 per rounding) through depth x 6 GEMMs; reported, not the parity bar
+  bf16 engine  calibrated, not guessed: the reference run under its own bf16 autocast sits 6.4e-2 (depth 2) / 1.9e-1
+               (Swift-B, depth 12) from its fp32 output on these random-weight nets (logit scales up to 100 make the
+               softmax sensitive to operand rounding); the bf16 engine must be no further from the fp32 reference than
+               1.25 x that distance (fixtures store it as bf16_autocast_rel).  Reported, not the parity bar.
 """
 import math
 
@@ -16,7 +19,7 @@ from swift_amd.utils.detinit import det_normal, swinv2_state
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-4
-BF16_TOL = 3e-2
+BF16_TOL = 1.0e-1  # depth-2 nets: 1.5 x the reference's own bf16-autocast-vs-fp32 distance (6.4e-2, tests/golden/swinv2_smallb.npz)
 
 SMALLB = dict(img=(64, 64), n_vars=69, n_forc=3, window=(16, 16), shift=(8, 8), patch=(2, 2), dim=1056, heads=12, depth=2)
 SWIFTB = dict(img=(128, 256), n_vars=69, n_forc=3, window=(16, 16), shift=(8, 8), patch=(2, 2), dim=1056, heads=12, depth=12)
@@ -62,7 +65,7 @@ def test_forward_vs_reference_golden(dev):
     e32, e16 = rel_l2(y.cpu(), g["y_flash"]), rel_l2(yb.cpu(), g["y_flash"])
     print(f"forward smallb: fp32 rel-L2 {e32:.3e}, bf16 rel-L2 {e16:.3e}")
     assert y.dtype == torch.float32 and e32 < FP32_TOL
-    assert e16 < BF16_TOL
+    assert e16 < 1.25 * float(g["bf16_autocast_rel"])
 
 
 def test_forward_logvar_and_split_sources(dev):
@@ -158,4 +161,4 @@ def test_swiftb_full_step_vs_reference_golden(dev):
     print(f"Swift-B scm step vs reference: fp32 rel-L2 {e32:.3e}, bf16 rel-L2 {e16:.3e}")
     assert e32 < FP32_TOL
     assert float(y.double().norm()) == pytest.approx(float(g["stats"][3]), rel=1e-4)
-    assert e16 < BF16_TOL
+    assert e16 < 1.25 * float(g["bf16_autocast_rel"])  # reference's own bf16 path: 1.9e-1 at depth 12

@@ -175,7 +175,12 @@ def fx_swinv2_smallb():
     aux = torch.tensor([[0.6], [2.4]])
     y = net.model(x, t, auxiliary=aux)
     yn = net.model(x, t, auxiliary=aux, jvp=True)
+    # the reference's own reduced-precision path (trainer.py:191-196 runs the net under bf16 autocast): its distance
+    # from its fp32 output calibrates the tolerance of the bf16 engine
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        yb = net.model(x, t, auxiliary=aux).float()
     save("swinv2_smallb", seed=seed, fingerprint=state_fingerprint(state), t=t, aux=aux, y_flash=y,
+         bf16_autocast_rel=float((yb - y).norm() / y.norm()),
          y_naive_stats=np.array([float(yn.mean()), float(yn.std()), float((yn - y).norm() / y.norm())]))
 
 
@@ -325,7 +330,10 @@ def fx_swiftb_step():
     t0 = time.time()
     y = DiffusionSampler(net).scm_solver(lat, condition=cond, num_steps=1, sigma_min=0.02, sigma_max=200.0, auxiliary=0.6)
     print(f"reference Swift-B scm step on CPU: {time.time() - t0:.2f} s ({torch.get_num_threads()} threads)")
+    yb = DiffusionSampler(net).scm_solver(lat, condition=cond, num_steps=1, sigma_min=0.02, sigma_max=200.0, auxiliary=0.6,
+                                          denoise_dtype=torch.bfloat16).float()
     save("swiftb_step", seed=seed, fingerprint=state_fingerprint(state), y_sub=y[0, ::4, ::8, ::8],
+         bf16_autocast_rel=float((yb - y).norm() / y.norm()),
          stats=np.array([float(y.mean()), float(y.std()), float(y.abs().max()), float(y.double().norm())]))
 
 
