@@ -44,6 +44,12 @@ extern "C" {
 #define SWIFTK_EPI_NONE 0      /* C = A W^T                                              */
 #define SWIFTK_EPI_BIAS_POS 1  /* C = A W^T + bias[n] + pos[(m % pos_rows)][n]           */
 #define SWIFTK_EPI_SWIGLU 2    /* C[m][j] = silu(acc[m][2j]) * acc[m][2j+1]  (W rows interleaved gate/up) */
+#define SWIFTK_EPI_QKNORM 3    /* to_qkv with head_dim 88: per token and head, q <- q/max(|q|,1e-12)*exp(min(ep0[h],ln100)),
+                                  k <- k/max(|k|,1e-12), v unchanged (swinv2.py:123-127); ep0 = scale[heads]          */
+
+/* swiftk_window_attention flags */
+#define SWIFTK_ATTN_PRENORM 1  /* q, k in `qkv` are already normalised / scaled (SWIFTK_EPI_QKNORM); `scale` unused */
+#define SWIFTK_ATTN_NO_PIPE 2  /* tuning: keep the one-workgroup-per-item kernel even where the pipelined one applies */
 
 int swiftk_version(void);
 
@@ -74,10 +80,11 @@ int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
  *         [h*3*hd, h*3*hd + 3*hd) hold q | k | v (swinv2.py:120-121)
  *   out   [B, gh*gw, ldo] dtype, channels h*hd + d
  *   scale [heads] fp32 (the nn.Parameter, un-exponentiated)
- * Supported: 16x16 windows, head_dim % 8 == 0 and <= 96.
+ * Supported: 16x16 windows, head_dim in {64, 80, 88}.  flags: SWIFTK_ATTN_* (bf16 + head_dim 88 + PRENORM
+ * runs the persistent LDS-DMA-pipelined kernel).
  */
 int swiftk_window_attention(const void* qkv, int64_t ldq, void* out, int64_t ldo, const float* scale, int B, int gh, int gw,
-                            int heads, int head_dim, int shift_h, int shift_w, int dtype, void* stream);
+                            int heads, int head_dim, int shift_h, int shift_w, int dtype, int flags, void* stream);
 
 /*
  * x += LayerNorm(y; gamma, beta, eps) * (1 + scale_b) + shift_b, fused with the
@@ -148,6 +155,9 @@ int swiftk_axpby(float* out, float a, const float* x, float b, const float* y, i
  * swiftk_profile_gemm(-1, 0) switches the hooks off.  At most 4096 launches per collection.
  */
 int swiftk_profile_gemm(int epilogue, int64_t N);
+/* Tuning knobs (A/B measurements only): key 0 = GEMM variant (0 one tile per workgroup, 1 persistent pipeline),
+ * key 1 = tile rows per group of the persistent tile order, key 2 = persistent grid size. */
+int swiftk_set_tuning(int key, int value);
 int swiftk_profile_collect(double* total_ms_host, int64_t* launches_host);
 
 /* fp32 -> dtype copy with row padding: dst[r][c] = src[r][c] for c < cols, 0 for cols <= c < ldd. */

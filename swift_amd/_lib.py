@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libswiftk.so")
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_BIAS_POS, EPI_SWIGLU = 0, 1, 2
+EPI_NONE, EPI_BIAS_POS, EPI_SWIGLU, EPI_QKNORM = 0, 1, 2, 3
+ATTN_PRENORM, ATTN_NO_PIPE = 1, 2
 
 _ERR = {-1: "SWIFTK_EINVAL (bad argument)", -2: "SWIFTK_ESHAPE (unsupported shape)",
         -3: "SWIFTK_EALIGN (misaligned pointer / leading dimension)", -4: "SWIFTK_EWORKSPACE (workspace too small)"}
@@ -46,7 +47,7 @@ _SIGS = {
     "swiftk_version": ([], C.c_int),
     "swiftk_gemm_k_pad": ([_i, _l], _l),
     "swiftk_gemm": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _i, _i, _i, _p, _p, _l, _p], _i),
-    "swiftk_window_attention": ([_p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "swiftk_window_attention": ([_p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_modnorm_residual": ([_p, _l, _p, _p, _l, _p, _p, _p, _l, _l, _i, _l, _f, _i, _p], _i),
     "swiftk_patchify": ([_p, _i, _f, _p, _i, _f, _p, _i, _f, _p, _l, _i, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_unpatchify_affine": ([_p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
@@ -56,6 +57,7 @@ _SIGS = {
     "swiftk_cast_pad": ([_p, _l, _p, _l, _l, _l, _i, _p], _i),
     "swiftk_axpby": ([_p, _f, _p, _f, _p, _l, _p], _i),
     "swiftk_profile_gemm": ([_i, _l], _i),
+    "swiftk_set_tuning": ([_i, _i], _i),
     "swiftk_profile_collect": ([C.POINTER(C.c_double), C.POINTER(C.c_int64)], _i),
     "swiftk_workspace_bytes": ([C.POINTER(Model), _i], _l),
     "swiftk_swinv2_forward": ([C.POINTER(Model), _p, _i, _f, _p, _i, _f, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p,

@@ -31,6 +31,7 @@ struct AttnArgs {
     const float* scale;
     int64_t ldq, ldo;
     int gh, gw, heads, sh, sw, nwx, nw;
+    int prenorm;  // q, k arrive L2-normalised (and q scaled) from the to_qkv GEMM epilogue
 };
 
 // token index (row-major, un-rolled grid) of window-local token j of window w: roll(-s)[p] = x[(p+s) mod n]
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(NT) void attn_bf16_kernel(AttnArgs a) {
                 }
             }
             const float tau = expf(fminf(a.scale[head], LN100));
-            const float inv = tau / fmaxf(sqrtf(ss), 1e-12f);
+            const float inv = a.prenorm ? 1.0f : tau / fmaxf(sqrtf(ss), 1e-12f);
             char* dst = sQ + j * KSTR;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(NT) void attn_bf16_kernel(AttnArgs a) {
                     ss += lo * lo + hi * hi;
                 }
             }
-            const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+            const float inv = a.prenorm ? 1.0f : 1.0f / fmaxf(sqrtf(ss), 1e-12f);
             char* dk = sK + j * KSTR;
             char* dv = sV + j * VSTR;
 #pragma unroll
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(NT) void attn_f32_kernel(AttnArgs a) {
         float ss = 0.f;
 #pragma unroll
         for (int c = 0; c < NF4; ++c) ss += kr[c].x * kr[c].x + kr[c].y * kr[c].y + kr[c].z * kr[c].z + kr[c].w * kr[c].w;
-        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+        const float nrm = a.prenorm ? 1.0f : fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
         for (int c = 0; c < NF4; ++c)
             *reinterpret_cast<float4*>(sKV + tid * KSTR32 + 4 * c) =
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(NT) void attn_f32_kernel(AttnArgs a) {
             ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         }
         ss += __shfl_xor(ss, 32, 64);
-        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-        const float tau = expf(fminf(a.scale[head], LN100));
+        const float nrm = a.prenorm ? 1.0f : fmaxf(sqrtf(ss), 1e-12f);
+        const float tau = a.prenorm ? 1.0f : expf(fminf(a.scale[head], LN100));
 #pragma unroll
         for (int k = 0; k < HALF; ++k) qreg[k] = qreg[k] / nrm * tau;
     }
@@ -373,8 +374,9 @@ int launch_hd(const AttnArgs& a, int B, int dtype, hipStream_t st) {
 
 extern "C" int swiftk_window_attention(const void* qkv, int64_t ldq, void* out, int64_t ldo, const float* scale, int B,
                                        int gh, int gw, int heads, int head_dim, int shift_h, int shift_w, int dtype,
-                                       void* stream) {
-    if (!qkv || !out || !scale || B <= 0 || heads <= 0) return SWIFTK_EINVAL;
+                                       int flags, void* stream) {
+    const bool prenorm = flags & SWIFTK_ATTN_PRENORM;
+    if (!qkv || !out || (!scale && !prenorm) || B <= 0 || heads <= 0) return SWIFTK_EINVAL;
     if (dtype != SWIFTK_F32 && dtype != SWIFTK_BF16) return SWIFTK_EINVAL;
     if (gh <= 0 || gw <= 0 || gh % 16 || gw % 16) return SWIFTK_ESHAPE;
     if (shift_h < 0 || shift_w < 0 || shift_h >= gh || shift_w >= gw) return SWIFTK_ESHAPE;
@@ -394,7 +396,12 @@ extern "C" int swiftk_window_attention(const void* qkv, int64_t ldq, void* out, 
     a.sw = shift_w;
     a.nwx = gw / 16;
     a.nw = (gh / 16) * (gw / 16);
+    a.prenorm = prenorm ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (prenorm && dtype == SWIFTK_BF16 && head_dim == 88 && !(flags & SWIFTK_ATTN_NO_PIPE)) {
+        AttnPipeArgs pa{qkv, out, ldq, ldo, B, gh, gw, heads, shift_h, shift_w};
+        return swiftk_launch_attn_pipe(pa, st);
+    }
     switch (head_dim) {
         case 88: return launch_hd<88>(a, B, dtype, st);
         case 80: return launch_hd<80>(a, B, dtype, st);

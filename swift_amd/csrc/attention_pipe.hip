@@ -1,0 +1,239 @@
+// Persistent, LDS-DMA-pipelined shifted-window attention for gfx950 (bf16, head_dim 88, pre-normalised q/k).
+//
+// The to_qkv GEMM epilogue (SWIFTK_EPI_QKNORM) has already L2-normalised q and k and applied the logit scale,
+// so this kernel is pure data movement + MFMA + softmax:
+//   * a fixed grid of workgroups walks contiguous runs of (sample, window, head) items;
+//   * K (256 x 176 B) and V tiles go HBM -> LDS by global_load_lds (no VGPR round trip, no VALU): V one item
+//     ahead into a 2-deep ring, K of the next item as soon as this item's QK^T has consumed the K buffer, so
+//     HBM latency sits behind the softmax / PV of the current item (1 K + 2 V buffers = 132 KiB of LDS);
+//   * Q fragments go straight to registers one item ahead; the output of item i is stored during item i+1
+//     (after its QK^T) so the vmcnt(0) that hands the DMA buffers over never waits on a fresh store;
+//   * rows are 88 bf16 = 176 B, unpadded: 16 consecutive rows hit 16 distinct 16-B bank slots (176/16 = 11 is
+//     odd), so the ds_read_b128 fragment reads are conflict-free; the k-step that covers d = 80..95 reads 16 B
+//     into the next row for d >= 88 and meets a zero Q fragment (all LDS is zero-filled once, so it is finite).
+// MFMA orientation and the accumulator-as-operand trick are those of attention.hip.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 512;
+constexpr int HD = 88;
+constexpr int ROW = HD * 2;            // 176 B
+constexpr int TILE = 256 * ROW;        // 45056 B = 44 DMA pieces
+constexpr int PIECES = TILE / 1024;    // 44
+constexpr int BUF = TILE + 64;         // zero tail behind every tile
+constexpr int LDS_TOTAL = 3 * BUF;     // K, V0, V1
+constexpr int KS = 6, DB = 3;
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int win_token(int wy, int wx, int j, int gh, int gw, int sh, int sw) {
+    int gy = wy * 16 + (j >> 4) + sh;
+    int gx = wx * 16 + (j & 15) + sw;
+    gy = gy >= gh ? gy - gh : gy;
+    gx = gx >= gw ? gx - gw : gx;
+    return gy * gw + gx;
+}
+
+__global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitems) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS_TOTAL];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwx = a.gw / 16, nw = (a.gh / 16) * nwx;
+    const int64_t ldq_b = a.ldq * 2;
+    const int64_t ntok = (int64_t)a.gh * a.gw;
+
+    // contiguous run of items for this workgroup (items of one window are adjacent: heads fastest)
+    const int first = (int)((int64_t)blockIdx.x * nitems / gridDim.x);
+    const int last = (int)((int64_t)(blockIdx.x + 1) * nitems / gridDim.x);
+    if (first >= last) return;
+
+    // zero all LDS once: the 16-B over-reads behind a row / a tile must see finite bits
+    for (int o = tid * 16; o < LDS_TOTAL; o += NT * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+    const uint32_t ldsK = lds0, ldsV0 = lds0 + BUF;
+
+    const int c32 = lane & 31, hh = lane >> 5;
+    const int i16 = lane & 15;
+    const int vbase = (4 * hh + (i16 >> 2)) * ROW + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
+
+    // per-lane DMA source offsets of this wave's pieces (piece p = wv + 8*i): 16-B chunk c = 64p + lane of the
+    // tile -> row c/11, chunk c%11 of the row; valid for one window, recomputed when the window changes
+    uint32_t voff[6];
+    int cur_w = -1;
+    auto set_window = [&](int w) {
+        const int wy = w / nwx, wx = w - wy * nwx;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = (wv + 8 * i) * 64 + lane;
+            const int row = (c * 2979) >> 15;  // c / 11 for c < 2816
+            const int cc = c - row * 11;
+            voff[i] = (uint32_t)(win_token(wy, wx, row & 255, a.gh, a.gw, a.sh, a.sw) * ldq_b) + 16u * cc;
+        }
+        cur_w = w;
+    };
+    auto decode = [&](int item, int& b, int& w, int& h) {
+        h = item % a.heads;
+        const int r = item / a.heads;
+        w = r % nw;
+        b = r / nw;
+    };
+    // tile base of (b, h): part 0 = q, 1 = k, 2 = v
+    auto tile_base = [&](int b, int h, int part) {
+        return static_cast<const char*>(a.qkv) + (int64_t)b * ntok * ldq_b + (int64_t)(h * 3 + part) * ROW;
+    };
+    auto dma_tile = [&](uint32_t dst, const char* base) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (i < 5 || wv < 4) dma_piece(dst + (wv + 8 * i) * 1024, base, voff[i]);
+    };
+    // Q fragments of query row 32*wv + c32: chunk 2*ks + hh of the row (chunk 11 does not exist -> zeros)
+    auto load_q = [&](int b, int w, int h, uint4 (&q)[KS]) {
+        const int wy = w / nwx, wx = w - wy * nwx;
+        const char* row = tile_base(b, h, 0) + (int64_t)win_token(wy, wx, wv * 32 + c32, a.gh, a.gw, a.sh, a.sw) * ldq_b;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks == KS - 1) {
+                const uint4 t = *reinterpret_cast<const uint4*>(row + (2 * ks) * 16);  // chunk 10 (hh = 0 lanes use it)
+                q[ks] = hh ? make_uint4(0, 0, 0, 0) : t;
+            } else {
+                q[ks] = *reinterpret_cast<const uint4*>(row + (2 * ks + hh) * 16);
+            }
+        }
+    };
+
+    f32x16 o[DB];       // output of the previous item, stored one phase late
+    float rl_prev = 0.f;
+    int pb = 0, pw = 0, ph = 0;
+    bool have_prev = false;
+    auto store_o = [&](int b, int w, int h, float rl) {
+        const int wy = w / nwx, wx = w - wy * nwx;
+        bf16_t* dst = static_cast<bf16_t*>(a.out) +
+                      ((int64_t)b * ntok + win_token(wy, wx, wv * 32 + c32, a.gh, a.gw, a.sh, a.sw)) * a.ldo + h * HD;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = db * 32 + g * 8 + hh * 4;
+                if (d < HD)
+                    *reinterpret_cast<uint2*>(dst + d) =
+                        make_uint2(pack_bf16(o[db][4 * g] * rl, o[db][4 * g + 1] * rl),
+                                   pack_bf16(o[db][4 * g + 2] * rl, o[db][4 * g + 3] * rl));
+            }
+    };
+
+    // ---- prologue: K and V of the first item, its Q fragments
+    int b, w, h;
+    decode(first, b, w, h);
+    set_window(w);
+    dma_tile(ldsK, tile_base(b, h, 1));
+    dma_tile(ldsV0, tile_base(b, h, 2));
+    uint4 qf[KS];
+    load_q(b, w, h, qf);
+
+    for (int item = first; item < last; ++item) {
+        const int par = (item - first) & 1;
+        const char* sK = smem;
+        const char* sV = smem + BUF + par * BUF;
+        int nb = b, nwn = w, nh = h;
+        const bool has_next = item + 1 < last;
+        if (has_next) decode(item + 1, nb, nwn, nh);
+
+        // K(item) and V(item) have landed (own pieces: vmcnt(0); everyone's: barrier).  Also orders the previous
+        // item's PV reads of the other V buffer before the DMA that refills it.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (has_next) {
+            if (nwn != cur_w) set_window(nwn);
+            dma_tile(ldsV0 + (par ^ 1) * BUF, tile_base(nb, nh, 2));
+        }
+
+        // S^T[key][q] = K Q^T
+        f32x16 s[8];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint4 kf = *reinterpret_cast<const uint4*>(sK + (kb * 32 + c32) * ROW + ks * 32 + hh * 16);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                                __builtin_bit_cast(bf16x8, qf[ks]), s[kb], 0, 0, 0);
+            }
+        }
+        // every wave is done with the K buffer -> refill it with the next item's K
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (has_next) dma_tile(ldsK, tile_base(nb, nh, 1));
+
+        // the previous item's output leaves now; the next item's Q fragments are requested
+        if (have_prev) store_o(pb, pw, ph, rl_prev);
+        if (has_next) load_q(nb, nwn, nh, qf);
+
+        // softmax over the 256 keys of query column c32: 128 values here, 128 in lane^32
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+        const float mb = mx * LOG2E;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kb][r] * LOG2E - mb);
+                s[kb][r] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 32, 64);
+
+        // O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                uint4 pf;
+                pf.x = pack_bf16(s[kb][8 * s2 + 0], s[kb][8 * s2 + 1]);
+                pf.y = pack_bf16(s[kb][8 * s2 + 2], s[kb][8 * s2 + 3]);
+                pf.z = pack_bf16(s[kb][8 * s2 + 4], s[kb][8 * s2 + 5]);
+                pf.w = pack_bf16(s[kb][8 * s2 + 6], s[kb][8 * s2 + 7]);
+                const char* vrow = sV + (kb * 32 + s2 * 16) * ROW + vbase;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(vrow + db * 64));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(vrow + db * 64 + 8 * ROW));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const s16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                                    __builtin_bit_cast(bf16x8, pf), o[db], 0, 0, 0);
+                }
+            }
+        }
+        rl_prev = 1.0f / l;
+        pb = b; pw = w; ph = h;
+        have_prev = true;
+        b = nb; w = nwn; h = nh;
+    }
+    store_o(pb, pw, ph, rl_prev);
+}
+
+}  // namespace
+
+int swiftk_launch_attn_pipe(const AttnPipeArgs& a, hipStream_t st) {
+    const int nitems = a.B * (a.gh / 16) * (a.gw / 16) * a.heads;
+    // one item per CU round is the floor; with fewer than ~2 items per workgroup shrink the grid so that runs stay
+    // balanced (every workgroup gets floor or ceil of nitems/grid)
+    int grid = 256;
+    if (nitems < grid) grid = nitems;
+    hipLaunchKernelGGL(attn_pipe_kernel, dim3(grid), dim3(NT), 0, st, a, nitems);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}

@@ -56,4 +56,30 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// One LDS-DMA piece, hand-issued: M0 <- LDS byte address of the piece (wave-uniform), then
+// global_load_lds_dwordx4 voff, s[base:base+1].  Inline asm keeps hipcc's waitcnt pass out of the picture (it would
+// otherwise drain vmcnt(0) before every ds_read that might alias the DMA target); the kernel waits for its own DMA
+// with an explicit vmcnt(0) before the barrier that hands a stage over.  `s_nop 4`: SALU-written SGPRs read by VMEM.
+__device__ __forceinline__ void dma_piece(uint32_t lds_dst, const char* base, uint32_t voff) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(lds_dst), "s"(base)
+        : "memory");
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// attention_pipe.hip: persistent, LDS-DMA-pipelined window attention on pre-normalised bf16 q/k (head_dim 88)
+struct AttnPipeArgs {
+    const void* qkv;
+    void* out;
+    int64_t ldq, ldo;
+    int B, gh, gw, heads, sh, sw;
+};
+int swiftk_launch_attn_pipe(const AttnPipeArgs& a, hipStream_t st);

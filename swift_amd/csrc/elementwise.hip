@@ -6,71 +6,90 @@
 namespace {
 
 // --------------------------------------------------------------------------------- modnorm + residual
-// One wave per token row; the row (d <= 2048) lives in registers between the two reduction passes.
-// Bytes per element: read y (2|4) + x (4), write x (4) + copy (2|0).
-template <typename T, int MAXV>
+// One wave per token row, 8 channels per lane per slot (16 B of bf16 y / 32 B of fp32).  All y and x loads of a
+// row are issued before the first reduction so ~5 KiB per wave is in flight; the row lives in registers
+// between the two reduction passes (exact two-pass variance).  Bytes per element: read y (2|4) + x (4),
+// write x (4) + operand copy (2|4).
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __uint_as_float(u[e] << 16);
+        v[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <>
+__device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    *reinterpret_cast<uint4*>(p) =
+        make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+}
+
+template <typename T, int SLOTS>
 __global__ __launch_bounds__(256) void modnorm_kernel(const T* __restrict__ y, int64_t ldy, float* __restrict__ x,
                                                       T* __restrict__ xc, int64_t ldc, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ mod,
                                                       int64_t ldmod, int64_t M, int d, int64_t rps, float eps) {
     const int lane = threadIdx.x & 63;
-    const int nv = d >> 2;  // float4 groups per row
+    const int nc = d >> 3;  // 8-channel slots per row
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t row = wave; row < M; row += nwaves) {
-        float v[MAXV][4];
-        float sum = 0.f;
+        float v[SLOTS][8], xr[SLOTS][8];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < SLOTS; ++i) {
             const int c = lane + 64 * i;
-            if (c < nv) {
-                if constexpr (sizeof(T) == 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(y + row * ldy + 4 * c);
-                    v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
-                } else {
-                    const uint2 t = *reinterpret_cast<const uint2*>(y + row * ldy + 4 * c);
-                    v[i][0] = __uint_as_float(t.x << 16); v[i][1] = __uint_as_float(t.x & 0xffff0000u);
-                    v[i][2] = __uint_as_float(t.y << 16); v[i][3] = __uint_as_float(t.y & 0xffff0000u);
-                }
-                sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            if (c < nc) {
+                load8<T>(y + row * ldy + 8 * c, v[i]);
+                load8<float>(x + row * d + 8 * c, xr[i]);
             }
         }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i)
+            if (lane + 64 * i < nc)
+                sum += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
         const float mean = wave_sum(sum) / (float)d;
         float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nv) {
+        for (int i = 0; i < SLOTS; ++i)
+            if (lane + 64 * i < nc) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 8; ++e) {
                     v[i][e] -= mean;
                     sq += v[i][e] * v[i][e];
                 }
             }
-        }
         const float rstd = rsqrtf(wave_sum(sq) / (float)d + eps);
         const float* mrow = mod + (row / rps) * ldmod;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < SLOTS; ++i) {
             const int c = lane + 64 * i;
-            if (c < nv) {
-                const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c);
-                const float4 bt = *reinterpret_cast<const float4*>(beta + 4 * c);
-                const float4 sc = *reinterpret_cast<const float4*>(mrow + 4 * c);
-                const float4 sh = *reinterpret_cast<const float4*>(mrow + d + 4 * c);
-                float4 xr = *reinterpret_cast<const float4*>(x + row * d + 4 * c);
-                xr.x += (v[i][0] * rstd * g.x + bt.x) * (1.0f + sc.x) + sh.x;
-                xr.y += (v[i][1] * rstd * g.y + bt.y) * (1.0f + sc.y) + sh.y;
-                xr.z += (v[i][2] * rstd * g.z + bt.z) * (1.0f + sc.z) + sh.z;
-                xr.w += (v[i][3] * rstd * g.w + bt.w) * (1.0f + sc.w) + sh.w;
-                *reinterpret_cast<float4*>(x + row * d + 4 * c) = xr;
-                if (xc) {
-                    if constexpr (sizeof(T) == 4)
-                        *reinterpret_cast<float4*>(xc + row * ldc + 4 * c) = xr;
-                    else
-                        *reinterpret_cast<uint2*>(xc + row * ldc + 4 * c) =
-                            make_uint2(pack_bf16(xr.x, xr.y), pack_bf16(xr.z, xr.w));
-                }
+            if (c < nc) {
+                float g[8], bt[8], sc[8], sh[8];
+                load8<float>(gamma + 8 * c, g);
+                load8<float>(beta + 8 * c, bt);
+                load8<float>(mrow + 8 * c, sc);
+                load8<float>(mrow + d + 8 * c, sh);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xr[i][e] += (v[i][e] * rstd * g[e] + bt[e]) * (1.0f + sc[e]) + sh[e];
+                store8<float>(x + row * d + 8 * c, xr[i]);
+                if (xc) store8<T>(xc + row * ldc + 8 * c, xr[i]);
             }
         }
     }
@@ -249,21 +268,25 @@ extern "C" int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, voi
                                        const float* beta, const float* mod, int64_t ldmod, int64_t M, int d,
                                        int64_t rows_per_sample, float eps, int dtype, void* stream) {
     if (!y || !x || !gamma || !beta || !mod || M <= 0 || d <= 0 || rows_per_sample <= 0) return SWIFTK_EINVAL;
-    if (d % 4 || d > 2048) return SWIFTK_ESHAPE;
+    if (d % 8 || d > 2048) return SWIFTK_ESHAPE;
     const int es = dtype == SWIFTK_BF16 ? 2 : 4;
-    if (((uintptr_t)y % (4 * es)) || (ldy * es) % (4 * es) || ((uintptr_t)x & 15) || ((uintptr_t)gamma & 15) ||
-        ((uintptr_t)beta & 15) || ((uintptr_t)mod & 15) || (ldmod % 4) || (xcopy && (((uintptr_t)xcopy % (4 * es)) || (ldc * es) % (4 * es))))
+    if (((uintptr_t)y & 15) || (ldy * es) % 16 || ((uintptr_t)x & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) ||
+        ((uintptr_t)mod & 15) || (ldmod % 4) || (xcopy && (((uintptr_t)xcopy & 15) || (ldc * es) % 16)))
         return SWIFTK_EALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = grid_for(M, 4, 256 * 32);
-    if (dtype == SWIFTK_BF16)
-        hipLaunchKernelGGL((modnorm_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(y), ldy, x,
-                           static_cast<bf16_t*>(xcopy), ldc, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps);
-    else if (dtype == SWIFTK_F32)
-        hipLaunchKernelGGL((modnorm_kernel<float, 8>), dim3(grid), dim3(256), 0, st, static_cast<const float*>(y), ldy, x,
-                           static_cast<float*>(xcopy), ldc, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps);
-    else
+    const bool small = d <= 3 * 512;  // three 8-channel slots per lane cover d <= 1536 with fewer registers
+#define SWIFTK_MODNORM(TT, SL)                                                                                             \
+    hipLaunchKernelGGL((modnorm_kernel<TT, SL>), dim3(grid), dim3(256), 0, st, static_cast<const TT*>(y), ldy, x,            \
+                       static_cast<TT*>(xcopy), ldc, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps)
+    if (dtype == SWIFTK_BF16) {
+        if (small) SWIFTK_MODNORM(bf16_t, 3); else SWIFTK_MODNORM(bf16_t, 4);
+    } else if (dtype == SWIFTK_F32) {
+        if (small) SWIFTK_MODNORM(float, 3); else SWIFTK_MODNORM(float, 4);
+    } else {
         return SWIFTK_EINVAL;
+    }
+#undef SWIFTK_MODNORM
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

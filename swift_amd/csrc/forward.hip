@@ -122,10 +122,12 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     for (int i = 0; i < m->depth; ++i) {
         const swiftk_layer& ly = m->layers_host[i];
         const bool shifted = do_shift && (i & 1);
-        RUN(swiftk_gemm(xT, m->kd, ly.qkv_w, m->kd, qkv, 3 * d, M, 3 * d, m->kd, dt, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0,
-                        stream));
+        // head_dim 88: cosine-attention's normalise/scale prologue rides in the to_qkv epilogue (fp32 accumulators)
+        const bool fuse_norm = (hd == 88);
+        RUN(swiftk_gemm(xT, m->kd, ly.qkv_w, m->kd, qkv, 3 * d, M, 3 * d, m->kd, dt, dt,
+                        fuse_norm ? SWIFTK_EPI_QKNORM : SWIFTK_EPI_NONE, fuse_norm ? ly.scale : nullptr, nullptr, 0, stream));
         RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
-                                    shifted ? m->sw : 0, dt, stream));
+                                    shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
         RUN(swiftk_gemm(att, m->kd, ly.wo_w, m->kd, y, d, M, d, m->kd, dt, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, stream));
         RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok,
                                     1e-6f, dt, stream));

@@ -86,6 +86,40 @@ __device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, float b) {
     *reinterpret_cast<uint32_t*>(p) = pack_bf16(a, b);
 }
 
+// SWIFTK_EPI_QKNORM: the wave's 64 x 176 tile of to_qkv's output is exactly two 88-wide head vectors per row
+// (columns [c0, c0+88) and [c0+88, c0+176); vector index v = column/88 -> head v/3, kind v%3 = q|k|v).  Cosine
+// attention's prologue (swinv2.py:123-127) happens here on the fp32 accumulators: q <- q/max(|q|,1e-12) *
+// exp(min(scale_h, ln 100)), k <- k/max(|k|,1e-12), v untouched.  A row's 88 values sit in the four 16-lane
+// groups of the wave: 22 accumulator quads -> register sums + two cross-group shuffles.
+__device__ __forceinline__ void qknorm_tile(f32x4 (&acc)[MI][NI], int lane, int c0, const float* __restrict__ scale) {
+    const int g4 = lane >> 4;
+    const int vA = c0 / 88, vB = vA + 1;
+    const int kA = vA % 3, kB = vB % 3;
+    const float tauA = kA == 0 ? expf(fminf(scale[vA / 3], 4.605170185988092f)) : 1.0f;
+    const float tauB = kB == 0 ? expf(fminf(scale[vB / 3], 4.605170185988092f)) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const f32x4 v = acc[i][j];
+            const float t = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            if (j < 5) sa += t;
+            else if (j > 5) sb += t;
+            else { sa += g4 < 2 ? t : 0.f; sb += g4 < 2 ? 0.f : t; }
+        }
+        sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+        sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+        const float fa = kA == 2 ? 1.0f : tauA / fmaxf(sqrtf(sa), 1e-12f);
+        const float fb = kB == 2 ? 1.0f : tauB / fmaxf(sqrtf(sb), 1e-12f);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const float f = j < 5 ? fa : (j > 5 ? fb : (g4 < 2 ? fa : fb));
+            acc[i][j] *= f;
+        }
+    }
+}
+
 template <typename T, typename OutT, int EPI>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
     // Two separate LDS objects (not one array carved in two): hipcc tags accesses to distinct LDS variables with
@@ -188,6 +222,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: lane holds C[m][nb .. nb+3] for m = ..+r16, nb = ..+4*(lane>>4) ----
+    if constexpr (EPI == SWIFTK_EPI_QKNORM) qknorm_tile(acc, lane, n0 + wn * 176, g.ep0);
     OutT* C = reinterpret_cast<OutT*>(g.C);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -217,7 +252,187 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Persistent variant: a fixed grid of workgroups walks the tile list, and the two-stage LDS-DMA pipeline runs
+// straight through tile boundaries -- the first k-tile of the next output tile is already in flight while the
+// epilogue of the current one stores, so there is no per-tile prologue bubble.  Tile order is grouped (GM tile
+// rows x all tile columns, column-major inside a group) so that the ~32 tiles an XCD works on at any moment
+// form an 8 x 4 block sharing A panels and W panels in that XCD's L2; the DMA pieces of the next stage are
+// issued between MFMA groups instead of in one burst after the barrier.
+struct TileIter {
+    int ntm, ntn, gm;  // tile rows, tile cols, group height
+    __device__ __forceinline__ void coords(int t, int& tm, int& tn) const {
+        const int per = gm * ntn;
+        const int grp = t / per, r = t - grp * per;
+        const int rows = min(gm, ntm - grp * gm);
+        tn = r / rows;
+        tm = grp * gm + (r - tn * rows);
+    }
+};
+
+template <typename T, typename OutT, int EPI>
+__global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const TileIter it{ntm, g.ntn, gm};
+    const int ntiles = ntm * g.ntn;
+    // workgroups with equal blockIdx%8 share an XCD: give each XCD a contiguous run of virtual ids
+    int vid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int stride = gridDim.x;
+    if (vid >= ntiles) return;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+
+    // LDS-DMA addressing: per piece a wave-uniform 64-bit base (SGPRs: tile origin + piece row + k offset) plus a
+    // per-lane 32-bit offset (row-in-piece * ld + swizzled 16-B chunk).  The swizzle term (row>>1)&7 depends on the
+    // piece only through its parity for A (pieces 4*wv+i) and not at all for W (pieces wv+8i), so three VGPRs serve
+    // all ten pieces.  Needs M % 8 == 0 and N % 8 == 0 (a piece is entirely inside or outside the matrix).
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const uint32_t va_even = (uint32_t)(prow * g.lda_b) + 16u * (pchunk ^ ((prow >> 1) & 7));
+    const uint32_t va_odd = (uint32_t)(prow * g.lda_b) + 16u * (pchunk ^ ((4 + (prow >> 1)) & 7));
+    const uint32_t vb = (uint32_t)(prow * g.ldw_b) + 16u * (pchunk ^ ((4 * (wv & 1) + (prow >> 1)) & 7));
+    int tile = vid, kt = 0;
+    int src_m0, src_n0;  // tile origin the DMA sources currently point at
+    auto set_sources = [&](int t) {
+        int tm, tn;
+        it.coords(t, tm, tn);
+        src_m0 = tm * BM;
+        src_n0 = tn * BN;
+    };
+    // piece p of the stage at LDS byte address `sa`: pieces 0-3 = A rows, 4-9 = W rows (1 KiB = 8 rows x 128 B)
+    auto issue_piece = [&](uint32_t sa, int64_t koff, int p) {
+        if (p < 4) {
+            int rb = src_m0 + (wv * 4 + p) * 8;
+            rb = rb < g.M ? rb : g.M - 8;
+            dma_piece(sa + (wv * 4 + p) * 1024, g.A + (int64_t)rb * g.lda_b + koff, (p & 1) ? va_odd : va_even);
+        } else {
+            const int i = p - 4;
+            if (i < 5 || wv < 4) {
+                int rb = src_n0 + (wv + 8 * i) * 8;
+                rb = rb < g.N ? rb : g.N - 8;
+                dma_piece(sa + A_BYTES + (wv + 8 * i) * 1024, g.W + (int64_t)rb * g.ldw_b + koff, vb);
+            }
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane & 15;
+    const int xoff = (wm * 64 + r16) * ROWB;
+    const int woff = A_BYTES + (wn * 176 + r16) * ROWB;
+    const int ch0 = (((lane >> 4) + 0) ^ (r16 >> 1)) * 16;
+    const int ch1 = (((lane >> 4) + 4) ^ (r16 >> 1)) * 16;
+
+    const int nk = g.K / (ROWB / (int)sizeof(T));
+    // Flattened (tile, k-tile) walk.  Each step computes from one stage while the DMA of the following step fills
+    // the other; past the very last step the "following step" is a harmless re-load of this tile's first k-tile.
+    set_sources(tile);
+#pragma unroll
+    for (int p = 0; p < 10; ++p) issue_piece(lds0, 0, p);
+    int par = 0;
+    for (;;) {
+        // own DMA of the stage about to be read has landed; after the barrier every wave's has, and every wave is
+        // done reading the other stage (its fragment reads were consumed by MFMAs before it got here)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* s = smem + par * STAGE;
+        const uint32_t fill = lds0 + (par ^ 1) * STAGE;
+        const bool last_k = (kt + 1 == nk);
+        int64_t koff = (int64_t)(kt + 1) * ROWB;
+        if (last_k) {
+            const int ntile = tile + stride;
+            if (ntile < ntiles) set_sources(ntile);
+            koff = 0;
+        }
+        // one k-tile = 22 steps of 4 MFMAs (one W fragment x four activation fragments); the fragment of step
+        // i+1 is requested before the MFMAs of step i issue, and one DMA piece of the next stage follows every
+        // second step, so LDS latency and DMA issue hide behind the matrix pipe instead of bunching up
+        {
+            uint4 xf[MI], xg[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch0);
+            uint4 wf = *reinterpret_cast<const uint4*>(s + woff + ch0);
+#pragma unroll
+            for (int step = 0; step < 2 * NI; ++step) {
+                const int ks = step / NI, j = step - ks * NI;
+                uint4 wn_ = wf;
+                if (step + 1 < 2 * NI) {
+                    const int ks1 = (step + 1) / NI, j1 = (step + 1) - ks1 * NI;
+                    wn_ = *reinterpret_cast<const uint4*>(s + woff + j1 * 16 * ROWB + (ks1 ? ch1 : ch0));
+                }
+                if (step == NI - 2) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) xg[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch1);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) mma_chunk<T>(acc[i][j], wf, ks ? xg[i] : xf[i]);
+                if ((step & 1) && (step >> 1) < 10) issue_piece(fill, koff, step >> 1);
+                wf = wn_;
+            }
+        }
+        par ^= 1;
+        if (!last_k) {
+            ++kt;
+            continue;
+        }
+        // ---- epilogue of `tile`: lane holds C[m][nb .. nb+3] for m = ..+r16, nb = ..+4*(lane>>4) ----
+        {
+            int tm, tn;
+            it.coords(tile, tm, tn);
+            const int m0 = tm * BM, n0 = tn * BN;
+            if constexpr (EPI == SWIFTK_EPI_QKNORM) qknorm_tile(acc, lane, n0 + wn * 176, g.ep0);
+            OutT* C = reinterpret_cast<OutT*>(g.C);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * 64 + i * 16 + r16;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int nb = n0 + wn * 176 + j * 16 + 4 * (lane >> 4);
+                    f32x4 v = acc[i][j];
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (m >= g.M || nb >= g.N) continue;
+                    if constexpr (EPI == SWIFTK_EPI_BIAS_POS) {
+                        const float4 b = *reinterpret_cast<const float4*>(g.ep0 + nb);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                        if (g.ep1) {
+                            const float4 pp =
+                                *reinterpret_cast<const float4*>(g.ep1 + (int64_t)(m % g.pos_rows) * g.N + nb);
+                            v[0] += pp.x; v[1] += pp.y; v[2] += pp.z; v[3] += pp.w;
+                        }
+                    }
+                    if constexpr (EPI == SWIFTK_EPI_SWIGLU) {
+                        const float h0 = v[0] / (1.0f + expf(-v[0])) * v[1];
+                        const float h1 = v[2] / (1.0f + expf(-v[2])) * v[3];
+                        store2<OutT>(C + (int64_t)m * g.ldc + (nb >> 1), h0, h1);
+                    } else {
+                        store4<OutT>(C + (int64_t)m * g.ldc + nb, v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        }
+        tile += stride;
+        kt = 0;
+        if (tile >= ntiles) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing dummy DMA must not outlive the LDS allocation
+}
+
 // ---- optional live timing of one GEMM flavour (bench.py's roofline leg): HIP events on the launch stream ----
+int g_variant = 1;   // 0: one tile per workgroup; 1: persistent, grouped tile order, interleaved DMA
+int g_group_m = 8;   // tile rows per group in the persistent order
+int g_persist_wgs = 256;
+
 struct Prof {
     int epilogue = -1, N = 0;
     static constexpr int MAXE = 4096;
@@ -238,7 +453,13 @@ int launch(const GemmArgs& g, hipStream_t st) {
         }
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     }
-    hipLaunchKernelGGL(kern, dim3(ntm * g.ntn), dim3(NT), 0, st, g);
+    if (g_variant == 0 || (g.M & 7) || (g.N & 7)) {  // ragged edges: per-lane clamped sources
+        hipLaunchKernelGGL(kern, dim3(ntm * g.ntn), dim3(NT), 0, st, g);
+    } else {
+        const int ntiles = ntm * g.ntn;
+        const int grid = ntiles < g_persist_wgs ? ntiles : g_persist_wgs;
+        hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+    }
     if (timed) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
         ++g_prof.used;
@@ -253,11 +474,21 @@ int dispatch_epi(int epi, const GemmArgs& g, hipStream_t st) {
         case SWIFTK_EPI_NONE: return launch<T, OutT, SWIFTK_EPI_NONE>(g, st);
         case SWIFTK_EPI_BIAS_POS: return launch<T, OutT, SWIFTK_EPI_BIAS_POS>(g, st);
         case SWIFTK_EPI_SWIGLU: return launch<T, OutT, SWIFTK_EPI_SWIGLU>(g, st);
+        case SWIFTK_EPI_QKNORM: return launch<T, OutT, SWIFTK_EPI_QKNORM>(g, st);
     }
     return SWIFTK_EINVAL;
 }
 
 }  // namespace
+
+extern "C" int swiftk_set_tuning(int key, int value) {
+    switch (key) {
+        case 0: g_variant = value; return 0;
+        case 1: g_group_m = value > 0 ? value : 1; return 0;
+        case 2: g_persist_wgs = value > 0 ? value : 1; return 0;
+    }
+    return SWIFTK_EINVAL;
+}
 
 extern "C" int swiftk_profile_gemm(int epilogue, int64_t N) {
     g_prof.epilogue = epilogue;
@@ -299,6 +530,7 @@ extern "C" int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ld
     const int ovec = (epilogue == SWIFTK_EPI_SWIGLU ? 2 : 4) * os;
     if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || (lda * es) % 16 || (ldw * es) % 16) return SWIFTK_EALIGN;
     if (((uintptr_t)C % ovec) || (ldc * os) % ovec) return SWIFTK_EALIGN;
+    if (epilogue == SWIFTK_EPI_QKNORM && (!ep0 || N % 264 != 0)) return SWIFTK_ESHAPE;  // whole heads of 3 x 88
     if (epilogue == SWIFTK_EPI_BIAS_POS && (!ep0 || ((uintptr_t)ep0 & 15) || (ep1 && (((uintptr_t)ep1 & 15) || pos_rows <= 0))))
         return SWIFTK_EINVAL;
     GemmArgs g;

@@ -12,7 +12,8 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_BIAS_POS, EPI_NONE, EPI_SWIGLU, F32, SwiftkError, check, lib
+from ._lib import (ATTN_NO_PIPE, ATTN_PRENORM, BF16, EPI_BIAS_POS, EPI_NONE, EPI_QKNORM, EPI_SWIGLU, F32, SwiftkError,
+                   check, lib)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -70,9 +71,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *
     return out
 
 
-def window_attention(qkv: torch.Tensor, scale: torch.Tensor, grid: Tuple[int, int], heads: int,
-                     shift: Tuple[int, int] = (0, 0), out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """qkv [B, gh*gw, >=3*heads*hd] -> out [B, gh*gw, heads*hd] (token order, un-rolled)."""
+def window_attention(qkv: torch.Tensor, scale: Optional[torch.Tensor], grid: Tuple[int, int], heads: int,
+                     shift: Tuple[int, int] = (0, 0), out: Optional[torch.Tensor] = None, flags: int = 0) -> torch.Tensor:
+    """qkv [B, gh*gw, >=3*heads*hd] -> out [B, gh*gw, heads*hd] (token order, un-rolled).
+
+    ``flags`` = ``_lib.ATTN_PRENORM`` when q/k were normalised by the ``EPI_QKNORM`` GEMM epilogue.
+    """
     _dev(qkv, scale, out)
     B, n, _ = qkv.shape
     gh, gw = grid
@@ -81,8 +85,9 @@ def window_attention(qkv: torch.Tensor, scale: torch.Tensor, grid: Tuple[int, in
     if out is None:
         out = torch.empty(B, n, heads * hd, dtype=qkv.dtype, device=qkv.device)
     check(lib().swiftk_window_attention(qkv.data_ptr(), qkv.stride(1), out.data_ptr(), out.stride(1),
-                                        scale.contiguous().data_ptr(), B, gh, gw, heads, hd, shift[0], shift[1],
-                                        dtype_code(qkv.dtype), _stream()), "swiftk_window_attention")
+                                        None if scale is None else scale.contiguous().data_ptr(), B, gh, gw, heads, hd,
+                                        shift[0], shift[1], dtype_code(qkv.dtype), flags, _stream()),
+          "swiftk_window_attention")
     return out
 
 

@@ -35,7 +35,7 @@ def test_host_side_argument_validation_needs_no_gpu():
     assert L.swiftk_gemm(None, 0, None, 0, None, 0, 1, 1, 1, 0, 0, 0, None, None, 0, None) == -1
     assert L.swiftk_gemm(16, 40, 16, 40, 16, 4, 4, 4, 40, _lib.BF16, _lib.BF16, 0, None, None, 0, None) == -2  # K % 64
     assert L.swiftk_gemm(8, 64, 16, 64, 16, 4, 4, 4, 64, _lib.BF16, _lib.BF16, 0, None, None, 0, None) == -3  # alignment
-    assert L.swiftk_window_attention(16, 3168, 16, 1056, 16, 1, 24, 16, 12, 88, 0, 0, 0, None) == -2
+    assert L.swiftk_window_attention(16, 3168, 16, 1056, 16, 1, 24, 16, 12, 88, 0, 0, 0, 0, None) == -2
     assert L.swiftk_workspace_bytes(None, 1) == 0
 
 

@@ -220,3 +220,49 @@ def test_rejects_cpu_tensors_and_bad_shapes(dev):
         ops.gemm(torch.zeros(4, 40, device=dev), torch.zeros(4, 40, device=dev))
     with pytest.raises(SwiftkError):  # grid not divisible by the 16x16 window
         ops.window_attention(torch.zeros(1, 24 * 16, 3168, device=dev), torch.zeros(12, device=dev), (24, 16), 12)
+
+
+def _prenorm_reference(qkv, scale, heads, hd):
+    """(q-hat | k-hat | v) laid out like qkv, in fp32: what SWIFTK_EPI_QKNORM must produce (swinv2.py:123-127)."""
+    B, n, _ = qkv.shape
+    v = qkv.reshape(B, n, heads, 3, hd).clone()
+    tau = torch.clamp(scale, max=math.log(100.0)).exp().view(1, 1, heads, 1)
+    v[:, :, :, 0] = v[:, :, :, 0] / v[:, :, :, 0].norm(dim=-1, keepdim=True).clamp_min(1e-12) * tau
+    v[:, :, :, 1] = v[:, :, :, 1] / v[:, :, :, 1].norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    return v.reshape(B, n, -1)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_qknorm_epilogue(dev, dt):
+    from swift_amd import ops
+    M, heads, hd = 1024, 12, 88
+    K = ops.k_pad(dt, 1056)
+    a, w = rnd((M, K), 40), rnd((3 * heads * hd, K), 41, 0.03)
+    scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 10.0]))
+    ad, wd = to_dt(a, dt, dev), to_dt(w, dt, dev)
+    c = ops.gemm(ad, wd, epilogue=ops.EPI_QKNORM, bias=scale.to(dev))
+    raw = (ad.float().cpu().double() @ wd.float().cpu().double().T).float()
+    ref = _prenorm_reference(raw.view(1, M, -1), scale, heads, hd)[0]
+    assert rel_l2(c.float().cpu(), ref) < (F32_TOL if dt == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("dt,flags", [(torch.bfloat16, 1), (torch.bfloat16, 3), (torch.float32, 1)])
+@pytest.mark.parametrize("shift", [(0, 0), (8, 8)])
+@pytest.mark.parametrize("B", [1, 3])
+def test_window_attention_prenormalised(dev, dt, flags, shift, B):
+    """flags 1 = PRENORM (bf16: persistent LDS-DMA-pipelined kernel), 3 = PRENORM|NO_PIPE (per-item kernel)."""
+    from oracle.swinv2 import window_token_index
+    from swift_amd import ops
+    grid, heads, hd = (32, 48), 12, 88
+    n = grid[0] * grid[1]
+    qkv = rnd((B, n, 3 * heads * hd), 42 + B)
+    scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 10.0]))
+    pre = to_dt(_prenorm_reference(qkv, scale, heads, hd), dt, dev)
+    out = ops.window_attention(pre, None, grid, heads, shift, flags=flags)
+    idx = window_token_index(grid, (16, 16), shift)
+    src = pre.float().cpu()[:, idx.reshape(-1)].reshape(B * idx.shape[0], 256, heads, 3, hd).permute(0, 2, 1, 3, 4)
+    ow = (src[..., 0, :] @ src[..., 1, :].transpose(-2, -1)).softmax(-1) @ src[..., 2, :]  # b h n d
+    ref = torch.empty(B, n, heads * hd)
+    ref[:, idx.reshape(-1)] = ow.permute(0, 2, 1, 3).reshape(B, n, -1)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out.float().cpu(), ref) < (2e-5 if dt == torch.float32 else 1.2e-2)
