@@ -142,6 +142,12 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
         // K(item) and V(item) have landed (own pieces: vmcnt(0); everyone's: barrier).  Also orders the previous
         // item's PV reads of the other V buffer before the DMA that refills it.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Make hipcc retire ITS wait for the Q-fragment loads here, while nothing is outstanding.  Its waitcnt pass
+        // does not see the asm DMA: left alone it would wait for "its" loads in front of the first QK^T MFMA with a
+        // count that, in hardware, also covers the V pieces issued just below -- i.e. stall on fresh DMA every item.
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
         __builtin_amdgcn_s_barrier();
         if (has_next) {
             if (nwn != cur_w) set_window(nwn);

@@ -26,8 +26,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// two fp32 -> one dword of two bf16 (RNE): the vector convert lowers to ONE v_cvt_pk_bf16_f32; converting the halves
+// separately and or-ing them costs four VALU instructions
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename T>
@@ -69,6 +74,18 @@ __device__ __forceinline__ void dma_piece(uint32_t lds_dst, const char* base, ui
         "global_load_lds_dwordx4 %1, %3\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
+        : "v"(voff), "s"(lds_dst), "s"(base)
+        : "memory");
+}
+
+// Same, for bases that were computed well before (no SALU-write -> VMEM-read hazard to pad) and callers that do
+// not need M0 preserved (nothing else in these kernels uses it): M0, one wait state, load.
+__device__ __forceinline__ void dma_piece_fast(uint32_t lds_dst, const char* base, uint32_t voff) {
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 1\n\t"
+        "global_load_lds_dwordx4 %0, %2"
+        :
         : "v"(voff), "s"(lds_dst), "s"(base)
         : "memory");
 }

@@ -46,6 +46,7 @@ struct GemmArgs {
     const float* ep1;
     int pos_rows;
     int ntn;
+    int dbg;  // tuning experiments only: 1 = no DMA in the loop, 2 = no barrier (both give wrong results)
 };
 
 template <typename T>
@@ -242,8 +243,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
                 }
             }
             if constexpr (EPI == SWIFTK_EPI_SWIGLU) {
-                const float h0 = v[0] / (1.0f + expf(-v[0])) * v[1];
-                const float h1 = v[2] / (1.0f + expf(-v[2])) * v[3];
+                const float h0 = v[0] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[0])) * v[1];
+                const float h1 = v[2] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[2])) * v[3];
                 store2<OutT>(C + (int64_t)m * g.ldc + (nb >> 1), h0, h1);
             } else {
                 store4<OutT>(C + (int64_t)m * g.ldc + nb, v[0], v[1], v[2], v[3]);
@@ -299,26 +300,35 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     const uint32_t va_odd = (uint32_t)(prow * g.lda_b) + 16u * (pchunk ^ ((4 + (prow >> 1)) & 7));
     const uint32_t vb = (uint32_t)(prow * g.ldw_b) + 16u * (pchunk ^ ((4 * (wv & 1) + (prow >> 1)) & 7));
     int tile = vid, kt = 0;
-    int src_m0, src_n0;  // tile origin the DMA sources currently point at
+    // Row bases of this wave's ten pieces for the tile the DMA currently feeds: computed once per tile and kept in
+    // SGPRs, so issuing a piece costs three instructions (M0, nop, load) instead of ~20 scalar address ops -- at
+    // ten pieces per k-tile the scalar arithmetic alone used to take as many issue slots as the 88 MFMAs.
+    const char* abase[4];
+    const char* wbase[6];
     auto set_sources = [&](int t) {
         int tm, tn;
         it.coords(t, tm, tn);
-        src_m0 = tm * BM;
-        src_n0 = tn * BN;
-    };
-    // piece p of the stage at LDS byte address `sa`: pieces 0-3 = A rows, 4-9 = W rows (1 KiB = 8 rows x 128 B)
-    auto issue_piece = [&](uint32_t sa, int64_t koff, int p) {
-        if (p < 4) {
-            int rb = src_m0 + (wv * 4 + p) * 8;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int rb = tm * BM + (wv * 4 + p) * 8;
             rb = rb < g.M ? rb : g.M - 8;
-            dma_piece(sa + (wv * 4 + p) * 1024, g.A + (int64_t)rb * g.lda_b + koff, (p & 1) ? va_odd : va_even);
+            abase[p] = g.A + (int64_t)rb * g.lda_b;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            int rb = tn * BN + (wv + 8 * i) * 8;
+            rb = rb < g.N ? rb : g.N - 8;
+            wbase[i] = g.W + (int64_t)rb * g.ldw_b;
+        }
+    };
+    // piece p of the stage at LDS byte address `sa`: pieces 0-3 = A rows, 4-9 = W rows (1 KiB = 8 rows x 128 B);
+    // `koff` = byte offset of the k-tile inside a row, carried in the per-lane offset
+    auto issue_piece = [&](uint32_t sa, uint32_t koff, int p) {
+        if (p < 4) {
+            dma_piece_fast(sa + (wv * 4 + p) * 1024, abase[p], ((p & 1) ? va_odd : va_even) + koff);
         } else {
             const int i = p - 4;
-            if (i < 5 || wv < 4) {
-                int rb = src_n0 + (wv + 8 * i) * 8;
-                rb = rb < g.N ? rb : g.N - 8;
-                dma_piece(sa + A_BYTES + (wv + 8 * i) * 1024, g.W + (int64_t)rb * g.ldw_b + koff, vb);
-            }
+            if (i < 5 || wv < 4) dma_piece_fast(sa + A_BYTES + (wv + 8 * i) * 1024, wbase[i], vb + koff);
         }
     };
 
@@ -345,11 +355,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         // own DMA of the stage about to be read has landed; after the barrier every wave's has, and every wave is
         // done reading the other stage (its fragment reads were consumed by MFMAs before it got here)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(g.dbg & 2)) __builtin_amdgcn_s_barrier();
         const char* s = smem + par * STAGE;
         const uint32_t fill = lds0 + (par ^ 1) * STAGE;
         const bool last_k = (kt + 1 == nk);
-        int64_t koff = (int64_t)(kt + 1) * ROWB;
+        uint32_t koff = (uint32_t)(kt + 1) * ROWB;
         if (last_k) {
             const int ntile = tile + stride;
             if (ntile < ntiles) set_sources(ntile);
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 }
 #pragma unroll
                 for (int i = 0; i < MI; ++i) mma_chunk<T>(acc[i][j], wf, ks ? xg[i] : xf[i]);
-                if ((step & 1) && (step >> 1) < 10) issue_piece(fill, koff, step >> 1);
+                if ((step & 1) && (step >> 1) < 10 && !(g.dbg & 1)) issue_piece(fill, koff, step >> 1);
                 wf = wn_;
             }
         }
@@ -387,12 +397,65 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             continue;
         }
         // ---- epilogue of `tile`: lane holds C[m][nb .. nb+3] for m = ..+r16, nb = ..+4*(lane>>4) ----
-        {
+        if (g.dbg & 4) {  // tuning experiment: drop the epilogue (keeps the accumulators live through a fake use)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    asm volatile("" ::"v"(acc[i][j]));
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        } else {
             int tm, tn;
             it.coords(tile, tm, tn);
             const int m0 = tm * BM, n0 = tn * BN;
             if constexpr (EPI == SWIFTK_EPI_QKNORM) qknorm_tile(acc, lane, n0 + wn * 176, g.ep0);
             OutT* C = reinterpret_cast<OutT*>(g.C);
+            if constexpr (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS) {
+                // bf16 output: transpose each 16-row slab of the wave's tile through LDS so that rows leave as whole
+                // 16-B chunks (one dwordx4 store covers 5.8 contiguous rows' worth) instead of 44 scattered 4..8-B
+                // stores per wave -- the scattered form is store-issue bound (4.6 us per tile, 14.5 us with SwiGLU).
+                // The stage just consumed (`s`) is free: its refill is issued only after the next barrier, which no
+                // wave passes before every wave has finished this epilogue.  Slabs are wave-private: no barrier.
+                constexpr int COLS = (EPI == SWIFTK_EPI_SWIGLU) ? 88 : 176;  // output columns of the wave tile
+                constexpr int CPR = COLS / 8;                                  // 16-B chunks per row
+                constexpr int RSTR = COLS * 2 + 16;                            // padded slab row stride (bytes)
+                char* slab = const_cast<char*>(s) + wv * (16 * RSTR);
+                const int g4 = lane >> 4;
+                const int ncol0 = (EPI == SWIFTK_EPI_SWIGLU ? (n0 >> 1) : n0) + wn * COLS;
+                const int nout = EPI == SWIFTK_EPI_SWIGLU ? (g.N >> 1) : g.N;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const f32x4 v = acc[i][j];
+                        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (EPI == SWIFTK_EPI_SWIGLU) {
+                            // silu(g) * u with v_exp_f32 / v_rcp_f32 (1 ulp each; the libm forms cost ~30 VALU apiece)
+                            const float h0 = v[0] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[0])) * v[1];
+                            const float h1 = v[2] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[2])) * v[3];
+                            *reinterpret_cast<uint32_t*>(slab + r16 * RSTR + (j * 8 + 2 * g4) * 2) = pack_bf16(h0, h1);
+                        } else {
+                            *reinterpret_cast<uint2*>(slab + r16 * RSTR + (j * 16 + 4 * g4) * 2) =
+                                make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();  // slab written (LDS ops of a wave execute in order)
+                    const int mrow0 = m0 + wm * 64 + i * 16;
+#pragma unroll
+                    for (int t = 0; t < (16 * CPR + 63) / 64; ++t) {
+                        const int c = lane + 64 * t;
+                        const int row = c / CPR, cc = c - row * CPR;
+                        if (c < 16 * CPR) {
+                            const uint4 q = *reinterpret_cast<const uint4*>(slab + row * RSTR + cc * 16);
+                            const int m = mrow0 + row, n = ncol0 + cc * 8;
+                            if (m < g.M && n < nout)
+                                *reinterpret_cast<uint4*>(C + (int64_t)m * g.ldc + n) = q;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();  // slab read before the next slab overwrites it
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int m = m0 + wm * 64 + i * 16 + r16;
@@ -412,8 +475,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                         }
                     }
                     if constexpr (EPI == SWIFTK_EPI_SWIGLU) {
-                        const float h0 = v[0] / (1.0f + expf(-v[0])) * v[1];
-                        const float h1 = v[2] / (1.0f + expf(-v[2])) * v[3];
+                        const float h0 = v[0] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[0])) * v[1];
+                        const float h1 = v[2] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[2])) * v[3];
                         store2<OutT>(C + (int64_t)m * g.ldc + (nb >> 1), h0, h1);
                     } else {
                         store4<OutT>(C + (int64_t)m * g.ldc + nb, v[0], v[1], v[2], v[3]);
@@ -432,6 +495,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 int g_variant = 1;   // 0: one tile per workgroup; 1: persistent, grouped tile order, interleaved DMA
 int g_group_m = 8;   // tile rows per group in the persistent order
 int g_persist_wgs = 256;
+int g_dbg = 0;
 
 struct Prof {
     int epilogue = -1, N = 0;
@@ -453,7 +517,9 @@ int launch(const GemmArgs& g, hipStream_t st) {
         }
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     }
-    if (g_variant == 0 || (g.M & 7) || (g.N & 7)) {  // ragged edges: per-lane clamped sources
+    const bool wide_ok = sizeof(OutT) != 2 || (!((uintptr_t)g.C & 15) && !(g.ldc & 7) &&
+                                               !(g.N & (EPI == SWIFTK_EPI_SWIGLU ? 15 : 7)));  // 16-B row chunks
+    if (g_variant == 0 || (g.M & 7) || (g.N & 7) || !wide_ok) {  // ragged edges: per-lane clamped sources
         hipLaunchKernelGGL(kern, dim3(ntm * g.ntn), dim3(NT), 0, st, g);
     } else {
         const int ntiles = ntm * g.ntn;
@@ -486,6 +552,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 0: g_variant = value; return 0;
         case 1: g_group_m = value > 0 ? value : 1; return 0;
         case 2: g_persist_wgs = value > 0 ? value : 1; return 0;
+        case 3: g_dbg = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -547,6 +614,7 @@ extern "C" int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ld
     g.ep1 = ep1;
     g.pos_rows = (int)pos_rows;
     g.ntn = (int)((N + BN - 1) / BN);
+    g.dbg = g_dbg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == SWIFTK_BF16) {
         if (out_dtype == SWIFTK_BF16) return dispatch_epi<bf16_t, bf16_t>(epilogue, g, st);

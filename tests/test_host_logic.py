@@ -1,0 +1,138 @@
+"""CPU-side host logic: config composition, dataset interface, unit sharding, and the world_size-2 (gloo)
+generate path with a stand-in network (the HIP kernels need a GPU; the sharding / output-placement logic does not)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "swift_amd", "configs")
+
+
+def test_compose_experiment_matches_reference_surface(monkeypatch):
+    from swift_amd.config import compose
+    monkeypatch.setenv("HYDRA_RUN_ID", "007")
+    c = compose(CFG, "train", [])
+    assert c.experiment_name == "era5-swinv2-1.4-scm" and c.seed == 1234
+    assert c.model._target_ == "swift.models.swinv2.SwinV2"
+    assert (c.model.depth, c.model.dim, c.model.heads) == (12, 1056, 12)
+    assert c.model.window_size == [16, 16] and c.model.shift_size == [8, 8] and c.model.patch_size == [2, 2]
+    assert c.precond._target_ == "swift.models.precond.PassPrecond" and c.precond.auxiliary_dim == 1
+    assert c.loss._target_.endswith("SCMLoss") and c.loss.noise.dist == "loguniform" and c.loss.noise.sigma_max == 200
+    assert c.loss.tangent_warmup_kimg == 3000
+    assert c.solver == {"num_steps": 1, "sigma_min": 0.02, "sigma_max": 200, "auxiliary": 0.6}
+    assert c.optimizer._target_.endswith("MuonWithAuxAdam")  # "override /optimizer: muon" of the experiment
+    assert len(c.data.dataset.variables) == 69 and len(c.data.dataset.forcings) == 3
+    assert c.data.dataset.residual is True and c.data.batch_size == 1
+    assert c.trainer.total_kimg == 15000 and c.trainer._target_ == "swift.training.trainer.Trainer"
+    assert c.hydra.run.dir == "results/era5-swinv2-1.4-scm/007"
+
+
+def test_compose_cli_overrides_and_finetune_packaging():
+    from swift_amd.config import compose
+    c = compose(CFG, "train", ["experiment=era5-swinv2-1.4-trigflow", "optimizer=adamw", "data.batch_size=64",
+                               "finetune=multistep", "data=era5-synthetic-1.4"])
+    assert c.loss._target_.endswith("TrigFlowLoss") and c.solver.num_steps == 20
+    assert c.optimizer._target_ == "torch.optim.AdamW" and c.data.batch_size == 64
+    assert c.data.dataset._target_ == "swift_amd.data.era5.SyntheticERA5Dataset"
+    # reference train.py:75-77 hoists these keys: they must arrive packaged under `finetune`
+    assert c.finetune.loss._target_.endswith("CRPSLoss") and c.finetune.optimizer.lr == 1e-5
+    assert c.finetune.finetune.intervals[0] == {"steps": 1, "kimg": 1500}
+
+
+def test_instantiate_aliases_reference_targets():
+    from swift_amd.config import instantiate
+    from swift_amd.models.precond import PassPrecond
+    from swift_amd.models.swinv2 import SwinV2
+    net = instantiate({"_target_": "swift.models.precond.PassPrecond", "sigma_min": 0, "sigma_data": 1.0, "auxiliary_dim": 1},
+                      model_config={"_target_": "swift.models.swinv2.SwinV2", "window_size": [16, 16], "shift_size": [8, 8],
+                                    "patch_size": [2, 2], "depth": 1, "dim": 96, "heads": 4},
+                      img_resolution=(32, 32), img_channels=4, condition_channels=7, sigma_max=float("inf"),
+                      _recursive_=False, _convert_="object")
+    assert isinstance(net, PassPrecond) and isinstance(net.model, SwinV2)
+    assert net.model.in_channels == 11 and list(net.img_resolution) == [32, 32]
+
+
+def test_dataset_interface_matches_oracle_stats():
+    from oracle.rollout import Stats
+    from swift_amd.data.era5 import SyntheticERA5Dataset
+    ds = SyntheticERA5Dataset([f"v{i}" for i in range(5)], ["f0", "f1"], img_resolution=(8, 16), length=12, seed=3,
+                              random_stats=True)
+    st = Stats(ds.x_means, ds.x_stds, {6: ds.t_stds[6]}, n_vars=5, n_forc=2)
+    x5, f2, x7 = torch.randn(2, 5, 8, 16), torch.randn(2, 2, 8, 16), torch.randn(2, 7, 8, 16)
+    for v in (x5, f2, x7):  # channel-count dispatch of era5.py:110-133
+        assert torch.allclose(ds.standardize_x(v.clone()), st.standardize_x(v))
+        assert torch.allclose(ds.unstandardize_x(v.clone()), st.unstandardize_x(v))
+    assert torch.allclose(ds.unstandardize_t(x5.clone(), 6), st.unstandardize_t(x5, 6))
+    (x, t), (idx, delta) = ds[(3, 1, 6)]
+    assert x.shape == (7, 8, 16) and t.shape == (5, 8, 16) and idx == 3 and float(delta) == pytest.approx(0.6)
+    mx, sx, stt = ds.rollout_stats(6, "cpu")
+    assert mx.shape == (5,) and torch.allclose(stt, torch.as_tensor(ds.t_stds[6]).reshape(-1))
+    # SST is forced to zero by zero_field unless delta == 24 (era5.py:135-149): folded into the flat statistics
+    ds2 = SyntheticERA5Dataset(["2m_temperature", "sea_surface_temperature"], [], img_resolution=(8, 16), random_stats=True)
+    mx, sx, stt = ds2.rollout_stats(6, "cpu")
+    assert (float(mx[1]), float(sx[1]), float(stt[1])) == (0.0, 1.0, 0.0)
+    assert float(ds2.rollout_stats(24, "cpu")[1][1]) != 1.0
+
+
+def test_shard_units_partition():
+    from swift_amd.dist import shard_units
+    for n, world in [(768, 8), (12, 8), (5, 8), (64, 3)]:
+        parts = [shard_units(n, r, world) for r in range(world)]
+        assert sorted(u for p in parts for u in p) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert len(shard_units(768, 0, 8)) == 96  # 12 members x 64 ICs over 8 GPUs: 96 units each, not 2/2/2/2/1/1/1/1 members
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, types, numpy as np, torch
+    sys.path.insert(0, %(root)r)
+    from swift_amd import dist
+    from swift_amd.generate import create_empty_numpy, rollout_and_save, select_indices
+    from swift_amd.data.era5 import SyntheticERA5Dataset
+    from swift_amd.rollout import unit_seed
+
+    class FakeEngine:   # stands in for RolloutEngine: a deterministic function of (X0, forcings, seed), CPU only
+        def stage_forcings(self, ics, steps, device):
+            return torch.stack([torch.stack([ds.get_forcings(j + i) for j in ics]) for i in range(steps)])
+        def run(self, X0, forc, steps, seeds=None, **kw):
+            out = [X0]
+            for i in range(steps):
+                z = torch.stack([torch.randn(X0.shape[1:], generator=torch.Generator().manual_seed(int(s) + i)) for s in seeds])
+                out.append(0.9 * out[-1] + 0.1 * z + forc[i].mean(dim=1, keepdim=True))
+            return torch.stack(out, 1)
+
+    dist.setup_torch(backend="gloo")
+    ds = SyntheticERA5Dataset([f"v{i}" for i in range(3)], ["f0"], img_resolution=(4, 8), length=40, seed=5)
+    members, steps = 3, 2
+    idx = select_indices(len(ds), 5, steps, 6)
+    ofile = sys.argv[1]
+    dist.run_on_rank0(create_empty_numpy, ofile, len(idx), 3, (4, 8), members, steps)
+    args = types.SimpleNamespace(dump="numpy", batch=4)
+    rollout_and_save(FakeEngine(), ds, idx, members, steps, ofile, torch.device("cpu"), args)
+    dist.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+""")
+
+
+@pytest.mark.timeout(300)
+def test_generate_sharding_world2_gloo_equals_world1(tmp_path):
+    """(member, IC) units sharded over 2 gloo ranks write the same npy as one rank (SURVEY.md section 4 item v)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    subprocess.run([sys.executable, str(script), one], check=True, env={**env, "WORLD_SIZE": "1", "RANK": "0"}, timeout=200)
+    port = str(29600 + os.getpid() % 300)
+    procs = [subprocess.Popen([sys.executable, str(script), two],
+                              env={**env, "WORLD_SIZE": "2", "RANK": str(r), "LOCAL_RANK": str(r), "MASTER_PORT": port})
+             for r in range(2)]
+    assert [p.wait(timeout=200) for p in procs] == [0, 0]
+    a, b = np.load(one), np.load(two)
+    assert a.shape == (5, 3, 3, 3, 4, 8) and np.isfinite(a).all() and np.abs(a).sum() > 0
+    np.testing.assert_array_equal(a, b)
