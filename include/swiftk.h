@@ -160,6 +160,67 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
 int swiftk_set_tuning(int key, int value);
 int swiftk_profile_collect(double* total_ms_host, int64_t* launches_host);
 
+/* ------------------------------------------------------------------------ *
+ * Training step (reference src/swift/training/trainer.py:189-247, loss.py).
+ * The backward pass reuses swiftk_gemm: dgrad = dY * W   as A = dY, "W" = W^T copy;
+ * wgrad = dY^T * X as A = dY^T, "W" = X^T, contraction over all tokens, split over
+ * workgroups into fp32 slabs (swiftk_gemm_splitk) that swiftk_reduce_slabs sums.
+ * ------------------------------------------------------------------------ */
+
+/* slabs[s][M, ldc] (fp32) = A[M, K_s] * W[N, K_s]^T for the s-th of `ksplit` equal k-ranges; slab s starts at
+ * slabs + s*slab_stride.  Same operand rules as swiftk_gemm; M % 8 == 0, N % 8 == 0. */
+int swiftk_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, float* slabs, int64_t ldc, int64_t slab_stride,
+                       int64_t M, int64_t N, int64_t K, int dtype, int ksplit, void* stream);
+/* out[r][c] (= | +=) sum_s slabs[s*slab_stride + r*ld_slab + c] */
+int swiftk_reduce_slabs(const float* slabs, int64_t ld_slab, int64_t slab_stride, int nslabs, float* out, int64_t ld_out,
+                        int64_t rows, int64_t cols, int accumulate, void* stream);
+/* dst[c][r] = src[r][c]; dst is [cols, ldd], columns rows..ldd-1 zero-filled */
+int swiftk_transpose(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype,
+                     void* stream);
+
+/* Un-fused SwiGLU on h [M, 2*mlp] with interleaved (gate_j, up_j) columns, and its backward (swinv2.py:99-100). */
+int swiftk_swiglu_fwd(const void* h, int64_t ldh, void* out, int64_t ldo, int64_t M, int mlp, int dtype, void* stream);
+int swiftk_swiglu_bwd(const void* h, int64_t ldh, const void* dout, int64_t ldo, void* dh, int64_t lddh, int64_t M, int mlp,
+                      int dtype, void* stream);
+
+/* Backward of swiftk_modnorm_residual's norm branch: g = dL/d(out) fp32 [M, d] -> dy (dtype), and fp32 atomic sums
+ * dgamma[d], dbeta[d], dmod[B, lddmod] (scale grads at [0,d), shift grads at [d,2d)); the residual branch is identity. */
+int swiftk_modnorm_bwd(const void* y, int64_t ldy, const float* g, void* dy, int64_t lddy, const float* gamma,
+                       const float* beta, const float* mod, int64_t ldmod, float* dgamma, float* dbeta, float* dmod,
+                       int64_t lddmod, int64_t M, int d, int64_t rows_per_sample, float eps, int dtype, void* stream);
+
+/* Backward of SWIFTK_EPI_QKNORM: qkvh / dqkvh [M, ld] (normalised values and their gradients), rn [M, 3*heads] the
+ * 1/max(|.|,1e-12) factors the epilogue stored through ep1 -> dqkv [M, ldo] (raw projections), dscale[heads] += . */
+int swiftk_qknorm_bwd(const void* qkvh, const void* dqkvh, int64_t ld, const float* rn, void* dqkv, int64_t ldo,
+                      const float* scale, float* dscale, int64_t M, int heads, int head_dim, int dtype, void* stream);
+
+/* Backward of the attention core (bf16, head_dim 88, PRENORM layout): dqkvh = d(q-hat | k-hat | v). */
+int swiftk_window_attention_bwd(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo, void* dqkvh, int B,
+                                int gh, int gw, int heads, int head_dim, int shift_h, int shift_w, int dtype, void* stream);
+
+/* out[c] += sum_r src[r][c]  (period == 0), or out[(r % period)][c] += src[r][c]  (bias / pos_embed gradients) */
+int swiftk_colsum(const float* src, int64_t lds, float* out, int64_t rows, int cols, int64_t period, void* stream);
+/* Backward of swiftk_linear_small (pre-activation gradient dz): dx += dz W (dx zero-filled by the caller, may be NULL),
+ * dW += dz^T x, dbias += sum_b dz (dW/dbias may be NULL). */
+int swiftk_linear_small_bwd(const float* dz, int64_t lddz, const float* x, int64_t ldx, const float* W, int64_t ldw, float* dx,
+                            int64_t lddx, float* dW, int64_t lddw, float* dbias, int B, int N, int K, void* stream);
+int swiftk_silu_bwd(const float* z, const float* dy, float* dz, int64_t n, void* stream);
+
+/* Almost-fair CRPS over m members (loss.py:343-371,445): *loss += 1/(B H W) sum w_var[c] w_lat[h] crps; dpreds optional. */
+int swiftk_crps_loss(const float* preds, const float* target, const float* w_var, const float* w_lat, float* loss,
+                     float* dpreds, int m, int B, int C, int H, int W, float alpha, float gscale, void* stream);
+/* TrigFlow (loss.py:132-160): x_t/sigma_d and v_t from (x, z ~ N(0,1), t); then the weighted loss and its gradients. */
+int swiftk_trigflow_prep(const float* x, const float* z, const float* t, float* xt_over_sd, float* vt, float sigma_data,
+                         int B, int64_t per_sample, void* stream);
+int swiftk_trigflow_loss(const float* F, const float* vt, const float* logvar, const float* w_var, const float* w_lat,
+                         float* loss, float* dF, float* dlogvar, float sigma_data, int B, int C, int H, int W, float gscale,
+                         void* stream);
+/* out = a[b]*x + c[b]*y (y may be NULL) ;  out = x + coef[channel]*y (x may be NULL) */
+int swiftk_axpby_per_sample(float* out, const float* a, const float* x, const float* c, const float* y, int B,
+                            int64_t per_sample, void* stream);
+int swiftk_channel_axpy(float* out, const float* x, const float* y, const float* coef, int B, int C, int64_t hw,
+                        void* stream);
+
 /* fp32 -> dtype copy with row padding: dst[r][c] = src[r][c] for c < cols, 0 for cols <= c < ldd. */
 int swiftk_cast_pad(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype,
                     void* stream);

@@ -56,6 +56,22 @@ _SIGS = {
     "swiftk_rollout_update": ([_p, _p, _p, _p, _p, _p, _i, _i, _l, _p], _i),
     "swiftk_cast_pad": ([_p, _l, _p, _l, _l, _l, _i, _p], _i),
     "swiftk_axpby": ([_p, _f, _p, _f, _p, _l, _p], _i),
+    "swiftk_gemm_splitk": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _l, _i, _i, _p], _i),
+    "swiftk_reduce_slabs": ([_p, _l, _l, _i, _p, _l, _l, _l, _i, _p], _i),
+    "swiftk_transpose": ([_p, _l, _p, _l, _l, _l, _i, _p], _i),
+    "swiftk_swiglu_fwd": ([_p, _l, _p, _l, _l, _i, _i, _p], _i),
+    "swiftk_swiglu_bwd": ([_p, _l, _p, _l, _p, _l, _l, _i, _i, _p], _i),
+    "swiftk_modnorm_bwd": ([_p, _l, _p, _p, _l, _p, _p, _p, _l, _p, _p, _p, _l, _l, _i, _l, _f, _i, _p], _i),
+    "swiftk_qknorm_bwd": ([_p, _p, _l, _p, _p, _l, _p, _p, _l, _i, _i, _i, _p], _i),
+    "swiftk_window_attention_bwd": ([_p, _l, _p, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "swiftk_colsum": ([_p, _l, _p, _l, _i, _l, _p], _i),
+    "swiftk_linear_small_bwd": ([_p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _p], _i),
+    "swiftk_silu_bwd": ([_p, _p, _p, _l, _p], _i),
+    "swiftk_crps_loss": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p], _i),
+    "swiftk_trigflow_prep": ([_p, _p, _p, _p, _p, _f, _i, _l, _p], _i),
+    "swiftk_trigflow_loss": ([_p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _i, _i, _i, _f, _p], _i),
+    "swiftk_axpby_per_sample": ([_p, _p, _p, _p, _p, _i, _l, _p], _i),
+    "swiftk_channel_axpy": ([_p, _p, _p, _p, _i, _i, _l, _p], _i),
     "swiftk_profile_gemm": ([_i, _l], _i),
     "swiftk_set_tuning": ([_i, _i], _i),
     "swiftk_profile_collect": ([C.POINTER(C.c_double), C.POINTER(C.c_int64)], _i),

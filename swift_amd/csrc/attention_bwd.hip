@@ -1,0 +1,300 @@
+// Backward of the shifted-window cosine attention core for gfx950 (bf16, head_dim 88, pre-normalised q/k).
+//
+// Given qh (scaled, normalised q), kh, v, the forward output O and dO, one workgroup per (sample, window, head)
+// recomputes P = softmax(qh kh^T) (the whole 256 x 256 problem is on chip) and produces
+//     dV = P^T dO,   dP = dO V^T,   dS = P o (dP - delta),  delta_q = dO_q . O_q,   dqh = dS kh,   dkh = dS^T qh.
+// Two passes so that no accumulation ever crosses waves:
+//   pass A  waves own 32 QUERY rows: S^T[key][q] orientation as in the forward kernel -> row statistics (m, 1/l), delta
+//           and dqh^T[d][q] = kh^T dS^T (dS^T accumulators reused as the MFMA B operand);
+//   pass B  waves own 32 KEYS: S[q][key] orientation (lane = key), P and dS rebuilt from the saved row statistics ->
+//           dv^T[d][key] = dO^T P and dkh^T[d][key] = qh^T dS, again accumulator-as-operand.
+// The recomputation costs two extra 256x256x88 products per item (attention is 4 % of the model's FLOPs) and buys
+// register-resident dq / dk / dv with plain stores -- no atomics, no cross-wave reduction.
+// LDS: two 256 x 208-B images (K,V in pass A; Q,dO in pass B: row reads for the A operands, ds_read_b64_tr_b16 for
+// the transposed ones) + 3 KiB of row statistics.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 512;
+constexpr int HD = 88;
+constexpr int NCH = HD / 8;   // 11 chunks of 16 B
+constexpr int KS = 6, DB = 3;
+constexpr int STR = 208;      // image row stride (96 bf16 + 16 B)
+constexpr int IMG = 256 * STR;
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct BwdArgs {
+    const bf16_t* qkvh;   // [B, ntok, ldq]  q-hat | k-hat | v per head
+    const bf16_t* o;      // [B, ntok, ldo]  forward output
+    const bf16_t* d_o;    // [B, ntok, ldo]  upstream gradient
+    bf16_t* dqkvh;        // [B, ntok, ldq]  gradient w.r.t. q-hat | k-hat | v
+    int64_t ldq, ldo;
+    int gh, gw, heads, sh, sw, nwx, nw;
+};
+
+__device__ __forceinline__ int wtoken(const BwdArgs& a, int w, int j) {
+    const int wy = w / a.nwx, wx = w - wy * a.nwx;
+    int gy = wy * 16 + (j >> 4) + a.sh;
+    int gx = wx * 16 + (j & 15) + a.sw;
+    gy = gy >= a.gh ? gy - a.gh : gy;
+    gx = gx >= a.gw ? gx - a.gw : gx;
+    return gy * a.gw + gx;
+}
+
+// copy one 88-element row (11 x 16 B) into an image row and zero the 16-B tail chunk (d = 88..95)
+__device__ __forceinline__ void stage_row(char* img, int j, const bf16_t* src) {
+    uint4 r[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) r[c] = *reinterpret_cast<const uint4*>(src + 8 * c);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) *reinterpret_cast<uint4*>(img + j * STR + 16 * c) = r[c];
+    *reinterpret_cast<uint4*>(img + j * STR + 16 * NCH) = make_uint4(0, 0, 0, 0);
+}
+
+// fragments of a row as the MFMA "B" operand with the row index on the lane: chunk 2*ks + hh (chunk 11 = zeros)
+__device__ __forceinline__ void row_frags(const bf16_t* row, int hh, uint4 (&f)[KS]) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks == KS - 1) {
+            const uint4 t = *reinterpret_cast<const uint4*>(row + 8 * (2 * ks));
+            f[ks] = hh ? make_uint4(0, 0, 0, 0) : t;
+        } else {
+            f[ks] = *reinterpret_cast<const uint4*>(row + 8 * (2 * ks + hh));
+        }
+    }
+}
+
+__device__ __forceinline__ float dot8(const uint4& a, const uint4& b) {
+    const uint32_t ua[4] = {a.x, a.y, a.z, a.w}, ub[4] = {b.x, b.y, b.z, b.w};
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s += __uint_as_float(ua[e] << 16) * __uint_as_float(ub[e] << 16);
+        s += __uint_as_float(ua[e] & 0xffff0000u) * __uint_as_float(ub[e] & 0xffff0000u);
+    }
+    return s;
+}
+
+__device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// A operand = transposed image block: rows (k-slots) base..base+15 of the image, columns d = 32*db + (lane&31)
+__device__ __forceinline__ uint4 tr_frag(const char* img, int base_row, int db, int vbase) {
+    const char* p = img + base_row * STR + vbase + db * 64;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 8 * STR));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(uint4, v);
+}
+
+__device__ __forceinline__ uint4 pack8(const f32x16& s, int s2) {
+    uint4 p;
+    p.x = pack_bf16(s[8 * s2 + 0], s[8 * s2 + 1]);
+    p.y = pack_bf16(s[8 * s2 + 2], s[8 * s2 + 3]);
+    p.z = pack_bf16(s[8 * s2 + 4], s[8 * s2 + 5]);
+    p.w = pack_bf16(s[8 * s2 + 6], s[8 * s2 + 7]);
+    return p;
+}
+
+// store a transposed accumulator set acc[db][reg] = X^T[d][row], row = lane&31 -> dst_row[d] (bf16, 8-B pieces)
+__device__ __forceinline__ void store_t(bf16_t* dst_row, const f32x16 (&acc)[DB], int hh) {
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = db * 32 + g * 8 + hh * 4;
+            if (d < HD)
+                *reinterpret_cast<uint2*>(dst_row + d) = make_uint2(pack_bf16(acc[db][4 * g], acc[db][4 * g + 1]),
+                                                                    pack_bf16(acc[db][4 * g + 2], acc[db][4 * g + 3]));
+        }
+}
+
+__global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
+    __shared__ __attribute__((aligned(16))) char imgA[IMG];
+    __shared__ __attribute__((aligned(16))) char imgB[IMG];
+    __shared__ __attribute__((aligned(16))) float st_m[256];
+    __shared__ __attribute__((aligned(16))) float st_il[256];
+    __shared__ __attribute__((aligned(16))) float st_dl[256];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = blockIdx.x % a.heads;
+    const int w = (blockIdx.x / a.heads) % a.nw;
+    const int b = blockIdx.x / (a.heads * a.nw);
+    const int64_t tok0 = (int64_t)b * a.gh * a.gw;
+    const int c32 = lane & 31, hh = lane >> 5, i16 = lane & 15;
+    const int vbase = (4 * hh + (i16 >> 2)) * STR + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
+    const int my_tok = wtoken(a, w, wv * 32 + c32);  // the query (pass A) / key (pass B) this lane's column stands for
+    const bf16_t* my_qkv = a.qkvh + (tok0 + my_tok) * a.ldq + head * 3 * HD;
+    const bf16_t* my_o = a.o + (tok0 + my_tok) * a.ldo + head * HD;
+    const bf16_t* my_do = a.d_o + (tok0 + my_tok) * a.ldo + head * HD;
+    bf16_t* my_dqkv = a.dqkvh + (tok0 + my_tok) * a.ldq + head * 3 * HD;
+
+    // ---------------------------------------------------------------- pass A images: K -> imgA, V -> imgB
+    if (tid < 256) {
+        const bf16_t* src = a.qkvh + (tok0 + wtoken(a, w, tid)) * a.ldq + head * 3 * HD;
+        stage_row(imgA, tid, src + HD);
+        stage_row(imgB, tid, src + 2 * HD);
+    }
+    uint4 qf[KS], dof[KS];
+    row_frags(my_qkv, hh, qf);
+    row_frags(my_do, hh, dof);
+    float delta;
+    {
+        uint4 of[KS];
+        row_frags(my_o, hh, of);
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s += dot8(dof[ks], of[ks]);
+        delta = s + __shfl_xor(s, 32, 64);
+    }
+    __syncthreads();
+
+    f32x16 s[8];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            s[kb] = mfma(*reinterpret_cast<const uint4*>(imgA + (kb * 32 + c32) * STR + ks * 32 + hh * 16), qf[ks], s[kb]);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float l = 0.f;
+    const float mb = mx * LOG2E;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(s[kb][r] * LOG2E - mb);
+            s[kb][r] = p;
+            l += p;
+        }
+    l += __shfl_xor(l, 32, 64);
+    const float il = 1.0f / l;
+    if (hh == 0) {
+        st_m[wv * 32 + c32] = mx;
+        st_il[wv * 32 + c32] = il;
+        st_dl[wv * 32 + c32] = delta;
+    }
+    // dS^T = P^T o (dP^T - delta),  dP^T[key][q] = V[key][:] . dO[q][:];  then dqh^T[d][q] += kh^T[d][key] dS^T[key][q]
+    f32x16 dq[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        f32x16 dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            dp = mfma(*reinterpret_cast<const uint4*>(imgB + (kb * 32 + c32) * STR + ks * 32 + hh * 16), dof[ks], dp);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = s[kb][r] * il * (dp[r] - delta);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const uint4 ds = pack8(s[kb], s2);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) dq[db] = mfma(tr_frag(imgA, kb * 32 + s2 * 16, db, vbase), ds, dq[db]);
+        }
+    }
+    store_t(my_dqkv, dq, hh);
+    __syncthreads();
+
+    // ---------------------------------------------------------------- pass B images: Q -> imgA, dO -> imgB
+    if (tid < 256) {
+        const int t = wtoken(a, w, tid);
+        stage_row(imgA, tid, a.qkvh + (tok0 + t) * a.ldq + head * 3 * HD);
+        stage_row(imgB, tid, a.d_o + (tok0 + t) * a.ldo + head * HD);
+    }
+    uint4 kf[KS], vf[KS];
+    row_frags(my_qkv + HD, hh, kf);
+    row_frags(my_qkv + 2 * HD, hh, vf);
+    __syncthreads();
+
+    f32x16 dk[DB], dv[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[db][r] = dv[db][r] = 0.f;
+#pragma unroll 1
+    for (int qb = 0; qb < 8; ++qb) {
+        // S[q][key] = Q K^T (rows q in registers, this lane's key on the column), dP[q][key] = dO V^T
+        f32x16 sq, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sq[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            sq = mfma(*reinterpret_cast<const uint4*>(imgA + (qb * 32 + c32) * STR + ks * 32 + hh * 16), kf[ks], sq);
+            dp = mfma(*reinterpret_cast<const uint4*>(imgB + (qb * 32 + c32) * STR + ks * 32 + hh * 16), vf[ks], dp);
+        }
+        f32x16 pp, ds;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int q0 = qb * 32 + 8 * g + 4 * hh;  // rows of registers 4g..4g+3
+            const float4 m4 = *reinterpret_cast<const float4*>(st_m + q0);
+            const float4 i4 = *reinterpret_cast<const float4*>(st_il + q0);
+            const float4 d4 = *reinterpret_cast<const float4*>(st_dl + q0);
+            const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = __builtin_amdgcn_exp2f((sq[4 * g + e] - mm[e]) * LOG2E) * ii[e];
+                pp[4 * g + e] = p;
+                ds[4 * g + e] = p * (dp[4 * g + e] - dd[e]);
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const uint4 pf = pack8(pp, s2), df = pack8(ds, s2);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                dv[db] = mfma(tr_frag(imgB, qb * 32 + s2 * 16, db, vbase), pf, dv[db]);  // dO^T[d][q] P[q][key]
+                dk[db] = mfma(tr_frag(imgA, qb * 32 + s2 * 16, db, vbase), df, dk[db]);  // qh^T[d][q] dS[q][key]
+            }
+        }
+    }
+    store_t(my_dqkv + HD, dk, hh);
+    store_t(my_dqkv + 2 * HD, dv, hh);
+}
+
+}  // namespace
+
+extern "C" int swiftk_window_attention_bwd(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo,
+                                           void* dqkvh, int B, int gh, int gw, int heads, int head_dim, int shift_h,
+                                           int shift_w, int dtype, void* stream) {
+    if (!qkvh || !o || !d_o || !dqkvh || B <= 0 || heads <= 0) return SWIFTK_EINVAL;
+    if (dtype != SWIFTK_BF16 || head_dim != 88) return SWIFTK_ESHAPE;  // training runs under bf16 autocast (trainer.py:191)
+    if (gh <= 0 || gw <= 0 || gh % 16 || gw % 16) return SWIFTK_ESHAPE;
+    if (shift_h < 0 || shift_w < 0 || shift_h >= gh || shift_w >= gw) return SWIFTK_ESHAPE;
+    if (ldq < 3 * heads * head_dim || ldo < heads * head_dim) return SWIFTK_ESHAPE;
+    if (((uintptr_t)qkvh & 15) || ((uintptr_t)o & 15) || ((uintptr_t)d_o & 15) || ((uintptr_t)dqkvh & 15) || (ldq * 2) % 16 ||
+        (ldo * 2) % 16)
+        return SWIFTK_EALIGN;
+    BwdArgs a;
+    a.qkvh = static_cast<const bf16_t*>(qkvh);
+    a.o = static_cast<const bf16_t*>(o);
+    a.d_o = static_cast<const bf16_t*>(d_o);
+    a.dqkvh = static_cast<bf16_t*>(dqkvh);
+    a.ldq = ldq;
+    a.ldo = ldo;
+    a.gh = gh;
+    a.gw = gw;
+    a.heads = heads;
+    a.sh = shift_h;
+    a.sw = shift_w;
+    a.nwx = gw / 16;
+    a.nw = (gh / 16) * (gw / 16);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * a.nw * heads), dim3(NT), 0, static_cast<hipStream_t>(stream), a);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}

@@ -47,6 +47,8 @@ struct GemmArgs {
     int pos_rows;
     int ntn;
     int dbg;  // tuning experiments only: 1 = no DMA in the loop, 2 = no barrier (both give wrong results)
+    int ksplit;        // persistent kernel: k-ranges per output tile (1 = plain)
+    int64_t c_split;   // elements between the fp32 slabs of consecutive splits
 };
 
 template <typename T>
@@ -92,7 +94,9 @@ __device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, float b) {
 // attention's prologue (swinv2.py:123-127) happens here on the fp32 accumulators: q <- q/max(|q|,1e-12) *
 // exp(min(scale_h, ln 100)), k <- k/max(|k|,1e-12), v untouched.  A row's 88 values sit in the four 16-lane
 // groups of the wave: 22 accumulator quads -> register sums + two cross-group shuffles.
-__device__ __forceinline__ void qknorm_tile(f32x4 (&acc)[MI][NI], int lane, int c0, const float* __restrict__ scale) {
+// `rn` (optional, training): 1/max(|.|, 1e-12) of every q / k vector, [M][N/88] fp32 (1 for v), for the backward pass.
+__device__ __forceinline__ void qknorm_tile(f32x4 (&acc)[MI][NI], int lane, int c0, const float* __restrict__ scale,
+                                            float* __restrict__ rn = nullptr, int mrow0 = 0, int M = 0, int nvec = 0) {
     const int g4 = lane >> 4;
     const int vA = c0 / 88, vB = vA + 1;
     const int kA = vA % 3, kB = vB % 3;
@@ -113,6 +117,13 @@ __device__ __forceinline__ void qknorm_tile(f32x4 (&acc)[MI][NI], int lane, int 
         sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
         const float fa = kA == 2 ? 1.0f : tauA / fmaxf(sqrtf(sa), 1e-12f);
         const float fb = kB == 2 ? 1.0f : tauB / fmaxf(sqrtf(sb), 1e-12f);
+        if (rn && g4 == 0) {
+            const int m = mrow0 + i * 16 + (lane & 15);
+            if (m < M) {
+                rn[(int64_t)m * nvec + vA] = kA == 2 ? 1.0f : 1.0f / fmaxf(sqrtf(sa), 1e-12f);
+                rn[(int64_t)m * nvec + vB] = kB == 2 ? 1.0f : 1.0f / fmaxf(sqrtf(sb), 1e-12f);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const float f = j < 5 ? fa : (j > 5 ? fb : (g4 < 2 ? fa : fb));
@@ -223,7 +234,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: lane holds C[m][nb .. nb+3] for m = ..+r16, nb = ..+4*(lane>>4) ----
-    if constexpr (EPI == SWIFTK_EPI_QKNORM) qknorm_tile(acc, lane, n0 + wn * 176, g.ep0);
+    if constexpr (EPI == SWIFTK_EPI_QKNORM)
+        qknorm_tile(acc, lane, n0 + wn * 176, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / 88);
     OutT* C = reinterpret_cast<OutT*>(g.C);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -279,7 +291,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const TileIter it{ntm, g.ntn, gm};
-    const int ntiles = ntm * g.ntn;
+    // work item = (output tile, k-split): with ksplit > 1 (weight gradients: few output tiles, K = all tokens) each
+    // split accumulates its k-range into its own fp32 slab C + split*c_split; a reduce kernel sums the slabs
+    const int ksplit = g.ksplit;
+    const int ntiles = ntm * g.ntn * ksplit;
     // workgroups with equal blockIdx%8 share an XCD: give each XCD a contiguous run of virtual ids
     int vid;
     {
@@ -299,7 +314,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     const uint32_t va_even = (uint32_t)(prow * g.lda_b) + 16u * (pchunk ^ ((prow >> 1) & 7));
     const uint32_t va_odd = (uint32_t)(prow * g.lda_b) + 16u * (pchunk ^ ((4 + (prow >> 1)) & 7));
     const uint32_t vb = (uint32_t)(prow * g.ldw_b) + 16u * (pchunk ^ ((4 * (wv & 1) + (prow >> 1)) & 7));
-    int tile = vid, kt = 0;
+    const int nk_all = g.K / (ROWB / (int)sizeof(T));
+    auto k_begin = [&](int item) { return (int)((int64_t)(item % ksplit) * nk_all / ksplit); };
+    auto k_end = [&](int item) { return (int)((int64_t)(item % ksplit + 1) * nk_all / ksplit); };
+    int tile = vid, kt = k_begin(vid);
     // Row bases of this wave's ten pieces for the tile the DMA currently feeds: computed once per tile and kept in
     // SGPRs, so issuing a piece costs three instructions (M0, nop, load) instead of ~20 scalar address ops -- at
     // ten pieces per k-tile the scalar arithmetic alone used to take as many issue slots as the 88 MFMAs.
@@ -307,7 +325,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     const char* wbase[6];
     auto set_sources = [&](int t) {
         int tm, tn;
-        it.coords(t, tm, tn);
+        it.coords(t / ksplit, tm, tn);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             int rb = tm * BM + (wv * 4 + p) * 8;
@@ -344,12 +362,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     const int ch0 = (((lane >> 4) + 0) ^ (r16 >> 1)) * 16;
     const int ch1 = (((lane >> 4) + 4) ^ (r16 >> 1)) * 16;
 
-    const int nk = g.K / (ROWB / (int)sizeof(T));
     // Flattened (tile, k-tile) walk.  Each step computes from one stage while the DMA of the following step fills
     // the other; past the very last step the "following step" is a harmless re-load of this tile's first k-tile.
     set_sources(tile);
+    int nk = k_end(tile);
 #pragma unroll
-    for (int p = 0; p < 10; ++p) issue_piece(lds0, 0, p);
+    for (int p = 0; p < 10; ++p) issue_piece(lds0, (uint32_t)kt * ROWB, p);
     int par = 0;
     for (;;) {
         // own DMA of the stage about to be read has landed; after the barrier every wave's has, and every wave is
@@ -363,7 +381,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         if (last_k) {
             const int ntile = tile + stride;
             if (ntile < ntiles) set_sources(ntile);
-            koff = 0;
+            koff = (uint32_t)k_begin(ntile < ntiles ? ntile : tile) * ROWB;
         }
         // one k-tile = 22 steps of 4 MFMAs (one W fragment x four activation fragments); the fragment of step
         // i+1 is requested before the MFMAs of step i issue, and one DMA piece of the next stage follows every
@@ -407,10 +425,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 }
         } else {
             int tm, tn;
-            it.coords(tile, tm, tn);
+            it.coords(tile / ksplit, tm, tn);
             const int m0 = tm * BM, n0 = tn * BN;
-            if constexpr (EPI == SWIFTK_EPI_QKNORM) qknorm_tile(acc, lane, n0 + wn * 176, g.ep0);
-            OutT* C = reinterpret_cast<OutT*>(g.C);
+            if constexpr (EPI == SWIFTK_EPI_QKNORM)
+                qknorm_tile(acc, lane, n0 + wn * 176, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / 88);
+            OutT* C = reinterpret_cast<OutT*>(g.C) + (int64_t)(tile % ksplit) * g.c_split;
             if constexpr (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS) {
                 // bf16 output: transpose each 16-row slab of the wave's tile through LDS so that rows leave as whole
                 // 16-B chunks (one dwordx4 store covers 5.8 contiguous rows' worth) instead of 44 scattered 4..8-B
@@ -485,8 +504,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             }
         }
         tile += stride;
-        kt = 0;
         if (tile >= ntiles) break;
+        kt = k_begin(tile);
+        nk = k_end(tile);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing dummy DMA must not outlive the LDS allocation
 }
@@ -520,9 +540,10 @@ int launch(const GemmArgs& g, hipStream_t st) {
     const bool wide_ok = sizeof(OutT) != 2 || (!((uintptr_t)g.C & 15) && !(g.ldc & 7) &&
                                                !(g.N & (EPI == SWIFTK_EPI_SWIGLU ? 15 : 7)));  // 16-B row chunks
     if (g_variant == 0 || (g.M & 7) || (g.N & 7) || !wide_ok) {  // ragged edges: per-lane clamped sources
+        if (g.ksplit != 1) return SWIFTK_ESHAPE;
         hipLaunchKernelGGL(kern, dim3(ntm * g.ntn), dim3(NT), 0, st, g);
     } else {
-        const int ntiles = ntm * g.ntn;
+        const int ntiles = ntm * g.ntn * g.ksplit;
         const int grid = ntiles < g_persist_wgs ? ntiles : g_persist_wgs;
         hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
     }
@@ -584,10 +605,11 @@ extern "C" int64_t swiftk_gemm_k_pad(int dtype, int64_t k) {
     return (k + g - 1) / g * g;
 }
 
-extern "C" int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
-                           int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, const float* ep0, const float* ep1,
-                           int64_t pos_rows, void* stream) {
-    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return SWIFTK_EINVAL;
+static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                     int64_t K, int dtype, int out_dtype, int epilogue, const float* ep0, const float* ep1, int64_t pos_rows,
+                     int ksplit, int64_t c_split, void* stream) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || ksplit < 1) return SWIFTK_EINVAL;
+    if (ksplit > 1 && (out_dtype != SWIFTK_F32 || epilogue != SWIFTK_EPI_NONE || c_split < M * ldc)) return SWIFTK_EINVAL;
     if (dtype != SWIFTK_F32 && dtype != SWIFTK_BF16) return SWIFTK_EINVAL;
     if (out_dtype != SWIFTK_F32 && out_dtype != dtype) return SWIFTK_EINVAL;
     const int es = dtype == SWIFTK_BF16 ? 2 : 4, os = out_dtype == SWIFTK_BF16 ? 2 : 4;
@@ -615,10 +637,24 @@ extern "C" int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ld
     g.pos_rows = (int)pos_rows;
     g.ntn = (int)((N + BN - 1) / BN);
     g.dbg = g_dbg;
+    g.ksplit = ksplit;
+    g.c_split = c_split;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == SWIFTK_BF16) {
         if (out_dtype == SWIFTK_BF16) return dispatch_epi<bf16_t, bf16_t>(epilogue, g, st);
         return dispatch_epi<bf16_t, float>(epilogue, g, st);
     }
     return dispatch_epi<float, float>(epilogue, g, st);
+}
+
+extern "C" int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
+                           int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, const float* ep0, const float* ep1,
+                           int64_t pos_rows, void* stream) {
+    return gemm_impl(A, lda, W, ldw, C, ldc, M, N, K, dtype, out_dtype, epilogue, ep0, ep1, pos_rows, 1, 0, stream);
+}
+
+extern "C" int swiftk_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, float* slabs, int64_t ldc,
+                                  int64_t slab_stride, int64_t M, int64_t N, int64_t K, int dtype, int ksplit, void* stream) {
+    return gemm_impl(A, lda, W, ldw, slabs, ldc, M, N, K, dtype, SWIFTK_F32, SWIFTK_EPI_NONE, nullptr, nullptr, 0, ksplit,
+                     slab_stride, stream);
 }

@@ -1,0 +1,544 @@
+// Backward-pass and loss kernels of the training step (reference src/swift/training/{trainer,loss}.py) for gfx950.
+// All HBM-bound; the MFMA work of the backward pass reuses gemm.hip (dgrad: A = dY, W = W^T copy; wgrad: A = dY^T,
+// W = X^T with split-K fp32 slabs) and attention_bwd.hip.
+#include "common.h"
+
+namespace {
+
+inline int grid_for(int64_t work_items, int per_block = 256, int cap = 256 * 16) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p);
+template <>
+__device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
+// ------------------------------------------------------------------------------------------ transpose
+// dst[c][r] = src[r][c], 64x64 tiles through LDS (+1 padding), columns [rows, ldd) of dst zero-filled.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, int64_t lds, T* __restrict__ dst,
+                                                        int64_t ldd, int64_t rows, int64_t cols) {
+    __shared__ T tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t r = r0 + ty + 4 * i, c = c0 + tx;
+        tile[ty + 4 * i][tx] = (r < rows && c < cols) ? src[r * lds + c] : T(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t c = c0 + ty + 4 * i, r = r0 + tx;
+        if (c < cols && r < ldd) dst[c * ldd + r] = tile[tx][ty + 4 * i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ slab reduction
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int64_t ld_slab,
+                                                           int64_t slab_stride, int nslabs, float* __restrict__ out,
+                                                           int64_t ld_out, int64_t rows, int64_t cols, int accumulate) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols, c = i - r * cols;
+        float s = accumulate ? out[r * ld_out + c] : 0.f;
+        for (int k = 0; k < nslabs; ++k) s += slabs[k * slab_stride + r * ld_slab + c];
+        out[r * ld_out + c] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ SwiGLU (unfused form)
+// h [M, 2*mlp] with columns interleaved (gate_j, up_j) -> hmid[m][j] = silu(gate) * up   (swinv2.py:99-100)
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* __restrict__ h, int64_t ldh, T* __restrict__ o, int64_t ldo,
+                                                         int64_t M, int mlp) {
+    const int64_t total = M * mlp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / mlp;
+        const int j = (int)(i - m * mlp);
+        const float g = ldf(h + m * ldh + 2 * j), u = ldf(h + m * ldh + 2 * j + 1);
+        o[m * ldo + j] = elem<T>::from_f(g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)) * u);
+    }
+}
+// dh[m][2j] = dho * up * (s + g s (1-s)),  dh[m][2j+1] = dho * g s,   s = sigmoid(gate)
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ h, int64_t ldh, const T* __restrict__ dho,
+                                                         int64_t ldo, T* __restrict__ dh, int64_t lddh, int64_t M, int mlp) {
+    const int64_t total = M * mlp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / mlp;
+        const int j = (int)(i - m * mlp);
+        const float g = ldf(h + m * ldh + 2 * j), u = ldf(h + m * ldh + 2 * j + 1), d = ldf(dho + m * ldo + j);
+        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
+        dh[m * lddh + 2 * j] = elem<T>::from_f(d * u * (s + g * s * (1.0f - s)));
+        dh[m * lddh + 2 * j + 1] = elem<T>::from_f(d * g * s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ modnorm backward
+// out = LN(y; gamma, beta) * (1 + sc_b) + sh_b,  upstream g = dL/dout (fp32 [M, d]).
+//   dy = rstd * (dn - mean(dn) - n * mean(dn * n)),  dn = g (1+sc) gamma,  n = (y - mu) rstd
+//   dgamma += sum_rows g (1+sc) n,  dbeta += sum_rows g (1+sc),  dsc_b += sum_rows g ln,  dsh_b += sum_rows g
+// One wave per chunk of ROWS_PER_WAVE rows of ONE sample; column sums live in registers and leave as fp32 atomics.
+template <typename T, int SLOTS>
+__global__ __launch_bounds__(256) void modnorm_bwd_kernel(const T* __restrict__ y, int64_t ldy, const float* __restrict__ g,
+                                                          T* __restrict__ dy, int64_t lddy, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ mod,
+                                                          int64_t ldmod, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ dmod, int64_t lddmod, int64_t M, int d,
+                                                          int64_t rps, int rows_per_wave, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nc = d >> 2;  // float4 slots
+    const int64_t chunks_per_sample = (rps + rows_per_wave - 1) / rows_per_wave;
+    const int64_t nchunks = (M / rps) * chunks_per_sample;
+    for (int64_t ch = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ch < nchunks; ch += (int64_t)gridDim.x * 4) {
+        const int64_t b = ch / chunks_per_sample;
+        const int64_t r0 = b * rps + (ch - b * chunks_per_sample) * rows_per_wave;
+        const int64_t r1 = min(r0 + rows_per_wave, (b + 1) * rps);
+        const float* mrow = mod + b * ldmod;
+        float ga[SLOTS][4], be[SLOTS][4], sc[SLOTS][4];
+        float a_dg[SLOTS][4], a_db[SLOTS][4], a_ds[SLOTS][4], a_dh[SLOTS][4];
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = lane + 64 * i;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = c < nc;
+                ga[i][e] = ok ? gamma[4 * c + e] : 0.f;
+                be[i][e] = ok ? beta[4 * c + e] : 0.f;
+                sc[i][e] = ok ? mrow[4 * c + e] : 0.f;
+                a_dg[i][e] = a_db[i][e] = a_ds[i][e] = a_dh[i][e] = 0.f;
+            }
+        }
+        for (int64_t row = r0; row < r1; ++row) {
+            float v[SLOTS][4], gg[SLOTS][4];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) {
+                const int c = lane + 64 * i;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[i][e] = c < nc ? ldf(y + row * ldy + 4 * c + e) : 0.f;
+                    gg[i][e] = c < nc ? g[row * d + 4 * c + e] : 0.f;
+                    sum += v[i][e];
+                }
+            }
+            const float mean = wave_sum(sum) / (float)d;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = (lane + 64 * i < nc) ? v[i][e] - mean : 0.f;
+                    v[i][e] = t;
+                    sq += t * t;
+                }
+            const float rstd = rsqrtf(wave_sum(sq) / (float)d + eps);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float n = v[i][e] * rstd;
+                    const float dl = gg[i][e] * (1.0f + sc[i][e]);  // dL/d ln
+                    a_dg[i][e] += dl * n;
+                    a_db[i][e] += dl;
+                    a_ds[i][e] += gg[i][e] * (n * ga[i][e] + be[i][e]);
+                    a_dh[i][e] += gg[i][e];
+                    const float dn = dl * ga[i][e];
+                    v[i][e] = n;
+                    gg[i][e] = dn;
+                    s1 += dn;
+                    s2 += dn * n;
+                }
+            s1 = wave_sum(s1) / (float)d;
+            s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nc) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        dy[row * lddy + 4 * c + e] = elem<T>::from_f(rstd * (gg[i][e] - s1 - v[i][e] * s2));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(dgamma + 4 * c + e, a_dg[i][e]);
+                    atomicAdd(dbeta + 4 * c + e, a_db[i][e]);
+                    atomicAdd(dmod + b * lddmod + 4 * c + e, a_ds[i][e]);
+                    atomicAdd(dmod + b * lddmod + d + 4 * c + e, a_dh[i][e]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ QK-norm backward
+// Forward (SWIFTK_EPI_QKNORM): qh = tau_h * q/|q|, kh = k/|k|, v unchanged; rn = 1/max(|.|, 1e-12) saved per vector.
+//   dq = tau rn (dqh - u (u . dqh)), u = qh/tau;   dk = rn (dkh - kh (kh . dkh));   dv = dvh
+//   d scale_h += tau * sum_tokens (u . dqh)   (zero when the clamp at ln 100 is active)
+// One lane per (token, 88-vector); a wave takes 64 consecutive vectors (rows are contiguous in memory).
+template <typename T>
+__global__ __launch_bounds__(256) void qknorm_bwd_kernel(const T* __restrict__ qkvh, const T* __restrict__ dqkvh,
+                                                         int64_t ld, const float* __restrict__ rn, T* __restrict__ dqkv,
+                                                         int64_t ldo, const float* __restrict__ scale,
+                                                         float* __restrict__ dscale, int64_t M, int heads, int hd) {
+    const int nvec = 3 * heads;
+    const int64_t total = M * nvec;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / nvec;
+        const int v = (int)(i - m * nvec), kind = v % 3, h = v / 3;
+        const T* a = qkvh + m * ld + (int64_t)v * hd;
+        const T* da = dqkvh + m * ld + (int64_t)v * hd;
+        T* o = dqkv + m * ldo + (int64_t)v * hd;
+        if (kind == 2) {
+            for (int e = 0; e < hd; ++e) o[e] = da[e];
+            continue;
+        }
+        const float s = scale[h];
+        const float tau = kind == 0 ? expf(fminf(s, 4.605170185988092f)) : 1.0f;
+        const float r = rn[i];
+        float dot = 0.f;
+        for (int e = 0; e < hd; ++e) dot += ldf(a + e) * ldf(da + e);
+        dot /= tau;  // u . d(qh)   (a = tau u)
+        const float f = tau * r;
+        for (int e = 0; e < hd; ++e) o[e] = elem<T>::from_f(f * (ldf(da + e) - (ldf(a + e) / tau) * dot));
+        if (kind == 0 && s < 4.605170185988092f) atomicAdd(dscale + h, tau * dot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ column sums
+// out[c] (+)= sum_r src[r][c]   (bias / pos_embed gradients); pos: out[(r % period)][c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ out,
+                                                     int64_t rows, int cols, int64_t period, int rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        if (period > 0) {
+            for (int64_t r = r0; r < min(r0 + rows_per_block, rows); ++r) atomicAdd(out + (r % period) * cols + c, src[r * lds + c]);
+        } else {
+            float s = 0.f;
+            for (int64_t r = r0; r < min(r0 + rows_per_block, rows); ++r) s += src[r * lds + c];
+            atomicAdd(out + c, s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ small linear backward
+// y[b][n] = act(x[b][:] . W[n][:] + bias[n]) with B <= 64 (time-embedding MLP, modulation, logvar)
+//   dz = dy * act'(z) (act = SiLU needs y's pre-activation z; we recompute from y via saved z),
+//   dx[b][k] = sum_n dz[b][n] W[n][k],  dW[n][k] += sum_b dz[b][n] x[b][k],  dbias[n] += sum_b dz[b][n]
+__global__ __launch_bounds__(256) void small_dgrad_kernel(const float* __restrict__ dz, int64_t lddz,
+                                                          const float* __restrict__ W, int64_t ldw, float* __restrict__ dx,
+                                                          int64_t lddx, int B, int N, int K, int n_chunk) {
+    // block (k-slab of 256, n-chunk): partial sums over its n range, atomically added
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int n0 = blockIdx.y * n_chunk, n1 = min(n0 + n_chunk, N);
+    if (k >= K) return;
+    for (int b = 0; b < B; ++b) {
+        float s = 0.f;
+        for (int n = n0; n < n1; ++n) s += dz[(int64_t)b * lddz + n] * W[(int64_t)n * ldw + k];
+        atomicAdd(dx + (int64_t)b * lddx + k, s);
+    }
+}
+__global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restrict__ dz, int64_t lddz,
+                                                          const float* __restrict__ x, int64_t ldx, float* __restrict__ dW,
+                                                          int64_t lddw, float* __restrict__ dbias, int B, int N, int K) {
+    const int n = blockIdx.x;
+    float db = 0.f;
+    for (int b = 0; b < B; ++b) db += dz[(int64_t)b * lddz + n];
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dz[(int64_t)b * lddz + n] * x[(int64_t)b * ldx + k];
+        dW[(int64_t)n * lddw + k] += s;
+    }
+    if (dbias && threadIdx.x == 0) dbias[n] += db;
+}
+// dz = dy * silu'(z): silu'(z) = s (1 + z (1 - s))
+__global__ void silu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dy, float* __restrict__ dz, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = 1.0f / (1.0f + expf(-z[i]));
+    dz[i] = dy[i] * s * (1.0f + z[i] * (1.0f - s));
+}
+
+// ------------------------------------------------------------------------------------------ losses
+// almost-fair CRPS over an ensemble of m members (training/loss.py:343-371), weighted and reduced:
+//   loss = 1/(B H W) sum_{b,c,h,w} w_var[c] w_lat[h] ( mean_i |x_i - y| - (1-eps)/(2 m (m-1)) sum_{i != j} |x_i - x_j| )
+// preds [m][B,C,H,W]; dpreds (same layout, optional) receives dloss/dpreds * gscale.
+__global__ __launch_bounds__(256) void crps_kernel(const float* __restrict__ preds, const float* __restrict__ target,
+                                                   const float* __restrict__ w_var, const float* __restrict__ w_lat,
+                                                   float* __restrict__ loss, float* __restrict__ dpreds, int m, int64_t n,
+                                                   int C, int H, int W, float alpha, float gscale, float inv_bhw) {
+    const float eps = (1.0f - alpha) / (float)m;
+    const float cs = (1.0f - eps) / (2.0f * m * (m - 1));
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int h = (int)((i / W) % H), c = (int)((i / ((int64_t)W * H)) % C);
+        const float w = w_var[c] * w_lat[h];
+        const float y = target[i];
+        float skill = 0.f, spread = 0.f;
+        for (int a = 0; a < m; ++a) {
+            const float xa = preds[(int64_t)a * n + i];
+            skill += fabsf(xa - y);
+            float ga = 0.f;
+            for (int b2 = 0; b2 < m; ++b2) {
+                const float xb = preds[(int64_t)b2 * n + i];
+                spread += fabsf(xa - xb);
+                ga += (xa > xb) - (xa < xb);
+            }
+            if (dpreds) {
+                const float sg = (float)((xa > y) - (xa < y));
+                dpreds[(int64_t)a * n + i] = gscale * inv_bhw * w * (sg / m - cs * 2.0f * ga);
+            }
+        }
+        acc += w * (skill / m - cs * spread);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv_bhw);
+}
+
+// TrigFlow (training/loss.py:132-160): prep  x_t/sd = (cos t x + sin t sd z)/sd,  v_t = cos t sd z - sin t x
+__global__ __launch_bounds__(256) void trigflow_prep_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                                                            const float* __restrict__ t, float* __restrict__ xt_over_sd,
+                                                            float* __restrict__ vt, float sd, int64_t per_sample, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float tt = t[i / per_sample], c = cosf(tt), s = sinf(tt);
+        const float zz = z[i] * sd;
+        xt_over_sd[i] = (c * x[i] + s * zz) / sd;
+        vt[i] = c * zz - s * x[i];
+    }
+}
+// loss = 1/(B H W) sum [ exp(-lv_b) w (sd F - v)^2 + lv_b ];  dF, dlv optional
+__global__ __launch_bounds__(256) void trigflow_loss_kernel(const float* __restrict__ F, const float* __restrict__ vt,
+                                                            const float* __restrict__ logvar, const float* __restrict__ w_var,
+                                                            const float* __restrict__ w_lat, float* __restrict__ loss,
+                                                            float* __restrict__ dF, float* __restrict__ dlogvar, float sd,
+                                                            int64_t n, int C, int H, int W, float gscale, float inv_bhw) {
+    float acc = 0.f;
+    const int64_t per_sample = (int64_t)C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int h = (int)((i / W) % H), c = (int)((i / ((int64_t)W * H)) % C);
+        const int64_t b = i / per_sample;
+        const float lv = logvar ? logvar[b] : 0.f, iv = expf(-lv);
+        const float w = w_var[c] * w_lat[h];
+        const float r = sd * F[i] - vt[i];
+        acc += iv * w * r * r + lv;
+        if (dF) dF[i] = gscale * inv_bhw * 2.0f * sd * iv * w * r;
+        if (dlogvar) atomicAdd(dlogvar + b, gscale * inv_bhw * (1.0f - iv * w * r * r));
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv_bhw);
+}
+
+// out = a[b] * x + c[b] * y  (per-sample coefficients, fp32)
+__global__ __launch_bounds__(256) void axpby_ps_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                       const float* __restrict__ x, const float* __restrict__ c,
+                                                       const float* __restrict__ y, int64_t per_sample, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / per_sample;
+        out[i] = a[b] * x[i] + (y ? c[b] * y[i] : 0.f);
+    }
+}
+
+// cond update of the multistep loss / rollout with gradient: x_next_std = x_std + y * (st/sx)   and its transpose
+__global__ __launch_bounds__(256) void chan_axpy_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                        const float* __restrict__ y, const float* __restrict__ coef, int C,
+                                                        int64_t hw, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i / hw) % C);
+        out[i] = (x ? x[i] : 0.f) + coef[c] * y[i];
+    }
+}
+
+}  // namespace
+
+#define DT_SWITCH(dtype, CALL_BF16, CALL_F32) \
+    if (dtype == SWIFTK_BF16) { CALL_BF16; } else if (dtype == SWIFTK_F32) { CALL_F32; } else return SWIFTK_EINVAL
+
+extern "C" int swiftk_transpose(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype,
+                                void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || lds < cols || ldd < rows) return SWIFTK_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((ldd + 63) / 64));
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, st, static_cast<const bf16_t*>(src), lds,
+                                 static_cast<bf16_t*>(dst), ldd, rows, cols),
+              hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, st, static_cast<const float*>(src), lds,
+                                 static_cast<float*>(dst), ldd, rows, cols));
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_reduce_slabs(const float* slabs, int64_t ld_slab, int64_t slab_stride, int nslabs, float* out,
+                                   int64_t ld_out, int64_t rows, int64_t cols, int accumulate, void* stream) {
+    if (!slabs || !out || nslabs <= 0 || rows <= 0 || cols <= 0) return SWIFTK_EINVAL;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, static_cast<hipStream_t>(stream), slabs,
+                       ld_slab, slab_stride, nslabs, out, ld_out, rows, cols, accumulate);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_swiglu_fwd(const void* h, int64_t ldh, void* out, int64_t ldo, int64_t M, int mlp, int dtype,
+                                 void* stream) {
+    if (!h || !out || M <= 0 || mlp <= 0) return SWIFTK_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(M * mlp);
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL(swiglu_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(h), ldh,
+                                 static_cast<bf16_t*>(out), ldo, M, mlp),
+              hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(h), ldh,
+                                 static_cast<float*>(out), ldo, M, mlp));
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_swiglu_bwd(const void* h, int64_t ldh, const void* dout, int64_t ldo, void* dh, int64_t lddh, int64_t M,
+                                 int mlp, int dtype, void* stream) {
+    if (!h || !dout || !dh || M <= 0 || mlp <= 0) return SWIFTK_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(M * mlp);
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL(swiglu_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(h), ldh,
+                                 static_cast<const bf16_t*>(dout), ldo, static_cast<bf16_t*>(dh), lddh, M, mlp),
+              hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(h), ldh,
+                                 static_cast<const float*>(dout), ldo, static_cast<float*>(dh), lddh, M, mlp));
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_modnorm_bwd(const void* y, int64_t ldy, const float* g, void* dy, int64_t lddy, const float* gamma,
+                                  const float* beta, const float* mod, int64_t ldmod, float* dgamma, float* dbeta, float* dmod,
+                                  int64_t lddmod, int64_t M, int d, int64_t rows_per_sample, float eps, int dtype,
+                                  void* stream) {
+    if (!y || !g || !dy || !gamma || !beta || !mod || !dgamma || !dbeta || !dmod || M <= 0 || rows_per_sample <= 0)
+        return SWIFTK_EINVAL;
+    if (d % 4 || d > 1536 || M % rows_per_sample) return SWIFTK_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rpw = 32;
+    const int64_t nchunks = (M / rows_per_sample) * ((rows_per_sample + rpw - 1) / rpw);
+    const int grid = grid_for(nchunks, 4, 256 * 8);
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL((modnorm_bwd_kernel<bf16_t, 6>), dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(y),
+                                 ldy, g, static_cast<bf16_t*>(dy), lddy, gamma, beta, mod, ldmod, dgamma, dbeta, dmod, lddmod, M,
+                                 d, rows_per_sample, rpw, eps),
+              hipLaunchKernelGGL((modnorm_bwd_kernel<float, 6>), dim3(grid), dim3(256), 0, st, static_cast<const float*>(y), ldy,
+                                 g, static_cast<float*>(dy), lddy, gamma, beta, mod, ldmod, dgamma, dbeta, dmod, lddmod, M, d,
+                                 rows_per_sample, rpw, eps));
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_qknorm_bwd(const void* qkvh, const void* dqkvh, int64_t ld, const float* rn, void* dqkv, int64_t ldo,
+                                 const float* scale, float* dscale, int64_t M, int heads, int head_dim, int dtype,
+                                 void* stream) {
+    if (!qkvh || !dqkvh || !rn || !dqkv || !scale || !dscale || M <= 0) return SWIFTK_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(M * 3 * heads);
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL(qknorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(qkvh),
+                                 static_cast<const bf16_t*>(dqkvh), ld, rn, static_cast<bf16_t*>(dqkv), ldo, scale, dscale, M,
+                                 heads, head_dim),
+              hipLaunchKernelGGL(qknorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(qkvh),
+                                 static_cast<const float*>(dqkvh), ld, rn, static_cast<float*>(dqkv), ldo, scale, dscale, M,
+                                 heads, head_dim));
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_colsum(const float* src, int64_t lds, float* out, int64_t rows, int cols, int64_t period, void* stream) {
+    if (!src || !out || rows <= 0 || cols <= 0) return SWIFTK_EINVAL;
+    const int rpb = 64;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       src, lds, out, rows, cols, period, rpb);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_linear_small_bwd(const float* dz, int64_t lddz, const float* x, int64_t ldx, const float* W, int64_t ldw,
+                                       float* dx, int64_t lddx, float* dW, int64_t lddw, float* dbias, int B, int N, int K,
+                                       void* stream) {
+    if (!dz || !W || B <= 0 || N <= 0 || K <= 0 || B > 64) return SWIFTK_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dx) {  // caller zero-fills dx (partial sums over n-chunks are added atomically)
+        const int n_chunk = 512;
+        hipLaunchKernelGGL(small_dgrad_kernel, dim3((K + 255) / 256, (N + n_chunk - 1) / n_chunk), dim3(256), 0, st, dz, lddz, W,
+                           ldw, dx, lddx, B, N, K, n_chunk);
+        SWIFTK_CHECK_LAUNCH();
+    }
+    if (dW) {
+        if (!x) return SWIFTK_EINVAL;
+        hipLaunchKernelGGL(small_wgrad_kernel, dim3(N), dim3(256), 0, st, dz, lddz, x, ldx, dW, lddw, dbias, B, N, K);
+        SWIFTK_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int swiftk_silu_bwd(const float* z, const float* dy, float* dz, int64_t n, void* stream) {
+    if (!z || !dy || !dz || n <= 0) return SWIFTK_EINVAL;
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), z, dy,
+                       dz, n);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_crps_loss(const float* preds, const float* target, const float* w_var, const float* w_lat, float* loss,
+                                float* dpreds, int m, int B, int C, int H, int W, float alpha, float gscale, void* stream) {
+    if (!preds || !target || !w_var || !w_lat || !loss || m < 2 || B <= 0) return SWIFTK_EINVAL;
+    const int64_t n = (int64_t)B * C * H * W;
+    hipLaunchKernelGGL(crps_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), preds, target, w_var,
+                       w_lat, loss, dpreds, m, n, C, H, W, alpha, gscale, 1.0f / ((float)B * H * W));
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_trigflow_prep(const float* x, const float* z, const float* t, float* xt_over_sd, float* vt,
+                                    float sigma_data, int B, int64_t per_sample, void* stream) {
+    if (!x || !z || !t || !xt_over_sd || !vt || B <= 0) return SWIFTK_EINVAL;
+    const int64_t n = (int64_t)B * per_sample;
+    hipLaunchKernelGGL(trigflow_prep_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, z, t,
+                       xt_over_sd, vt, sigma_data, per_sample, n);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_trigflow_loss(const float* F, const float* vt, const float* logvar, const float* w_var,
+                                    const float* w_lat, float* loss, float* dF, float* dlogvar, float sigma_data, int B, int C,
+                                    int H, int W, float gscale, void* stream) {
+    if (!F || !vt || !w_var || !w_lat || !loss || B <= 0) return SWIFTK_EINVAL;
+    const int64_t n = (int64_t)B * C * H * W;
+    hipLaunchKernelGGL(trigflow_loss_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), F, vt, logvar,
+                       w_var, w_lat, loss, dF, dlogvar, sigma_data, n, C, H, W, gscale, 1.0f / ((float)B * H * W));
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_axpby_per_sample(float* out, const float* a, const float* x, const float* c, const float* y, int B,
+                                       int64_t per_sample, void* stream) {
+    if (!out || !a || !x || B <= 0 || (y && !c)) return SWIFTK_EINVAL;
+    const int64_t n = (int64_t)B * per_sample;
+    hipLaunchKernelGGL(axpby_ps_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), out, a, x, c, y,
+                       per_sample, n);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_channel_axpy(float* out, const float* x, const float* y, const float* coef, int B, int C, int64_t hw,
+                                   void* stream) {
+    if (!out || !y || !coef || B <= 0 || C <= 0) return SWIFTK_EINVAL;
+    const int64_t n = (int64_t)B * C * hw;
+    hipLaunchKernelGGL(chan_axpy_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), out, x, y, coef, C,
+                       hw, n);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,334 @@
+"""Forward-with-activations and backward of the SwinV2 denoiser on the gfx950 kernels (training step).
+
+The reference trains under ``torch.autocast(bfloat16)`` (training/trainer.py:189-197) and lets autograd differentiate
+the ATen graph.  Here the backward pass is explicit: every product is a hand-written kernel called through the C ABI --
+``swiftk_gemm`` for the data gradients (A = dY, operand = W^T copy), ``swiftk_gemm_splitk`` + ``swiftk_reduce_slabs``
+for the weight gradients (A = dY^T, operand = X^T, contraction over all tokens split across workgroups),
+``swiftk_window_attention_bwd`` / ``swiftk_qknorm_bwd`` / ``swiftk_modnorm_bwd`` / ``swiftk_swiglu_bwd`` for the rest.
+Activations are saved per layer (3.4 GB per sample at Swift-B; the multistep loss recomputes one rollout step at a time,
+as the reference's ``checkpoint_sequential`` does).  Parameter gradients accumulate into ``param.grad`` (fp32).
+
+bf16 GEMM operands, fp32 accumulation, fp32 residual stream / normalisation statistics / gradients of the residual
+stream -- the same precision split as the inference engine.  Only head_dim 88 (Swift-B) is supported.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+from ._lib import (ATTN_PRENORM, BF16, EPI_BIAS_POS, EPI_NONE, EPI_QKNORM, F32, SwiftkError, check, lib)
+
+_BF = torch.bfloat16
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gemm(a, w, out, epi=EPI_NONE, ep0=None, ep1=None, pos_rows=0):
+    """out[M,N] = a[M,K] @ w[N,K]^T (row-major 2-D tensors, explicit strides)."""
+    M, K = a.shape
+    check(lib().swiftk_gemm(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, w.shape[0],
+                            K, ops.dtype_code(a.dtype), ops.dtype_code(out.dtype), epi, None if ep0 is None else ep0.data_ptr(),
+                            None if ep1 is None else ep1.data_ptr(), pos_rows, _s()), "swiftk_gemm")
+    return out
+
+
+def _transpose(src, rows, cols, ldd=None):
+    """[rows, >=cols] -> [cols, ldd] (ldd >= rows, zero padded)."""
+    ldd = ldd or rows
+    dst = torch.empty(cols, ldd, dtype=src.dtype, device=src.device)
+    check(lib().swiftk_transpose(src.data_ptr(), src.stride(0), dst.data_ptr(), ldd, rows, cols, ops.dtype_code(src.dtype),
+                                 _s()), "swiftk_transpose")
+    return dst
+
+
+class SwinTrainEngine:
+    def __init__(self, module):
+        self.m = module
+        if module.dim // module.heads != 88:
+            raise SwiftkError("the training kernels are built for head_dim 88 (Swift-B)")
+        self._stamp = None
+        self._slabs = None
+
+    # ------------------------------------------------------------------ operands
+    def refresh(self):
+        m = self.m
+        stamp = tuple((p.data_ptr(), p._version) for p in m.parameters())
+        if stamp == self._stamp:
+            return
+        d, mlp = m.dim, m.mlp_dim
+        self.kd, self.kmlp = ops.k_pad(_BF, d), ops.k_pad(_BF, mlp)
+        self.kpe = ops.k_pad(_BF, m.in_channels * m.patch_size[0] * m.patch_size[1])
+        self.kqkv = ops.k_pad(_BF, 3 * d)
+        self.kh = ops.k_pad(_BF, 2 * mlp)
+        po = m.out_channels * m.patch_size[0] * m.patch_size[1]
+        self.kpo = ops.k_pad(_BF, po)
+        cast = lambda w, k: ops.pad_cols(w.detach(), k, _BF)
+        tr = lambda w, k: ops.pad_cols(w.detach().t().contiguous(), k, _BF)  # W^T operand for the data gradient
+        self.L = []
+        for att, ff in m.transformer.layers:
+            w1i = ff.w1.weight.detach().view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)
+            self.L.append(dict(
+                qkv=cast(att.to_qkv.weight, self.kd), qkv_t=tr(att.to_qkv.weight, self.kqkv),
+                wo=cast(att.wo.weight, self.kd), wo_t=tr(att.wo.weight, self.kd),
+                w1=cast(w1i, self.kd), w1_t=tr(w1i, self.kh),
+                w2=cast(ff.w2.weight, self.kmlp), w2_t=tr(ff.w2.weight, self.kd),
+                scale=att.scale.detach().reshape(-1).float().contiguous()))
+        self.pe = cast(m.patch_embed.emb.weight, self.kpe)
+        self.pe_t = tr(m.patch_embed.emb.weight, self.kd)
+        self.head = cast(m.head.head[0].weight, self.kd)
+        self.head_t = tr(m.head.head[0].weight, self.kpo)
+        mods_w, mods_b = [], []
+        for att, ff in m.transformer.layers:
+            mods_w += [att.norm.modulation.weight.detach(), ff.norm.modulation.weight.detach()]
+            mods_b += [att.norm.modulation.bias.detach(), ff.norm.modulation.bias.detach()]
+        self.mod_w, self.mod_b = torch.cat(mods_w, 0).float().contiguous(), torch.cat(mods_b, 0).float().contiguous()
+        half = d // 2
+        self.freqs = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32) / half).to(self.mod_w.device)
+        self._stamp = stamp
+
+    # ------------------------------------------------------------------ helpers
+    def _small(self, x, w, b, act=0):
+        return ops.linear_small(x, w.detach().float().contiguous(), None if b is None else b.detach().float().contiguous(), act)
+
+    def _wgrad(self, dy_t, x_t, rows, cols, out_grad, accumulate=True):
+        """out_grad[rows, cols] (+)= dy_t[rows, M] @ x_t[cols, M]^T via split-K fp32 slabs."""
+        Mtok = dy_t.shape[1]
+        tiles = ((rows + 255) // 256) * ((cols + 351) // 352)
+        ks = max(1, min(32, 512 // tiles, Mtok // 64))
+        need = ks * rows * cols
+        if self._slabs is None or self._slabs.numel() < need:
+            self._slabs = torch.empty(need, dtype=torch.float32, device=dy_t.device)
+        check(lib().swiftk_gemm_splitk(dy_t.data_ptr(), dy_t.stride(0), x_t.data_ptr(), x_t.stride(0), self._slabs.data_ptr(), cols,
+                                       rows * cols, rows, cols, Mtok, BF16, ks, _s()), "swiftk_gemm_splitk")
+        check(lib().swiftk_reduce_slabs(self._slabs.data_ptr(), cols, rows * cols, ks, out_grad.data_ptr(), out_grad.stride(0),
+                                        rows, cols, int(accumulate), _s()), "swiftk_reduce_slabs")
+
+    @staticmethod
+    def _grad_buf(p):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, dtype=torch.float32)
+        return p.grad
+
+    # ------------------------------------------------------------------ forward (saves activations)
+    def forward(self, srcs: Sequence[torch.Tensor], scales: Sequence[float], t, aux, want_logvar=False):
+        self.refresh()
+        m = self.m
+        dev = srcs[0].device
+        B = srcs[0].shape[0]
+        d, heads, mlp = m.dim, m.heads, m.mlp_dim
+        gh, gw = m.grid_size
+        ntok = gh * gw
+        M = B * ntok
+        srcs = [s.contiguous().float() for s in srcs]
+        ctx = dict(B=B, M=M, srcs_ch=[s.shape[1] for s in srcs], scales=list(scales), layers=[])
+        # time embedding -> latent -> modulation
+        t = t.contiguous().float()
+        aux_s = None
+        if m.auxiliary_embed is not None and aux is not None:
+            aux_s = aux.contiguous().float()
+        emb = ops.timestep_embed(t, aux_s, self.freqs,
+                                 None if aux_s is None else m.auxiliary_embed.weight.detach().float().contiguous(),
+                                 None if aux_s is None else m.auxiliary_embed.bias.detach().float().contiguous(), d,
+                                 float(m.timestep_weight))
+        z1 = self._small(emb, m.latent_embed.l1.weight, m.latent_embed.l1.bias, 0)
+        h1 = self._small(emb, m.latent_embed.l1.weight, m.latent_embed.l1.bias, 1)
+        z2 = self._small(h1, m.latent_embed.l2.weight, m.latent_embed.l2.bias, 0)
+        lat = self._small(h1, m.latent_embed.l2.weight, m.latent_embed.l2.bias, 1)
+        mod = ops.linear_small(lat, self.mod_w, self.mod_b, 0)  # [B, depth*2*2d]
+        ctx.update(aux=aux_s, emb=emb, z1=z1, h1=h1, z2=z2, lat=lat, mod=mod)
+        logvar = None
+        if want_logvar:
+            logvar = self._small(lat, m.logvar_embed.weight, m.logvar_embed.bias, 0).reshape(B)
+        # patch embedding
+        ape = ops.patchify(srcs, scales, m.patch_size, self.kpe, _BF)
+        x = torch.empty(M, d, dtype=torch.float32, device=dev)
+        _gemm(ape, self.pe, x, EPI_BIAS_POS, m.patch_embed.emb.bias.detach().float().contiguous(),
+              m.pos_embed.detach().reshape(ntok, d).float().contiguous(), ntok)
+        xT = ops.pad_cols(x, self.kd, _BF)
+        ctx["ape"] = ape
+        do_shift = any(m.shift_size)
+        for i, (att, ff) in enumerate(m.transformer.layers):
+            W = self.L[i]
+            sh = tuple(m.shift_size) if (do_shift and i % 2) else (0, 0)
+            qkvh = torch.empty(M, 3 * d, dtype=_BF, device=dev)
+            rn = torch.empty(M, 3 * heads, dtype=torch.float32, device=dev)
+            _gemm(xT, W["qkv"], qkvh, EPI_QKNORM, W["scale"], rn)
+            a = torch.zeros(M, self.kd, dtype=_BF, device=dev)
+            ops.window_attention(qkvh.view(B, ntok, 3 * d), None, (gh, gw), heads, sh, out=a.view(B, ntok, self.kd),
+                                 flags=ATTN_PRENORM)
+            y1 = torch.empty(M, d, dtype=_BF, device=dev)
+            _gemm(a, W["wo"], y1)
+            xT_mid = torch.zeros(M, self.kd, dtype=_BF, device=dev)
+            msl1 = mod[:, (2 * i) * 2 * d:(2 * i + 1) * 2 * d]
+            ops.modnorm_residual(y1, x, att.norm.norm.weight.detach().float(), att.norm.norm.bias.detach().float(), msl1, ntok,
+                                 xcopy=xT_mid)
+            h = torch.empty(M, 2 * mlp, dtype=_BF, device=dev)
+            _gemm(xT_mid, W["w1"], h)
+            hmid = torch.empty(M, self.kmlp, dtype=_BF, device=dev)
+            if self.kmlp > mlp:
+                hmid.zero_()
+            check(lib().swiftk_swiglu_fwd(h.data_ptr(), h.stride(0), hmid.data_ptr(), hmid.stride(0), M, mlp, BF16, _s()),
+                  "swiftk_swiglu_fwd")
+            y2 = torch.empty(M, d, dtype=_BF, device=dev)
+            _gemm(hmid, W["w2"], y2)
+            xT_out = torch.zeros(M, self.kd, dtype=_BF, device=dev)
+            msl2 = mod[:, (2 * i + 1) * 2 * d:(2 * i + 2) * 2 * d]
+            ops.modnorm_residual(y2, x, ff.norm.norm.weight.detach().float(), ff.norm.norm.bias.detach().float(), msl2, ntok,
+                                 xcopy=xT_out)
+            ctx["layers"].append(dict(xT_in=xT, qkvh=qkvh, rn=rn, att=a, y1=y1, xT_mid=xT_mid, h=h, hmid=hmid, y2=y2, shift=sh))
+            xT = xT_out
+        ctx["xT_final"] = xT
+        po = m.out_channels * m.patch_size[0] * m.patch_size[1]
+        tok = torch.empty(M, po, dtype=torch.float32, device=dev)
+        _gemm(xT, self.head, tok)
+        out = ops.unpatchify_affine(tok.view(B, ntok, po), (B, m.out_channels, *m.image_size), m.patch_size)
+        return (out, logvar, ctx) if want_logvar else (out, ctx)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ctx, dout: torch.Tensor, dlogvar: Optional[torch.Tensor] = None, need_input_grad: Sequence[bool] = ()):
+        """Accumulate parameter gradients into .grad; return input gradients for the sources flagged in need_input_grad."""
+        m = self.m
+        dev = dout.device
+        B, M = ctx["B"], ctx["M"]
+        d, heads, mlp = m.dim, m.heads, m.mlp_dim
+        gh, gw = m.grid_size
+        ntok = gh * gw
+        L = lib()
+        po = m.out_channels * m.patch_size[0] * m.patch_size[1]
+        G = self._grad_buf
+        # ---- head: tok = xT_final @ Whead^T ; dtok = patchify(dout)
+        dtok = ops.patchify([dout.contiguous().float()], [1.0], m.patch_size, self.kpo, _BF)  # [M, kpo] bf16, pad zero
+        # feature order of the head is (c, p1, p2) while patchify emits (p1, p2, c): permute columns accordingly
+        p1, p2 = m.patch_size
+        C = m.out_channels
+        perm = torch.arange(po, device=dev).view(p1 * p2, C).t().reshape(-1)  # head col (c*p1*p2 + pp) <- patchify col pp*C + c
+        dtok_h = torch.zeros_like(dtok)
+        dtok_h[:, :po] = dtok[:, perm]
+        dx = torch.empty(M, d, dtype=torch.float32, device=dev)
+        _gemm(dtok_h, self.head_t, dx)                                     # dgrad -> d xT_final
+        # the split-K kernel wants row counts in multiples of 8: use the zero-padded kpo rows and keep the first po
+        gh_pad = torch.empty(self.kpo, d, dtype=torch.float32, device=dev)
+        self._wgrad(_transpose(dtok_h, M, self.kpo), _transpose(ctx["xT_final"], M, d), self.kpo, d, gh_pad, accumulate=False)
+        G(m.head.head[0].weight).add_(gh_pad[:po])
+        dmod = torch.zeros(B, m.depth * 4 * d, dtype=torch.float32, device=dev)
+        for i in reversed(range(m.depth)):
+            att, ff = m.transformer.layers[i]
+            W, A = self.L[i], ctx["layers"][i]
+            mod = ctx["mod"]
+            # ---- feed-forward branch
+            dy2 = torch.zeros(M, self.kd, dtype=_BF, device=dev)
+            self._modnorm_bwd(A["y2"], dx, dy2, ff.norm.norm, mod[:, (2 * i + 1) * 2 * d:(2 * i + 2) * 2 * d],
+                              dmod[:, (2 * i + 1) * 2 * d:(2 * i + 2) * 2 * d], M, d, ntok)
+            dhmid = torch.empty(M, mlp, dtype=_BF, device=dev)
+            _gemm(dy2, W["w2_t"], dhmid)
+            self._wgrad(_transpose(dy2, M, d), _transpose(A["hmid"], M, mlp), d, mlp, G(ff.w2.weight))
+            dh = torch.zeros(M, self.kh, dtype=_BF, device=dev) if self.kh > 2 * mlp else torch.empty(M, 2 * mlp, dtype=_BF, device=dev)
+            check(L.swiftk_swiglu_bwd(A["h"].data_ptr(), A["h"].stride(0), dhmid.data_ptr(), dhmid.stride(0), dh.data_ptr(),
+                                      dh.stride(0), M, mlp, BF16, _s()), "swiftk_swiglu_bwd")
+            dxt = torch.empty(M, d, dtype=torch.float32, device=dev)
+            _gemm(dh, W["w1_t"], dxt)
+            g1i = torch.empty(2 * mlp, d, dtype=torch.float32, device=dev)
+            self._wgrad(_transpose(dh, M, 2 * mlp), _transpose(A["xT_mid"], M, d), 2 * mlp, d, g1i, accumulate=False)
+            G(ff.w1.weight).add_(g1i.view(mlp, 2, d).permute(1, 0, 2).reshape(2 * mlp, d))  # undo the gate/up interleave
+            ops.axpby(1.0, dx, 1.0, dxt, out=dx)                             # residual + w1 path
+            # ---- attention branch
+            dy1 = torch.zeros(M, self.kd, dtype=_BF, device=dev)
+            self._modnorm_bwd(A["y1"], dx, dy1, att.norm.norm, mod[:, (2 * i) * 2 * d:(2 * i + 1) * 2 * d],
+                              dmod[:, (2 * i) * 2 * d:(2 * i + 1) * 2 * d], M, d, ntok)
+            datt = torch.empty(M, self.kd, dtype=_BF, device=dev)
+            _gemm(dy1, W["wo_t"], datt)  # N = d columns written, row stride kd
+            self._wgrad(_transpose(dy1, M, d), _transpose(A["att"], M, d), d, d, G(att.wo.weight))
+            dqkvh = torch.empty(M, 3 * d, dtype=_BF, device=dev)
+            sh = A["shift"]
+            check(L.swiftk_window_attention_bwd(A["qkvh"].data_ptr(), 3 * d, A["att"].data_ptr(), datt.data_ptr(), self.kd,
+                                                dqkvh.data_ptr(), B, gh, gw, heads, 88, sh[0], sh[1], BF16, _s()),
+                  "swiftk_window_attention_bwd")
+            dqkv = torch.zeros(M, self.kqkv, dtype=_BF, device=dev)
+            dscale = torch.zeros(heads, dtype=torch.float32, device=dev)
+            check(L.swiftk_qknorm_bwd(A["qkvh"].data_ptr(), dqkvh.data_ptr(), 3 * d, A["rn"].data_ptr(), dqkv.data_ptr(), self.kqkv,
+                                      W["scale"].data_ptr(), dscale.data_ptr(), M, heads, 88, BF16, _s()), "swiftk_qknorm_bwd")
+            G(att.scale).add_(dscale.view_as(att.scale))
+            _gemm(dqkv, W["qkv_t"], dxt)
+            self._wgrad(_transpose(dqkv, M, 3 * d), _transpose(A["xT_in"], M, d), 3 * d, d, G(att.to_qkv.weight))
+            ops.axpby(1.0, dx, 1.0, dxt, out=dx)
+        # ---- patch embedding: x0 = ape @ Wpe^T + b + pos
+        G(m.pos_embed).view(ntok, d)  # ensure buffer exists
+        check(L.swiftk_colsum(dx.data_ptr(), d, G(m.patch_embed.emb.bias).data_ptr(), M, d, 0, _s()), "swiftk_colsum")
+        check(L.swiftk_colsum(dx.data_ptr(), d, m.pos_embed.grad.data_ptr(), M, d, ntok, _s()), "swiftk_colsum")
+        dxb = ops.pad_cols(dx, self.kd, _BF)
+        pf = m.in_channels * p1 * p2
+        gpe = torch.empty(d, self.kpe, dtype=torch.float32, device=dev)  # kpe (multiple of 8) columns; the pad ones are 0
+        self._wgrad(_transpose(dxb, M, d), _transpose(ctx["ape"], M, self.kpe), d, self.kpe, gpe, accumulate=False)
+        G(m.patch_embed.emb.weight).add_(gpe[:, :pf])
+        dins: List[Optional[torch.Tensor]] = []
+        if any(need_input_grad):
+            dape = torch.empty(M, pf, dtype=torch.float32, device=dev)
+            _gemm(dxb, self.pe_t[:pf], dape)                                 # [M, pf] grads of the patch features
+            # features are (pp, c) ordered over the concatenated channels: scatter back per source
+            Cin = m.in_channels
+            c0 = 0
+            for k, need in enumerate(need_input_grad):
+                ck = ctx["srcs_ch"][k]
+                if need:
+                    cols = (torch.arange(p1 * p2, device=dev).view(-1, 1) * Cin + torch.arange(c0, c0 + ck, device=dev).view(1, -1))
+                    # unpatchify expects (c, p1, p2) feature order
+                    sub = dape[:, cols.t().reshape(-1)].contiguous()
+                    gk = ops.unpatchify_affine(sub.view(B, ntok, ck * p1 * p2), (B, ck, *m.image_size), m.patch_size)
+                    dins.append(gk * float(ctx["scales"][k]) if ctx["scales"][k] != 1.0 else gk)
+                else:
+                    dins.append(None)
+                c0 += ck
+        # ---- modulation / latent / time embedding (fp32, B rows)
+        self._embed_bwd(ctx, dmod, dlogvar)
+        return dins
+
+    def _modnorm_bwd(self, y, g, dy, ln, mod_slice, dmod_slice, M, d, ntok):
+        check(lib().swiftk_modnorm_bwd(y.data_ptr(), y.stride(0), g.data_ptr(), dy.data_ptr(), dy.stride(0),
+                                       ln.weight.detach().float().data_ptr(), ln.bias.detach().float().data_ptr(),
+                                       mod_slice.data_ptr(), mod_slice.stride(0), self._grad_buf(ln.weight).data_ptr(),
+                                       self._grad_buf(ln.bias).data_ptr(), dmod_slice.data_ptr(), dmod_slice.stride(0), M, d, ntok,
+                                       1e-6, BF16, _s()), "swiftk_modnorm_bwd")
+
+    def _small_bwd(self, dz, x, lin, want_dx=True, w=None, dW=None, db=None):
+        w = lin.weight.detach().float().contiguous() if w is None else w
+        B, N = dz.shape
+        K = w.shape[1]
+        dx = torch.zeros(B, K, dtype=torch.float32, device=dz.device) if want_dx else None
+        dW = self._grad_buf(lin.weight) if dW is None else dW
+        db = (self._grad_buf(lin.bias) if lin is not None and lin.bias is not None else None) if db is None else db
+        check(lib().swiftk_linear_small_bwd(dz.data_ptr(), dz.stride(0), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+                                            None if dx is None else dx.data_ptr(), K, dW.data_ptr(), dW.stride(0),
+                                            None if db is None else db.data_ptr(), B, N, K, _s()), "swiftk_linear_small_bwd")
+        return dx
+
+    def _embed_bwd(self, ctx, dmod, dlogvar):
+        m = self.m
+        d = m.dim
+        dev = dmod.device
+        # all modulation Linears at once: gradients land in a concatenated buffer, then split onto the parameters
+        dWm = torch.zeros_like(self.mod_w)
+        dbm = torch.zeros_like(self.mod_b)
+        dlat = self._small_bwd(dmod, ctx["lat"], None, w=self.mod_w, dW=dWm, db=dbm)
+        r = 0
+        for att, ff in m.transformer.layers:
+            for mn in (att.norm, ff.norm):
+                self._grad_buf(mn.modulation.weight).add_(dWm[r:r + 2 * d])
+                self._grad_buf(mn.modulation.bias).add_(dbm[r:r + 2 * d])
+                r += 2 * d
+        if dlogvar is not None and m.logvar_embed is not None:
+            dl2 = self._small_bwd(dlogvar.reshape(-1, 1).contiguous().float(), ctx["lat"], m.logvar_embed)
+            ops.axpby(1.0, dlat, 1.0, dl2, out=dlat)
+        dz2 = torch.empty_like(dlat)
+        check(lib().swiftk_silu_bwd(ctx["z2"].data_ptr(), dlat.data_ptr(), dz2.data_ptr(), dz2.numel(), _s()), "swiftk_silu_bwd")
+        dh1 = self._small_bwd(dz2, ctx["h1"], m.latent_embed.l2)
+        dz1 = torch.empty_like(dh1)
+        check(lib().swiftk_silu_bwd(ctx["z1"].data_ptr(), dh1.data_ptr(), dz1.data_ptr(), dz1.numel(), _s()), "swiftk_silu_bwd")
+        demb = self._small_bwd(dz1, ctx["emb"], m.latent_embed.l1, want_dx=(ctx["aux"] is not None))
+        if ctx["aux"] is not None and m.auxiliary_embed is not None:
+            xa = (ctx["aux"] * math.sqrt(m.auxiliary_dim)).contiguous()
+            self._small_bwd(demb, xa, m.auxiliary_embed, want_dx=False)

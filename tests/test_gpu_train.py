@@ -1,0 +1,266 @@
+"""-m gpu: backward-pass and loss kernels (C ABI) against torch autograd of the CPU oracle's formulas.
+
+The training path runs bf16 GEMM operands like the reference's autocast(bfloat16) training (trainer.py:189-197), so
+gradients are compared with fp32 autograd at bf16-level tolerances: per kernel on the SAME rounded inputs
+(1-2e-2 relative L2, layout bugs give O(1)), and end to end by cosine similarity and relative L2 per parameter.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda", 0)
+
+
+def rnd(shape, seed, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * std
+
+
+def s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def test_transpose_and_splitk_wgrad(dev):
+    from swift_amd import _lib
+    from swift_amd.train_engine import _transpose
+    L = _lib.lib()
+    M, N, K = 2048, 1056, 704  # dW[N,K] = dY^T[N,M] @ X[M,K]
+    dy, x = rnd((M, N), 1).to(dev).to(BF), rnd((M, K), 2).to(dev).to(BF)
+    dyt, xt = _transpose(dy, M, N), _transpose(x, M, K)
+    assert torch.equal(dyt, dy.t().contiguous())
+    ks = 4
+    slabs = torch.empty(ks, N, K, dtype=torch.float32, device=dev)
+    rc = L.swiftk_gemm_splitk(dyt.data_ptr(), M, xt.data_ptr(), M, slabs.data_ptr(), K, N * K, N, K, M, _lib.BF16, ks, s())
+    assert rc == 0
+    out = torch.full((N, K), 1.0, device=dev)
+    assert L.swiftk_reduce_slabs(slabs.data_ptr(), K, N * K, ks, out.data_ptr(), K, N, K, 1, s()) == 0
+    ref = dy.float().cpu().double().t() @ x.float().cpu().double() + 1.0
+    assert rel_l2(out.cpu(), ref) < 1e-5
+    # each slab alone is the partial product of its k-range
+    ref0 = dy[: M // ks].float().cpu().double().t() @ x[: M // ks].float().cpu().double()
+    assert rel_l2(slabs[0].cpu(), ref0) < 1e-5
+
+
+def test_swiglu_fwd_bwd(dev):
+    from swift_amd import _lib
+    L = _lib.lib()
+    M, mlp = 300, 2816
+    h = rnd((M, 2 * mlp), 3).to(dev).to(BF)
+    do = rnd((M, mlp), 4).to(dev).to(BF)
+    o, dh = torch.empty(M, mlp, dtype=BF, device=dev), torch.empty(M, 2 * mlp, dtype=BF, device=dev)
+    assert L.swiftk_swiglu_fwd(h.data_ptr(), 2 * mlp, o.data_ptr(), mlp, M, mlp, _lib.BF16, s()) == 0
+    assert L.swiftk_swiglu_bwd(h.data_ptr(), 2 * mlp, do.data_ptr(), mlp, dh.data_ptr(), 2 * mlp, M, mlp, _lib.BF16, s()) == 0
+    hc = h.float().cpu().requires_grad_(True)
+    ref = F.silu(hc[:, 0::2]) * hc[:, 1::2]
+    ref.backward(do.float().cpu())
+    assert rel_l2(o.float().cpu(), ref.detach()) < 4e-3
+    assert rel_l2(dh.float().cpu(), hc.grad) < 4e-3
+
+
+def test_modnorm_bwd(dev):
+    from oracle.swinv2 import modulated_norm
+    from swift_amd import _lib, ops
+    L = _lib.lib()
+    B, rps, d = 2, 96, 1056
+    M = B * rps
+    y = (rnd((M, d), 5, 2.0) + 0.3).to(dev).to(BF)
+    g = rnd((M, d), 6).to(dev)
+    gamma, beta = (1 + 0.1 * rnd((d,), 7)).to(dev), (0.1 * rnd((d,), 8)).to(dev)
+    mod = (0.3 * rnd((B, 3 * 2 * d), 9)).to(dev)
+    msl = mod[:, 2 * d: 4 * d]
+    dy = torch.zeros(M, ops.k_pad(BF, d), dtype=BF, device=dev)
+    dgam, dbet = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    dmod = torch.zeros(B, 3 * 2 * d, device=dev)
+    dsl = dmod[:, 2 * d: 4 * d]
+    rc = L.swiftk_modnorm_bwd(y.data_ptr(), d, g.data_ptr(), dy.data_ptr(), dy.stride(0), gamma.data_ptr(), beta.data_ptr(),
+                              msl.data_ptr(), msl.stride(0), dgam.data_ptr(), dbet.data_ptr(), dsl.data_ptr(), dsl.stride(0), M,
+                              d, rps, 1e-6, _lib.BF16, s())
+    assert rc == 0
+    yc = y.float().cpu().requires_grad_(True)
+    gc, bc = gamma.cpu().requires_grad_(True), beta.cpu().requires_grad_(True)
+    mc = msl.cpu().clone().requires_grad_(True)
+    # modulated_norm(x [B,n,d], lat) computes the modulation Linear itself; feed an identity "Linear"
+    p = {"n.norm.weight": gc, "n.norm.bias": bc}
+    ln = F.layer_norm(yc.view(B, rps, d), (d,), gc, bc, 1e-6)
+    out = ln * (1 + mc[:, None, :d]) + mc[:, None, d:]
+    out.backward(g.cpu().view(B, rps, d))
+    assert rel_l2(dy[:, :d].float().cpu(), yc.grad) < 6e-3
+    assert rel_l2(dgam.cpu(), gc.grad) < 1e-4 and rel_l2(dbet.cpu(), bc.grad) < 1e-4
+    assert rel_l2(dsl.cpu(), mc.grad) < 1e-4
+    assert float(dmod[:, : 2 * d].abs().max()) == 0.0 and float(dy[:, d:].float().abs().max()) == 0.0
+
+
+def _prenorm(qkv, scale, heads, hd):
+    B, n, _ = qkv.shape
+    v = qkv.reshape(B, n, heads, 3, hd)
+    tau = torch.clamp(scale, max=math.log(100.0)).exp().view(1, 1, heads, 1)
+    q = v[:, :, :, 0] / v[:, :, :, 0].norm(dim=-1, keepdim=True).clamp_min(1e-12) * tau
+    k = v[:, :, :, 1] / v[:, :, :, 1].norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    return torch.stack([q, k, v[:, :, :, 2]], dim=3).reshape(B, n, -1)
+
+
+def test_qknorm_epilogue_rn_and_bwd(dev):
+    from swift_amd import _lib, ops
+    L = _lib.lib()
+    M, heads, hd = 512, 12, 88
+    K = ops.k_pad(BF, 1056)
+    a, w = rnd((M, K), 10).to(dev).to(BF), rnd((3 * heads * hd, K), 11, 0.03).to(dev).to(BF)
+    scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 10.0])).to(dev)
+    qkvh = torch.empty(M, 3 * heads * hd, dtype=BF, device=dev)
+    rn = torch.empty(M, 3 * heads, device=dev)
+    rc = L.swiftk_gemm(a.data_ptr(), K, w.data_ptr(), K, qkvh.data_ptr(), 3168, M, 3168, K, _lib.BF16, _lib.BF16, _lib.EPI_QKNORM,
+                       scale.data_ptr(), rn.data_ptr(), 0, s())
+    assert rc == 0
+    raw = (a.float().cpu().double() @ w.float().cpu().double().t()).float().requires_grad_(True)
+    sc = scale.cpu().clone().requires_grad_(True)
+    ref = _prenorm(raw.view(1, M, -1), sc, heads, hd)[0]
+    nr = raw.detach().view(M, heads, 3, hd).norm(dim=-1)
+    nr[:, :, 2] = 1.0
+    assert rel_l2(rn.cpu(), (1.0 / nr).reshape(M, -1)) < 1e-5
+    dq = rnd((M, 3168), 12).to(dev).to(BF)
+    ref.backward(dq.float().cpu())
+    dqkv = torch.zeros(M, ops.k_pad(BF, 3168), dtype=BF, device=dev)
+    dscale = torch.zeros(heads, device=dev)
+    # feed the kernel the exact fp32-derived normalised values rounded to bf16, as the forward would have stored them
+    rc = L.swiftk_qknorm_bwd(qkvh.data_ptr(), dq.data_ptr(), 3168, rn.data_ptr(), dqkv.data_ptr(), dqkv.stride(0),
+                             scale.data_ptr(), dscale.data_ptr(), M, heads, hd, _lib.BF16, s())
+    assert rc == 0
+    assert rel_l2(dqkv[:, :3168].float().cpu(), raw.grad) < 1.5e-2
+    assert rel_l2(dscale.cpu(), sc.grad) < 2e-2
+    assert float(dscale[3]) == 0.0 and float(dscale[8]) == 0.0  # heads clamped at ln(100): no gradient (swinv2.py:125)
+
+
+@pytest.mark.parametrize("shift", [(0, 0), (8, 8)])
+def test_window_attention_bwd(dev, shift):
+    from oracle.swinv2 import window_token_index
+    from swift_amd import _lib, ops
+    L = _lib.lib()
+    B, grid, heads, hd = 2, (32, 32), 12, 88
+    n = grid[0] * grid[1]
+    scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 60.0, 1.0, 10.0, 50.0, 20.0, 15.0, 5.0, 20.0, 10.0]))
+    pre = _prenorm(rnd((B, n, 3 * heads * hd), 13), scale, heads, hd).to(dev).to(BF)
+    o = ops.window_attention(pre, None, grid, heads, shift, flags=_lib.ATTN_PRENORM)
+    do = rnd((B, n, heads * hd), 14).to(dev).to(BF)
+    dpre = torch.empty_like(pre)
+    rc = L.swiftk_window_attention_bwd(pre.data_ptr(), 3168, o.data_ptr(), do.data_ptr(), 1056, dpre.data_ptr(), B, grid[0],
+                                       grid[1], heads, hd, shift[0], shift[1], _lib.BF16, s())
+    assert rc == 0
+    idx = window_token_index(grid, (16, 16), shift)
+    pc = pre.float().cpu().requires_grad_(True)
+    src = pc[:, idx.reshape(-1)].reshape(B * idx.shape[0], 256, heads, 3, hd).permute(0, 2, 1, 3, 4)
+    ow = (src[..., 0, :] @ src[..., 1, :].transpose(-2, -1)).softmax(-1) @ src[..., 2, :]
+    ref = torch.zeros(B, n, heads * hd).index_add(1, idx.reshape(-1), ow.permute(0, 2, 1, 3).reshape(B, n, -1))
+    ref.backward(do.float().cpu())
+    g = dpre.float().cpu().view(B, n, heads, 3, hd)
+    gr = pc.grad.view(B, n, heads, 3, hd)
+    for part, name in enumerate("qkv"):
+        e = rel_l2(g[..., part, :], gr[..., part, :])
+        print(f"attention bwd d{name}: rel-L2 {e:.3e}")
+        assert e < 2.5e-2, name
+
+
+def test_loss_kernels(dev):
+    from oracle import loss as oloss
+    from swift_amd import _lib
+    L = _lib.lib()
+    m, B, C, H, W = 2, 2, 5, 16, 32
+    preds, target = rnd((m, B, C, H, W), 15), rnd((B, C, H, W), 16)
+    w_var, w_lat = torch.rand(C) + 0.1, oloss.latitude_weights(H).reshape(-1)
+    pd, td = preds.to(dev), target.to(dev)
+    loss, dp = torch.zeros(1, device=dev), torch.empty_like(pd)
+    assert L.swiftk_crps_loss(pd.data_ptr(), td.data_ptr(), w_var.to(dev).data_ptr(), w_lat.to(dev).data_ptr(), loss.data_ptr(),
+                              dp.data_ptr(), m, B, C, H, W, 0.95, 1.0, s()) == 0
+    pc = preds.clone().requires_grad_(True)
+    ref = (w_var.view(1, C, 1, 1) * w_lat.view(1, 1, H, 1) * oloss.almost_fair_crps(pc, target, 0.95)).sum(1).mean()
+    ref.backward()
+    assert float(loss) == pytest.approx(float(ref), rel=1e-5)
+    assert rel_l2(dp.cpu(), pc.grad) < 1e-5
+    # TrigFlow
+    x, z, t = rnd((B, C, H, W), 17), rnd((B, C, H, W), 18), torch.tensor([0.4, 1.3])
+    Fo, lv = rnd((B, C, H, W), 19), torch.tensor([0.2, -0.3])
+    xt, vt = torch.empty(B, C, H, W, device=dev), torch.empty(B, C, H, W, device=dev)
+    assert L.swiftk_trigflow_prep(x.to(dev).data_ptr(), z.to(dev).data_ptr(), t.to(dev).data_ptr(), xt.data_ptr(), vt.data_ptr(),
+                                  1.0, B, C * H * W, s()) == 0
+    loss.zero_()
+    dF, dlv = torch.empty(B, C, H, W, device=dev), torch.zeros(B, device=dev)
+    assert L.swiftk_trigflow_loss(Fo.to(dev).data_ptr(), vt.data_ptr(), lv.to(dev).data_ptr(), w_var.to(dev).data_ptr(),
+                                  w_lat.to(dev).data_ptr(), loss.data_ptr(), dF.data_ptr(), dlv.data_ptr(), 1.0, B, C, H, W, 1.0,
+                                  s()) == 0
+    Fc, lc = Fo.clone().requires_grad_(True), lv.clone().requires_grad_(True)
+    net = lambda xx, tt, c, a, return_logvar=False: (Fc, lc)
+    tau = torch.tan(t).view(B, 1, 1, 1)
+    ref = oloss.trigflow_loss(net, x, tau, z, w_var.view(1, C, 1, 1), w_lat.view(1, 1, H, 1), 1.0, return_logvar=True)
+    ref.backward()
+    assert float(loss) == pytest.approx(float(ref), rel=1e-5)
+    assert rel_l2(dF.cpu(), Fc.grad) < 1e-5 and rel_l2(dlv.cpu(), lc.grad) < 1e-4
+    c, sn = torch.cos(t).view(B, 1, 1, 1), torch.sin(t).view(B, 1, 1, 1)
+    assert rel_l2(xt.cpu(), c * x + sn * z) < 1e-6 and rel_l2(vt.cpu(), c * z - sn * x) < 1e-6
+
+
+SMALLB = dict(img=(64, 64), n_vars=69, n_forc=3, window=(16, 16), shift=(8, 8), patch=(2, 2), dim=1056, heads=12, depth=2)
+
+
+def test_train_engine_gradients_vs_oracle_autograd(dev):
+    from oracle.swinv2 import OracleNet, SwinCfg
+    from swift_amd.models.precond import PassPrecond
+    from swift_amd.train_engine import SwinTrainEngine
+    from swift_amd.utils.detinit import det_normal, swinv2_state
+    c, seed = SMALLB, 21
+    nv, nf = c["n_vars"], c["n_forc"]
+    mcfg = dict(_target_="swift.models.swinv2.SwinV2", window_size=[16, 16], shift_size=[8, 8], patch_size=[2, 2],
+                depth=c["depth"], dim=c["dim"], heads=c["heads"], logvar=True)
+    net = PassPrecond(mcfg, img_resolution=list(c["img"]), img_channels=nv, condition_channels=nv + nf, auxiliary_dim=1)
+    state = swinv2_state(grid=(32, 32), in_channels=2 * nv + nf, out_channels=nv, patch_size=(2, 2), depth=c["depth"],
+                         dim=c["dim"], heads=c["heads"], logvar=True, seed=seed)
+    for k in state:  # no head clamped at ln(100) here: keep every scale gradient alive
+        if k.endswith(".scale"):
+            state[k] = state[k].clamp(max=4.0)
+    net.load_state_dict(state)
+    net = net.to(dev)
+    B = 2
+    x, cond = det_normal((B, nv, 64, 64), seed, "x"), det_normal((B, nv + nf, 64, 64), seed, "cond")
+    t, aux = torch.tensor([0.5, 1.4]), torch.tensor([[0.6], [1.2]])
+    R, rl = det_normal((B, nv, 64, 64), seed, "R"), torch.tensor([0.7, -0.4])
+    eng = SwinTrainEngine(net.model)
+    out, lv, ctx = eng.forward([x.to(dev), cond[:, :nv].to(dev), cond[:, nv:].to(dev)], [1.0, 1.0, 1.0], t.to(dev), aux.to(dev),
+                               want_logvar=True)
+    dins = eng.backward(ctx, R.to(dev), rl.to(dev), need_input_grad=(True, True, False))
+    torch.cuda.synchronize()
+    # oracle: fp32 autograd on the CPU
+    st = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    ocfg = SwinCfg(img_resolution=c["img"], in_channels=2 * nv + nf, out_channels=nv, window_size=(16, 16), shift_size=(8, 8),
+                   patch_size=(2, 2), depth=c["depth"], dim=c["dim"], heads=c["heads"], auxiliary_dim=1, logvar=True)
+    onet = OracleNet(ocfg, st, nv, nv + nf)
+    xo, co = x.clone().requires_grad_(True), cond.clone().requires_grad_(True)
+    yo, lvo = onet(xo, t, co, aux, return_logvar=True)
+    ((yo * R).sum() + (lvo * rl).sum()).backward()
+    e_out = rel_l2(out.cpu(), yo.detach())
+    print(f"train-engine forward vs oracle: rel-L2 {e_out:.3e}")
+    assert e_out < 1e-1 and rel_l2(lv.cpu(), lvo.detach()) < 1e-3
+    worst = 0.0
+    named = dict(net.named_parameters())
+    for k, p in named.items():
+        g, gr = p.grad.float().cpu().flatten().double(), st[k].grad.flatten().double()
+        cos = float((g @ gr) / (g.norm() * gr.norm()).clamp_min(1e-30))
+        e = rel_l2(g, gr)
+        worst = max(worst, e)
+        print(f"{k:55s} cos {cos:.4f} rel-L2 {e:.3e}")
+        assert cos > 0.97, (k, cos, e)
+    for gi, ref in ((dins[0], xo.grad), (dins[1], co.grad[:, :nv])):
+        gg, rr = gi.cpu().flatten().double(), ref.flatten().double()
+        cos = float((gg @ rr) / (gg.norm() * rr.norm()))
+        print(f"input grad: cos {cos:.4f} rel-L2 {rel_l2(gg, rr):.3e}")
+        assert cos > 0.97
+    assert dins[2] is None
