@@ -137,6 +137,17 @@ class SwinV2(AbstractNetwork):
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
 
+    def __deepcopy__(self, memo):
+        """EMA copies (trainer.py:87) must not drag the device-side engines (ctypes descriptors) along."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in ("_engines", "_train_engine"):
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        new.__dict__["_engines"] = {}
+        return new
+
     # ------------------------------------------------------------------ engine plumbing
     @staticmethod
     def compute_dtype(device_type: str = "cuda") -> torch.dtype:

@@ -1,0 +1,125 @@
+"""Training entry point -- ``python -m swift_amd.train experiment=... data.batch_size=... resume=... [finetune=multistep]``
+(mirrors reference src/swift/train.py: Hydra-style overrides, run directory ``results/<experiment>/<HYDRA_RUN_ID>``
+with ``.hydra/config.yaml``, resume / finetune hoisting, per-rank seeding, AdamW parameter groups, Trainer wiring).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import sys
+from datetime import datetime
+from glob import glob
+
+import numpy as np
+import torch
+import torch.distributed as tdist
+from torch.utils.data import DataLoader
+
+from . import dist
+from .config import Cfg, compose, instantiate, load_saved, to_yaml
+from .data.samplers import DeltaBatchSampler, InfiniteSampler
+from .generate import get_ckpt_num
+from .models.swinv2 import SwinV2
+
+CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
+
+
+def string_to_int(s: str) -> int:
+    return int(hashlib.sha256(s.encode("utf-8")).hexdigest(), 16) % (1 << 31)
+
+
+def resume_setup(cfg: Cfg):
+    """train.py:44-99: continue from the latest checkpoint of run `cfg.resume`; finetune keys overwrite the old config."""
+    if cfg.get("resume") is None:
+        return cfg, None
+    finetune = cfg.get("finetune")
+    run_dir = cfg.resume
+    if not os.path.isdir(run_dir):
+        run_dir = os.path.join(os.path.dirname(os.getcwd()), str(cfg.resume))
+    assert os.path.isdir(run_dir), FileNotFoundError(f"{run_dir} is not a directory")
+    config = load_saved(os.path.join(run_dir, ".hydra", "config.yaml"))
+    ckpts = sorted(glob(os.path.join(run_dir, "checkpoints", "checkpoint*.pt")), key=get_ckpt_num)
+    assert ckpts, FileNotFoundError(f"No checkpoints in {os.path.join(run_dir, 'checkpoints')}")
+    ckpt = ckpts[-1]
+    if dist.get_rank() == 0:
+        shutil.copytree(os.path.join(run_dir, ".hydra"), os.path.join(os.getcwd(), ".hydra"), dirs_exist_ok=True)
+    if finetune is not None:
+        for k, v in finetune.items():
+            config[k] = v
+        if config.finetune.get("name") == "multistep":
+            config.trainer.total_kimg = get_ckpt_num(ckpt) + sum(iv["kimg"] for iv in config.finetune.get("intervals", []))
+            config.trainer.lr_cosine_anneal = False
+            config.trainer.checkpoint_ticks = 200
+            config.trainer.val_ticks = 50
+        if dist.get_rank() == 0:
+            with open(os.path.join(os.getcwd(), ".hydra", "config.yaml"), "w") as f:
+                f.write(to_yaml(config))
+    dist.log0(f"Resuming from {ckpt}")
+    return config, ckpt
+
+
+def adamw_param_groups(net, weight_decay: float):
+    """no weight decay for pos_embed and LayerNorm affine parameters (train.py:275-286)."""
+    decay, no_decay = [], []
+    for name, p in net.named_parameters():
+        (no_decay if ("pos_embed" in name or ("norm" in name and "modulation" not in name)) else decay).append(p)
+    return [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
+
+
+def main(overrides=None):
+    os.environ.setdefault("HYDRA_RUN_ID", datetime.now().strftime("%Y%m%d_%H%M%S"))
+    cfg = compose(CONFIG_DIR, "train", list(sys.argv[1:] if overrides is None else overrides))
+    run_dir = cfg.hydra.run.dir
+    os.makedirs(os.path.join(run_dir, ".hydra"), exist_ok=True)
+    os.chdir(run_dir)  # hydra.job.chdir: true
+    dist.setup_torch(backend=cfg.system.torch.backend)
+    if dist.get_rank() == 0:
+        with open(os.path.join(".hydra", "config.yaml"), "w") as f:
+            f.write(to_yaml({k: v for k, v in cfg.items() if k != "hydra"}))
+    cfg, ckpt = resume_setup(cfg)
+    if cfg.get("finetune") is not None and ckpt is None:
+        dist.log0("ERROR: must have resume path to finetune")
+        return None
+    cfg.seed = cfg.seed + string_to_int(os.environ["HYDRA_RUN_ID"])
+    np.random.seed((cfg.seed * dist.get_world_size() + dist.get_rank()) % (1 << 31))
+    torch.manual_seed(np.random.randint(1 << 31))
+    device = dist.get_torch_device()
+
+    dataset = instantiate(cfg.data.dataset, _convert_="object")
+    sampler = InfiniteSampler(dataset, rank=dist.get_rank(), num_replicas=dist.get_world_size(), shuffle=True, seed=cfg.seed)
+    local_bs = cfg.data.batch_size // dist.get_world_size()
+    common = dict(dataset=dataset, pin_memory=True, num_workers=cfg.data.data_workers,
+                  prefetch_factor=(2 if cfg.data.data_workers > 0 else None), persistent_workers=cfg.data.data_workers > 0)
+    if cfg.get("finetune") is not None:
+        loader = DataLoader(batch_sampler=DeltaBatchSampler(sampler, local_bs, dataset.intervals, seed=cfg.seed), **common)
+    else:
+        loader = DataLoader(sampler=sampler, batch_size=local_bs, **common)
+
+    net = instantiate(cfg.precond, model_config=cfg.model, img_resolution=dataset.img_resolution,
+                      img_channels=dataset.n_target_channels, condition_channels=dataset.n_condition_channels,
+                      _recursive_=False, _convert_="object")
+    net.train().requires_grad_(True).to(device)
+    if dist.get_world_size() > 1:  # identical initial weights on every rank (DDP's initial broadcast)
+        for p in net.parameters():
+            tdist.broadcast(p.data, src=0)
+
+    target = cfg.optimizer.get("_target_", "")
+    params = net.parameters()
+    if isinstance(net.model, SwinV2) and target in ("torch.optim.Adam", "torch.optim.AdamW"):
+        params = adamw_param_groups(net, cfg.optimizer.weight_decay)
+    elif target.endswith("MuonWithAuxAdam"):
+        raise NotImplementedError("MuonWithAuxAdam is 'next' (SURVEY.md section 8f); use optimizer=adamw")
+    optimizer = instantiate(cfg.optimizer, params, _convert_="object")
+    loss_fn = instantiate(cfg.loss, dataset=dataset, _convert_="object").to(device)
+    trainer_cfg = {k: v for k, v in cfg.trainer.items()}
+    trainer = instantiate(trainer_cfg, net=net, optimizer=optimizer, loss_fn=loss_fn, amp_type=cfg.system.torch.amp_type,
+                          ckpt=ckpt, flop_count=0, solver_kwargs=cfg.get("solver"), finetune_kwargs=cfg.get("finetune"))
+    out = trainer.train(loader, None)
+    if tdist.is_initialized():
+        tdist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

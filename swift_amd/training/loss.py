@@ -1,0 +1,233 @@
+"""TrigFlow and multistep-CRPS losses on the gfx950 training kernels (mirrors reference src/swift/training/loss.py).
+
+Same constructor kwargs and call signatures as the reference's ``TrigFlowLoss`` (:117-160) and ``CRPSLoss`` (:306-445):
+``loss = loss_fn(net_or_ddp, target, condition=x, auxiliary=delta, **kw)``; ``loss.backward()`` accumulates parameter
+gradients.  The backward pass is not an autograd graph: the returned scalar hangs on a one-node ``autograd.Function``
+whose backward runs the explicit kernels of ``train_engine`` (for the multistep loss: one rollout step at a time,
+recomputing that step's activations first -- what the reference does with ``checkpoint_sequential``).
+
+``SCMLoss`` (forward-mode JVP through the network, loss.py:163-260) is listed "next" in SURVEY.md section 8f and is not
+built; instantiating it raises.
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import ops
+from .._lib import check, lib
+from ..models.precond import _process_auxiliary
+from ..train_engine import SwinTrainEngine
+
+PRESSURE_LEVELS = [50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925, 1000]
+LEVEL_VARS = ["geopotential", "u_component_of_wind", "v_component_of_wind", "vertical_velocity", "wind_speed", "temperature",
+              "relative_humidity", "specific_humidity", "vorticity", "potential_vorticity"]
+SURFACE_W = {"2m_temperature": 1.0, "sea_surface_temperature": 0.1, "10m_u_component_of_wind": 0.1,
+             "10m_v_component_of_wind": 0.1, "mean_sea_level_pressure": 0.1}
+
+
+def _calculate_latitude_weights(lat_dim: int) -> torch.Tensor:
+    """cos(latitude) / mean, floored at 0.1 -> [1,1,H,1]  (loss.py:28-32)."""
+    w = torch.cos(torch.deg2rad(torch.linspace(-90, 90, lat_dim)))
+    return torch.clamp(w / w.mean(), min=0.1).view(1, 1, -1, 1)
+
+
+def _calculate_variable_weights(variables: Sequence[str]) -> torch.Tensor:
+    """surface table + level/sum(levels) per pressure level, normalised to 1 -> [1,C,1,1]  (loss.py:35-55)."""
+    tot = float(sum(PRESSURE_LEVELS))
+    table = dict(SURFACE_W)
+    for v in LEVEL_VARS:
+        for lev in PRESSURE_LEVELS:
+            table[f"{v}_{lev}"] = lev / tot
+    w = torch.tensor([table.get(v, 1.0 / max(len(variables), 1)) for v in variables], dtype=torch.float32).view(1, -1, 1, 1)
+    return w / w.sum()
+
+
+def lognormal(x: torch.Tensor, P_mean: float, P_std: float) -> torch.Tensor:
+    return torch.exp(torch.randn([x.shape[0], 1, 1, 1], device=x.device) * P_std + P_mean)
+
+
+def loguniform(x: torch.Tensor, sigma_min: float, sigma_max: float) -> torch.Tensor:
+    lo, hi = math.log(sigma_min), math.log(sigma_max)
+    return torch.exp(lo + torch.rand([x.shape[0], 1, 1, 1], device=x.device) * (hi - lo))
+
+
+NOISE_SAMPLING_METHODS = {"lognormal": lognormal, "loguniform": loguniform}
+
+
+class _Deferred(torch.autograd.Function):
+    """Scalar whose .backward() runs an explicit backward pass (accumulating into param.grad)."""
+
+    @staticmethod
+    def forward(ctx, anchor, runner):
+        ctx.runner = runner
+        return runner.value.detach().clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.runner.run_backward(float(g))
+        return None, None
+
+
+def _engine(net) -> SwinTrainEngine:
+    mod = getattr(net, "module", net)
+    eng = getattr(mod.model, "_train_engine", None)
+    if eng is None:
+        eng = SwinTrainEngine(mod.model)
+        mod.model._train_engine = eng
+    return eng
+
+
+class _LossBase(torch.nn.Module):
+    def __init__(self, dataset, sigma_data: float):
+        super().__init__()
+        self.dataset = dataset
+        self.sigma_data = sigma_data
+        self.register_buffer("w_lat", _calculate_latitude_weights(dataset._shape[1]))
+        self.register_buffer("w_var", _calculate_variable_weights(dataset.variables))
+
+    def _w(self, dev):
+        return self.w_var.reshape(-1).to(dev).contiguous(), self.w_lat.reshape(-1).to(dev).contiguous()
+
+    @staticmethod
+    def _anchor(dev):
+        return torch.zeros((), device=dev, requires_grad=True)
+
+
+class TrigFlowLoss(_LossBase):
+    """loss = mean_{b,h,w} sum_c [ e^{-lv} w_var w_lat (sigma_d F - v_t)^2 + lv ]   (loss.py:132-160)."""
+
+    def __init__(self, dataset, noise: dict, sigma_data: float):
+        super().__init__(dataset, sigma_data)
+        self.cfg = dict(noise)
+        self._sampling_fn = partial(NOISE_SAMPLING_METHODS[self.cfg.pop("dist")], **self.cfg)
+
+    def forward(self, net, x, condition=None, auxiliary=None, _tau=None, _z=None, **kwargs):
+        mod = getattr(net, "module", net)
+        eng = _engine(net)
+        dev = x.device
+        B, C, H, W = x.shape
+        sd = float(self.sigma_data)
+        tau = self._sampling_fn(x) if _tau is None else _tau
+        t = torch.atan(tau.reshape(B).float() / sd).contiguous()
+        z = (torch.randn_like(x) if _z is None else _z).contiguous().float()
+        x = x.contiguous().float()
+        xt, vt = torch.empty_like(x), torch.empty_like(x)
+        st = torch.cuda.current_stream().cuda_stream
+        check(lib().swiftk_trigflow_prep(x.data_ptr(), z.data_ptr(), t.data_ptr(), xt.data_ptr(), vt.data_ptr(), sd, B, C * H * W,
+                                         st), "swiftk_trigflow_prep")
+        aux = _process_auxiliary(auxiliary, mod.auxiliary_dim, B, dev)
+        want_lv = mod.model.logvar_embed is not None
+        srcs, scales = [xt], [1.0]
+        if condition is not None and mod.condition_channels > 0:
+            srcs.append(condition)
+            scales.append(1.0)
+        res = eng.forward(srcs, scales, t, aux, want_logvar=want_lv)
+        Fx, lv, ctx = res if want_lv else (res[0], None, res[1])
+        wv, wl = self._w(dev)
+        loss = torch.zeros(1, device=dev)
+        dF = torch.empty_like(Fx)
+        dlv = torch.zeros(B, device=dev) if want_lv else None
+        check(lib().swiftk_trigflow_loss(Fx.data_ptr(), vt.data_ptr(), None if lv is None else lv.contiguous().data_ptr(),
+                                         wv.data_ptr(), wl.data_ptr(), loss.data_ptr(), dF.data_ptr(),
+                                         None if dlv is None else dlv.data_ptr(), sd, B, C, H, W, 1.0, st), "swiftk_trigflow_loss")
+
+        class Runner:
+            value = loss.reshape(())
+
+            @staticmethod
+            def run_backward(g):
+                if g != 1.0:
+                    dF.mul_(g)
+                    if dlv is not None:
+                        dlv.mul_(g)
+                eng.backward(ctx, dF, dlv)
+
+        return _Deferred.apply(self._anchor(dev), Runner)
+
+
+class SCMLoss(_LossBase):
+    def __init__(self, *a, **k):
+        raise NotImplementedError("SCMLoss needs forward-mode JVP kernels (SURVEY.md section 8f item 2); "
+                                  "use loss=trigflow or finetune=multistep (CRPS) on the gfx950 path")
+
+
+class CRPSLoss(_LossBase):
+    """Multistep almost-fair CRPS (loss.py:306-445): ensemble_size rollouts of `steps` network calls each."""
+
+    def __init__(self, dataset, sigma_data: float, ensemble_size: int = 2, alpha: float = 1.0):
+        super().__init__(dataset, sigma_data)
+        self.ensemble_size, self.alpha = ensemble_size, alpha
+
+    def _forcings(self, idx, auxiliary, i, dev):
+        f = torch.stack([self.dataset.get_forcings(int(j) + int(i * float(dt) * 10 // 6)) for j, dt in zip(idx, auxiliary)], 0)
+        return self.dataset.standardize_x(f).to(dev, non_blocking=True).float().contiguous()
+
+    def forward(self, net, target, condition, auxiliary, idx, steps: int = 1, chunk_size: int = 2, _latents=None, **kwargs):
+        mod = getattr(net, "module", net)
+        eng = _engine(net)
+        dev = target.device
+        B, C, H, W = target.shape
+        sd = float(self.sigma_data)
+        nv = len(self.dataset.variables)
+        delta = int(float(auxiliary[0]) * 10)  # NOTE: assumes same delta within a batch (loss.py:378)
+        mx, sx, stt = self.dataset.rollout_stats(delta, dev)
+        coef = (stt / sx).contiguous()         # cond_std += pred * st/sx  ==  standardize(unstd(cond) + unstd_t(pred))
+        aux = _process_auxiliary(auxiliary, mod.auxiliary_dim, B, dev)
+        t = torch.full((B,), math.pi / 2, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        hw = H * W
+        forc = [self._forcings(idx, auxiliary, i, dev) for i in range(steps)]
+        target = target.contiguous().float()
+        E = self.ensemble_size
+        lat = [[(torch.randn_like(target) if _latents is None else _latents[e][i].to(dev)).contiguous() for i in range(steps)]
+               for e in range(E)]
+        conds = [[None] * steps for _ in range(E)]
+        preds = torch.empty(E, B, C, H, W, device=dev)
+        # ---- pass 1: the rollouts, nothing saved but each step's input state (inference engine, bf16 operands)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            for e in range(E):
+                cond = condition[:, :nv].contiguous().float()
+                for i in range(steps):
+                    conds[e][i] = cond
+                    out = mod(lat[e][i], t, (cond, forc[i]), aux, x_scale=1.0)  # x_t / sigma_d with x_t = z * sigma_d
+                    if i < steps - 1:
+                        nxt = torch.empty_like(cond)
+                        # pred = -sigma_d * out ; cond' = cond + pred * st/sx
+                        check(lib().swiftk_channel_axpy(nxt.data_ptr(), cond.data_ptr(), out.data_ptr(), (-sd * coef).data_ptr(),
+                                                        B, C, hw, st), "swiftk_channel_axpy")
+                        cond = nxt
+                    else:
+                        ops.axpby(-sd, out, 0.0, out, out=preds[e])
+        wv, wl = self._w(dev)
+        loss = torch.zeros(1, device=dev)
+        dpreds = torch.empty_like(preds)
+        check(lib().swiftk_crps_loss(preds.data_ptr(), target.data_ptr(), wv.data_ptr(), wl.data_ptr(), loss.data_ptr(),
+                                     dpreds.data_ptr(), E, B, C, H, W, float(self.alpha), 1.0, st), "swiftk_crps_loss")
+
+        def run_backward(g):
+            # ---- pass 2: per member, walk the steps backwards; recompute one step with activations, then backprop it
+            for e in range(E):
+                gcond = None  # dL/d cond_{i+1}
+                for i in reversed(range(steps)):
+                    out, ctx = eng.forward([lat[e][i], conds[e][i], forc[i]], [1.0, 1.0, 1.0], t, aux)
+                    dout = torch.empty_like(out)
+                    if i == steps - 1:
+                        ops.axpby(-sd * g, dpreds[e], 0.0, dpreds[e], out=dout)
+                    else:
+                        check(lib().swiftk_channel_axpy(dout.data_ptr(), None, gcond.data_ptr(), (-sd * coef).data_ptr(), B, C, hw,
+                                                        torch.cuda.current_stream().cuda_stream), "swiftk_channel_axpy")
+                    need = i > 0
+                    dins = eng.backward(ctx, dout, None, need_input_grad=(False, need, False))
+                    if need:
+                        gcond = dins[1] if gcond is None else ops.axpby(1.0, gcond, 1.0, dins[1])
+
+        class Runner:
+            value = loss.reshape(())
+
+        Runner.run_backward = staticmethod(run_backward)
+        return _Deferred.apply(self._anchor(dev), Runner)

@@ -264,3 +264,119 @@ def test_train_engine_gradients_vs_oracle_autograd(dev):
         print(f"input grad: cos {cos:.4f} rel-L2 {rel_l2(gg, rr):.3e}")
         assert cos > 0.97
     assert dins[2] is None
+
+
+def _build_pair(dev, seed, logvar=False, depth=2):
+    from oracle.swinv2 import OracleNet, SwinCfg
+    from swift_amd.models.precond import PassPrecond
+    from swift_amd.utils.detinit import swinv2_state
+    c = dict(SMALLB, depth=depth)
+    nv, nf = c["n_vars"], c["n_forc"]
+    mcfg = dict(_target_="swift.models.swinv2.SwinV2", window_size=[16, 16], shift_size=[8, 8], patch_size=[2, 2],
+                depth=depth, dim=c["dim"], heads=c["heads"], logvar=logvar)
+    net = PassPrecond(mcfg, img_resolution=list(c["img"]), img_channels=nv, condition_channels=nv + nf, auxiliary_dim=1)
+    state = swinv2_state(grid=(32, 32), in_channels=2 * nv + nf, out_channels=nv, patch_size=(2, 2), depth=depth, dim=c["dim"],
+                         heads=c["heads"], logvar=logvar, seed=seed)
+    for k in state:
+        if k.endswith(".scale"):
+            state[k] = state[k].clamp(max=3.0)
+    net.load_state_dict(state)
+    st = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    ocfg = SwinCfg(img_resolution=c["img"], in_channels=2 * nv + nf, out_channels=nv, window_size=(16, 16), shift_size=(8, 8),
+                   patch_size=(2, 2), depth=depth, dim=c["dim"], heads=c["heads"], auxiliary_dim=1, logvar=logvar)
+    return net.to(dev), OracleNet(ocfg, st, nv, nv + nf), st
+
+
+def _grad_report(net, st, floor=0.97):
+    worst = 1.0
+    for k, p in net.named_parameters():
+        g, gr = p.grad.float().cpu().flatten().double(), st[k].grad.flatten().double()
+        cos = float((g @ gr) / (g.norm() * gr.norm()).clamp_min(1e-30))
+        worst = min(worst, cos)
+        assert cos > floor, (k, cos)
+    return worst
+
+
+def _dataset(seed):
+    from swift_amd.data.era5 import SyntheticERA5Dataset
+    names = ["2m_temperature", "10m_u_component_of_wind", "10m_v_component_of_wind", "mean_sea_level_pressure"]
+    for v in ["geopotential", "u_component_of_wind", "v_component_of_wind", "temperature", "specific_humidity"]:
+        names += [f"{v}_{l}" for l in [50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925, 1000]]
+    return SyntheticERA5Dataset(names, ["f0", "f1", "f2"], img_resolution=(64, 64), length=40, seed=seed, random_stats=True)
+
+
+def test_trigflow_loss_and_grads_vs_oracle(dev):
+    from oracle import loss as oloss
+    from swift_amd.training.loss import TrigFlowLoss
+    from swift_amd.utils.detinit import det_normal
+    net, onet, st = _build_pair(dev, 31, logvar=True)
+    ds = _dataset(31)
+    L = TrigFlowLoss(ds, dict(dist="loguniform", sigma_min=0.02, sigma_max=200.0), sigma_data=1.0).to(dev)
+    B = 2
+    x, cond, z = det_normal((B, 69, 64, 64), 31, "x"), det_normal((B, 72, 64, 64), 31, "c"), det_normal((B, 69, 64, 64), 31, "z")
+    tau, aux = torch.tensor([0.3, 4.0]).view(B, 1, 1, 1), torch.tensor([0.6, 0.6])
+    from swift_amd.training.trainer import GradAllReduce
+    ddp = GradAllReduce(net)
+    ddp.zero_grad_flat()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = L(ddp, x.to(dev), condition=cond.to(dev), auxiliary=aux.to(dev), _tau=tau.to(dev), _z=z.to(dev))
+    loss.backward()
+    ref = oloss.trigflow_loss(onet, x, tau, z, L.w_var.cpu(), L.w_lat.cpu(), 1.0, condition=cond, auxiliary=aux, return_logvar=True)
+    ref.backward()
+    print(f"trigflow loss {float(loss):.6f} vs oracle {float(ref):.6f}; worst grad cosine {_grad_report(net, st):.4f}")
+    assert float(loss) == pytest.approx(float(ref), rel=2e-2)
+
+
+def test_crps_multistep_loss_and_grads_vs_oracle(dev):
+    from oracle import loss as oloss
+    from oracle.rollout import Stats
+    from swift_amd.training.loss import CRPSLoss
+    from swift_amd.training.trainer import GradAllReduce
+    from swift_amd.utils.detinit import det_normal
+    net, onet, st = _build_pair(dev, 32)
+    ds = _dataset(32)
+    L = CRPSLoss(ds, sigma_data=1.0, ensemble_size=2, alpha=0.95).to(dev)
+    B, steps = 2, 3
+    target, cond = det_normal((B, 69, 64, 64), 32, "t"), det_normal((B, 72, 64, 64), 32, "c")
+    aux, idx = torch.tensor([0.6, 0.6]), [0, 4]
+    lat = [[det_normal((B, 69, 64, 64), 32, f"l{e}{i}") for i in range(steps)] for e in range(2)]
+    ddp = GradAllReduce(net)
+    ddp.zero_grad_flat()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = L(ddp, target.to(dev), condition=cond.to(dev), auxiliary=aux.to(dev), idx=idx, steps=steps, _latents=lat)
+    loss.backward()
+    stats = Stats(ds.x_means, ds.x_stds, {6: ds.t_stds[6]}, n_vars=69, n_forc=3)
+    forc = lambda i: torch.stack([ds.get_forcings(j + i) for j in idx], 0)
+    ref = oloss.crps_multistep_loss(onet, stats, target, cond, aux, forc, lat, L.w_var.cpu(), L.w_lat.cpu(), steps=steps, alpha=0.95)
+    ref.backward()
+    print(f"CRPS(steps=3) loss {float(loss):.6f} vs oracle {float(ref):.6f}; worst grad cosine {_grad_report(net, st, 0.95):.4f}")
+    assert float(loss) == pytest.approx(float(ref), rel=2e-2)
+
+
+def test_trainer_steps_ema_and_checkpoint(dev, tmp_path, monkeypatch):
+    from swift_amd.training.loss import CRPSLoss
+    from swift_amd.training.trainer import Trainer
+    from swift_amd.train import adamw_param_groups
+    from swift_amd.utils.detinit import det_normal
+    monkeypatch.chdir(tmp_path)
+    net, _, _ = _build_pair(dev, 33)
+    net.train().requires_grad_(True)
+    ds = _dataset(33)
+    opt = torch.optim.AdamW(adamw_param_groups(net, 1e-5), lr=2e-4, betas=(0.9, 0.95), eps=1e-6)
+    assert len(opt.param_groups[1]["params"]) == 1 + 2 * 2 * 2  # pos_embed + LayerNorm affine of 2 layers x 2 norms
+    tr = Trainer(net, opt, CRPSLoss(ds, 1.0, 2, 1.0).to(dev), total_kimg=1, ema_halflife_kimg=1, ema_rampup_ratio=0.05,
+                 lr_rampup_kimg=0, lr_min_factor=1.0, kimg_per_tick=1, checkpoint_ticks=None, device=dev)
+    tr.global_batch_size = 2
+    x = det_normal((2, 72, 64, 64), 33, "c").to(dev)
+    t = (0.5 * det_normal((2, 69, 64, 64), 33, "t")).to(dev)
+    delta, idx = torch.tensor([0.6, 0.6], device=dev), [0, 3]
+    p0 = net.model.head.head[0].weight.detach().clone()
+    e0 = tr.ema.model.head.head[0].weight.detach().clone()
+    torch.manual_seed(0)
+    losses = [float(tr.train_step(x, t, idx, delta, global_nimg=2 * (k + 1), steps=1)) for k in range(6)]
+    print("CRPS finetune losses:", [f"{v:.4f}" for v in losses])
+    assert all(math.isfinite(v) for v in losses) and min(losses[3:]) < losses[0]
+    assert not torch.equal(p0, net.model.head.head[0].weight) and not torch.equal(e0, tr.ema.model.head.head[0].weight)
+    tr._save_checkpoint(3000)
+    state = torch.load(tmp_path / "checkpoints" / "checkpoint-000003.pt", weights_only=True)
+    assert set(state) == {"ema", "net", "optimizer", "scaler"} and len(state["ema"]) == len(net.state_dict())

@@ -1,5 +1,6 @@
 """CPU-side host logic: config composition, dataset interface, unit sharding, and the world_size-2 (gloo)
 generate path with a stand-in network (the HIP kernels need a GPU; the sharding / output-placement logic does not)."""
+import math
 import os
 import subprocess
 import sys
@@ -136,3 +137,65 @@ def test_generate_sharding_world2_gloo_equals_world1(tmp_path):
     a, b = np.load(one), np.load(two)
     assert a.shape == (5, 3, 3, 3, 4, 8) and np.isfinite(a).all() and np.abs(a).sum() > 0
     np.testing.assert_array_equal(a, b)
+
+
+DDP_WORKER = textwrap.dedent("""
+    import os, sys, torch
+    sys.path.insert(0, %(root)r)
+    from swift_amd import dist
+    from swift_amd.training.trainer import GradAllReduce
+    dist.setup_torch(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    ddp = GradAllReduce(net)
+    g = torch.Generator().manual_seed(1)
+    X, Y = torch.randn(8, 8, generator=g), torch.randn(8, 3, generator=g)
+    lo, hi = rank * 8 // world, (rank + 1) * 8 // world
+    ddp.zero_grad_flat()
+    ((ddp(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
+    flat = ddp.sync()
+    if rank == 0:
+        torch.save(flat.clone(), sys.argv[1])
+    dist.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+""")
+
+
+@pytest.mark.timeout(300)
+def test_gradient_allreduce_world2_equals_single_process(tmp_path):
+    """2 ranks x local batch 4 with one averaged all-reduce == 1 process x batch 8 (SURVEY.md section 4 item iv)."""
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(DDP_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    one, two = str(tmp_path / "g1.pt"), str(tmp_path / "g2.pt")
+    subprocess.run([sys.executable, str(script), one], check=True, env={**env, "WORLD_SIZE": "1", "RANK": "0"}, timeout=200)
+    port = str(29900 + os.getpid() % 90)
+    procs = [subprocess.Popen([sys.executable, str(script), two],
+                              env={**env, "WORLD_SIZE": "2", "RANK": str(r), "LOCAL_RANK": str(r), "MASTER_PORT": port})
+             for r in range(2)]
+    assert [p.wait(timeout=200) for p in procs] == [0, 0]
+    a, b = torch.load(one), torch.load(two)
+    assert a.abs().sum() > 0 and torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_lr_schedule_and_param_groups():
+    """trainer.py:201-217 and train.py:275-286 on a CPU-only stand-in (no kernels involved)."""
+    from swift_amd.train import adamw_param_groups
+    from swift_amd.training.trainer import Trainer
+    net = torch.nn.Linear(4, 4)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    tr = Trainer.__new__(Trainer)
+    tr.optimizer, tr.base_lr = opt, [1e-3]
+    tr.lr_rampup_kimg, tr.lr_min_factor, tr.lr_cosine_anneal, tr.total_kimg = 2, 0.01, True, 10
+    tr._set_lr(0)
+    assert opt.param_groups[0]["lr"] == pytest.approx(1e-5)
+    tr._set_lr(1000)
+    assert opt.param_groups[0]["lr"] == pytest.approx(1e-5 + (1e-3 - 1e-5) * 0.5)
+    tr._set_lr(2000)
+    assert opt.param_groups[0]["lr"] == pytest.approx(1e-3)
+    tr._set_lr(6000)
+    assert opt.param_groups[0]["lr"] == pytest.approx(1e-5 + 0.5 * (1e-3 - 1e-5) * (1 + math.cos(math.pi * 0.5)))
+    tr._set_lr(10_000)
+    assert opt.param_groups[0]["lr"] == pytest.approx(1e-5)
