@@ -18,6 +18,30 @@ __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <>
 __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
 
+template <typename T>
+__device__ __forceinline__ void ld4(const T* p, float (&v)[4]);
+template <>
+__device__ __forceinline__ void ld4<float>(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <>
+__device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <typename T>
+__device__ __forceinline__ void st4(T* p, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void st4<float>(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16(a, b), pack_bf16(c, d));
+}
+
 // ------------------------------------------------------------------------------------------ transpose
 // dst[c][r] = src[r][c], 64x64 tiles through LDS (+1 padding), columns [rows, ldd) of dst zero-filled.
 template <typename T>
@@ -121,12 +145,14 @@ __global__ __launch_bounds__(256) void modnorm_bwd_kernel(const T* __restrict__ 
 #pragma unroll
             for (int i = 0; i < SLOTS; ++i) {
                 const int c = lane + 64 * i;
+                if (c < nc) {
+                    ld4<T>(y + row * ldy + 4 * c, v[i]);
+                    ld4<float>(g + row * d + 4 * c, gg[i]);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[i][e] = c < nc ? ldf(y + row * ldy + 4 * c + e) : 0.f;
-                    gg[i][e] = c < nc ? g[row * d + 4 * c + e] : 0.f;
-                    sum += v[i][e];
+                    for (int e = 0; e < 4; ++e) v[i][e] = gg[i][e] = 0.f;
                 }
+                sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
             const float mean = wave_sum(sum) / (float)d;
             float sq = 0.f;
@@ -161,11 +187,9 @@ __global__ __launch_bounds__(256) void modnorm_bwd_kernel(const T* __restrict__ 
 #pragma unroll
             for (int i = 0; i < SLOTS; ++i) {
                 const int c = lane + 64 * i;
-                if (c < nc) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        dy[row * lddy + 4 * c + e] = elem<T>::from_f(rstd * (gg[i][e] - s1 - v[i][e] * s2));
-                }
+                if (c < nc)
+                    st4<T>(dy + row * lddy + 4 * c, rstd * (gg[i][0] - s1 - v[i][0] * s2), rstd * (gg[i][1] - s1 - v[i][1] * s2),
+                           rstd * (gg[i][2] - s1 - v[i][2] * s2), rstd * (gg[i][3] - s1 - v[i][3] * s2));
             }
         }
 #pragma unroll
@@ -194,7 +218,12 @@ __global__ __launch_bounds__(256) void qknorm_bwd_kernel(const T* __restrict__ q
                                                          int64_t ld, const float* __restrict__ rn, T* __restrict__ dqkv,
                                                          int64_t ldo, const float* __restrict__ scale,
                                                          float* __restrict__ dscale, int64_t M, int heads, int hd) {
-    const int nvec = 3 * heads;
+    constexpr int PER = 16 / (int)sizeof(T);  // elements per 16-B chunk
+    constexpr int MAXC = 96 / PER;            // head_dim <= 96
+    __shared__ float sacc[64];
+    if (threadIdx.x < 64) sacc[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int nvec = 3 * heads, nch = hd / PER;
     const int64_t total = M * nvec;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t m = i / nvec;
@@ -202,20 +231,50 @@ __global__ __launch_bounds__(256) void qknorm_bwd_kernel(const T* __restrict__ q
         const T* a = qkvh + m * ld + (int64_t)v * hd;
         const T* da = dqkvh + m * ld + (int64_t)v * hd;
         T* o = dqkv + m * ldo + (int64_t)v * hd;
+        uint4 ra[MAXC], rd[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < nch) {
+                rd[c] = *reinterpret_cast<const uint4*>(da + c * PER);
+                if (kind != 2) ra[c] = *reinterpret_cast<const uint4*>(a + c * PER);
+            }
         if (kind == 2) {
-            for (int e = 0; e < hd; ++e) o[e] = da[e];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < nch) *reinterpret_cast<uint4*>(o + c * PER) = rd[c];
             continue;
         }
         const float s = scale[h];
         const float tau = kind == 0 ? expf(fminf(s, 4.605170185988092f)) : 1.0f;
         const float r = rn[i];
         float dot = 0.f;
-        for (int e = 0; e < hd; ++e) dot += ldf(a + e) * ldf(da + e);
-        dot /= tau;  // u . d(qh)   (a = tau u)
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < nch) {
+                const T* pa = reinterpret_cast<const T*>(&ra[c]);
+                const T* pd = reinterpret_cast<const T*>(&rd[c]);
+#pragma unroll
+                for (int e = 0; e < PER; ++e) dot += elem<T>::to_f(pa[e]) * elem<T>::to_f(pd[e]);
+            }
+        const float itau = 1.0f / tau;
+        dot *= itau;  // u . d(qh)   (a = tau u)
         const float f = tau * r;
-        for (int e = 0; e < hd; ++e) o[e] = elem<T>::from_f(f * (ldf(da + e) - (ldf(a + e) / tau) * dot));
-        if (kind == 0 && s < 4.605170185988092f) atomicAdd(dscale + h, tau * dot);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < nch) {
+                const T* pa = reinterpret_cast<const T*>(&ra[c]);
+                const T* pd = reinterpret_cast<const T*>(&rd[c]);
+                uint4 ov;
+                T* po = reinterpret_cast<T*>(&ov);
+#pragma unroll
+                for (int e = 0; e < PER; ++e)
+                    po[e] = elem<T>::from_f(f * (elem<T>::to_f(pd[e]) - elem<T>::to_f(pa[e]) * itau * dot));
+                *reinterpret_cast<uint4*>(o + c * PER) = ov;
+            }
+        if (kind == 0 && s < 4.605170185988092f) atomicAdd(&sacc[h], tau * dot);  // LDS first: 12 hot addresses
     }
+    __syncthreads();
+    if (threadIdx.x < heads && sacc[threadIdx.x] != 0.f) atomicAdd(dscale + threadIdx.x, sacc[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------ column sums

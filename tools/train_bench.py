@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""BASELINE config 5 on one GPU: Swift-B multistep-CRPS finetune iteration (ensemble 2, `steps` rollout steps, AdamW),
+local batch B.  Prints seconds per iteration and a per-kernel share if run under rocprofv3."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from swift_amd.data.era5 import SyntheticERA5Dataset
+from swift_amd.models.precond import PassPrecond
+from swift_amd.train import adamw_param_groups
+from swift_amd.training.loss import CRPSLoss
+from swift_amd.training.trainer import Trainer
+from swift_amd.utils.detinit import swinv2_state
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=8); ap.add_argument("--steps", type=int, default=4)
+ap.add_argument("--iters", type=int, default=2); ap.add_argument("--depth", type=int, default=12)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+names = ["2m_temperature", "10m_u_component_of_wind", "10m_v_component_of_wind", "mean_sea_level_pressure"]
+for v in ["geopotential", "u_component_of_wind", "v_component_of_wind", "temperature", "specific_humidity"]:
+    names += [f"{v}_{l}" for l in [50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925, 1000]]
+ds = SyntheticERA5Dataset(names, ["f0", "f1", "f2"], img_resolution=(128, 256), length=64, seed=1)
+mcfg = dict(_target_="swift.models.swinv2.SwinV2", window_size=[16, 16], shift_size=[8, 8], patch_size=[2, 2], depth=a.depth,
+            dim=1056, heads=12)
+net = PassPrecond(mcfg, img_resolution=[128, 256], img_channels=69, condition_channels=72, auxiliary_dim=1)
+net.load_state_dict(swinv2_state(grid=(64, 128), in_channels=141, out_channels=69, patch_size=(2, 2), depth=a.depth, dim=1056,
+                                 heads=12, seed=1))
+net = net.to(dev).train().requires_grad_(True)
+opt = torch.optim.AdamW(adamw_param_groups(net, 1e-5), lr=1e-5, betas=(0.9, 0.95), eps=1e-6)
+tr = Trainer(net, opt, CRPSLoss(ds, 1.0, 2, 1.0).to(dev), total_kimg=1, lr_rampup_kimg=0, lr_min_factor=1.0, device=dev,
+             checkpoint_ticks=None)
+tr.global_batch_size = a.batch
+g = torch.Generator(device=dev).manual_seed(0)
+x = torch.randn(a.batch, 72, 128, 256, generator=g, device=dev)
+t = 0.3 * torch.randn(a.batch, 69, 128, 256, generator=g, device=dev)
+delta, idx = torch.full((a.batch,), 0.6, device=dev), list(range(a.batch))
+loss = tr.train_step(x, t, idx, delta, 1000, steps=a.steps)  # warm-up (operand prep, allocator)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for k in range(a.iters):
+    loss = tr.train_step(x, t, idx, delta, 1000 * (k + 2), steps=a.steps)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.iters
+evals = 2 * a.steps
+print(f"CRPS finetune: batch {a.batch}, steps {a.steps}, depth {a.depth}: {dt:.3f} s/iteration, loss {float(loss):.4f}; "
+      f"{a.batch / dt:.2f} samples/s; fwd-equivalents/iter = {evals} fwd + {evals} recompute + {evals} bwd(2x) -> "
+      f"{(4 * evals * a.batch * 2.7535e12 * a.depth / 12) / dt / 1e12:.0f} TFLOP/s; peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
