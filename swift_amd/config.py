@@ -183,6 +183,8 @@ def _collect_overrides(config_dir, group, name, choices):
 
 
 def _parse_value(s: str):
+    if len(s) > 1 and s.isdigit() and s[0] == "0":  # run ids like 000 / 001 stay strings (resume=000)
+        return s
     try:
         return yaml.safe_load(s)
     except yaml.YAMLError:
