@@ -118,20 +118,24 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
         SWIFTK_CHECK_LAUNCH();
     }
 
+    // valid K of the d-wide GEMMs: when it ends half-way into the last 128-B k-tile (1056 bf16 = 16.5 tiles) the GEMM
+    // skips the padded half; otherwise it is the padded width itself
+    const int64_t half_tile = (dt == SWIFTK_BF16 ? 64 : 32) / 2;
+    const int64_t kdv = (m->kd - d == half_tile) ? d : m->kd;
     const bool do_shift = (m->sh != 0) || (m->sw != 0);
     for (int i = 0; i < m->depth; ++i) {
         const swiftk_layer& ly = m->layers_host[i];
         const bool shifted = do_shift && (i & 1);
         // head_dim 88: cosine-attention's normalise/scale prologue rides in the to_qkv epilogue (fp32 accumulators)
         const bool fuse_norm = (hd == 88);
-        RUN(swiftk_gemm(xT, m->kd, ly.qkv_w, m->kd, qkv, 3 * d, M, 3 * d, m->kd, dt, dt,
+        RUN(swiftk_gemm(xT, m->kd, ly.qkv_w, m->kd, qkv, 3 * d, M, 3 * d, kdv, dt, dt,
                         fuse_norm ? SWIFTK_EPI_QKNORM : SWIFTK_EPI_NONE, fuse_norm ? ly.scale : nullptr, nullptr, 0, stream));
         RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
                                     shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
-        RUN(swiftk_gemm(att, m->kd, ly.wo_w, m->kd, y, d, M, d, m->kd, dt, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, stream));
+        RUN(swiftk_gemm(att, m->kd, ly.wo_w, m->kd, y, d, M, d, kdv, dt, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, stream));
         RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok,
                                     1e-6f, dt, stream));
-        RUN(swiftk_gemm(xT, m->kd, ly.w1_w, m->kd, hmid, m->kmlp, M, 2 * m->mlp, m->kd, dt, dt, SWIFTK_EPI_SWIGLU, nullptr,
+        RUN(swiftk_gemm(xT, m->kd, ly.w1_w, m->kd, hmid, m->kmlp, M, 2 * m->mlp, kdv, dt, dt, SWIFTK_EPI_SWIGLU, nullptr,
                         nullptr, 0, stream));
         RUN(swiftk_gemm(hmid, m->kmlp, ly.w2_w, m->kmlp, y, d, M, d, m->kmlp, dt, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0,
                         stream));
@@ -140,7 +144,7 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     }
 
     const int po = m->out_ch * m->p1 * m->p2;
-    RUN(swiftk_gemm(xT, m->kd, m->head_w, m->kd, tok, po, M, po, m->kd, dt, SWIFTK_F32, SWIFTK_EPI_NONE, nullptr, nullptr, 0,
+    RUN(swiftk_gemm(xT, m->kd, m->head_w, m->kd, tok, po, M, po, kdv, dt, SWIFTK_F32, SWIFTK_EPI_NONE, nullptr, nullptr, 0,
                     stream));
     RUN(swiftk_unpatchify_affine(tok, po, xt, alpha, beta, out, B, m->out_ch, m->H, m->W, m->p1, m->p2, stream));
     return 0;

@@ -47,6 +47,7 @@ struct GemmArgs {
     int pos_rows;
     int ntn;
     int dbg;  // tuning experiments only: 1 = no DMA in the loop, 2 = no barrier (both give wrong results)
+    int khalf;         // the last k-tile holds data in its first half only (K = 16.5 tiles for d = 1056)
     int ksplit;        // persistent kernel: k-ranges per output tile (1 = plain)
     int64_t c_split;   // elements between the fp32 slabs of consecutive splits
 };
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         const char* s = smem + par * STAGE;
         const uint32_t fill = lds0 + (par ^ 1) * STAGE;
         const bool last_k = (kt + 1 == nk);
+        const bool half = g.khalf && (kt + 1 == nk_all);
         uint32_t koff = (uint32_t)(kt + 1) * ROWB;
         if (last_k) {
             const int ntile = tile + stride;
@@ -403,9 +405,19 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 #pragma unroll
                     for (int i = 0; i < MI; ++i) xg[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch1);
                 }
+                // K = 1056 is 16.5 k-tiles: the last k-tile of the K range carries data only in its first half
+                // (ks = 0); its second half meets zero pad columns, so those 44 MFMAs are skipped (3 % of the GEMM)
+                if (step < NI || !half) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i) mma_chunk<T>(acc[i][j], wf, ks ? xg[i] : xf[i]);
-                if ((step & 1) && (step >> 1) < 10 && !(g.dbg & 1)) issue_piece(fill, koff, step >> 1);
+                    for (int i = 0; i < MI; ++i) mma_chunk<T>(acc[i][j], wf, ks ? xg[i] : xf[i]);
+                }
+                if (!(g.dbg & 1)) {
+                    if (half) {
+                        if (step < 10) issue_piece(fill, koff, step);
+                    } else if ((step & 1) && (step >> 1) < 10) {
+                        issue_piece(fill, koff, step >> 1);
+                    }
+                }
                 wf = wn_;
             }
         }
@@ -613,7 +625,15 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     if (dtype != SWIFTK_F32 && dtype != SWIFTK_BF16) return SWIFTK_EINVAL;
     if (out_dtype != SWIFTK_F32 && out_dtype != dtype) return SWIFTK_EINVAL;
     const int es = dtype == SWIFTK_BF16 ? 2 : 4, os = out_dtype == SWIFTK_BF16 ? 2 : 4;
-    if (K % (ROWB / es) != 0 || N % 4 != 0) return SWIFTK_ESHAPE;
+    // K must fill whole 128-B k-tiles, or end exactly half-way into the last one provided both operands' rows extend
+    // (zero- / finitely-padded) to the end of that tile; the persistent kernel then skips the empty half.
+    const int tile_k = ROWB / es;
+    int khalf = 0;
+    if (K % tile_k == tile_k / 2 && lda >= K + tile_k / 2 && ldw >= K + tile_k / 2) {
+        khalf = 1;
+        K += tile_k / 2;
+    }
+    if (K % tile_k != 0 || N % 4 != 0) return SWIFTK_ESHAPE;
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SWIFTK_ESHAPE;
     if (lda < K || ldw < K) return SWIFTK_ESHAPE;
     const int ovec = (epilogue == SWIFTK_EPI_SWIGLU ? 2 : 4) * os;
@@ -639,6 +659,7 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     g.dbg = g_dbg;
     g.ksplit = ksplit;
     g.c_split = c_split;
+    g.khalf = khalf;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == SWIFTK_BF16) {
         if (out_dtype == SWIFTK_BF16) return dispatch_epi<bf16_t, bf16_t>(epilogue, g, st);
