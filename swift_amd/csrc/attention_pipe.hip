@@ -183,23 +183,20 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float l = 0.f;
         const float mb = mx * LOG2E;
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kb][r] * LOG2E - mb);
-                s[kb][r] = p;
-                l += p;
-            }
-        l += __shfl_xor(l, 32, 64);
-
-        // O^T[d][q] += V^T[d][key] P^T[key][q]
+        // O^T[d][q] += V^T[d][key] P^T[key][q].  The row sum l rides on the matrix pipe: an all-ones A row gives
+        // sum_key P^T[key][q] (exactly the bf16-rounded probabilities the numerator uses) -- no 128 v_add, no shuffle.
+        // It costs no extra MFMA: the third 32-wide d block only has 24 real rows (d = 64..87); lanes that would feed
+        // rows d = 88..95 of V^T supply ones instead, so those (otherwise discarded) output rows ARE the row sum.
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+        const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] * LOG2E - mb);
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) {
 #pragma unroll
@@ -217,12 +214,14 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(vrow + db * 64 + 8 * ROW));
                     typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    const s16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    uint4 vf = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    if (db == DB - 1 && c32 >= HD - 32 * (DB - 1)) vf = ones;
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
                                                                     __builtin_bit_cast(bf16x8, pf), o[db], 0, 0, 0);
                 }
             }
         }
+        const float l = o[DB - 1][12];  // row 24 (hh = 0) / 28 (hh = 1) of the last block: d = 88 / 92, both "ones" rows
         rl_prev = 1.0f / l;
         pb = b; pw = w; ph = h;
         have_prev = true;
