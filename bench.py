@@ -101,6 +101,8 @@ def main():
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = sdist.get_torch_device()
     lib = _lib.lib()
+    for kv in filter(None, os.environ.get("SWIFTK_TUNE", "").split(",")):  # kernel A/B knobs, e.g. "3:8" (swiftk_set_tuning)
+        lib.swiftk_set_tuning(*(int(x) for x in kv.split(":")))
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     B, K, W = a.batch, a.steps, a.warmup
 

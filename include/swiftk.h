@@ -153,10 +153,13 @@ int swiftk_axpby(float* out, float a, const float* x, float b, const float* y, i
  * N != 0) is bracketed by a HIP event pair recorded on its launch stream; swiftk_profile_collect
  * synchronises on them, returns the summed kernel time and the launch count, and re-arms.
  * swiftk_profile_gemm(-1, 0) switches the hooks off.  At most 4096 launches per collection.
+ * epilogue = SWIFTK_PROF_ATTENTION times the swiftk_window_attention launches instead (N ignored).
  */
+#define SWIFTK_PROF_ATTENTION 100
 int swiftk_profile_gemm(int epilogue, int64_t N);
 /* Tuning knobs (A/B measurements only): key 0 = GEMM variant (0 one tile per workgroup, 1 persistent pipeline),
- * key 1 = tile rows per group of the persistent tile order, key 2 = persistent grid size. */
+ * key 1 = tile rows per group of the persistent tile order, key 2 = persistent grid size, keys 3 / 4 = ablation
+ * bits of the GEMM / attention kernels (timing experiments; results are wrong while set). */
 int swiftk_set_tuning(int key, int value);
 int swiftk_profile_collect(double* total_ms_host, int64_t* launches_host);
 

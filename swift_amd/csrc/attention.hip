@@ -399,8 +399,11 @@ extern "C" int swiftk_window_attention(const void* qkv, int64_t ldq, void* out, 
     a.prenorm = prenorm ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (prenorm && dtype == SWIFTK_BF16 && head_dim == 88 && !(flags & SWIFTK_ATTN_NO_PIPE)) {
-        AttnPipeArgs pa{qkv, out, ldq, ldo, B, gh, gw, heads, shift_h, shift_w};
-        return swiftk_launch_attn_pipe(pa, st);
+        AttnPipeArgs pa{qkv, out, ldq, ldo, B, gh, gw, heads, shift_h, shift_w, g_attn_dbg, scale};
+        const bool timed = swiftk_prof_begin(SWIFTK_PROF_ATTENTION, 0, st);
+        const int rc = swiftk_launch_attn_pipe(pa, st);
+        if (timed) swiftk_prof_end(st);
+        return rc;
     }
     switch (head_dim) {
         case 88: return launch_hd<88>(a, B, dtype, st);

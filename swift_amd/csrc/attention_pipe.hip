@@ -14,6 +14,8 @@
 // MFMA orientation and the accumulator-as-operand trick are those of attention.hip.
 #include "common.h"
 
+int g_attn_dbg = 0;
+
 namespace {
 
 constexpr int NT = 512;
@@ -22,7 +24,8 @@ constexpr int ROW = HD * 2;            // 176 B
 constexpr int TILE = 256 * ROW;        // 45056 B = 44 DMA pieces
 constexpr int PIECES = TILE / 1024;    // 44
 constexpr int BUF = TILE + 64;         // zero tail behind every tile
-constexpr int LDS_TOTAL = 3 * BUF;     // K, V0, V1
+constexpr int OSLAB = 16 * ROW;        // per-wave output staging slab (2816 B)
+constexpr int LDS_TOTAL = 3 * BUF + 8 * OSLAB;  // K, V0, V1, output slabs
 constexpr int KS = 6, DB = 3;
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -34,6 +37,8 @@ __device__ __forceinline__ int win_token(int wy, int wx, int j, int gh, int gw, 
     return gy * gw + gx;
 }
 
+// DBG: ablation bits for timing experiments (1 no steady-state DMA, 2 no S/softmax/PV, 4 no Q loads, 8 no O stores)
+template <int DBG>
 __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitems) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_TOTAL];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -83,6 +88,12 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
         return static_cast<const char*>(a.qkv) + (int64_t)b * ntok * ldq_b + (int64_t)(h * 3 + part) * ROW;
     };
     auto dma_tile = [&](uint32_t dst, const char* base) {
+        if constexpr (DBG & 2) {  // the stripped-down ablation build loses hipcc's uniformity proof: pin to SGPRs
+            const uint64_t u = (uint64_t)base;
+            base = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(u >> 32)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)u));
+            dst = __builtin_amdgcn_readfirstlane(dst);
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i)
             if (i < 5 || wv < 4) dma_piece(dst + (wv + 8 * i) * 1024, base, voff[i]);
@@ -106,20 +117,41 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
     float rl_prev = 0.f;
     int pb = 0, pw = 0, ph = 0;
     bool have_prev = false;
+    // The output tile leaves through a wave-private LDS slab (16 rows x 176 B, two rounds per item): written as the
+    // 8-B pieces the MFMA layout yields (row stride 176 B = 44 banks: 16 rows land on 16 distinct bank groups), read
+    // back as whole 16-B chunks of consecutive row bytes, so one dwordx4 store covers ~5.8 complete 176-B row
+    // segments instead of 32 rows x 16 B -- the scattered form cost a third of the kernel's time in the TA.
+    char* oslab = smem + 3 * BUF + wv * OSLAB;
     auto store_o = [&](int b, int w, int h, float rl) {
         const int wy = w / nwx, wx = w - wy * nwx;
-        bf16_t* dst = static_cast<bf16_t*>(a.out) +
-                      ((int64_t)b * ntok + win_token(wy, wx, wv * 32 + c32, a.gh, a.gw, a.sh, a.sw)) * a.ldo + h * HD;
+        bf16_t* obase = static_cast<bf16_t*>(a.out) + (int64_t)b * ntok * a.ldo + h * HD;
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if ((c32 >> 4) == rnd) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = db * 32 + g * 8 + hh * 4;
-                if (d < HD)
-                    *reinterpret_cast<uint2*>(dst + d) =
-                        make_uint2(pack_bf16(o[db][4 * g] * rl, o[db][4 * g + 1] * rl),
-                                   pack_bf16(o[db][4 * g + 2] * rl, o[db][4 * g + 3] * rl));
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int d = db * 32 + g * 8 + hh * 4;
+                        if (d < HD)
+                            *reinterpret_cast<uint2*>(oslab + (c32 & 15) * ROW + d * 2) =
+                                make_uint2(pack_bf16(o[db][4 * g] * rl, o[db][4 * g + 1] * rl),
+                                           pack_bf16(o[db][4 * g + 2] * rl, o[db][4 * g + 3] * rl));
+                    }
             }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int c = lane + 64 * t;
+                if (c < 16 * 11) {
+                    const int row = (c * 2979) >> 15, cc = c - row * 11;
+                    const uint4 v = *reinterpret_cast<const uint4*>(oslab + row * ROW + cc * 16);
+                    const int tok = win_token(wy, wx, wv * 32 + rnd * 16 + row, a.gh, a.gw, a.sh, a.sw);
+                    *reinterpret_cast<uint4*>(obase + (int64_t)tok * a.ldo + cc * 8) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     };
 
     // ---- prologue: K and V of the first item, its Q fragments
@@ -151,39 +183,79 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
         __builtin_amdgcn_s_barrier();
         if (has_next) {
             if (nwn != cur_w) set_window(nwn);
-            dma_tile(ldsV0 + (par ^ 1) * BUF, tile_base(nb, nh, 2));
+            if (!(DBG & 1)) dma_tile(ldsV0 + (par ^ 1) * BUF, tile_base(nb, nh, 2));
         }
+        // the previous item's output leaves now (not at the end of its own iteration, where the vmcnt(0) above would
+        // wait for the fresh stores), before the score blocks claim the registers
+        if (have_prev && !(DBG & 8)) store_o(pb, pw, ph, rl_prev);
 
-        // S^T[key][q] = K Q^T
-        f32x16 s[8];
+        // P^T[key][q] = exp(S^T - m), S^T = K Q^T, kept as packed bf16 MFMA operands (8 key blocks x 2 k-steps).
+        // |logit| <= |q||k| = exp(min(scale, ln 100)) because q and k arrive normalised.  When that bound is small
+        // (<= 48: e^48 and 256 * e^48 * |v| are far inside fp32 / bf16 range) softmax needs no row maximum at all --
+        // m = 0 is as exact as any other offset in floating point -- so each 32-key block is exponentiated as soon
+        // as its six MFMAs retire, under the MFMAs of the next block: matrix pipe and VALU overlap inside one wave,
+        // and only two fp32 score blocks are ever live.  Heads with a larger bound take the two-pass form.
+        uint4 pf[8][2];
+        const float bound = a.scale ? __expf(fminf(a.scale[h], 4.605170185988092f)) : INFINITY;
+        auto s_block = [&](int kb) {
+            f32x16 acc;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const uint4 kf = *reinterpret_cast<const uint4*>(sK + (kb * 32 + c32) * ROW + ks * 32 + hh * 16);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
-                                                                __builtin_bit_cast(bf16x8, qf[ks]), s[kb], 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                              __builtin_bit_cast(bf16x8, qf[ks]), acc, 0, 0, 0);
             }
+            return acc;
+        };
+        auto exp_pack = [&](const f32x16& sc, float mb, uint4 (&dst)[2]) {
+            float e[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(sc[r] * LOG2E - mb);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                dst[s2].x = pack_bf16(e[8 * s2 + 0], e[8 * s2 + 1]);
+                dst[s2].y = pack_bf16(e[8 * s2 + 2], e[8 * s2 + 3]);
+                dst[s2].z = pack_bf16(e[8 * s2 + 4], e[8 * s2 + 5]);
+                dst[s2].w = pack_bf16(e[8 * s2 + 6], e[8 * s2 + 7]);
+            }
+        };
+        if constexpr (DBG & 2) {
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) pf[kb][0] = pf[kb][1] = make_uint4(0, 0, 0, 0);
+        } else if (bound <= 48.f) {
+            f32x16 sc = s_block(0);
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                f32x16 sn = sc;
+                if (kb + 1 < 8) sn = s_block(kb + 1);
+                exp_pack(sc, 0.f, pf[kb]);
+                sc = sn;
+            }
+        } else {
+            f32x16 sa[8];
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) sa[kb] = s_block(kb);
+            // row maximum over the 256 keys of query column c32: 128 values here, 128 in lane^32
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sa[kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mb = mx * LOG2E;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) exp_pack(sa[kb], mb, pf[kb]);
         }
         // every wave is done with the K buffer -> refill it with the next item's K
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (has_next) dma_tile(ldsK, tile_base(nb, nh, 1));
+        if (has_next && !(DBG & 1)) dma_tile(ldsK, tile_base(nb, nh, 1));
 
-        // the previous item's output leaves now; the next item's Q fragments are requested
-        if (have_prev) store_o(pb, pw, ph, rl_prev);
-        if (has_next) load_q(nb, nwn, nh, qf);
+        // the next item's Q fragments are requested
+        if (has_next && !(DBG & 4)) load_q(nb, nwn, nh, qf);
 
-        // softmax over the 256 keys of query column c32: 128 values here, 128 in lane^32
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mb = mx * LOG2E;
         // O^T[d][q] += V^T[d][key] P^T[key][q].  The row sum l rides on the matrix pipe: an all-ones A row gives
         // sum_key P^T[key][q] (exactly the bf16-rounded probabilities the numerator uses) -- no 128 v_add, no shuffle.
         // It costs no extra MFMA: the third 32-wide d block only has 24 real rows (d = 64..87); lanes that would feed
@@ -193,35 +265,27 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
         const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+        if constexpr (!(DBG & 2)) {
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb)
+            for (int kb = 0; kb < 8; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] * LOG2E - mb);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const char* vrow = sV + (kb * 32 + s2 * 16) * ROW + vbase;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                uint4 pf;
-                pf.x = pack_bf16(s[kb][8 * s2 + 0], s[kb][8 * s2 + 1]);
-                pf.y = pack_bf16(s[kb][8 * s2 + 2], s[kb][8 * s2 + 3]);
-                pf.z = pack_bf16(s[kb][8 * s2 + 4], s[kb][8 * s2 + 5]);
-                pf.w = pack_bf16(s[kb][8 * s2 + 6], s[kb][8 * s2 + 7]);
-                const char* vrow = sV + (kb * 32 + s2 * 16) * ROW + vbase;
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(vrow + db * 64));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(vrow + db * 64 + 8 * ROW));
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    uint4 vf = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                    if (db == DB - 1 && c32 >= HD - 32 * (DB - 1)) vf = ones;
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
-                                                                    __builtin_bit_cast(bf16x8, pf), o[db], 0, 0, 0);
+                    for (int db = 0; db < DB; ++db) {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(vrow + db * 64));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(vrow + db * 64 + 8 * ROW));
+                        uint4 vf = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        if (db == DB - 1 && c32 >= HD - 32 * (DB - 1)) vf = ones;
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                                        __builtin_bit_cast(bf16x8, pf[kb][s2]), o[db], 0, 0, 0);
+                    }
                 }
             }
         }
-        const float l = o[DB - 1][12];  // row 24 (hh = 0) / 28 (hh = 1) of the last block: d = 88 / 92, both "ones" rows
+        const float l = (DBG & 2) ? 1.f : o[DB - 1][12];  // row 24 (hh = 0) / 28 (hh = 1) of the last block: d = 88 / 92, both "ones" rows
         rl_prev = 1.0f / l;
         pb = b; pw = w; ph = h;
         have_prev = true;
@@ -238,7 +302,16 @@ int swiftk_launch_attn_pipe(const AttnPipeArgs& a, hipStream_t st) {
     // balanced (every workgroup gets floor or ceil of nitems/grid)
     int grid = 256;
     if (nitems < grid) grid = nitems;
-    hipLaunchKernelGGL(attn_pipe_kernel, dim3(grid), dim3(NT), 0, st, a, nitems);
+    switch (a.dbg) {
+        case 0: hipLaunchKernelGGL(attn_pipe_kernel<0>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        case 1: hipLaunchKernelGGL(attn_pipe_kernel<1>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        case 2: hipLaunchKernelGGL(attn_pipe_kernel<2>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        case 5: hipLaunchKernelGGL(attn_pipe_kernel<5>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        case 8: hipLaunchKernelGGL(attn_pipe_kernel<8>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        case 13: hipLaunchKernelGGL(attn_pipe_kernel<13>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        case 14: hipLaunchKernelGGL(attn_pipe_kernel<14>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        default: return SWIFTK_EINVAL;
+    }
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

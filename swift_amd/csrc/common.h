@@ -97,6 +97,13 @@ struct AttnPipeArgs {
     const void* qkv;
     void* out;
     int64_t ldq, ldo;
-    int B, gh, gw, heads, sh, sw;
+    int B, gh, gw, heads, sh, sw, dbg;
+    const float* scale;  // per-head logit scale parameter (bounds |logit|); null = unknown
 };
 int swiftk_launch_attn_pipe(const AttnPipeArgs& a, hipStream_t st);
+
+// live per-kernel timing (bench.py's roofline legs; state lives in gemm.hip): a launch of kind `kind` (a GEMM
+// epilogue code, or SWIFTK_PROF_ATTENTION) with matching n is bracketed by HIP events on its own stream
+bool swiftk_prof_begin(int kind, int n, hipStream_t st);
+void swiftk_prof_end(hipStream_t st);
+extern int g_attn_dbg;  // tuning key 4: attention ablation bits (timing experiments only)

@@ -370,10 +370,23 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 #pragma unroll
     for (int p = 0; p < 10; ++p) issue_piece(lds0, (uint32_t)kt * ROWB, p);
     int par = 0;
+    // vector stores one wave issues per fully-interior tile epilogue (edge tiles may skip some: they wait for all)
+    constexpr int EPI_STORES = (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS)
+                                   ? MI * ((16 * ((EPI == SWIFTK_EPI_SWIGLU ? 88 : 176) / 8) + 63) / 64)
+                                   : MI * NI;
+    bool stores_pending = false;
     for (;;) {
         // own DMA of the stage about to be read has landed; after the barrier every wave's has, and every wave is
         // done reading the other stage (its fragment reads were consumed by MFMAs before it got here)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Right after an epilogue the wave's youngest VMEM operations are that tile's output stores; the DMA of this
+        // stage is older (VMEM retires in issue order), so a counted wait lets the stores drain behind the first
+        // k-tile's MFMAs instead of stalling every CU on the chip-wide write burst.
+        if (stores_pending) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EPI_STORES) : "memory");
+            stores_pending = false;
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (!(g.dbg & 2)) __builtin_amdgcn_s_barrier();
         const char* s = smem + par * STAGE;
         const uint32_t fill = lds0 + (par ^ 1) * STAGE;
@@ -439,6 +452,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             int tm, tn;
             it.coords(tile / ksplit, tm, tn);
             const int m0 = tm * BM, n0 = tn * BN;
+            stores_pending = !(g.dbg & 8) && m0 + BM <= g.M && n0 + BN <= g.N;
             if constexpr (EPI == SWIFTK_EPI_QKNORM)
                 qknorm_tile(acc, lane, n0 + wn * 176, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / 88);
             OutT* C = reinterpret_cast<OutT*>(g.C) + (int64_t)(tile % ksplit) * g.c_split;
@@ -540,15 +554,7 @@ template <typename T, typename OutT, int EPI>
 int launch(const GemmArgs& g, hipStream_t st) {
     auto kern = gemm_kernel<T, OutT, EPI>;
     const int ntm = (g.M + BM - 1) / BM;
-    const bool timed = (g_prof.epilogue == EPI) && (g_prof.N == 0 || g_prof.N == g.N) && g_prof.used < Prof::MAXE;
-    if (timed) {
-        while (g_prof.created <= g_prof.used) {
-            if (hipEventCreate(&g_prof.ev[2 * g_prof.created]) != hipSuccess) return SWIFTK_EINVAL;
-            if (hipEventCreate(&g_prof.ev[2 * g_prof.created + 1]) != hipSuccess) return SWIFTK_EINVAL;
-            ++g_prof.created;
-        }
-        (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
-    }
+    const bool timed = swiftk_prof_begin(EPI, g.N, st);
     const bool wide_ok = sizeof(OutT) != 2 || (!((uintptr_t)g.C & 15) && !(g.ldc & 7) &&
                                                !(g.N & (EPI == SWIFTK_EPI_SWIGLU ? 15 : 7)));  // 16-B row chunks
     if (g_variant == 0 || (g.M & 7) || (g.N & 7) || !wide_ok) {  // ragged edges: per-lane clamped sources
@@ -559,10 +565,7 @@ int launch(const GemmArgs& g, hipStream_t st) {
         const int grid = ntiles < g_persist_wgs ? ntiles : g_persist_wgs;
         hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
     }
-    if (timed) {
-        (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
-        ++g_prof.used;
-    }
+    if (timed) swiftk_prof_end(st);
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }
@@ -580,12 +583,28 @@ int dispatch_epi(int epi, const GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
+bool swiftk_prof_begin(int kind, int n, hipStream_t st) {
+    if (g_prof.epilogue != kind || (g_prof.N != 0 && g_prof.N != n) || g_prof.used >= Prof::MAXE) return false;
+    while (g_prof.created <= g_prof.used) {
+        if (hipEventCreate(&g_prof.ev[2 * g_prof.created]) != hipSuccess) return false;
+        if (hipEventCreate(&g_prof.ev[2 * g_prof.created + 1]) != hipSuccess) return false;
+        ++g_prof.created;
+    }
+    return hipEventRecord(g_prof.ev[2 * g_prof.used], st) == hipSuccess;
+}
+
+void swiftk_prof_end(hipStream_t st) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
+    ++g_prof.used;
+}
+
 extern "C" int swiftk_set_tuning(int key, int value) {
     switch (key) {
         case 0: g_variant = value; return 0;
         case 1: g_group_m = value > 0 ? value : 1; return 0;
         case 2: g_persist_wgs = value > 0 ? value : 1; return 0;
         case 3: g_dbg = value; return 0;
+        case 4: g_attn_dbg = value; return 0;
     }
     return SWIFTK_EINVAL;
 }

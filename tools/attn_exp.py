@@ -1,0 +1,44 @@
+"""Window-attention kernel timing at the Swift-B layer shape, with the ablation bits of tuning key 4
+(1 no steady-state DMA, 2 no S/softmax/PV, 4 no Q loads, 8 no O stores).  Timing experiment: outputs are wrong
+while a bit is set.  python tools/attn_exp.py [B]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from swift_amd import _lib, ops
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    heads, hd, gh, gw = 12, 88, 64, 128
+    qkv = torch.randn(B, gh * gw, 3 * heads * hd, device=dev).to(torch.bfloat16)
+    out = torch.empty(B, gh * gw, 1088, device=dev, dtype=torch.bfloat16)[:, :, :heads * hd]
+    bytes_alg = B * gh * gw * 4 * heads * hd * 2
+    flops = B * 32 * heads * 2 * 2 * 256 * 256 * hd
+    import math
+    small = torch.full((heads,), math.log(10.0), device=dev)   # |logit| <= 10: max-free streaming softmax
+    large = torch.full((heads,), 5.0, device=dev)              # clamps to 100: two-pass softmax
+    for dbg, scale in ((0, small), (0, large), (1, small), (2, small), (5, small), (8, small), (13, small), (14, small)):
+        lib.swiftk_set_tuning(4, dbg)
+        print("scale bound", "10" if scale is small else "100", end="  ")
+        for shift in ((0, 0),):
+            for _ in range(3):
+                ops.window_attention(qkv, scale, (gh, gw), heads, shift=shift, out=out, flags=_lib.ATTN_PRENORM)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.window_attention(qkv, scale, (gh, gw), heads, shift=shift, out=out, flags=_lib.ATTN_PRENORM)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 20 * 1e3
+            print(f"dbg {dbg:2d} shift {shift}: {us:7.1f} us  {bytes_alg / us / 1e6:6.2f} TB/s  {flops / us / 1e6:7.1f} TFLOP/s",
+                  flush=True)
+    lib.swiftk_set_tuning(4, 0)
+
+
+main()
