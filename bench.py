@@ -147,6 +147,16 @@ def main():
     lib.swiftk_profile_gemm(-1, 0)
     if not torch.isfinite(phys).all():
         raise SystemExit("non-finite forecast state")
+    # second roofline leg, outside the timed region: the window-attention kernel (north_star's named kernel) over two
+    # more steps, HIP events on its launch stream
+    att_ms, att_n = ctypes.c_double(0), ctypes.c_int64(0)
+    if a.dtype == "bf16":
+        lib.swiftk_profile_gemm(_lib.PROF_ATTENTION, 0)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        lib.swiftk_profile_collect(ctypes.byref(att_ms), ctypes.byref(att_n))
+        lib.swiftk_profile_gemm(-1, 0)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -183,6 +193,16 @@ def main():
                          "launches": int(n_launch.value), "avg_launch_ms": avg_s * 1e3,
                          "flop_per_launch": flop_launch},
         }
+        if att_n.value > 0:
+            # per sample-layer the kernel reads qkv (8192 x 3168 bf16) and writes 8192 x 1056 bf16
+            # = 69.2 MB, for 8.858 GFLOP of QK^T + PV: HBM-bound in bf16 (ridge 312 flop/B > 128 flop/B)
+            att_s = att_ms.value / att_n.value * 1e-3
+            att_bytes, att_flop = B * 8192 * 4 * 1056 * 2.0, B * 8.858e9
+            line["attention_roofline"] = {
+                "kernel": "attn_pipe_kernel (shifted-window attention, bf16, window-tiled q/k/v)", "bound": "hbm",
+                "achieved": att_bytes / att_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": att_bytes / att_s / 8e12,
+                "traffic": None, "launches": int(att_n.value), "avg_launch_ms": att_s * 1e3, "bytes_per_launch": att_bytes,
+                "mfma_tflops": att_flop / att_s / 1e12, "mfma_frac": att_flop / att_s / PEAK_BF16}
         if world == 1 and a.cpu_steps > 0:
             line["cpu_baseline"] = cpu_baseline(state, a.cpu_steps)
             line["vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]

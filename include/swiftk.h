@@ -48,7 +48,10 @@ extern "C" {
                                   k <- k/max(|k|,1e-12), v unchanged (swinv2.py:123-127); ep0 = scale[heads]          */
 
 /* swiftk_window_attention flags */
-#define SWIFTK_ATTN_PRENORM 1  /* q, k in `qkv` are already normalised / scaled (SWIFTK_EPI_QKNORM); `scale` unused */
+#define SWIFTK_ATTN_PRENORM 1  /* q, k in `qkv` are already normalised / scaled (SWIFTK_EPI_QKNORM); `scale` (optional) bounds
+                                  |logit| <= exp(min(scale, ln 100)): where <= 48 softmax needs no row maximum */
+#define SWIFTK_ATTN_TILED 4    /* `qkv` is window-tiled (swiftk_gemm_qkv_tiled): [B][window][head][q|k|v][256][88] bf16, windows
+                                  of the grid rolled by (shift_h, shift_w); needs PRENORM, bf16, head_dim 88; ldq unused */
 #define SWIFTK_ATTN_NO_PIPE 2  /* tuning: keep the one-workgroup-per-item kernel even where the pipelined one applies */
 
 int swiftk_version(void);
@@ -169,6 +172,18 @@ int swiftk_profile_collect(double* total_ms_host, int64_t* launches_host);
  * wgrad = dY^T * X as A = dY^T, "W" = X^T, contraction over all tokens, split over
  * workgroups into fp32 slabs (swiftk_gemm_splitk) that swiftk_reduce_slabs sums.
  * ------------------------------------------------------------------------ */
+
+/*
+ * to_qkv for the streamed window-attention kernel (swinv2.py:113-121 + window_partition :17-26 + the roll :185-189 in
+ * one pass): C = normalise/scale(A W^T) exactly as swiftk_gemm(..., SWIFTK_EPI_QKNORM, scale, ...) computes it, bf16 in
+ * and out, N = 3*heads*88, M = B*gh*gw, but stored window-tiled instead of row-major:
+ *   qkv_tiled[B][window][head][q|k|v][256][88], window = (ry/16)*(gw/16) + rx/16, index in window = (ry%16)*16 + rx%16,
+ *   (ry, rx) = ((y - shift_h) mod gh, (x - shift_w) mod gw) for the token at grid position (y, x)
+ * so that every (window, head) operand of attention is one contiguous, cache-line-aligned 45,056-byte block.
+ * Consumed by swiftk_window_attention(..., SWIFTK_ATTN_PRENORM | SWIFTK_ATTN_TILED) with the same shift.
+ */
+int swiftk_gemm_qkv_tiled(const void* A, int64_t lda, const void* W, int64_t ldw, void* qkv_tiled, int64_t K,
+                          const float* scale, int B, int gh, int gw, int heads, int shift_h, int shift_w, void* stream);
 
 /* slabs[s][M, ldc] (fp32) = A[M, K_s] * W[N, K_s]^T for the s-th of `ksplit` equal k-ranges; slab s starts at
  * slabs + s*slab_stride.  Same operand rules as swiftk_gemm; M % 8 == 0, N % 8 == 0. */

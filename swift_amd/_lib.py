@@ -11,11 +11,13 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libswiftk.so")
+# SWIFTK_LIB: A/B builds of the same ABI (csrc/Makefile `variant` target); the product always loads csrc/libswiftk.so
+LIB_PATH = os.environ.get("SWIFTK_LIB") or os.path.join(_HERE, "csrc", "libswiftk.so")
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_BIAS_POS, EPI_SWIGLU, EPI_QKNORM = 0, 1, 2, 3
-ATTN_PRENORM, ATTN_NO_PIPE = 1, 2
+ATTN_PRENORM, ATTN_NO_PIPE, ATTN_TILED = 1, 2, 4
+PROF_ATTENTION = 100
 
 _ERR = {-1: "SWIFTK_EINVAL (bad argument)", -2: "SWIFTK_ESHAPE (unsupported shape)",
         -3: "SWIFTK_EALIGN (misaligned pointer / leading dimension)", -4: "SWIFTK_EWORKSPACE (workspace too small)"}
@@ -56,6 +58,7 @@ _SIGS = {
     "swiftk_rollout_update": ([_p, _p, _p, _p, _p, _p, _i, _i, _l, _p], _i),
     "swiftk_cast_pad": ([_p, _l, _p, _l, _l, _l, _i, _p], _i),
     "swiftk_axpby": ([_p, _f, _p, _f, _p, _l, _p], _i),
+    "swiftk_gemm_qkv_tiled": ([_p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_gemm_splitk": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _l, _i, _i, _p], _i),
     "swiftk_reduce_slabs": ([_p, _l, _l, _i, _p, _l, _l, _l, _i, _p], _i),
     "swiftk_transpose": ([_p, _l, _p, _l, _l, _l, _i, _p], _i),

@@ -399,12 +399,14 @@ extern "C" int swiftk_window_attention(const void* qkv, int64_t ldq, void* out, 
     a.prenorm = prenorm ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (prenorm && dtype == SWIFTK_BF16 && head_dim == 88 && !(flags & SWIFTK_ATTN_NO_PIPE)) {
-        AttnPipeArgs pa{qkv, out, ldq, ldo, B, gh, gw, heads, shift_h, shift_w, g_attn_dbg, scale};
+        AttnPipeArgs pa{qkv, out, ldq, ldo, B, gh, gw, heads, shift_h, shift_w, g_attn_dbg, scale,
+                        (flags & SWIFTK_ATTN_TILED) ? 1 : 0};
         const bool timed = swiftk_prof_begin(SWIFTK_PROF_ATTENTION, 0, st);
         const int rc = swiftk_launch_attn_pipe(pa, st);
         if (timed) swiftk_prof_end(st);
         return rc;
     }
+    if (flags & SWIFTK_ATTN_TILED) return SWIFTK_ESHAPE;  // window-tiled input exists for the pipelined kernel only
     switch (head_dim) {
         case 88: return launch_hd<88>(a, B, dtype, st);
         case 80: return launch_hd<80>(a, B, dtype, st);

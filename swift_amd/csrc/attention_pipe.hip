@@ -1,16 +1,28 @@
-// Persistent, LDS-DMA-pipelined shifted-window attention for gfx950 (bf16, head_dim 88, pre-normalised q/k).
+// Persistent, LDS-DMA-streamed shifted-window attention for gfx950 (bf16, head_dim 88, pre-normalised q/k).
 //
 // The to_qkv GEMM epilogue (SWIFTK_EPI_QKNORM) has already L2-normalised q and k and applied the logit scale,
-// so this kernel is pure data movement + MFMA + softmax:
-//   * a fixed grid of workgroups walks contiguous runs of (sample, window, head) items;
-//   * K (256 x 176 B) and V tiles go HBM -> LDS by global_load_lds (no VGPR round trip, no VALU): V one item
-//     ahead into a 2-deep ring, K of the next item as soon as this item's QK^T has consumed the K buffer, so
-//     HBM latency sits behind the softmax / PV of the current item (1 K + 2 V buffers = 132 KiB of LDS);
-//   * Q fragments go straight to registers one item ahead; the output of item i is stored during item i+1
-//     (after its QK^T) so the vmcnt(0) that hands the DMA buffers over never waits on a fresh store;
-//   * rows are 88 bf16 = 176 B, unpadded: 16 consecutive rows hit 16 distinct 16-B bank slots (176/16 = 11 is
-//     odd), so the ds_read_b128 fragment reads are conflict-free; the k-step that covers d = 80..95 reads 16 B
-//     into the next row for d >= 88 and meets a zero Q fragment (all LDS is zero-filled once, so it is finite).
+// so this kernel is pure data movement + MFMA + softmax.  A (sample, window, head) item is 3 x 45 KB in and
+// 45 KB out for 23 MFLOP x 2: HBM-bound, so the design goal is an HBM stream that never
+// stops while the matrix pipe and the VALU work underneath it:
+//   * a fixed grid of workgroups walks contiguous runs of items (heads fastest: the twelve 528-B [q|k|v] slices of
+//     a token are neighbours in memory and are consumed back to back by the same CU);
+//   * every input byte travels HBM -> LDS by global_load_lds (no VGPR round trip, no VALU, 16 B per lane with
+//     whole 176-B row segments per instruction).  K and V stream through a ring of four 64-key stages three
+//     stages ahead of the compute; the Q tile of the NEXT item is requested a whole item ahead into a buffer that
+//     the waves drain into registers at the start of each item;
+//   * softmax is streamed over the four key chunks.  |logit| <= |q||k| = exp(min(scale, ln 100)) because q and k
+//     arrive normalised; when that bound is <= 48 no maximum is needed at all (offset 0 is as exact as any other
+//     in floating point, and e^48 * 256 * |v| is far inside the fp32 / bf16 range).  Heads with a larger bound
+//     use the running-maximum (online) form: each lane owns one query column, so the rescale is a per-lane scalar;
+//   * the row sum l rides on the matrix pipe (ones fed to the unused V^T rows d = 88..95), so rescaling O
+//     rescales l with it;
+//   * the output tile of item i leaves during item i+1 through wave-private LDS slabs, as whole 176-B row
+//     segments per dwordx4 store;
+//   * waits are counted: VMEM retires in issue order, so `s_waitcnt vmcnt(N)` with N = the operations issued
+//     after the stage that is needed leaves the younger prefetches in flight across the barrier.
+// Rows are 88 bf16 = 176 B, unpadded: 16 consecutive rows hit 16 distinct 16-B bank slots (176/16 = 11 is odd), so
+// the ds_read_b128 fragment reads are conflict-free; the k-step that covers d = 80..95 reads 16 B into the next row
+// for d >= 88 and meets a zero Q fragment (all LDS is zero-filled once, so those bits are finite).
 // MFMA orientation and the accumulator-as-operand trick are those of attention.hip.
 #include "common.h"
 
@@ -20,12 +32,16 @@ namespace {
 
 constexpr int NT = 512;
 constexpr int HD = 88;
-constexpr int ROW = HD * 2;            // 176 B
-constexpr int TILE = 256 * ROW;        // 45056 B = 44 DMA pieces
-constexpr int PIECES = TILE / 1024;    // 44
-constexpr int BUF = TILE + 64;         // zero tail behind every tile
-constexpr int OSLAB = 16 * ROW;        // per-wave output staging slab (2816 B)
-constexpr int LDS_TOTAL = 3 * BUF + 8 * OSLAB;  // K, V0, V1, output slabs
+constexpr int ROW = HD * 2;             // 176 B
+constexpr int TILE = 256 * ROW;         // 45056 B = 44 DMA pieces
+constexpr int CH = 64;                  // keys per ring stage
+constexpr int CHB = CH * ROW;           // 11264 B = 11 pieces
+constexpr int NST = 4;                  // ring stages = chunks per item
+constexpr int OSLAB = 16 * ROW;         // per-wave output staging slab (2816 B)
+constexpr int OFF_K = TILE;             // Q tile | K ring | V ring | zero tail | output slabs
+constexpr int OFF_V = OFF_K + NST * CHB;
+constexpr int OFF_O = OFF_V + NST * CHB + 64;
+constexpr int LDS_TOTAL = OFF_O + 8 * OSLAB;
 constexpr int KS = 6, DB = 3;
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -37,7 +53,13 @@ __device__ __forceinline__ int win_token(int wy, int wx, int j, int gh, int gw, 
     return gy * gw + gx;
 }
 
-// DBG: ablation bits for timing experiments (1 no steady-state DMA, 2 no S/softmax/PV, 4 no Q loads, 8 no O stores)
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// DBG: ablation bits for timing experiments (1 no steady-state K/V DMA, 2 no S/softmax/PV, 4 no steady-state Q DMA,
+// 8 no O stores)
 template <int DBG>
 __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitems) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_TOTAL];
@@ -48,33 +70,71 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
     const int64_t ntok = (int64_t)a.gh * a.gw;
 
     // contiguous run of items for this workgroup (items of one window are adjacent: heads fastest)
-    const int first = (int)((int64_t)blockIdx.x * nitems / gridDim.x);
-    const int last = (int)((int64_t)(blockIdx.x + 1) * nitems / gridDim.x);
+    // Item order.  Items are numbered (sample, window, head), heads fastest.  The workgroups that share an XCD
+    // (blockIdx & 7: they share its L2) take CONSECUTIVE items at the same time, each XCD walking its own contiguous
+    // eighth of the list in rounds: the 176-B head slices of a token row are neighbours in memory, so partial cache
+    // lines -- the output's above all, which would otherwise go back to HBM half-written and be merged there by
+    // read-modify-write -- are completed in L2 by the neighbouring CUs while they are still resident.
+    // (Measured at 8 samples: 157 us with one contiguous run per workgroup, 140 us in this order.)
+    int first, last, istep;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, nx = gridDim.x >> 3;
+        first = (int)((int64_t)xcd * nitems / 8) + (blockIdx.x >> 3);
+        last = (int)((int64_t)(xcd + 1) * nitems / 8);
+        istep = nx;
+    } else {
+        first = (int)((int64_t)blockIdx.x * nitems / gridDim.x);
+        last = (int)((int64_t)(blockIdx.x + 1) * nitems / gridDim.x);
+        istep = 1;
+    }
     if (first >= last) return;
 
-    // zero all LDS once: the 16-B over-reads behind a row / a tile must see finite bits
+    // zero all LDS once: the 16-B over-reads behind a row / a stage must see finite bits
     for (int o = tid * 16; o < LDS_TOTAL; o += NT * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
-    const uint32_t ldsK = lds0, ldsV0 = lds0 + BUF;
 
     const int c32 = lane & 31, hh = lane >> 5;
     const int i16 = lane & 15;
     const int vbase = (4 * hh + (i16 >> 2)) * ROW + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
 
-    // per-lane DMA source offsets of this wave's pieces (piece p = wv + 8*i): 16-B chunk c = 64p + lane of the
-    // tile -> row c/11, chunk c%11 of the row; valid for one window, recomputed when the window changes
-    uint32_t voff[6];
+    // ---- DMA bookkeeping.  A piece is 1 KiB = 64 lanes x 16 B; piece p of a 256-row tile covers its 16-B chunks
+    // 64p .. 64p+63 (chunk c -> row c/11, chunk c%11 of the row), i.e. 5.8 whole 176-B row segments.
+    //   Q tile: 44 pieces, wave wv issues slots wv + 8i, i = 0..5; slots 44..47 repeat pieces 0..3 (same bytes to the
+    //           same place) so that every wave issues exactly 6 -- the counted waits below need uniform counts;
+    //   K/V chunk c: 11 + 11 pieces (tile pieces 11c .. 11c+10 of K, then of V), wave wv issues slots wv + 8s,
+    //           s = 0..2; slots 22, 23 repeat slots 0, 1.
+    // Per-lane source offsets depend on the window only; they are recomputed when the window changes.
+    uint32_t qoff[6], coff[NST][3];
     int cur_w = -1;
+    int tb_w = 0;  // window of the item the DMA helpers are fetching (tiled storage addresses tiles by window)
+    auto piece_off = [&](int wy, int wx, int p) {
+        const int c = p * 64 + lane;
+        const int row = (c * 2979) >> 15;  // c / 11 for c < 2816
+        const int cc = c - row * 11;
+        if (a.tiled) return (uint32_t)(p * 1024 + lane * 16);  // window-tiled storage: a tile is one contiguous block
+        return (uint32_t)(win_token(wy, wx, row, a.gh, a.gw, a.sh, a.sw) * ldq_b) + 16u * cc;
+    };
+    int cslot_part[3], cslot_j[3];  // wave-uniform: which tensor (0 K, 1 V) and which piece of the chunk a slot is
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        int q = wv + 8 * s;
+        q = q >= 22 ? q - 22 : q;
+        cslot_part[s] = q >= 11;
+        cslot_j[s] = q - 11 * cslot_part[s];
+    }
     auto set_window = [&](int w) {
         const int wy = w / nwx, wx = w - wy * nwx;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const int c = (wv + 8 * i) * 64 + lane;
-            const int row = (c * 2979) >> 15;  // c / 11 for c < 2816
-            const int cc = c - row * 11;
-            voff[i] = (uint32_t)(win_token(wy, wx, row & 255, a.gh, a.gw, a.sh, a.sw) * ldq_b) + 16u * cc;
+            int p = wv + 8 * i;
+            p = p >= 44 ? p - 44 : p;
+            qoff[i] = piece_off(wy, wx, p);
         }
+#pragma unroll
+        for (int c = 0; c < NST; ++c)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) coff[c][s] = piece_off(wy, wx, 11 * c + cslot_j[s]);
         cur_w = w;
     };
     auto decode = [&](int item, int& b, int& w, int& h) {
@@ -85,43 +145,43 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
     };
     // tile base of (b, h): part 0 = q, 1 = k, 2 = v
     auto tile_base = [&](int b, int h, int part) {
+        if (a.tiled)
+            return static_cast<const char*>(a.qkv) + (((int64_t)(b * nw + tb_w) * a.heads + h) * 3 + part) * TILE;
         return static_cast<const char*>(a.qkv) + (int64_t)b * ntok * ldq_b + (int64_t)(h * 3 + part) * ROW;
     };
-    auto dma_tile = [&](uint32_t dst, const char* base) {
-        if constexpr (DBG & 2) {  // the stripped-down ablation build loses hipcc's uniformity proof: pin to SGPRs
-            const uint64_t u = (uint64_t)base;
-            base = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(u >> 32)) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)u));
-            dst = __builtin_amdgcn_readfirstlane(dst);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-            if (i < 5 || wv < 4) dma_piece(dst + (wv + 8 * i) * 1024, base, voff[i]);
+    auto pin = [&](const char* base) {  // keep a provably wave-uniform pointer in SGPRs for the asm operand
+        const uint64_t u = (uint64_t)base;
+        return (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(u >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)u));
     };
-    // Q fragments of query row 32*wv + c32: chunk 2*ks + hh of the row (chunk 11 does not exist -> zeros)
-    auto load_q = [&](int b, int w, int h, uint4 (&q)[KS]) {
-        const int wy = w / nwx, wx = w - wy * nwx;
-        const char* row = tile_base(b, h, 0) + (int64_t)win_token(wy, wx, wv * 32 + c32, a.gh, a.gw, a.sh, a.sw) * ldq_b;
+    auto dma_q = [&](int b, int h) {
+        const char* base = pin(tile_base(b, h, 0));
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks == KS - 1) {
-                const uint4 t = *reinterpret_cast<const uint4*>(row + (2 * ks) * 16);  // chunk 10 (hh = 0 lanes use it)
-                q[ks] = hh ? make_uint4(0, 0, 0, 0) : t;
-            } else {
-                q[ks] = *reinterpret_cast<const uint4*>(row + (2 * ks + hh) * 16);
-            }
+        for (int i = 0; i < 6; ++i) {
+            int p = wv + 8 * i;
+            p = p >= 44 ? p - 44 : p;
+            dma_piece(lds0 + p * 1024, base, qoff[i]);
+        }
+    };
+    auto dma_chunk = [&](int b, int h, int c) {  // chunk c of the item -> ring stage c
+        const char* kb_ = pin(tile_base(b, h, 1));
+        const char* vb_ = pin(tile_base(b, h, 2));
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const uint32_t dst = lds0 + (cslot_part[s] ? OFF_V : OFF_K) + c * CHB + cslot_j[s] * 1024;
+            dma_piece(__builtin_amdgcn_readfirstlane(dst), cslot_part[s] ? vb_ : kb_, coff[c][s]);
         }
     };
 
-    f32x16 o[DB];       // output of the previous item, stored one phase late
+    f32x16 o[DB];  // output of the current item; stored one step into the next item
     float rl_prev = 0.f;
     int pb = 0, pw = 0, ph = 0;
     bool have_prev = false;
     // The output tile leaves through a wave-private LDS slab (16 rows x 176 B, two rounds per item): written as the
     // 8-B pieces the MFMA layout yields (row stride 176 B = 44 banks: 16 rows land on 16 distinct bank groups), read
     // back as whole 16-B chunks of consecutive row bytes, so one dwordx4 store covers ~5.8 complete 176-B row
-    // segments instead of 32 rows x 16 B -- the scattered form cost a third of the kernel's time in the TA.
-    char* oslab = smem + 3 * BUF + wv * OSLAB;
+    // segments instead of 32 rows x 16 B.  Always exactly 6 store instructions per wave (counted waits).
+    char* oslab = smem + OFF_O + wv * OSLAB;
     auto store_o = [&](int b, int w, int h, float rl) {
         const int wy = w / nwx, wx = w - wy * nwx;
         bf16_t* obase = static_cast<bf16_t*>(a.out) + (int64_t)b * ntok * a.ldo + h * HD;
@@ -154,123 +214,124 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
         }
     };
 
-    // ---- prologue: K and V of the first item, its Q fragments
+    // ---- prologue, in the order the steady state issues (chunk 0, Q, chunk 1, chunk 2 of the coming item)
     int b, w, h;
     decode(first, b, w, h);
     set_window(w);
-    dma_tile(ldsK, tile_base(b, h, 1));
-    dma_tile(ldsV0, tile_base(b, h, 2));
-    uint4 qf[KS];
-    load_q(b, w, h, qf);
+    tb_w = w;
+    dma_chunk(b, h, 0);
+    dma_q(b, h);
+    dma_chunk(b, h, 1);
+    dma_chunk(b, h, 2);
 
-    for (int item = first; item < last; ++item) {
-        const int par = (item - first) & 1;
-        const char* sK = smem;
-        const char* sV = smem + BUF + par * BUF;
+    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+    for (int item = first; item < last; item += istep) {
+        // the item after this one; past the end of the run the "next item" is this one again: the re-loads put the
+        // same bytes where they already are and keep every count below uniform
         int nb = b, nwn = w, nh = h;
-        const bool has_next = item + 1 < last;
-        if (has_next) decode(item + 1, nb, nwn, nh);
-
-        // K(item) and V(item) have landed (own pieces: vmcnt(0); everyone's: barrier).  Also orders the previous
-        // item's PV reads of the other V buffer before the DMA that refills it.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // Make hipcc retire ITS wait for the Q-fragment loads here, while nothing is outstanding.  Its waitcnt pass
-        // does not see the asm DMA: left alone it would wait for "its" loads in front of the first QK^T MFMA with a
-        // count that, in hardware, also covers the V pieces issued just below -- i.e. stall on fresh DMA every item.
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
-        __builtin_amdgcn_s_barrier();
-        if (has_next) {
-            if (nwn != cur_w) set_window(nwn);
-            if (!(DBG & 1)) dma_tile(ldsV0 + (par ^ 1) * BUF, tile_base(nb, nh, 2));
-        }
-        // the previous item's output leaves now (not at the end of its own iteration, where the vmcnt(0) above would
-        // wait for the fresh stores), before the score blocks claim the registers
-        if (have_prev && !(DBG & 8)) store_o(pb, pw, ph, rl_prev);
-
-        // P^T[key][q] = exp(S^T - m), S^T = K Q^T, kept as packed bf16 MFMA operands (8 key blocks x 2 k-steps).
-        // |logit| <= |q||k| = exp(min(scale, ln 100)) because q and k arrive normalised.  When that bound is small
-        // (<= 48: e^48 and 256 * e^48 * |v| are far inside fp32 / bf16 range) softmax needs no row maximum at all --
-        // m = 0 is as exact as any other offset in floating point -- so each 32-key block is exponentiated as soon
-        // as its six MFMAs retire, under the MFMAs of the next block: matrix pipe and VALU overlap inside one wave,
-        // and only two fp32 score blocks are ever live.  Heads with a larger bound take the two-pass form.
-        uint4 pf[8][2];
+        if (item + istep < last) decode(item + istep, nb, nwn, nh);
         const float bound = a.scale ? __expf(fminf(a.scale[h], 4.605170185988092f)) : INFINITY;
-        auto s_block = [&](int kb) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const uint4 kf = *reinterpret_cast<const uint4*>(sK + (kb * 32 + c32) * ROW + ks * 32 + hh * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
-                                                              __builtin_bit_cast(bf16x8, qf[ks]), acc, 0, 0, 0);
-            }
-            return acc;
-        };
-        auto exp_pack = [&](const f32x16& sc, float mb, uint4 (&dst)[2]) {
-            float e[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(sc[r] * LOG2E - mb);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                dst[s2].x = pack_bf16(e[8 * s2 + 0], e[8 * s2 + 1]);
-                dst[s2].y = pack_bf16(e[8 * s2 + 2], e[8 * s2 + 3]);
-                dst[s2].z = pack_bf16(e[8 * s2 + 4], e[8 * s2 + 5]);
-                dst[s2].w = pack_bf16(e[8 * s2 + 6], e[8 * s2 + 7]);
-            }
-        };
-        if constexpr (DBG & 2) {
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) pf[kb][0] = pf[kb][1] = make_uint4(0, 0, 0, 0);
-        } else if (bound <= 48.f) {
-            f32x16 sc = s_block(0);
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                f32x16 sn = sc;
-                if (kb + 1 < 8) sn = s_block(kb + 1);
-                exp_pack(sc, 0.f, pf[kb]);
-                sc = sn;
-            }
-        } else {
-            f32x16 sa[8];
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) sa[kb] = s_block(kb);
-            // row maximum over the 256 keys of query column c32: 128 values here, 128 in lane^32
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sa[kb][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mb = mx * LOG2E;
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) exp_pack(sa[kb], mb, pf[kb]);
-        }
-        // every wave is done with the K buffer -> refill it with the next item's K
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (has_next && !(DBG & 1)) dma_tile(ldsK, tile_base(nb, nh, 1));
+        const bool online = !(bound <= 48.f);
+        float m_run = -INFINITY;  // running row maximum (online form only)
+        uint4 qf[KS];
 
-        // the next item's Q fragments are requested
-        if (has_next && !(DBG & 4)) load_q(nb, nwn, nh, qf);
+#pragma unroll
+        for (int c = 0; c < NST; ++c) {
+            // ---- hand-over of stage c.  Younger VMEM operations that may stay in flight (per wave, issue order):
+            //  c = 0: needs chunk 0 and Q of this item (Q was issued right after chunk 0): chunk 1, chunk 2       = 6
+            //  c = 1: chunk 2, chunk 3 (step 0), O stores (step 0; none on the first item)                       = 12 / 6
+            //  c = 2: chunk 3, O stores, next chunk 0 + next Q (step 1)                                          = 18 / 12
+            //  c = 3: O stores, next chunk 0, next Q, next chunk 1 (step 2)                                      = 18 / 12
+            if (DBG & 5) {
+                wait_vm<0>();
+            } else if (c == 0) {
+                wait_vm<6>();
+            } else if (c == 1) {
+                if (have_prev && !(DBG & 8)) wait_vm<12>(); else wait_vm<6>();
+            } else {
+                if (have_prev && !(DBG & 8)) wait_vm<18>(); else wait_vm<12>();
+            }
+            __builtin_amdgcn_s_barrier();
+            // every wave's pieces of stage c have landed, and every wave is done with stage c-1 (its fragment reads
+            // were consumed by MFMAs before it arrived here) -> refill that stage with the chunk three ahead
+            if (c == 0) {
+                tb_w = w;
+                if (!(DBG & 1)) dma_chunk(b, h, 3);
+                // Q fragments of query row 32*wv + c32: chunk 2*ks + hh of the row (chunk 11 does not exist -> zeros)
+                const char* qrow = smem + (wv * 32 + c32) * ROW;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks == KS - 1) {
+                        const uint4 t = *reinterpret_cast<const uint4*>(qrow + (2 * ks) * 16);
+                        qf[ks] = hh ? make_uint4(0, 0, 0, 0) : t;
+                    } else {
+                        qf[ks] = *reinterpret_cast<const uint4*>(qrow + (2 * ks + hh) * 16);
+                    }
+                }
+                if (have_prev) {
+                    if (!(DBG & 8)) store_o(pb, pw, ph, rl_prev);
+                }
+                // only now may the accumulators be recycled for this item
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+            } else {
+                if (c == 1 && nwn != cur_w && !a.tiled) set_window(nwn);
+                tb_w = nwn;
+                if (!(DBG & 1)) dma_chunk(nb, nh, c - 1);
+                // every wave has its Q fragments in registers (they were consumed by step 0's MFMAs): the buffer
+                // takes the next item's Q, a whole item ahead of its use
+                if (c == 1 && !(DBG & 4)) dma_q(nb, nh);
+            }
+            if constexpr (DBG & 2) continue;
 
-        // O^T[d][q] += V^T[d][key] P^T[key][q].  The row sum l rides on the matrix pipe: an all-ones A row gives
-        // sum_key P^T[key][q] (exactly the bf16-rounded probabilities the numerator uses) -- no 128 v_add, no shuffle.
-        // It costs no extra MFMA: the third 32-wide d block only has 24 real rows (d = 64..87); lanes that would feed
-        // rows d = 88..95 of V^T supply ones instead, so those (otherwise discarded) output rows ARE the row sum.
+            // S^T[key][q] = K Q^T for the 64 keys of this stage, as two 32-key blocks
+            const char* sK = smem + OFF_K + c * CHB;
+            const char* sV = smem + OFF_V + c * CHB;
+            f32x16 sc[2];
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+            for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-        const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
-        if constexpr (!(DBG & 2)) {
+                for (int r = 0; r < 16; ++r) sc[k2][r] = 0.f;
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
+                for (int ks = 0; ks < KS; ++ks) {
+                    const uint4 kf = *reinterpret_cast<const uint4*>(sK + (k2 * 32 + c32) * ROW + ks * 32 + hh * 16);
+                    sc[k2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                                     __builtin_bit_cast(bf16x8, qf[ks]), sc[k2], 0, 0, 0);
+                }
+            }
+            float mb = 0.f;
+            if (online) {
+                // running maximum of query column c32 (this lane's 32 values and lane^32's), rescale O and l with it
+                float mx = m_run;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[k2][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * LOG2E);  // 0 on the first chunk (O is 0 too)
+                m_run = mx;
+                mb = mx * LOG2E;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+            }
+            // P^T = exp(S^T - m) as packed bf16 B operands, then O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                float e[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(sc[k2][r] * LOG2E - mb);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const char* vrow = sV + (kb * 32 + s2 * 16) * ROW + vbase;
+                    uint4 pf;
+                    pf.x = pack_bf16(e[8 * s2 + 0], e[8 * s2 + 1]);
+                    pf.y = pack_bf16(e[8 * s2 + 2], e[8 * s2 + 3]);
+                    pf.z = pack_bf16(e[8 * s2 + 4], e[8 * s2 + 5]);
+                    pf.w = pack_bf16(e[8 * s2 + 6], e[8 * s2 + 7]);
+                    const char* vrow = sV + (k2 * 32 + s2 * 16) * ROW + vbase;
 #pragma unroll
                     for (int db = 0; db < DB; ++db) {
                         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -278,30 +339,33 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
                         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (__attribute__((address_space(3))) s16x4*)(vrow + db * 64 + 8 * ROW));
                         uint4 vf = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        // rows d = 88..95 of V^T do not exist: feeding ones there makes those output rows the row sum
+                        // of exactly the bf16-rounded probabilities the numerator uses -- no v_add chain, no shuffle
                         if (db == DB - 1 && c32 >= HD - 32 * (DB - 1)) vf = ones;
                         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
-                                                                        __builtin_bit_cast(bf16x8, pf[kb][s2]), o[db], 0, 0, 0);
+                                                                        __builtin_bit_cast(bf16x8, pf), o[db], 0, 0, 0);
                     }
                 }
             }
         }
-        const float l = (DBG & 2) ? 1.f : o[DB - 1][12];  // row 24 (hh = 0) / 28 (hh = 1) of the last block: d = 88 / 92, both "ones" rows
+        const float l = (DBG & 2) ? 1.f : o[DB - 1][12];  // row 24 (hh = 0) / 28 (hh = 1) of the last block: "ones" rows
         rl_prev = 1.0f / l;
         pb = b; pw = w; ph = h;
         have_prev = true;
         b = nb; w = nwn; h = nh;
     }
-    store_o(pb, pw, ph, rl_prev);
+    wait_vm<0>();  // trailing re-loads must not outlive the LDS allocation
+    if (!(DBG & 8)) store_o(pb, pw, ph, rl_prev);
 }
 
 }  // namespace
 
 int swiftk_launch_attn_pipe(const AttnPipeArgs& a, hipStream_t st) {
     const int nitems = a.B * (a.gh / 16) * (a.gw / 16) * a.heads;
-    // one item per CU round is the floor; with fewer than ~2 items per workgroup shrink the grid so that runs stay
-    // balanced (every workgroup gets floor or ceil of nitems/grid)
+    // one item per CU round is the floor; with fewer items than CUs shrink the grid (every workgroup gets floor or
+    // ceil of nitems/grid)
     int grid = 256;
-    if (nitems < grid) grid = nitems;
+    if (nitems < grid) grid = nitems >= 8 ? (nitems & ~7) : nitems;  // a multiple of 8 keeps the XCD-concurrent order
     switch (a.dbg) {
         case 0: hipLaunchKernelGGL(attn_pipe_kernel<0>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
         case 1: hipLaunchKernelGGL(attn_pipe_kernel<1>, dim3(grid), dim3(NT), 0, st, a, nitems); break;

@@ -99,6 +99,7 @@ struct AttnPipeArgs {
     int64_t ldq, ldo;
     int B, gh, gw, heads, sh, sw, dbg;
     const float* scale;  // per-head logit scale parameter (bounds |logit|); null = unknown
+    int tiled;           // qkv is window-tiled: [sample][window][head][q|k|v][256][88] (SWIFTK_ATTN_TILED)
 };
 int swiftk_launch_attn_pipe(const AttnPipeArgs& a, hipStream_t st);
 
@@ -106,4 +107,5 @@ int swiftk_launch_attn_pipe(const AttnPipeArgs& a, hipStream_t st);
 // epilogue code, or SWIFTK_PROF_ATTENTION) with matching n is bracketed by HIP events on its own stream
 bool swiftk_prof_begin(int kind, int n, hipStream_t st);
 void swiftk_prof_end(hipStream_t st);
+extern int g_fwd_tiled;  // tuning key 5
 extern int g_attn_dbg;  // tuning key 4: attention ablation bits (timing experiments only)

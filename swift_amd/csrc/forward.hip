@@ -3,6 +3,8 @@
 // Mirrors reference src/swift/models/swinv2.py:305-330 (+ precond.py:139-148, diffusion.py:459 folded in).
 #include "common.h"
 
+int g_fwd_tiled = 1;  // tuning key 5 (A/B only): 0 keeps q/k/v row-major between to_qkv and attention
+
 namespace {
 
 __global__ __launch_bounds__(256) void zero_cols_kernel(char* p, int64_t ld_b, int64_t col0_b, int64_t ncol_b, int64_t rows) {
@@ -128,10 +130,19 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
         const bool shifted = do_shift && (i & 1);
         // head_dim 88: cosine-attention's normalise/scale prologue rides in the to_qkv epilogue (fp32 accumulators)
         const bool fuse_norm = (hd == 88);
-        RUN(swiftk_gemm(xT, m->kd, ly.qkv_w, m->kd, qkv, 3 * d, M, 3 * d, kdv, dt, dt,
-                        fuse_norm ? SWIFTK_EPI_QKNORM : SWIFTK_EPI_NONE, fuse_norm ? ly.scale : nullptr, nullptr, 0, stream));
-        RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
-                                    shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
+        if (fuse_norm && dt == SWIFTK_BF16 && g_fwd_tiled) {
+            // bf16: q/k/v leave the GEMM window-tiled, so every attention operand is one contiguous 44-KiB block
+            RUN(swiftk_gemm_qkv_tiled(xT, m->kd, ly.qkv_w, m->kd, qkv, kdv, ly.scale, B, gh, gw, m->heads,
+                                      shifted ? m->sh : 0, shifted ? m->sw : 0, stream));
+            RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
+                                        shifted ? m->sw : 0, dt, SWIFTK_ATTN_PRENORM | SWIFTK_ATTN_TILED, stream));
+        } else {
+            RUN(swiftk_gemm(xT, m->kd, ly.qkv_w, m->kd, qkv, 3 * d, M, 3 * d, kdv, dt, dt,
+                            fuse_norm ? SWIFTK_EPI_QKNORM : SWIFTK_EPI_NONE, fuse_norm ? ly.scale : nullptr, nullptr, 0,
+                            stream));
+            RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
+                                        shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
+        }
         RUN(swiftk_gemm(att, m->kd, ly.wo_w, m->kd, y, d, M, d, kdv, dt, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, stream));
         RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok,
                                     1e-6f, dt, stream));

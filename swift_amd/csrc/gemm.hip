@@ -35,6 +35,8 @@ constexpr int A_PIECES = A_BYTES / 1024;  // 32 (4 per wave)
 constexpr int B_PIECES = B_BYTES / 1024;  // 44 (5 or 6 per wave)
 constexpr int MI = 4, NI = 11;
 
+constexpr int EPI_QKNORM_TILED = 4;  // internal: SWIFTK_EPI_QKNORM with the window-tiled store (swiftk_gemm_qkv_tiled)
+
 struct GemmArgs {
     const char* A;
     const char* W;
@@ -50,6 +52,8 @@ struct GemmArgs {
     int khalf;         // the last k-tile holds data in its first half only (K = 16.5 tiles for d = 1056)
     int ksplit;        // persistent kernel: k-ranges per output tile (1 = plain)
     int64_t c_split;   // elements between the fp32 slabs of consecutive splits
+    // QKNORM only: window-tiled output [sample][window][head][q|k|v][256][88] (t_gw = 0: plain row-major C)
+    int t_gh, t_gw, t_sh, t_sw, t_heads;
 };
 
 template <typename T>
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: lane holds C[m][nb .. nb+3] for m = ..+r16, nb = ..+4*(lane>>4) ----
-    if constexpr (EPI == SWIFTK_EPI_QKNORM)
+    if constexpr (EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED)
         qknorm_tile(acc, lane, n0 + wn * 176, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / 88);
     OutT* C = reinterpret_cast<OutT*>(g.C);
 #pragma unroll
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             it.coords(tile / ksplit, tm, tn);
             const int m0 = tm * BM, n0 = tn * BN;
             stores_pending = !(g.dbg & 8) && m0 + BM <= g.M && n0 + BN <= g.N;
-            if constexpr (EPI == SWIFTK_EPI_QKNORM)
+            if constexpr (EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED)
                 qknorm_tile(acc, lane, n0 + wn * 176, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / 88);
             OutT* C = reinterpret_cast<OutT*>(g.C) + (int64_t)(tile % ksplit) * g.c_split;
             if constexpr (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS) {
@@ -467,6 +471,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 constexpr int RSTR = COLS * 2 + 16;                            // padded slab row stride (bytes)
                 char* slab = const_cast<char*>(s) + wv * (16 * RSTR);
                 const int g4 = lane >> 4;
+                const int elane = lane;
                 const int ncol0 = (EPI == SWIFTK_EPI_SWIGLU ? (n0 >> 1) : n0) + wn * COLS;
                 const int nout = EPI == SWIFTK_EPI_SWIGLU ? (g.N >> 1) : g.N;
 #pragma unroll
@@ -487,15 +492,42 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                     }
                     __builtin_amdgcn_wave_barrier();  // slab written (LDS ops of a wave execute in order)
                     const int mrow0 = m0 + wm * 64 + i * 16;
+                    // Window-tiled destination (to_qkv for the streamed attention kernel): the 16 rows of a slab are 16
+                    // consecutive tokens of one grid row (gw % 16 == 0), so sample / grid row / column base are
+                    // wave-uniform per slab; a row's 88-wide q, k or v slice lands at [window][head][part][idx][0..87],
+                    // where the window partition is that of the grid rolled by (-t_sh, -t_sw) (swinv2.py:185-189).
+                    int tb = 0, try_ = 0, tx16 = 0, twin0 = 0;
+                    if constexpr (EPI == EPI_QKNORM_TILED) {
+                        {
+                            const int ntok = g.t_gh * g.t_gw;
+                            tb = mrow0 / ntok;
+                            const int tt = mrow0 - tb * ntok, y = tt / g.t_gw;
+                            tx16 = tt - y * g.t_gw;
+                            try_ = y - g.t_sh;
+                            try_ += try_ < 0 ? g.t_gh : 0;
+                            twin0 = tb * ((g.t_gh >> 4) * (g.t_gw >> 4)) + (try_ >> 4) * (g.t_gw >> 4);
+                        }
+                    }
 #pragma unroll
                     for (int t = 0; t < (16 * CPR + 63) / 64; ++t) {
-                        const int c = lane + 64 * t;
+                        const int c = elane + 64 * t;
                         const int row = c / CPR, cc = c - row * CPR;
                         if (c < 16 * CPR) {
                             const uint4 q = *reinterpret_cast<const uint4*>(slab + row * RSTR + cc * 16);
                             const int m = mrow0 + row, n = ncol0 + cc * 8;
-                            if (m < g.M && n < nout)
-                                *reinterpret_cast<uint4*>(C + (int64_t)m * g.ldc + n) = q;
+                            int64_t dst = (int64_t)m * g.ldc + n;
+                            if constexpr (EPI == EPI_QKNORM_TILED) {
+                                {
+                                    int rx = tx16 + row - g.t_sw;
+                                    rx += rx < 0 ? g.t_gw : 0;
+                                    const int hi = cc >= 11;
+                                    // tile = ((sample * windows + window) * heads + head) * 3 + part; the last two terms
+                                    // are the row's 88-wide slice number 4 * tn + 2 * wn + hi
+                                    const int tile_ = (twin0 + (rx >> 4)) * (3 * g.t_heads) + tn * 4 + wn * 2 + hi;
+                                    dst = (int64_t)tile_ * (256 * 88) + ((((try_ & 15) << 4) | (rx & 15)) * 88 + (cc - 11 * hi) * 8);
+                                }
+                            }
+                            if (m < g.M && n < nout) *reinterpret_cast<uint4*>(C + dst) = q;
                         }
                     }
                     __builtin_amdgcn_wave_barrier();  // slab read before the next slab overwrites it
@@ -558,7 +590,7 @@ int launch(const GemmArgs& g, hipStream_t st) {
     const bool wide_ok = sizeof(OutT) != 2 || (!((uintptr_t)g.C & 15) && !(g.ldc & 7) &&
                                                !(g.N & (EPI == SWIFTK_EPI_SWIGLU ? 15 : 7)));  // 16-B row chunks
     if (g_variant == 0 || (g.M & 7) || (g.N & 7) || !wide_ok) {  // ragged edges: per-lane clamped sources
-        if (g.ksplit != 1) return SWIFTK_ESHAPE;
+        if (g.ksplit != 1 || g.t_gw) return SWIFTK_ESHAPE;
         hipLaunchKernelGGL(kern, dim3(ntm * g.ntn), dim3(NT), 0, st, g);
     } else {
         const int ntiles = ntm * g.ntn * g.ksplit;
@@ -576,7 +608,10 @@ int dispatch_epi(int epi, const GemmArgs& g, hipStream_t st) {
         case SWIFTK_EPI_NONE: return launch<T, OutT, SWIFTK_EPI_NONE>(g, st);
         case SWIFTK_EPI_BIAS_POS: return launch<T, OutT, SWIFTK_EPI_BIAS_POS>(g, st);
         case SWIFTK_EPI_SWIGLU: return launch<T, OutT, SWIFTK_EPI_SWIGLU>(g, st);
-        case SWIFTK_EPI_QKNORM: return launch<T, OutT, SWIFTK_EPI_QKNORM>(g, st);
+        case SWIFTK_EPI_QKNORM:
+            if constexpr (sizeof(OutT) == 2)
+                if (g.t_gw) return launch<T, OutT, EPI_QKNORM_TILED>(g, st);
+            return launch<T, OutT, SWIFTK_EPI_QKNORM>(g, st);
     }
     return SWIFTK_EINVAL;
 }
@@ -605,6 +640,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 2: g_persist_wgs = value > 0 ? value : 1; return 0;
         case 3: g_dbg = value; return 0;
         case 4: g_attn_dbg = value; return 0;
+        case 5: g_fwd_tiled = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -638,7 +674,7 @@ extern "C" int64_t swiftk_gemm_k_pad(int dtype, int64_t k) {
 
 static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
                      int64_t K, int dtype, int out_dtype, int epilogue, const float* ep0, const float* ep1, int64_t pos_rows,
-                     int ksplit, int64_t c_split, void* stream) {
+                     int ksplit, int64_t c_split, void* stream, const int* tiling = nullptr) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || ksplit < 1) return SWIFTK_EINVAL;
     if (ksplit > 1 && (out_dtype != SWIFTK_F32 || epilogue != SWIFTK_EPI_NONE || c_split < M * ldc)) return SWIFTK_EINVAL;
     if (dtype != SWIFTK_F32 && dtype != SWIFTK_BF16) return SWIFTK_EINVAL;
@@ -679,6 +715,10 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     g.ksplit = ksplit;
     g.c_split = c_split;
     g.khalf = khalf;
+    g.t_gh = g.t_gw = g.t_sh = g.t_sw = g.t_heads = 0;
+    if (tiling) {
+        g.t_gh = tiling[0]; g.t_gw = tiling[1]; g.t_sh = tiling[2]; g.t_sw = tiling[3]; g.t_heads = tiling[4];
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == SWIFTK_BF16) {
         if (out_dtype == SWIFTK_BF16) return dispatch_epi<bf16_t, bf16_t>(epilogue, g, st);
@@ -691,6 +731,19 @@ extern "C" int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ld
                            int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, const float* ep0, const float* ep1,
                            int64_t pos_rows, void* stream) {
     return gemm_impl(A, lda, W, ldw, C, ldc, M, N, K, dtype, out_dtype, epilogue, ep0, ep1, pos_rows, 1, 0, stream);
+}
+
+extern "C" int swiftk_gemm_qkv_tiled(const void* A, int64_t lda, const void* W, int64_t ldw, void* qkv_tiled, int64_t K,
+                                     const float* scale, int B, int gh, int gw, int heads, int shift_h, int shift_w,
+                                     void* stream) {
+    if (B <= 0 || heads <= 0 || gh <= 0 || gw <= 0 || gh % 16 || gw % 16) return SWIFTK_ESHAPE;
+    if (shift_h < 0 || shift_w < 0 || shift_h >= gh || shift_w >= gw) return SWIFTK_ESHAPE;
+    if ((uintptr_t)qkv_tiled & 15) return SWIFTK_EALIGN;
+    if (g_variant == 0) return SWIFTK_ESHAPE;  // the tiled store lives in the persistent kernel's epilogue
+    const int tiling[5] = {gh, gw, shift_h, shift_w, heads};
+    const int64_t M = (int64_t)B * gh * gw, N = 3 * (int64_t)heads * 88;
+    return gemm_impl(A, lda, W, ldw, qkv_tiled, N, M, N, K, SWIFTK_BF16, SWIFTK_BF16, SWIFTK_EPI_QKNORM, scale, nullptr, 0, 1,
+                     0, stream, tiling);
 }
 
 extern "C" int swiftk_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, float* slabs, int64_t ldc,

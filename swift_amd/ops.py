@@ -12,7 +12,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ATTN_NO_PIPE, ATTN_PRENORM, BF16, EPI_BIAS_POS, EPI_NONE, EPI_QKNORM, EPI_SWIGLU, F32, SwiftkError,
+from ._lib import (ATTN_NO_PIPE, ATTN_PRENORM, ATTN_TILED, BF16, EPI_BIAS_POS, EPI_NONE, EPI_QKNORM, EPI_SWIGLU, F32, SwiftkError,
                    check, lib)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
@@ -68,6 +68,38 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *
     check(lib().swiftk_gemm(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K,
                             dtype_code(a.dtype), dtype_code(out.dtype), epilogue, _ptr(bias), _ptr(pos),
                             0 if pos is None else pos.shape[0], _stream()), "swiftk_gemm")
+    return out
+
+
+def gemm_qkv_tiled(a: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, B: int, grid: Tuple[int, int], heads: int,
+                   shift: Tuple[int, int] = (0, 0), out: Optional[torch.Tensor] = None, k: Optional[int] = None) -> torch.Tensor:
+    """to_qkv with the QK-norm epilogue, stored window-tiled: out[B, windows, heads, 3, 256, 88] (bf16).
+
+    ``k``: valid K when it ends half-way into the last k-tile of the (padded) operand rows.
+    """
+    _dev(a, w, scale, out)
+    gh, gw = grid
+    assert a.shape[0] == B * gh * gw and w.shape[0] == 3 * heads * 88 and a.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty(B, (gh // 16) * (gw // 16), heads, 3, 256, 88, dtype=torch.bfloat16, device=a.device)
+    check(lib().swiftk_gemm_qkv_tiled(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(),
+                                      k or a.shape[1], scale.contiguous().data_ptr(), B, gh, gw, heads, shift[0], shift[1],
+                                      _stream()), "swiftk_gemm_qkv_tiled")
+    return out
+
+
+def window_attention_tiled(qkv_tiled: torch.Tensor, scale: Optional[torch.Tensor], grid: Tuple[int, int], heads: int,
+                           shift: Tuple[int, int] = (0, 0), out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Attention over ``gemm_qkv_tiled`` output -> out [B, gh*gw, heads*88] (token order, un-rolled)."""
+    _dev(qkv_tiled, scale, out)
+    B = qkv_tiled.shape[0]
+    gh, gw = grid
+    if out is None:
+        out = torch.empty(B, gh * gw, heads * 88, dtype=torch.bfloat16, device=qkv_tiled.device)
+    check(lib().swiftk_window_attention(qkv_tiled.data_ptr(), 3 * heads * 88, out.data_ptr(), out.stride(1),
+                                        None if scale is None else scale.contiguous().data_ptr(), B, gh, gw, heads, 88,
+                                        shift[0], shift[1], BF16, ATTN_PRENORM | ATTN_TILED, _stream()),
+          "swiftk_window_attention")
     return out
 
 

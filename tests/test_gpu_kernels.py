@@ -248,7 +248,7 @@ def test_gemm_qknorm_epilogue(dev, dt):
 
 @pytest.mark.parametrize("dt,flags", [(torch.bfloat16, 1), (torch.bfloat16, 3), (torch.float32, 1)])
 @pytest.mark.parametrize("shift", [(0, 0), (8, 8)])
-@pytest.mark.parametrize("B", [1, 3])
+@pytest.mark.parametrize("B", [1, 3, 8])  # 8: 576 items > 256 workgroups, the steady state of the streamed kernel
 def test_window_attention_prenormalised(dev, dt, flags, shift, B):
     """flags 1 = PRENORM (bf16: persistent LDS-DMA-pipelined kernel), 3 = PRENORM|NO_PIPE (per-item kernel)."""
     from oracle.swinv2 import window_token_index
@@ -266,3 +266,37 @@ def test_window_attention_prenormalised(dev, dt, flags, shift, B):
     ref[:, idx.reshape(-1)] = ow.permute(0, 2, 1, 3).reshape(B, n, -1)
     assert torch.isfinite(out.float()).all()
     assert rel_l2(out.float().cpu(), ref) < (2e-5 if dt == torch.float32 else 1.2e-2)
+
+
+@pytest.mark.parametrize("shift", [(0, 0), (8, 8), (3, 5)])
+@pytest.mark.parametrize("B", [1, 3, 8])  # 8: several tiles per GEMM workgroup and several items per attention workgroup
+def test_window_tiled_qkv_path(dev, shift, B):
+    """to_qkv stored window-tiled (swiftk_gemm_qkv_tiled) + SWIFTK_ATTN_TILED attention: the tiled tensor is an exact
+    permutation of the row-major QK-norm GEMM output (window_partition of the rolled grid, swinv2.py:17-26,185-189),
+    attention over it is bit-identical to attention over the row-major tensor, and both match the fp32 formula.
+    The scale vector mixes heads whose logit bound is <= 48 (max-free streaming softmax) and > 48 (online form)."""
+    from oracle.swinv2 import window_token_index
+    from swift_amd import ops
+    grid, heads, hd = (32, 48), 12, 88
+    n = grid[0] * grid[1]
+    K = ops.k_pad(torch.bfloat16, 1056)
+    a, w = rnd((B * n, K), 50 + B), rnd((3 * heads * hd, K), 51, 0.03)
+    a[:, 1056:] = 0
+    scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 48.0])).to(dev)
+    ad, wd = to_dt(a, torch.bfloat16, dev), to_dt(w, torch.bfloat16, dev)
+    c = ops.gemm(ad, wd, epilogue=ops.EPI_QKNORM, bias=scale)
+    ct = ops.gemm_qkv_tiled(ad, wd, scale, B, grid, heads, shift)
+    idx = window_token_index(grid, (16, 16), shift)  # [windows, 256] token of each window slot
+    perm = c.view(B, n, heads, 3, hd)[:, idx.reshape(-1).to(dev)].view(B, idx.shape[0], 256, heads, 3, hd)
+    assert torch.equal(ct, perm.permute(0, 1, 3, 4, 2, 5).contiguous())
+    # K ending half-way into the last k-tile (1056 of 1088) gives the same numbers
+    assert torch.equal(ct, ops.gemm_qkv_tiled(ad, wd, scale, B, grid, heads, shift, k=1056))
+    out_rm = ops.window_attention(c.view(B, n, -1), scale, grid, heads, shift, flags=ops.ATTN_PRENORM)
+    out_t = ops.window_attention_tiled(ct, scale, grid, heads, shift)
+    assert torch.equal(out_rm, out_t)
+    src = c.float().cpu().view(B, n, -1)[:, idx.reshape(-1)].reshape(B * idx.shape[0], 256, heads, 3, hd).permute(0, 2, 1, 3, 4)
+    ow = (src[..., 0, :] @ src[..., 1, :].transpose(-2, -1)).softmax(-1) @ src[..., 2, :]
+    ref = torch.empty(B, n, heads * hd)
+    ref[:, idx.reshape(-1)] = ow.permute(0, 2, 1, 3).reshape(B, n, -1)
+    assert torch.isfinite(out_t.float()).all()
+    assert rel_l2(out_t.float().cpu(), ref) < 1.2e-2
