@@ -224,6 +224,38 @@ int swiftk_linear_small_bwd(const float* dz, int64_t lddz, const float* x, int64
                             int64_t lddx, float* dW, int64_t lddw, float* dbias, int B, int N, int K, void* stream);
 int swiftk_silu_bwd(const float* z, const float* dy, float* dz, int64_t n, void* stream);
 
+/*
+ * Forward-mode tangent rules of the sCM pre-training loss (reference training/loss.py:186-260 runs torch.func.jvp through
+ * the denoiser with jvp=True, swinv2.py:105-139).  The linear maps carry the tangent as extra GEMM rows (primal rows
+ * 0..M-1, tangent rows M..2M-1 of one swiftk_gemm call); these entry points are the non-linear steps.  fp32 arithmetic,
+ * `dtype` is the storage type of the activation tensors.
+ */
+/* d/dt of timestep_embedding (swinv2.py:44-60): demb = [cos | -sin](t w f) * w f * dt[b]. */
+int swiftk_timestep_embed_jvp(const float* t, const float* dt, const float* freqs, float* demb, int B, int d,
+                              float timestep_weight, void* stream);
+/* y = silu(z) (y may be NULL), dy = silu'(z) dz  (LatentEmbedding, swinv2.py:67-74). */
+int swiftk_silu_jvp(const float* z, const float* dz, float* y, float* dy, int64_t n, void* stream);
+/* In place on qkv / dqkv [M, ld] (head layout [q88|k88|v88]): q <- q/|q| * exp(min(scale,ln100)), k <- k/|k| and their
+ * tangents dq, dk (swinv2.py:123-127); v, dv untouched. */
+int swiftk_qknorm_jvp(void* qkv, void* dqkv, int64_t ld, const float* scale, int64_t M, int heads, int dtype, void* stream);
+/* Explicit-softmax window attention and its tangent on pre-normalised q, k (swinv2.py:129-133 with jvp=True):
+ * out = softmax(q k^T) v, dout = d/d(eps) of the same along (dq, dk, dv).  Same window/shift addressing as
+ * swiftk_window_attention; head_dim 88. */
+int swiftk_window_attention_jvp(const void* qkv, const void* dqkv, int64_t ldq, void* out, void* dout, int64_t ldo, int B,
+                                int gh, int gw, int heads, int head_dim, int shift_h, int shift_w, int dtype, void* stream);
+/* ModulatedNorm + residual and its tangent (swinv2.py:77-86): x += LN(y)(1+sc)+sh; dx += dLN(y)[dy](1+sc) + LN(y) dsc + dsh,
+ * (sc|sh) = mod[b], (dsc|dsh) = dmod[b] (per sample, ld = ldmod); xT / dxT receive the new x / dx as GEMM operands. */
+int swiftk_modnorm_jvp(const void* y, const void* dy, int64_t ldy, float* x, float* dx, void* xT, void* dxT, int64_t ldxT,
+                       const float* gamma, const float* beta, const float* mod, const float* dmod, int64_t ldmod, int64_t M,
+                       int d, int64_t rows_per_sample, float eps, int dtype, void* stream);
+/* SwiGLU and its tangent on interleaved (gate_j, up_j) columns (swinv2.py:99-100). */
+int swiftk_swiglu_jvp(const void* h, const void* dh, int64_t ldh, void* out, void* dout, int64_t ldo, int64_t M, int mlp,
+                      int dtype, void* stream);
+/* sCM regression target (loss.py:236-247): g = -cos^2 t (sd F - dxt) - r (cos t sin t x_t + sd dF), g /= (rms_b(g) + 0.1),
+ * target = F + g; x_t = xt_over_sd * sd.  ss_scratch: B floats. */
+int swiftk_scm_target(const float* F, const float* dxt, const float* xt_over_sd, const float* dF, const float* t, float r,
+                      float sigma_data, float* target, float* ss_scratch, int B, int64_t per_sample, void* stream);
+
 /* Almost-fair CRPS over m members (loss.py:343-371,445): *loss += 1/(B H W) sum w_var[c] w_lat[h] crps; dpreds optional. */
 int swiftk_crps_loss(const float* preds, const float* target, const float* w_var, const float* w_lat, float* loss,
                      float* dpreds, int m, int B, int C, int H, int W, float alpha, float gscale, void* stream);

@@ -1,0 +1,504 @@
+// Forward-mode (tangent) kernels of the sCM pre-training loss for gfx950 (reference src/swift/training/loss.py:186-260:
+// torch.func.jvp through the denoiser with jvp=True, i.e. the explicit softmax(q k^T) v attention of swinv2.py:129-133).
+//
+// The network's linear maps carry the tangent as extra rows of the same GEMM (primal rows 0..M-1, tangent rows M..2M-1,
+// gemm.hip unchanged); what lives here are the tangent rules of the non-linear steps:
+//   time embedding, SiLU, q/k L2-normalisation, windowed softmax attention, LayerNorm + modulation, SwiGLU,
+// and the loss-side target construction.  All arithmetic is fp32 (bf16 only as storage), the attention products run on
+// the fp32 matrix pipe (v_mfma_f32_16x16x4_f32): this path exists for exactness first, it is not on the forecast path.
+#include "common.h"
+
+namespace {
+
+inline int grid_for(int64_t work_items, int per_block = 256, int cap = 256 * 16) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p) { return elem<T>::to_f(*p); }
+
+constexpr float LN100 = 4.605170185988092f;
+
+// --------------------------------------------------------------------------------- time embedding / SiLU tangents
+// emb = [sin(t w f) | cos(t w f)] (swinv2.py:44-60)  =>  d emb = [cos(.) | -sin(.)] * w f * dt
+__global__ void temb_jvp_kernel(const float* __restrict__ t, const float* __restrict__ dt, const float* __restrict__ freqs,
+                                float* __restrict__ demb, int B, int d, float tw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * d) return;
+    const int b = i / d, k = i - b * d, half = d >> 1;
+    float v = 0.f;
+    if (k < 2 * half) {
+        const float f = freqs[k < half ? k : k - half];
+        const float arg = (t[b] * tw) * f;
+        v = (k < half ? cosf(arg) : -sinf(arg)) * (tw * f) * dt[b];
+    }
+    demb[i] = v;
+}
+
+__global__ void silu_jvp_kernel(const float* __restrict__ z, const float* __restrict__ dz, float* __restrict__ y,
+                                float* __restrict__ dy, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = z[i], s = 1.0f / (1.0f + expf(-v));
+        if (y) y[i] = v * s;
+        dy[i] = dz[i] * (s + v * s * (1.0f - s));
+    }
+}
+
+// --------------------------------------------------------------------------------- q/k normalisation tangent
+// v_hat = v / max(|v|, 1e-12) * tau,  d v_hat = tau / n * (dv - v (v . dv) / n^2)   (swinv2.py:123-127; tau = 1 for k)
+// One 16-lane group per (row, head, q|k) vector of 88; in place on the primal and the tangent tensor.
+template <typename T>
+__global__ __launch_bounds__(256) void qknorm_jvp_kernel(T* __restrict__ qkv, T* __restrict__ dqkv, int64_t ld,
+                                                         const float* __restrict__ scale, int64_t M, int heads) {
+    const int l16 = threadIdx.x & 15;
+    const int64_t nvec = M * heads * 2;
+    for (int64_t vid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; vid < nvec; vid += ((int64_t)gridDim.x * 256) >> 4) {
+        const int part = (int)(vid & 1);
+        const int64_t mh = vid >> 1;
+        const int h = (int)(mh % heads);
+        const int64_t m = mh / heads;
+        T* p = qkv + m * ld + (h * 3 + part) * 88;
+        T* dp = dqkv + m * ld + (h * 3 + part) * 88;
+        float v[6], dv[6], ss = 0.f, dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int e = l16 + 16 * i;
+            v[i] = e < 88 ? ldf(p + e) : 0.f;
+            dv[i] = e < 88 ? ldf(dp + e) : 0.f;
+            ss += v[i] * v[i];
+            dot += v[i] * dv[i];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            ss += __shfl_xor(ss, o, 64);
+            dot += __shfl_xor(dot, o, 64);
+        }
+        const float n = fmaxf(sqrtf(ss), 1e-12f);
+        const float tau = part == 0 ? expf(fminf(scale[h], LN100)) : 1.0f;
+        const float a = tau / n, c = dot / (n * n);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int e = l16 + 16 * i;
+            if (e < 88) {
+                p[e] = elem<T>::from_f(v[i] * a);
+                dp[e] = elem<T>::from_f(a * (dv[i] - v[i] * c));
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------- SwiGLU tangent
+// h [M, 2*mlp] with columns interleaved (gate_j, up_j):  o = silu(g) u,  do = silu'(g) dg u + silu(g) du
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_jvp_kernel(const T* __restrict__ h, const T* __restrict__ dh, int64_t ldh,
+                                                         T* __restrict__ o, T* __restrict__ dout, int64_t ldo, int64_t M,
+                                                         int mlp) {
+    const int64_t total = M * mlp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / mlp;
+        const int j = (int)(i - m * mlp);
+        const float g = ldf(h + m * ldh + 2 * j), u = ldf(h + m * ldh + 2 * j + 1);
+        const float dg = ldf(dh + m * ldh + 2 * j), du = ldf(dh + m * ldh + 2 * j + 1);
+        const float s = 1.0f / (1.0f + expf(-g));
+        o[m * ldo + j] = elem<T>::from_f(g * s * u);
+        dout[m * ldo + j] = elem<T>::from_f((s + g * s * (1.0f - s)) * dg * u + g * s * du);
+    }
+}
+
+// --------------------------------------------------------------------------------- LayerNorm + modulation tangent
+// primal:  x += (n gamma + beta)(1 + sc) + sh,          n = (y - mu) rstd            (swinv2.py:77-86, post-norm :137,:101)
+// tangent: dx += gamma dn (1 + sc) + (n gamma + beta) dsc + dsh,  dn = (dy - mean(dy) - n mean(n dy)) rstd
+// One wave per row; the row (d <= 1536) lives in registers.
+template <typename T>
+__global__ __launch_bounds__(256) void modnorm_jvp_kernel(const T* __restrict__ y, const T* __restrict__ dy, int64_t ldy,
+                                                          float* __restrict__ x, float* __restrict__ dx, T* __restrict__ xT,
+                                                          T* __restrict__ dxT, int64_t ldxT, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ mod,
+                                                          const float* __restrict__ dmod, int64_t ldmod, int64_t M, int d,
+                                                          int64_t rps, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t b = row / rps;
+    float yv[24], dv[24];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const int e = lane + 64 * i;
+        yv[i] = e < d ? ldf(y + row * ldy + e) : 0.f;
+        dv[i] = e < d ? ldf(dy + row * ldy + e) : 0.f;
+        s0 += yv[i];
+        s1 += dv[i];
+    }
+    const float inv_d = 1.0f / (float)d;
+    const float mu = wave_sum(s0) * inv_d, mdy = wave_sum(s1) * inv_d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const int e = lane + 64 * i;
+        const float c = e < d ? yv[i] - mu : 0.f;
+        s2 += c * c;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) * inv_d + eps);
+    float s3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const int e = lane + 64 * i;
+        yv[i] = e < d ? (yv[i] - mu) * rstd : 0.f;  // n
+        s3 += yv[i] * dv[i];
+    }
+    const float mndy = wave_sum(s3) * inv_d;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const int e = lane + 64 * i;
+        if (e < d) {
+            const float n = yv[i], dn = (dv[i] - mdy - n * mndy) * rstd;
+            const float ga = gamma[e], ln = n * ga + beta[e];
+            const float sc = mod[b * ldmod + e], sh = mod[b * ldmod + d + e];
+            const float dsc = dmod[b * ldmod + e], dsh = dmod[b * ldmod + d + e];
+            const float xn = x[row * d + e] + ln * (1.0f + sc) + sh;
+            const float dxn = dx[row * d + e] + ga * dn * (1.0f + sc) + ln * dsc + dsh;
+            x[row * d + e] = xn;
+            dx[row * d + e] = dxn;
+            xT[row * ldxT + e] = elem<T>::from_f(xn);
+            dxT[row * ldxT + e] = elem<T>::from_f(dxn);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------- windowed softmax attention tangent
+// Per (sample, window, head), q_hat/k_hat pre-normalised (qknorm_jvp), softmax scale 1 (swinv2.py:129-133):
+//   S = Q K^T,  P = softmax(S),  O = P V
+//   dS = dQ K^T + Q dK^T,  dP = P o (dS - rowsum(P o dS)),  dO = dP V + P dV
+// With unnormalised e = exp(S - max), l = rowsum(e), W = e o dS, r = rowsum(W):
+//   O = (e V) / l,   dO = (W V + e dV - (r / l) (e V)) / l
+// One workgroup per (item, query half): 8 waves x 16 query rows, v_mfma_f32_16x16x4_f32.  One fp32 LDS image
+// (256 rows x 96, stride 100 floats: conflict-free for both read patterns below) holds K, dK, V, dV in turn.
+// S^T[key][q] orientation: a lane owns query column c16 and keys 16 blk + 4 g + r (g = lane >> 4), so the accumulator
+// registers are, register for register, the B operand of the four-key k-steps {16 blk + 4 kk + r : kk = 0..3} of
+// O^T[d][q] = V^T[d][key] P^T[key][q].
+constexpr int ISTR = 100;
+
+struct AttnJvpArgs {
+    const void* qkv;
+    const void* dqkv;
+    void* out;
+    void* dout;
+    int64_t ldq, ldo;
+    int gh, gw, heads, sh, sw, nwx, nw;
+};
+
+__device__ __forceinline__ int jvp_window_token(const AttnJvpArgs& a, int w, int j) {
+    const int wy = w / a.nwx, wx = w - wy * a.nwx;
+    int gy = wy * 16 + (j >> 4) + a.sh;
+    int gx = wx * 16 + (j & 15) + a.sw;
+    gy = gy >= a.gh ? gy - a.gh : gy;
+    gx = gx >= a.gw ? gx - a.gw : gx;
+    return gy * a.gw + gx;
+}
+
+template <typename T>
+__device__ __forceinline__ void load_row88(const T* src, float* dst);
+template <>
+__device__ __forceinline__ void load_row88<float>(const float* src, float* dst) {
+#pragma unroll
+    for (int c = 0; c < 22; ++c) *reinterpret_cast<float4*>(dst + 4 * c) = *reinterpret_cast<const float4*>(src + 4 * c);
+}
+template <>
+__device__ __forceinline__ void load_row88<bf16_t>(const bf16_t* src, float* dst) {
+#pragma unroll
+    for (int c = 0; c < 11; ++c) {
+        const uint4 u = *reinterpret_cast<const uint4*>(src + 8 * c);
+        *reinterpret_cast<float4*>(dst + 8 * c) = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                                              __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+        *reinterpret_cast<float4*>(dst + 8 * c + 4) = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                                                                  __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void attn_jvp_kernel(AttnJvpArgs a) {
+    __shared__ __attribute__((aligned(16))) float img[256 * ISTR];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qh = blockIdx.x & 1;
+    const int item = blockIdx.x >> 1;
+    const int head = item % a.heads;
+    const int w = (item / a.heads) % a.nw;
+    const int b = item / (a.heads * a.nw);
+    const int64_t tok0 = (int64_t)b * a.gh * a.gw;
+    const T* qkv = static_cast<const T*>(a.qkv);
+    const T* dqkv = static_cast<const T*>(a.dqkv);
+    const int c16 = lane & 15, g = lane >> 4;
+
+    // fill the image with part `part` (1 = k, 2 = v) of the primal (tan = 0) or tangent (tan = 1) tensor
+    auto fill = [&](int part, int tan) {
+        if (tid < 256) {
+            const T* src = (tan ? dqkv : qkv) + (tok0 + jvp_window_token(a, w, tid)) * a.ldq + (head * 3 + part) * 88;
+            float* dst = img + tid * ISTR;
+            load_row88<T>(src, dst);
+            *reinterpret_cast<float4*>(dst + 88) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(dst + 92) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    // this lane's slice of its query row: d = 24 g + i, i = 0..23 (zero for d >= 88)
+    float qv[24], dqv[24];
+    {
+        const int tq = jvp_window_token(a, w, qh * 128 + wv * 16 + c16);
+        const T* qs = qkv + (tok0 + tq) * a.ldq + head * 3 * 88;
+        const T* dqs = dqkv + (tok0 + tq) * a.ldq + head * 3 * 88;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            const int d = 24 * g + i;
+            qv[i] = d < 88 ? ldf(qs + d) : 0.f;
+            dqv[i] = d < 88 ? ldf(dqs + d) : 0.f;
+        }
+    }
+    fill(1, 0);
+    __syncthreads();
+
+    f32x4 s[16], ds[16];
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk) {
+        s[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ds[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* krow = img + (blk * 16 + c16) * ISTR + 24 * g;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const float4 kf = *reinterpret_cast<const float4*>(krow + 4 * c);
+            const float kk[4] = {kf.x, kf.y, kf.z, kf.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[e], qv[4 * c + e], s[blk], 0, 0, 0);
+                ds[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[e], dqv[4 * c + e], ds[blk], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    fill(1, 1);
+    __syncthreads();
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk) {
+        const float* krow = img + (blk * 16 + c16) * ISTR + 24 * g;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const float4 kf = *reinterpret_cast<const float4*>(krow + 4 * c);
+            const float kk[4] = {kf.x, kf.y, kf.z, kf.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ds[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[e], qv[4 * c + e], ds[blk], 0, 0, 0);
+        }
+    }
+
+    // softmax statistics of query column c16: 64 keys here, the rest in lanes c16 + 16, + 32, + 48
+    float mx = -INFINITY;
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[blk][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float l = 0.f, rs = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = expf(s[blk][r] - mx);
+            const float wgt = e * ds[blk][r];
+            s[blk][r] = e;
+            ds[blk][r] = wgt;
+            l += e;
+            rs += wgt;
+        }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+
+    __syncthreads();
+    fill(2, 0);
+    __syncthreads();
+    f32x4 o[6], u[6], tt[6];
+#pragma unroll
+    for (int db = 0; db < 6; ++db) {
+        o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tt[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* vrow = img + (blk * 16 + 4 * g + r) * ISTR + c16;
+#pragma unroll
+            for (int db = 0; db < 6; ++db) {
+                const float vf = vrow[16 * db];
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, s[blk][r], o[db], 0, 0, 0);
+                u[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, ds[blk][r], u[db], 0, 0, 0);
+            }
+        }
+    __syncthreads();
+    fill(2, 1);
+    __syncthreads();
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* vrow = img + (blk * 16 + 4 * g + r) * ISTR + c16;
+#pragma unroll
+            for (int db = 0; db < 6; ++db) tt[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[16 * db], s[blk][r], tt[db], 0, 0, 0);
+        }
+
+    // lane holds O^T[d = 16 db + 4 g + 0..3][q = c16]
+    const float rl = 1.0f / l, rr = rs * rl;
+    const int64_t orow = (tok0 + jvp_window_token(a, w, qh * 128 + wv * 16 + c16)) * a.ldo + head * 88;
+    T* po = static_cast<T*>(a.out) + orow;
+    T* pdo = static_cast<T*>(a.dout) + orow;
+#pragma unroll
+    for (int db = 0; db < 6; ++db) {
+        const int d = 16 * db + 4 * g;
+        if (d < 88) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                po[d + r] = elem<T>::from_f(o[db][r] * rl);
+                pdo[d + r] = elem<T>::from_f((u[db][r] + tt[db][r] - rr * o[db][r]) * rl);
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------- sCM target (loss.py:236-247)
+// g = -cos^2 t (sd F - dxt) - r (cos t sin t x_t + sd dF);  g /= (rms_sample(g) + 0.1);  target = F + g
+// (the loss kernel then sees (F - target)^2 = g^2 with gradient -2 w g through F only, as Fx - Fx.detach() - g does)
+__global__ __launch_bounds__(256) void scm_g_kernel(const float* __restrict__ F, const float* __restrict__ dxt,
+                                                    const float* __restrict__ xt_over_sd, const float* __restrict__ dF,
+                                                    const float* __restrict__ t, float r, float sd, float* __restrict__ gbuf,
+                                                    float* __restrict__ ss, int64_t per) {
+    const int b = blockIdx.y;
+    const float c = cosf(t[b]), s = sinf(t[b]);
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+        const int64_t k = (int64_t)b * per + i;
+        const float gv = -(c * c) * (sd * F[k] - dxt[k]) - r * ((c * s) * (xt_over_sd[k] * sd) + sd * dF[k]);
+        gbuf[k] = gv;
+        acc += gv * gv;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(ss + b, acc);
+}
+__global__ __launch_bounds__(256) void scm_target_kernel(const float* __restrict__ F, float* __restrict__ gbuf,
+                                                         const float* __restrict__ ss, int64_t per) {
+    const int b = blockIdx.y;
+    const float inv = 1.0f / (sqrtf(ss[b] / (float)per) + 0.1f);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+        const int64_t k = (int64_t)b * per + i;
+        gbuf[k] = F[k] + gbuf[k] * inv;
+    }
+}
+
+}  // namespace
+
+#define DT_SWITCH(dtype, CALL_BF16, CALL_F32) \
+    if (dtype == SWIFTK_BF16) { CALL_BF16; } else if (dtype == SWIFTK_F32) { CALL_F32; } else return SWIFTK_EINVAL
+
+extern "C" int swiftk_timestep_embed_jvp(const float* t, const float* dt, const float* freqs, float* demb, int B, int d,
+                                         float timestep_weight, void* stream) {
+    if (!t || !dt || !freqs || !demb || B <= 0 || d <= 0) return SWIFTK_EINVAL;
+    hipLaunchKernelGGL(temb_jvp_kernel, dim3((B * d + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), t, dt, freqs,
+                       demb, B, d, timestep_weight);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_silu_jvp(const float* z, const float* dz, float* y, float* dy, int64_t n, void* stream) {
+    if (!z || !dz || !dy || n <= 0) return SWIFTK_EINVAL;
+    hipLaunchKernelGGL(silu_jvp_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), z, dz, y, dy, n);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_qknorm_jvp(void* qkv, void* dqkv, int64_t ld, const float* scale, int64_t M, int heads, int dtype,
+                                 void* stream) {
+    if (!qkv || !dqkv || !scale || M <= 0 || heads <= 0) return SWIFTK_EINVAL;
+    if (ld < 3 * heads * 88) return SWIFTK_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(M * heads * 2, 16);
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL(qknorm_jvp_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<bf16_t*>(qkv),
+                                 static_cast<bf16_t*>(dqkv), ld, scale, M, heads),
+              hipLaunchKernelGGL(qknorm_jvp_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<float*>(qkv),
+                                 static_cast<float*>(dqkv), ld, scale, M, heads));
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_swiglu_jvp(const void* h, const void* dh, int64_t ldh, void* out, void* dout, int64_t ldo, int64_t M,
+                                 int mlp, int dtype, void* stream) {
+    if (!h || !dh || !out || !dout || M <= 0 || mlp <= 0) return SWIFTK_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(M * mlp);
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL(swiglu_jvp_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(h),
+                                 static_cast<const bf16_t*>(dh), ldh, static_cast<bf16_t*>(out), static_cast<bf16_t*>(dout),
+                                 ldo, M, mlp),
+              hipLaunchKernelGGL(swiglu_jvp_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(h),
+                                 static_cast<const float*>(dh), ldh, static_cast<float*>(out), static_cast<float*>(dout), ldo,
+                                 M, mlp));
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_modnorm_jvp(const void* y, const void* dy, int64_t ldy, float* x, float* dx, void* xT, void* dxT,
+                                  int64_t ldxT, const float* gamma, const float* beta, const float* mod, const float* dmod,
+                                  int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps, int dtype,
+                                  void* stream) {
+    if (!y || !dy || !x || !dx || !xT || !dxT || !gamma || !beta || !mod || !dmod || M <= 0 || rows_per_sample <= 0)
+        return SWIFTK_EINVAL;
+    if (d > 1536 || M % rows_per_sample || ldxT < d || ldy < d) return SWIFTK_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)((M + 3) / 4);
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL(modnorm_jvp_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(y),
+                                 static_cast<const bf16_t*>(dy), ldy, x, dx, static_cast<bf16_t*>(xT), static_cast<bf16_t*>(dxT),
+                                 ldxT, gamma, beta, mod, dmod, ldmod, M, d, rows_per_sample, eps),
+              hipLaunchKernelGGL(modnorm_jvp_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(y),
+                                 static_cast<const float*>(dy), ldy, x, dx, static_cast<float*>(xT), static_cast<float*>(dxT),
+                                 ldxT, gamma, beta, mod, dmod, ldmod, M, d, rows_per_sample, eps));
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_window_attention_jvp(const void* qkv, const void* dqkv, int64_t ldq, void* out, void* dout, int64_t ldo,
+                                           int B, int gh, int gw, int heads, int head_dim, int shift_h, int shift_w, int dtype,
+                                           void* stream) {
+    if (!qkv || !dqkv || !out || !dout || B <= 0 || heads <= 0) return SWIFTK_EINVAL;
+    if (head_dim != 88) return SWIFTK_ESHAPE;
+    if (gh <= 0 || gw <= 0 || gh % 16 || gw % 16) return SWIFTK_ESHAPE;
+    if (shift_h < 0 || shift_w < 0 || shift_h >= gh || shift_w >= gw) return SWIFTK_ESHAPE;
+    if (ldq < 3 * heads * 88 || ldo < heads * 88) return SWIFTK_ESHAPE;
+    const int es = dtype == SWIFTK_BF16 ? 2 : 4;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)dqkv & 15) || (ldq * es) % 16) return SWIFTK_EALIGN;
+    AttnJvpArgs a{qkv, dqkv, out, dout, ldq, ldo, gh, gw, heads, shift_h, shift_w, gw / 16, (gh / 16) * (gw / 16)};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = B * a.nw * heads * 2;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(attn_jvp_kernel<bf16_t>, dim3(grid), dim3(512), 0, st, a),
+              hipLaunchKernelGGL(attn_jvp_kernel<float>, dim3(grid), dim3(512), 0, st, a));
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_scm_target(const float* F, const float* dxt, const float* xt_over_sd, const float* dF, const float* t,
+                                 float r, float sigma_data, float* target, float* ss_scratch, int B, int64_t per_sample,
+                                 void* stream) {
+    if (!F || !dxt || !xt_over_sd || !dF || !t || !target || !ss_scratch || B <= 0 || per_sample <= 0) return SWIFTK_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(ss_scratch, 0, sizeof(float) * B, st) != hipSuccess) return SWIFTK_EINVAL;
+    const dim3 grid((unsigned)grid_for(per_sample, 256, 512), (unsigned)B);
+    hipLaunchKernelGGL(scm_g_kernel, grid, dim3(256), 0, st, F, dxt, xt_over_sd, dF, t, r, sigma_data, target, ss_scratch,
+                       per_sample);
+    hipLaunchKernelGGL(scm_target_kernel, grid, dim3(256), 0, st, F, target, ss_scratch, per_sample);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}

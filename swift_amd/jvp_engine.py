@@ -1,0 +1,162 @@
+"""Forward-mode tangent of the SwinV2 denoiser on the gfx950 kernels: (x, t; dx, dt) -> dF.
+
+What the reference obtains with ``torch.func.jvp(lambda x, t: net.module(x, t, cond, aux, jvp=True), ...)``
+(training/loss.py:212-220; ``jvp=True`` selects the explicit ``softmax(q k^T) v`` attention, swinv2.py:129-133).
+Here the tangent is propagated explicitly, one kernel per step:
+
+  * linear maps (patch embedding, to_qkv, wo, w1, w2, head, the small latent/modulation linears): the tangent rides
+    as extra rows of the same GEMM -- primal rows 0..M-1, tangent rows M..2M-1 of one ``swiftk_gemm`` launch, so the
+    weight panels are streamed once for both;
+  * non-linear steps: ``swiftk_timestep_embed_jvp``, ``swiftk_silu_jvp``, ``swiftk_qknorm_jvp``,
+    ``swiftk_window_attention_jvp``, ``swiftk_modnorm_jvp``, ``swiftk_swiglu_jvp`` (csrc/jvp_kernels.hip).
+
+The condition and auxiliary inputs carry no tangent (loss.py:212-213 closes over them).  ``dtype`` is the storage /
+GEMM-operand type of the activations (bf16 under the trainer's autocast, fp32 for parity checks); residual stream,
+normalisation statistics and the attention products are fp32 either way.  No parameter gradients: the sCM loss detaches
+the tangent (loss.py:238-240).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import ops
+from ._lib import EPI_BIAS_POS, EPI_NONE, SwiftkError, check, lib
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gemm(a, w, out, epi=EPI_NONE, ep0=None, ep1=None, pos_rows=0):
+    M, K = a.shape
+    check(lib().swiftk_gemm(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, w.shape[0],
+                            K, ops.dtype_code(a.dtype), ops.dtype_code(out.dtype), epi, None if ep0 is None else ep0.data_ptr(),
+                            None if ep1 is None else ep1.data_ptr(), pos_rows, _s()), "swiftk_gemm")
+    return out
+
+
+class SwinJvpEngine:
+    def __init__(self, module, dtype: torch.dtype = torch.bfloat16):
+        self.m = module
+        if module.dim // module.heads != 88:
+            raise SwiftkError("the tangent kernels are built for head_dim 88 (Swift-B)")
+        self.dt = dtype
+        self._stamp = None
+
+    def refresh(self):
+        m, dt = self.m, self.dt
+        stamp = tuple((p.data_ptr(), p._version) for p in m.parameters())
+        if stamp == self._stamp:
+            return
+        d, mlp = m.dim, m.mlp_dim
+        self.kd, self.kmlp = ops.k_pad(dt, d), ops.k_pad(dt, mlp)
+        self.kpe = ops.k_pad(dt, m.in_channels * m.patch_size[0] * m.patch_size[1])
+        cast = lambda w, k: ops.pad_cols(w.detach(), k, dt)
+        self.L = []
+        mods_w, mods_b = [], []
+        for att, ff in m.transformer.layers:
+            w1i = ff.w1.weight.detach().view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)  # (gate_j, up_j) interleaved
+            self.L.append(dict(qkv=cast(att.to_qkv.weight, self.kd), wo=cast(att.wo.weight, self.kd), w1=cast(w1i, self.kd),
+                               w2=cast(ff.w2.weight, self.kmlp), scale=att.scale.detach().reshape(-1).float().contiguous(),
+                               g1=att.norm.norm.weight.detach().float().contiguous(),
+                               b1=att.norm.norm.bias.detach().float().contiguous(),
+                               g2=ff.norm.norm.weight.detach().float().contiguous(),
+                               b2=ff.norm.norm.bias.detach().float().contiguous()))
+            mods_w += [att.norm.modulation.weight.detach(), ff.norm.modulation.weight.detach()]
+            mods_b += [att.norm.modulation.bias.detach(), ff.norm.modulation.bias.detach()]
+        self.pe = cast(m.patch_embed.emb.weight, self.kpe)
+        self.head = cast(m.head.head[0].weight, self.kd)
+        self.mod_w, self.mod_b = torch.cat(mods_w, 0).float().contiguous(), torch.cat(mods_b, 0).float().contiguous()
+        half = d // 2
+        self.freqs = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32) / half).to(self.mod_w.device)
+        self._stamp = stamp
+
+    @staticmethod
+    def _f(p):
+        return p.detach().float().contiguous()
+
+    def jvp(self, srcs: Sequence[torch.Tensor], dsrc0: torch.Tensor, t: torch.Tensor, dt_: torch.Tensor,
+            aux: Optional[torch.Tensor]) -> torch.Tensor:
+        """srcs: channel-concatenated network inputs (srcs[0] carries the tangent ``dsrc0``); t, dt_: [B].  Returns dF."""
+        self.refresh()
+        m, T = self.m, self.dt
+        tc = ops.dtype_code(T)
+        dev = srcs[0].device
+        B = srcs[0].shape[0]
+        d, heads, mlp = m.dim, m.heads, m.mlp_dim
+        gh, gw = m.grid_size
+        ntok = gh * gw
+        M = B * ntok
+        L = lib()
+        srcs = [s.contiguous().float() for s in srcs]
+        dsrc0 = dsrc0.contiguous().float()
+        t, dt_ = t.contiguous().float(), dt_.contiguous().float()
+        # ---- time embedding -> latent -> modulation, and their tangents
+        aux_s = aux.contiguous().float() if (m.auxiliary_embed is not None and aux is not None) else None
+        emb = ops.timestep_embed(t, aux_s, self.freqs, None if aux_s is None else self._f(m.auxiliary_embed.weight),
+                                 None if aux_s is None else self._f(m.auxiliary_embed.bias), d, float(m.timestep_weight))
+        demb = torch.empty_like(emb)
+        check(L.swiftk_timestep_embed_jvp(t.data_ptr(), dt_.data_ptr(), self.freqs.data_ptr(), demb.data_ptr(), B, d,
+                                          float(m.timestep_weight), _s()), "swiftk_timestep_embed_jvp")
+
+        def silu_pair(z, dz):
+            y, dy = torch.empty_like(z), torch.empty_like(z)
+            check(L.swiftk_silu_jvp(z.data_ptr(), dz.data_ptr(), y.data_ptr(), dy.data_ptr(), z.numel(), _s()), "swiftk_silu_jvp")
+            return y, dy
+
+        l1w, l1b = self._f(m.latent_embed.l1.weight), self._f(m.latent_embed.l1.bias)
+        l2w, l2b = self._f(m.latent_embed.l2.weight), self._f(m.latent_embed.l2.bias)
+        h1, dh1 = silu_pair(ops.linear_small(emb, l1w, l1b, 0), ops.linear_small(demb, l1w, None, 0))
+        lat, dlat = silu_pair(ops.linear_small(h1, l2w, l2b, 0), ops.linear_small(dh1, l2w, None, 0))
+        mod = ops.linear_small(lat, self.mod_w, self.mod_b, 0)      # [B, depth * 2 * 2d]
+        dmod = ops.linear_small(dlat, self.mod_w, None, 0)
+        ldmod = mod.stride(0)
+        # ---- patch embedding: primal with bias + pos_embed, tangent without
+        rest = sum(s.shape[1] for s in srcs[1:])
+        ape = ops.patchify(srcs, [1.0] * len(srcs), m.patch_size, self.kpe, T)
+        dsr = [dsrc0] + ([torch.zeros(B, rest, *dsrc0.shape[2:], device=dev)] if rest else [])
+        dape = ops.patchify(dsr, [1.0] * len(dsr), m.patch_size, self.kpe, T)
+        X = torch.empty(2 * M, d, dtype=torch.float32, device=dev)   # residual stream: primal rows, then tangent rows
+        x, dx = X[:M], X[M:]
+        _gemm(ape, self.pe, x, EPI_BIAS_POS, self._f(m.patch_embed.emb.bias), self._f(m.pos_embed).reshape(ntok, d), ntok)
+        _gemm(dape, self.pe, dx)
+        XT = torch.zeros(2 * M, self.kd, dtype=T, device=dev)        # GEMM-operand copy (K padding stays zero)
+        check(L.swiftk_cast_pad(X.data_ptr(), d, XT.data_ptr(), self.kd, 2 * M, d, tc, _s()), "swiftk_cast_pad")
+        QKV = torch.empty(2 * M, 3 * d, dtype=T, device=dev)
+        ATT = torch.zeros(2 * M, self.kd, dtype=T, device=dev)
+        Y = torch.empty(2 * M, d, dtype=T, device=dev)
+        H = torch.empty(2 * M, 2 * mlp, dtype=T, device=dev)
+        HM = torch.zeros(2 * M, self.kmlp, dtype=T, device=dev)
+        es = XT.element_size()
+
+        def modnorm(i2, gamma, beta):
+            off = i2 * 2 * d * 4
+            check(L.swiftk_modnorm_jvp(Y.data_ptr(), Y.data_ptr() + M * d * es, d, x.data_ptr(), dx.data_ptr(), XT.data_ptr(),
+                                       XT.data_ptr() + M * self.kd * es, self.kd, gamma.data_ptr(), beta.data_ptr(),
+                                       mod.data_ptr() + off, dmod.data_ptr() + off, ldmod, M, d, ntok, 1e-6, tc, _s()),
+                  "swiftk_modnorm_jvp")
+
+        do_shift = any(m.shift_size)
+        for i in range(len(self.L)):
+            W = self.L[i]
+            sh = tuple(m.shift_size) if (do_shift and i % 2) else (0, 0)
+            _gemm(XT, W["qkv"], QKV)
+            check(L.swiftk_qknorm_jvp(QKV.data_ptr(), QKV.data_ptr() + M * 3 * d * es, 3 * d, W["scale"].data_ptr(), M, heads, tc,
+                                      _s()), "swiftk_qknorm_jvp")
+            check(L.swiftk_window_attention_jvp(QKV.data_ptr(), QKV.data_ptr() + M * 3 * d * es, 3 * d, ATT.data_ptr(),
+                                                ATT.data_ptr() + M * self.kd * es, self.kd, B, gh, gw, heads, 88, sh[0], sh[1],
+                                                tc, _s()), "swiftk_window_attention_jvp")
+            _gemm(ATT, W["wo"], Y)
+            modnorm(2 * i, W["g1"], W["b1"])
+            _gemm(XT, W["w1"], H)
+            check(L.swiftk_swiglu_jvp(H.data_ptr(), H.data_ptr() + M * 2 * mlp * es, 2 * mlp, HM.data_ptr(),
+                                      HM.data_ptr() + M * self.kmlp * es, self.kmlp, M, mlp, tc, _s()), "swiftk_swiglu_jvp")
+            _gemm(HM, W["w2"], Y)
+            modnorm(2 * i + 1, W["g2"], W["b2"])
+        po = m.out_channels * m.patch_size[0] * m.patch_size[1]
+        tok = torch.empty(M, po, dtype=torch.float32, device=dev)
+        _gemm(XT[M:], self.head, tok)
+        return ops.unpatchify_affine(tok.view(B, ntok, po), (B, m.out_channels, *m.image_size), m.patch_size)

@@ -6,8 +6,8 @@ gradients.  The backward pass is not an autograd graph: the returned scalar hang
 whose backward runs the explicit kernels of ``train_engine`` (for the multistep loss: one rollout step at a time,
 recomputing that step's activations first -- what the reference does with ``checkpoint_sequential``).
 
-``SCMLoss`` (forward-mode JVP through the network, loss.py:163-260) is listed "next" in SURVEY.md section 8f and is not
-built; instantiating it raises.
+``SCMLoss`` (loss.py:163-260) gets its forward-mode tangent from ``jvp_engine.SwinJvpEngine`` (explicit tangent kernels,
+csrc/jvp_kernels.hip) instead of ``torch.func.jvp``.
 """
 from __future__ import annotations
 
@@ -151,9 +151,90 @@ class TrigFlowLoss(_LossBase):
 
 
 class SCMLoss(_LossBase):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("SCMLoss needs forward-mode JVP kernels (SURVEY.md section 8f item 2); "
-                                  "use loss=trigflow or finetune=multistep (CRPS) on the gfx950 path")
+    """Continuous-time consistency (sCM) loss, loss.py:163-260, with the tangent from ``jvp_engine.SwinJvpEngine``.
+
+    Same constructor kwargs and call signature as the reference.  Per iteration: one tangent pass (no gradient; it
+    carries primal and tangent rows through every GEMM, ~2 forward passes of work), one forward-with-activations pass
+    and its backward.  ``jvp_dtype``: operand type of the tangent pass (bf16 = the trainer's autocast; fp32 for
+    parity checks against the fp32 oracle).
+    """
+
+    def __init__(self, dataset, noise: dict, sigma_data: float, tangent_warmup_kimg: int = 0, distillation: bool = False,
+                 jvp_dtype: str = "bf16"):
+        super().__init__(dataset, sigma_data)
+        self.cfg = dict(noise)
+        self._sampling_fn = partial(NOISE_SAMPLING_METHODS[self.cfg.pop("dist")], **self.cfg)
+        self.tangent_warmup_kimg = tangent_warmup_kimg
+        self.distillation = distillation
+        self.jvp_dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32}[jvp_dtype]
+
+    def _jvp_engine(self, mod):
+        from ..jvp_engine import SwinJvpEngine
+        eng = getattr(mod.model, "_jvp_engine", None)
+        if eng is None or eng.dt != self.jvp_dtype:
+            eng = SwinJvpEngine(mod.model, self.jvp_dtype)
+            mod.model._jvp_engine = eng
+        return eng
+
+    def forward(self, net, x, step, condition=None, auxiliary=None, net_pretrained=None, _tau=None, _z=None, **kwargs):
+        mod = getattr(net, "module", net)
+        eng = _engine(net)
+        dev = x.device
+        B, C, H, W = x.shape
+        per = C * H * W
+        sd = float(self.sigma_data)
+        tau = self._sampling_fn(x) if _tau is None else _tau
+        t = torch.atan(tau.reshape(B).float() / sd).contiguous()
+        z = (torch.randn_like(x) if _z is None else _z).contiguous().float()
+        x = x.contiguous().float()
+        xt, dxt = torch.empty_like(x), torch.empty_like(x)  # x_t / sigma_d and dx_t/dt = cos t z sd - sin t x
+        st = torch.cuda.current_stream().cuda_stream
+        check(lib().swiftk_trigflow_prep(x.data_ptr(), z.data_ptr(), t.data_ptr(), xt.data_ptr(), dxt.data_ptr(), sd, B, per, st),
+              "swiftk_trigflow_prep")
+        aux = _process_auxiliary(auxiliary, mod.auxiliary_dim, B, dev)
+        srcs = [xt]
+        if condition is not None and mod.condition_channels > 0:
+            srcs.append(condition.contiguous().float())
+        if self.distillation and net_pretrained is not None:  # v-prediction teacher (loss.py:204-208)
+            with torch.no_grad():
+                dxt = (sd * net_pretrained(xt, t, condition, auxiliary)).float().contiguous()
+        # tangent direction (loss.py:215-216): v_x = cos t sin t dxt / sd, v_t = cos t sin t
+        cs = (torch.cos(t) * torch.sin(t)).contiguous()
+        vx = torch.empty_like(x)
+        check(lib().swiftk_axpby_per_sample(vx.data_ptr(), (cs / sd).contiguous().data_ptr(), dxt.data_ptr(), None, None, B, per,
+                                            st), "swiftk_axpby_per_sample")
+        with torch.no_grad():
+            dF = self._jvp_engine(mod).jvp(srcs, vx, t, cs, aux)
+        want_lv = mod.model.logvar_embed is not None
+        res = eng.forward(srcs, [1.0] * len(srcs), t, aux, want_logvar=want_lv)
+        Fx, lv, ctx = res if want_lv else (res[0], None, res[1])
+        r = min(1.0, step / (self.tangent_warmup_kimg * 1000)) if self.tangent_warmup_kimg > 0 else 1.0
+        target = torch.empty_like(Fx)
+        ss = torch.empty(B, device=dev)
+        check(lib().swiftk_scm_target(Fx.data_ptr(), dxt.data_ptr(), xt.data_ptr(), dF.contiguous().data_ptr(), t.data_ptr(),
+                                      float(r), sd, target.data_ptr(), ss.data_ptr(), B, per, st), "swiftk_scm_target")
+        # (F - F.detach() - g)^2 == (1 * F - target)^2 with target = F.detach() + g held constant
+        wv, wl = self._w(dev)
+        loss = torch.zeros(1, device=dev)
+        dFx = torch.empty_like(Fx)
+        dlv = torch.zeros(B, device=dev) if want_lv else None
+        check(lib().swiftk_trigflow_loss(Fx.data_ptr(), target.data_ptr(), None if lv is None else lv.contiguous().data_ptr(),
+                                         wv.data_ptr(), wl.data_ptr(), loss.data_ptr(), dFx.data_ptr(),
+                                         None if dlv is None else dlv.data_ptr(), 1.0, B, C, H, W, 1.0, st), "swiftk_trigflow_loss")
+
+        class Runner:
+            value = loss.reshape(())
+
+            @staticmethod
+            def run_backward(g):
+                if g != 1.0:
+                    dFx.mul_(g)
+                    if dlv is not None:
+                        dlv.mul_(g)
+                eng.backward(ctx, dFx, dlv)
+
+        self._last = dict(dF=dF, Fx=Fx)  # kept for tests / diagnostics
+        return _Deferred.apply(self._anchor(dev), Runner)
 
 
 class CRPSLoss(_LossBase):

@@ -353,6 +353,61 @@ def test_crps_multistep_loss_and_grads_vs_oracle(dev):
     assert float(loss) == pytest.approx(float(ref), rel=2e-2)
 
 
+def test_network_tangent_vs_oracle_jvp(dev):
+    """jvp_engine.SwinJvpEngine (explicit tangent kernels) against torch.func.jvp of the CPU oracle with jvp=True
+    (what loss.py:212-220 does with the reference network): fp32 operands tight, bf16 operands at bf16 noise."""
+    from swift_amd.jvp_engine import SwinJvpEngine
+    from swift_amd.models.precond import _process_auxiliary
+    from swift_amd.utils.detinit import det_normal
+    net, onet, _ = _build_pair(dev, 41)
+    B = 2
+    x, cond = det_normal((B, 69, 64, 64), 41, "x"), det_normal((B, 72, 64, 64), 41, "c")
+    vx = det_normal((B, 69, 64, 64), 41, "vx")
+    t, vt, aux = torch.tensor([0.4, 1.3]), torch.tensor([0.35, 0.2]), torch.tensor([0.6, 0.6])
+    with torch.no_grad():
+        f = lambda xx, tt: onet(xx, tt, cond, aux, jvp=True)
+        Fref, dref = torch.func.jvp(f, (x, t), (vx, vt))
+    auxd = _process_auxiliary(aux.to(dev), 1, B, dev)
+    errs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        eng = SwinJvpEngine(net.model, dt)
+        dF = eng.jvp([x.to(dev), cond.to(dev)], vx.to(dev), t.to(dev), vt.to(dev), auxd)
+        assert torch.isfinite(dF).all()
+        errs[dt] = rel_l2(dF.cpu(), dref)
+    print(f"network tangent vs oracle jvp: fp32 rel-L2 {errs[torch.float32]:.3e}, bf16 rel-L2 {errs[torch.bfloat16]:.3e}")
+    assert errs[torch.float32] < 1e-4
+    assert errs[torch.bfloat16] < 8e-2
+
+
+def test_scm_loss_and_grads_vs_oracle(dev):
+    from oracle import loss as oloss
+    from swift_amd.training.loss import SCMLoss
+    from swift_amd.training.trainer import GradAllReduce
+    from swift_amd.utils.detinit import det_normal
+    net, onet, st = _build_pair(dev, 42, logvar=True)
+    ds = _dataset(42)
+    L = SCMLoss(ds, dict(dist="loguniform", sigma_min=0.02, sigma_max=200.0), sigma_data=1.0, tangent_warmup_kimg=3,
+                jvp_dtype="f32").to(dev)
+    B = 2
+    x, cond, z = det_normal((B, 69, 64, 64), 42, "x"), det_normal((B, 72, 64, 64), 42, "c"), det_normal((B, 69, 64, 64), 42, "z")
+    tau, aux = torch.tensor([0.3, 4.0]).view(B, 1, 1, 1), torch.tensor([0.6, 0.6])
+    ddp = GradAllReduce(net)
+    ddp.zero_grad_flat()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = L(ddp, x.to(dev), 1200, condition=cond.to(dev), auxiliary=aux.to(dev), _tau=tau.to(dev), _z=z.to(dev))
+    loss.backward()
+    ref = oloss.scm_loss(onet, x, tau, z, L.w_var.cpu(), L.w_lat.cpu(), step=1200, sigma_data=1.0, tangent_warmup_kimg=3,
+                         condition=cond, auxiliary=aux, return_logvar=True)
+    ref.backward()
+    print(f"sCM loss {float(loss):.6f} vs oracle {float(ref):.6f}; worst grad cosine {_grad_report(net, st, 0.95):.4f}")
+    assert float(loss) == pytest.approx(float(ref), rel=2e-2)
+    # bf16 tangent pass (the trainer's autocast): same loss within bf16 noise
+    L.jvp_dtype = torch.bfloat16
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lb = L(ddp, x.to(dev), 1200, condition=cond.to(dev), auxiliary=aux.to(dev), _tau=tau.to(dev), _z=z.to(dev))
+    assert float(lb) == pytest.approx(float(ref), rel=5e-2)
+
+
 def test_trainer_steps_ema_and_checkpoint(dev, tmp_path, monkeypatch):
     from swift_amd.training.loss import CRPSLoss
     from swift_amd.training.trainer import Trainer
