@@ -59,6 +59,24 @@ def resume_setup(cfg: Cfg):
     return config, ckpt
 
 
+def distill_setup(cfg, dataset):
+    """Teacher for sCM distillation: the EMA weights of the latest checkpoint of run ``cfg.distill`` (train.py:100-132)."""
+    if cfg.get("distill") is None:
+        return None
+    run_dir = cfg.distill
+    config = load_saved(os.path.join(run_dir, ".hydra", "config.yaml"))
+    ckpts = sorted(glob(os.path.join(run_dir, "checkpoints", "checkpoint*.pt")), key=get_ckpt_num)
+    assert ckpts, FileNotFoundError(f"No checkpoints in {os.path.join(run_dir, 'checkpoints')}")
+    dist.log0(f"Loading distillation model: {ckpts[-1]}")
+    teacher = instantiate(config.precond, model_config=config.model, img_resolution=dataset.img_resolution,
+                          img_channels=dataset.n_target_channels, condition_channels=dataset.n_condition_channels,
+                          _recursive_=False, _convert_="object")
+    teacher.eval().to(dist.get_torch_device())
+    state = torch.load(ckpts[-1], map_location=dist.get_torch_device(), weights_only=True)
+    teacher.load_state_dict(state["ema"])
+    return teacher
+
+
 def adamw_param_groups(net, weight_decay: float):
     """no weight decay for pos_embed and LayerNorm affine parameters (train.py:275-286)."""
     decay, no_decay = [], []
@@ -114,7 +132,8 @@ def main(overrides=None):
     loss_fn = instantiate(cfg.loss, dataset=dataset, _convert_="object").to(device)
     trainer_cfg = {k: v for k, v in cfg.trainer.items()}
     trainer = instantiate(trainer_cfg, net=net, optimizer=optimizer, loss_fn=loss_fn, amp_type=cfg.system.torch.amp_type,
-                          ckpt=ckpt, flop_count=0, solver_kwargs=cfg.get("solver"), finetune_kwargs=cfg.get("finetune"))
+                          ckpt=ckpt, flop_count=0, net_pretrained=distill_setup(cfg, dataset), solver_kwargs=cfg.get("solver"),
+                          finetune_kwargs=cfg.get("finetune"))
     out = trainer.train(loader, None)
     if tdist.is_initialized():
         tdist.destroy_process_group()

@@ -103,6 +103,7 @@ class Trainer:
         else:
             self.resume_kimg = 0
         self.loss_fn, self.optimizer = loss_fn, optimizer
+        self.net_pretrained = None if net_pretrained is None else net_pretrained.to(self.device).eval()  # trainer.py:119-123
         self.lr_rampup_kimg, self.lr_min_factor, self.lr_cosine_anneal = lr_rampup_kimg, lr_min_factor, lr_cosine_anneal
         self.finetune_kwargs = dict(finetune_kwargs or {})
         if self.finetune_kwargs.get("name") == "multistep":  # cumulative interval ends (trainer.py:140-145)
@@ -157,8 +158,12 @@ class Trainer:
         """One optimisation step on a prepared batch; returns the (rank-local) loss value."""
         self.ddp.zero_grad_flat()
         kw = {}
-        if isinstance(self.loss_fn, CRPSLoss):
-            kw = dict(steps=steps, idx=idx)
+        if self.net_pretrained is not None:
+            kw["net_pretrained"] = self.net_pretrained
+        if isinstance(self.loss_fn, SCMLoss):      # trainer.py:382-386
+            kw["step"] = global_nimg
+        elif isinstance(self.loss_fn, CRPSLoss):
+            kw.update(steps=steps, idx=idx)
         loss = self._forward_step(x, t, delta, **kw)
         self._backward_step(global_nimg, loss)
         return loss.detach()

@@ -43,6 +43,15 @@ def test_train_then_generate_cli(tmp_path):
     rdir2 = tmp_path / "results" / "era5-swinv2-1.4-trigflow" / "001"
     cfg2 = yaml.safe_load(open(rdir2 / ".hydra" / "config.yaml"))
     assert cfg2["loss"]["_target_"].endswith("CRPSLoss") and cfg2["finetune"]["name"] == "multistep"
+    # sCM training (forward-mode tangent through the network) distilling from the trigflow run's EMA weights
+    run(["swift_amd.train", "experiment=era5-swinv2-1.4-scm", f"distill={rdir}", "loss.distillation=true",
+         "loss.tangent_warmup_kimg=1"] + small, cwd=str(tmp_path), env={"HYDRA_RUN_ID": "002"})
+    rdir3 = tmp_path / "results" / "era5-swinv2-1.4-scm" / "002"
+    cfg3 = yaml.safe_load(open(rdir3 / ".hydra" / "config.yaml"))
+    assert cfg3["loss"]["_target_"].endswith("SCMLoss") and cfg3["loss"]["distillation"] is True
+    lines3 = [yaml.safe_load(l) for l in open(rdir3 / "stats.jsonl")]
+    assert len(lines3) >= 2 and all(np.isfinite(l["train/loss"]) for l in lines3)
+    assert sorted(os.listdir(rdir3 / "checkpoints"))
     # generation from the first run's latest checkpoint
     run(["swift_amd.generate", "--input", str(rdir), "--members", "2", "--steps", "3", "--samples", "3", "--batch", "4",
          "--dump", "numpy"], cwd=str(tmp_path))
