@@ -7,13 +7,14 @@ import torch
 from swift_amd.data.era5 import SyntheticERA5Dataset
 from swift_amd.models.precond import PassPrecond
 from swift_amd.train import adamw_param_groups
-from swift_amd.training.loss import CRPSLoss
+from swift_amd.training.loss import CRPSLoss, SCMLoss
 from swift_amd.training.trainer import Trainer
 from swift_amd.utils.detinit import swinv2_state
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8); ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--iters", type=int, default=2); ap.add_argument("--depth", type=int, default=12)
+ap.add_argument("--loss", default="crps", choices=["crps", "scm"])
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 names = ["2m_temperature", "10m_u_component_of_wind", "10m_v_component_of_wind", "mean_sea_level_pressure"]
@@ -27,7 +28,9 @@ net.load_state_dict(swinv2_state(grid=(64, 128), in_channels=141, out_channels=6
                                  heads=12, seed=1))
 net = net.to(dev).train().requires_grad_(True)
 opt = torch.optim.AdamW(adamw_param_groups(net, 1e-5), lr=1e-5, betas=(0.9, 0.95), eps=1e-6)
-tr = Trainer(net, opt, CRPSLoss(ds, 1.0, 2, 1.0).to(dev), total_kimg=1, lr_rampup_kimg=0, lr_min_factor=1.0, device=dev,
+loss_fn = (CRPSLoss(ds, 1.0, 2, 1.0) if a.loss == "crps" else
+           SCMLoss(ds, dict(dist="loguniform", sigma_min=0.02, sigma_max=200.0), 1.0, tangent_warmup_kimg=1)).to(dev)
+tr = Trainer(net, opt, loss_fn, total_kimg=1, lr_rampup_kimg=0, lr_min_factor=1.0, device=dev,
              checkpoint_ticks=None)
 tr.global_batch_size = a.batch
 g = torch.Generator(device=dev).manual_seed(0)
@@ -41,6 +44,12 @@ for k in range(a.iters):
     loss = tr.train_step(x, t, idx, delta, 1000 * (k + 2), steps=a.steps)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
+if a.loss == "scm":
+    # tangent pass = every GEMM on 2M rows (2 fwd) + forward-with-activations (1) + backward (2)
+    print(f"sCM pre-training: batch {a.batch}, depth {a.depth}: {dt:.3f} s/iteration, loss {float(loss):.4f}; "
+          f"{a.batch / dt:.2f} samples/s; ~5 fwd-equivalents -> {(5 * a.batch * 2.7535e12 * a.depth / 12) / dt / 1e12:.0f} TFLOP/s; "
+          f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    sys.exit(0)
 evals = 2 * a.steps
 print(f"CRPS finetune: batch {a.batch}, steps {a.steps}, depth {a.depth}: {dt:.3f} s/iteration, loss {float(loss):.4f}; "
       f"{a.batch / dt:.2f} samples/s; fwd-equivalents/iter = {evals} fwd + {evals} recompute + {evals} bwd(2x) -> "
