@@ -126,9 +126,15 @@ def main(overrides=None):
     params = net.parameters()
     if isinstance(net.model, SwinV2) and target in ("torch.optim.Adam", "torch.optim.AdamW"):
         params = adamw_param_groups(net, cfg.optimizer.weight_decay)
-    elif target.endswith("MuonWithAuxAdam"):
-        raise NotImplementedError("MuonWithAuxAdam is 'next' (SURVEY.md section 8f); use optimizer=adamw")
-    optimizer = instantiate(cfg.optimizer, params, _convert_="object")
+    elif target.endswith("MuonWithAuxAdam"):  # train.py:286-309: matrices of the transformer -> Muon, the rest -> Adam
+        muon_p = [p for n, p in net.named_parameters() if p.ndim >= 2 and "transformer" in n]
+        adam_p = [p for n, p in net.named_parameters() if not (p.ndim >= 2 and "transformer" in n)]
+        params = [dict(params=muon_p, use_muon=True, lr=cfg.optimizer.lr, weight_decay=cfg.optimizer.weight_decay),
+                  dict(params=adam_p, use_muon=False, lr=cfg.optimizer.adam_lr, betas=tuple(cfg.optimizer.adam_betas),
+                       weight_decay=cfg.optimizer.adam_weight_decay, eps=cfg.optimizer.adam_eps)]
+        optimizer = instantiate(dict(_target_=target), params, _convert_="object")
+    if not target.endswith("MuonWithAuxAdam"):
+        optimizer = instantiate(cfg.optimizer, params, _convert_="object")
     loss_fn = instantiate(cfg.loss, dataset=dataset, _convert_="object").to(device)
     trainer_cfg = {k: v for k, v in cfg.trainer.items()}
     trainer = instantiate(trainer_cfg, net=net, optimizer=optimizer, loss_fn=loss_fn, amp_type=cfg.system.torch.amp_type,

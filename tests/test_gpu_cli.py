@@ -45,10 +45,12 @@ def test_train_then_generate_cli(tmp_path):
     assert cfg2["loss"]["_target_"].endswith("CRPSLoss") and cfg2["finetune"]["name"] == "multistep"
     # sCM training (forward-mode tangent through the network) distilling from the trigflow run's EMA weights
     run(["swift_amd.train", "experiment=era5-swinv2-1.4-scm", f"distill={rdir}", "loss.distillation=true",
-         "loss.tangent_warmup_kimg=1"] + small, cwd=str(tmp_path), env={"HYDRA_RUN_ID": "002"})
+         "loss.tangent_warmup_kimg=1"] + [o for o in small if o != "optimizer=adamw"], cwd=str(tmp_path),
+        env={"HYDRA_RUN_ID": "002"})  # the experiment's own optimiser: MuonWithAuxAdam
     rdir3 = tmp_path / "results" / "era5-swinv2-1.4-scm" / "002"
     cfg3 = yaml.safe_load(open(rdir3 / ".hydra" / "config.yaml"))
     assert cfg3["loss"]["_target_"].endswith("SCMLoss") and cfg3["loss"]["distillation"] is True
+    assert cfg3["optimizer"]["_target_"].endswith("MuonWithAuxAdam")
     lines3 = [yaml.safe_load(l) for l in open(rdir3 / "stats.jsonl")]
     assert len(lines3) >= 2 and all(np.isfinite(l["train/loss"]) for l in lines3)
     assert sorted(os.listdir(rdir3 / "checkpoints"))

@@ -408,6 +408,40 @@ def test_scm_loss_and_grads_vs_oracle(dev):
     assert float(lb) == pytest.approx(float(ref), rel=5e-2)
 
 
+def test_muon_with_aux_adam_vs_reference_golden(dev):
+    """swift_amd MuonWithAuxAdam (Newton-Schulz products on swiftk_gemm) against two steps of the reference's
+    SingleDeviceMuonWithAuxAdam (tests/golden/muon_tiny.npz).  The orthogonalisation runs in bf16 in both; a different
+    summation order inside the bf16 GEMMs moves the update by bf16 noise, amplified by 5 quintic iterations."""
+    import numpy as np
+    from conftest import load_golden
+    from swift_amd.training.optimizers.muon import MuonWithAuxAdam, zeropower_via_newtonschulz5
+    from oracle import muon as omuon
+    g = load_golden("muon_tiny")
+    params = [torch.nn.Parameter(torch.from_numpy(g[f"p{i}_0"]).to(dev)) for i in range(5)]
+    opt = MuonWithAuxAdam([dict(params=params[:3], use_muon=True, lr=0.02, weight_decay=0.01),
+                           dict(params=params[3:], use_muon=False, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-10)])
+    for st in range(2):
+        for i, p in enumerate(params):
+            p.grad = torch.from_numpy(g[f"g{i}_{st}"]).to(dev)
+        opt.step()
+        for i, p in enumerate(params):
+            # compare the STEP taken (p_new - p_old of the golden trajectory is ~4 % of |p| for the Muon groups)
+            mine = p.detach().cpu() - torch.from_numpy(g[f"p{i}_{st}"])
+            ref = torch.from_numpy(g[f"p{i}_{st + 1}"] - g[f"p{i}_{st}"])
+            err = rel_l2(mine, ref)
+            print(f"step {st} param {i} {tuple(p.shape)}: update rel-L2 {err:.3e}")
+            assert err < (8e-2 if i < 3 else 1e-4), (st, i, err)
+            p.data.copy_(torch.from_numpy(g[f"p{i}_{st + 1}"]).to(dev))  # continue from the golden trajectory
+    # the orthogonaliser alone at a Swift-B shape (wo: 1056 x 1056) against the CPU restatement
+    G = rnd((1056, 1056), 55)
+    X = zeropower_via_newtonschulz5(G.to(dev), 5).float().cpu()
+    Xr = omuon.newton_schulz5(G, 5).float()
+    e = rel_l2(X, Xr)
+    sv = torch.linalg.svdvals(X.double())
+    print(f"Newton-Schulz 1056x1056: rel-L2 vs CPU restatement {e:.3e}; singular values in [{float(sv.min()):.3f}, {float(sv.max()):.3f}]")
+    assert e < 3e-2 and float(sv.max()) < 1.7 and float((sv > 0.5).double().mean()) > 0.8  # most of the spectrum pushed to ~1
+
+
 def test_trainer_steps_ema_and_checkpoint(dev, tmp_path, monkeypatch):
     from swift_amd.training.loss import CRPSLoss
     from swift_amd.training.trainer import Trainer

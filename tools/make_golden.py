@@ -346,7 +346,27 @@ def fx_weights_aux():
          w_var69=_calculate_variable_weights(variables), w_lat32=_calculate_latitude_weights(32))
 
 
-ALL = dict(swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
+def fx_muon_tiny():
+    """Two steps of the reference's SingleDeviceMuonWithAuxAdam on seeded parameters / gradients (muon.py:267-338)."""
+    from swift.training.optimizers.muon import SingleDeviceMuonWithAuxAdam
+    shapes = [(96, 64), (64, 160), (128, 128), (48,), (7, 5)]
+    params = [torch.nn.Parameter(det_normal(sh, 77, f"p{i}") * 0.05) for i, sh in enumerate(shapes)]
+    groups = [dict(params=params[:3], use_muon=True, lr=0.02, weight_decay=0.01),
+              dict(params=params[3:], use_muon=False, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-10)]
+    opt = SingleDeviceMuonWithAuxAdam(groups)
+    out = {f"p{i}_0": p.detach().clone().numpy() for i, p in enumerate(params)}
+    for st in range(2):
+        for i, p in enumerate(params):
+            g = det_normal(p.shape, 78 + st, f"g{i}")
+            out[f"g{i}_{st}"] = g.numpy()
+            p.grad = g.clone()
+        opt.step()
+        for i, p in enumerate(params):
+            out[f"p{i}_{st + 1}"] = p.detach().clone().numpy()
+    save("muon_tiny", **out)
+
+
+ALL = dict(muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
            samplers_tiny=fx_samplers_tiny, rollout_tiny=fx_rollout_tiny, losses_tiny=fx_losses_tiny,
            swiftb_step=fx_swiftb_step, weights_aux=fx_weights_aux)
 
