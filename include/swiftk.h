@@ -256,6 +256,11 @@ int swiftk_swiglu_jvp(const void* h, const void* dh, int64_t ldh, void* out, voi
 int swiftk_scm_target(const float* F, const float* dxt, const float* xt_over_sd, const float* dF, const float* t, float r,
                       float sigma_data, float* target, float* ss_scratch, int B, int64_t per_sample, void* stream);
 
+/* Validation RMSE sums (training/validate.py:96-107): sq[0] += sum (y - t)^2 over everything, sq[1 + c] += sum_{b,h,w}
+ * w_lat[h] (y - t)^2 per channel; y [B,C,H,W] contiguous, t the same with batch stride t_batch_stride (a [B, days, C, H, W]
+ * slice).  The caller zero-fills sq (1 + C floats), divides by the counts and takes the roots. */
+int swiftk_rmse_sums(const float* y, const float* t, int64_t t_batch_stride, const float* w_lat, float* sq, int B, int C, int H,
+                     int W, void* stream);
 /* Almost-fair CRPS over m members (loss.py:343-371,445): *loss += 1/(B H W) sum w_var[c] w_lat[h] crps; dpreds optional. */
 int swiftk_crps_loss(const float* preds, const float* target, const float* w_var, const float* w_lat, float* loss,
                      float* dpreds, int m, int B, int C, int H, int W, float alpha, float gscale, void* stream);

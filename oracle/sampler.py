@@ -76,3 +76,35 @@ def dpm_solver_2s(net, latents, condition=None, auxiliary=None, num_steps: int =
         else:
             x = xe
     return x
+
+
+@torch.no_grad()
+def dpm_solver(net, latents, condition=None, auxiliary=None, num_steps: int = 20, use_pp: bool = True,
+               sigma_min: float = 0.002, sigma_max: float = 80.0, rho: float = 7.0):
+    """DPM-Solver(++) on the TrigFlow ODE with the EDM rho time grid (diffusion.py:289-353): num_steps net calls,
+    first and last step first-order (DDIM), 2nd-order multistep correction in between."""
+    sd = net.sigma_data
+    B = latents.size(0)
+    ramp = torch.linspace(0, 1, num_steps, device=latents.device)
+    lo, hi = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+    sigmas = (hi + ramp * (lo - hi)) ** rho
+    ts = torch.atan(sigmas / sd)
+    ts = torch.cat([ts, torch.zeros_like(ts[:1])])
+    logtan = lambda u: torch.log(torch.tan(torch.clamp(u, 1e-4, 1.569)))
+    x = latents * sd
+    t_prev = pred_prev = None
+    for k in range(num_steps):
+        s, t = ts[k], ts[k + 1]
+        delta = s - t
+        Fs = net(x / sd, s.repeat(B), condition, auxiliary)
+        if use_pp:
+            pred, denom = torch.cos(s) * x - torch.sin(s) * sd * Fs, torch.sin(s)
+        else:
+            pred, denom = torch.sin(s) * x + torch.cos(s) * sd * Fs, torch.cos(s)
+        nxt = torch.cos(delta) * x - torch.sin(delta) * sd * Fs
+        if not (k == 0 or k == num_steps - 1):
+            r_s = (logtan(s) - logtan(t_prev)) / (logtan(s) - logtan(t))
+            corr = (torch.sin(delta) / (2 * r_s * max(denom, 1e-3))) * (pred_prev - pred)
+            nxt = nxt + (corr if use_pp else -corr)
+        t_prev, pred_prev, x = s, pred, nxt
+    return x

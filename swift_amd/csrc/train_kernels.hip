@@ -420,6 +420,36 @@ __global__ __launch_bounds__(256) void chan_axpy_kernel(float* __restrict__ out,
     }
 }
 
+// ------------------------------------------------------------------------------------------ validation RMSE sums
+// sq[0] += sum (y - t)^2 ;  sq[1 + c] += sum_{b,h,w} w_lat[h] (y - t)^2   (training/validate.py:96-107; the caller divides
+// and takes the roots).  One block per (channel, chunk): block-reduced, two atomics per block.
+__global__ __launch_bounds__(256) void rmse_sums_kernel(const float* __restrict__ y, const float* __restrict__ t,
+                                                        int64_t t_batch_stride, const float* __restrict__ w_lat,
+                                                        float* __restrict__ sq, int B, int C, int H, int W) {
+    __shared__ float red[2][4];
+    const int c = blockIdx.y;
+    const int64_t hw = (int64_t)H * W, per = (int64_t)B * hw;
+    float a0 = 0.f, a1 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / hw, r = i - b * hw;
+        const int h = (int)(r / W);
+        const float d = y[(b * C + c) * hw + r] - t[b * t_batch_stride + c * hw + r];
+        a0 += d * d;
+        a1 += w_lat[h] * d * d;
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = a0;
+        red[1][threadIdx.x >> 6] = a1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sq, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(sq + 1 + c, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
 }  // namespace
 
 #define DT_SWITCH(dtype, CALL_BF16, CALL_F32) \
@@ -598,6 +628,16 @@ extern "C" int swiftk_channel_axpy(float* out, const float* x, const float* y, c
     const int64_t n = (int64_t)B * C * hw;
     hipLaunchKernelGGL(chan_axpy_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), out, x, y, coef, C,
                        hw, n);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_rmse_sums(const float* y, const float* t, int64_t t_batch_stride, const float* w_lat, float* sq, int B,
+                                int C, int H, int W, void* stream) {
+    if (!y || !t || !w_lat || !sq || B <= 0 || C <= 0 || H <= 0 || W <= 0) return SWIFTK_EINVAL;
+    const dim3 grid((unsigned)grid_for((int64_t)B * H * W, 256, 64), (unsigned)C);
+    hipLaunchKernelGGL(rmse_sums_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), y, t, t_batch_stride, w_lat, sq, B,
+                       C, H, W);
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

@@ -147,6 +147,11 @@ class ERA5Dataset(_ERA5Base):
     def get_forcings(self, idx: int) -> torch.Tensor:
         return torch.from_numpy(self._load_file(self.files[idx], self.forcings)).float()
 
+    def get_lat_lon(self):
+        """data/era5.py:172-175."""
+        return (np.load(os.path.join(self.root, "lat.npy")).astype(np.float32),
+                np.load(os.path.join(self.root, "lon.npy")).astype(np.float32))
+
     def __len__(self):
         return len(self.files[: -(max(self.intervals) * 1 // 6)])
 
@@ -227,3 +232,46 @@ class SyntheticERA5Dataset(_ERA5Base):
         t = self.standardize_t(t.numpy(), delta)
         return (torch.from_numpy(np.asarray(x)).float(), torch.from_numpy(np.asarray(t)).float()), \
                (idx, torch.tensor(delta / 10.0).float())
+
+
+class SyntheticERA5RollOutDataset(SyntheticERA5Dataset):
+    """Validation items of the reference's ERA5RollOutDataset (data/era5.py:230-256) on the synthetic fields:
+    ``(x standardised [C,H,W], targets physical [interval/4 + 1, C, H, W] = (6 h, day 1, day 2, ...), idx)``."""
+
+    def __init__(self, interval: int, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.interval = int(interval)
+
+    def __len__(self):
+        return self.length - self.interval
+
+    def get_lat_lon(self):
+        H, W = self._shape[1], self._shape[2]
+        return np.linspace(-90.0, 90.0, H, dtype=np.float32), np.linspace(0.0, 360.0, W, endpoint=False, dtype=np.float32)
+
+    def __getitem__(self, idx: int):
+        idx = int(idx)
+        nv = len(self.variables)
+        assert self.interval >= 4, "cannot even predict one day"
+        x = torch.from_numpy(np.asarray(self.standardize_x(self._fields(idx, "state", nv).numpy()))).float()
+        ts = [self._fields(idx + 1, "state", nv)] + [self._fields(i, "state", nv) for i in range(idx + 4, idx + 4 + self.interval, 4)]
+        return x, torch.stack(ts, 0).float(), idx
+
+
+class ERA5RollOutDataset(ERA5Dataset):
+    """data/era5.py:230-256: validation items ``(x standardised, targets physical [interval/4 + 1, C, H, W], idx)``."""
+
+    def __init__(self, interval: int, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.interval = int(interval)
+
+    def __len__(self):
+        return len(self.files[: -self.interval])
+
+    def __getitem__(self, idx: int):
+        idx = int(idx)
+        assert self.interval >= 4, "cannot even predict one day"
+        x = torch.from_numpy(self.standardize_x(self._load_file(self.files[idx], self.variables))).float()
+        ts = [self._load_file(self.files[idx + 1], self.variables)]
+        ts += [self._load_file(self.files[i], self.variables) for i in range(idx + 4, idx + 4 + self.interval, 4)]
+        return x, torch.from_numpy(np.stack(ts, 0)).float(), idx

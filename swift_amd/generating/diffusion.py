@@ -8,8 +8,8 @@ Same solver names, keyword arguments and time grids as the reference's ``Diffusi
   * the remaining state arithmetic (re-noising, Heun average) runs in ``swiftk_axpby``;
   * the time grid is built on the host in fp32 with the same torch ops as the reference and
     read back once (no per-step device->host sync).
-EDM-family solvers (edm_sampler, ablation_sampler, scm_solve2) and dpm_solver are out of scope
-(SURVEY.md section 2 row 4).
+``dpm_solver`` (:289-353, the in-training validation solver) is built the same way.  EDM-family solvers (edm_sampler,
+ablation_sampler, scm_solve2) are out of scope.
 """
 from __future__ import annotations
 
@@ -99,4 +99,35 @@ class DiffusionSampler:
                     x_t = self.net(x_e, tt, condition, auxiliary, x_scale=1.0 / sd, xt=half, alpha=a, beta=b)
             else:
                 x_t = x_e
+        return x_t
+
+    @torch.no_grad()
+    def dpm_solver(self, latents: torch.Tensor, condition=None, auxiliary=None, randn_like: Callable = torch.randn_like,
+                   num_steps: int = 20, use_pp: bool = True, sigma_min: float = 0.002, sigma_max: float = 80.0, rho: float = 7,
+                   denoise_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        """DPM-Solver(++) multistep on the TrigFlow ODE, EDM rho grid (diffusion.py:289-353): num_steps network calls; the
+        first and last steps are first-order (DDIM), the others add the 2nd-order correction from the previous prediction."""
+        sd = self._module().sigma_data
+        ramp = torch.linspace(0, 1, num_steps)
+        lo, hi = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+        ts = torch.atan((hi + ramp * (lo - hi)) ** rho / sd)
+        ts = torch.cat([ts, torch.zeros_like(ts[:1])])
+        logtan = lambda u: torch.log(torch.tan(torch.clamp(u, 1e-4, 1.569)))
+        x_t = (latents * sd).contiguous().float()
+        t_prev = pred_prev = None
+        for k in range(num_steps):
+            s, t = ts[k], ts[k + 1]
+            delta = s - t
+            F = self._call(x_t, s, condition, auxiliary, 0.0, 1.0, denoise_dtype)        # F_s itself
+            nxt = ops.axpby(float(torch.cos(delta)), x_t, -float(torch.sin(delta)) * sd, F)
+            if use_pp:
+                pred, denom = ops.axpby(float(torch.cos(s)), x_t, -float(torch.sin(s)) * sd, F), float(torch.sin(s))
+            else:
+                pred, denom = ops.axpby(float(torch.sin(s)), x_t, float(torch.cos(s)) * sd, F), float(torch.cos(s))
+            if not (k == 0 or k == num_steps - 1):
+                r_s = (logtan(s) - logtan(t_prev)) / (logtan(s) - logtan(t))
+                coef = float(torch.sin(delta) / (2 * r_s * max(denom, 1e-3)))
+                corr = ops.axpby(coef, pred_prev, -coef, pred)
+                nxt = ops.axpby(1.0, nxt, 1.0 if use_pp else -1.0, corr)
+            t_prev, pred_prev, x_t = s, pred, nxt
         return x_t

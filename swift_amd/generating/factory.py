@@ -22,7 +22,9 @@ def sampler_factory(mode: str, net: torch.nn.Module, denoise_dtype: torch.dtype 
         solve = O.scm_solver
     elif mode == "2s":
         solve = O.dpm_solver_2s
-    elif mode in ("edm", "dpm"):
+    elif mode == "dpm":
+        solve = O.dpm_solver
+    elif mode == "edm":
         raise NotImplementedError(f"solver mode {mode!r} is outside the sCM/TrigFlow forecast path built here")
     else:
         raise ValueError(f"Unknown solver mode: {mode}")
@@ -30,8 +32,9 @@ def sampler_factory(mode: str, net: torch.nn.Module, denoise_dtype: torch.dtype 
     def sampler(X: torch.Tensor, generator: Optional[torch.Generator] = None, *args,
                 latents: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
         if latents is None:
-            latents = torch.randn((X.shape[0], mod.img_channels, *mod.img_resolution), generator=generator,
-                                  device=X.device)
+            X0 = X[0] if isinstance(X, (tuple, list)) else X  # condition may arrive as (state, forcings), never concatenated
+            latents = torch.randn((X0.shape[0], mod.img_channels, *mod.img_resolution), generator=generator,
+                                  device=X0.device)
         return solve(latents=latents, condition=X, denoise_dtype=denoise_dtype, **solver_kwargs)
 
     return sampler

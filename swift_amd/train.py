@@ -114,6 +114,20 @@ def main(overrides=None):
     else:
         loader = DataLoader(sampler=sampler, batch_size=local_bs, **common)
 
+    # rollout validation set (train.py:224-260): the roll-out flavour of the training dataset's class, split "val"
+    val_loader = None
+    tgt = str(cfg.data.dataset._target_)
+    if cfg.trainer.get("val_ticks") is not None and "era5" in tgt.lower():
+        roll = tgt.replace("SyntheticERA5Dataset", "SyntheticERA5RollOutDataset").replace("ERA5Dataset", "ERA5RollOutDataset") \
+            if "RollOut" not in tgt else tgt
+        val_cfg = {k: v for k, v in cfg.data.dataset.items() if k not in ("intervals",)}
+        val_cfg.update(_target_=roll, split="val", interval=cfg.trainer.val_target_interval)
+        val_dataset = instantiate(val_cfg, _convert_="object")
+        val_sampler = InfiniteSampler(dataset=val_dataset, rank=dist.get_rank(), num_replicas=dist.get_world_size(), shuffle=True,
+                                      seed=cfg.seed)
+        val_loader = DataLoader(dataset=val_dataset, sampler=val_sampler, batch_size=cfg.data.get("val_local_batch_size", 4),
+                                pin_memory=True, num_workers=0)
+
     net = instantiate(cfg.precond, model_config=cfg.model, img_resolution=dataset.img_resolution,
                       img_channels=dataset.n_target_channels, condition_channels=dataset.n_condition_channels,
                       _recursive_=False, _convert_="object")
@@ -140,7 +154,7 @@ def main(overrides=None):
     trainer = instantiate(trainer_cfg, net=net, optimizer=optimizer, loss_fn=loss_fn, amp_type=cfg.system.torch.amp_type,
                           ckpt=ckpt, flop_count=0, net_pretrained=distill_setup(cfg, dataset), solver_kwargs=cfg.get("solver"),
                           finetune_kwargs=cfg.get("finetune"))
-    out = trainer.train(loader, None)
+    out = trainer.train(loader, val_loader)
     if tdist.is_initialized():
         tdist.destroy_process_group()
     return out

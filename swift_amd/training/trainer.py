@@ -103,6 +103,8 @@ class Trainer:
         else:
             self.resume_kimg = 0
         self.loss_fn, self.optimizer = loss_fn, optimizer
+        self.val_ticks, self.val_target_interval, self.val_variables = val_ticks, val_target_interval, val_variables
+        self.solver_type, self.solver_kwargs = "dpm", dict(solver_kwargs or {})  # trainer.py:136-137
         self.net_pretrained = None if net_pretrained is None else net_pretrained.to(self.device).eval()  # trainer.py:119-123
         self.lr_rampup_kimg, self.lr_min_factor, self.lr_cosine_anneal = lr_rampup_kimg, lr_min_factor, lr_cosine_anneal
         self.finetune_kwargs = dict(finetune_kwargs or {})
@@ -168,9 +170,39 @@ class Trainer:
         self._backward_step(global_nimg, loss)
         return loss.detach()
 
+    # ------------------------------------------------------------------ validation (trainer.py:249-307)
+    def _val_step(self, val_loader, val_dataset, cur_tick, global_nimg, val_stats_jsonl):
+        from ..generating.factory import sampler_factory
+        from .validate import RMSE_rollout
+        kw = {k: v for k, v in self.solver_kwargs.items() if k != "intermediates"}
+        sampler = sampler_factory(self.solver_type, self.ema, denoise_dtype=torch.bfloat16, **kw)
+        agg, sep = RMSE_rollout(sampler, val_loader, val_dataset, self.val_target_interval, self.device, num_batches=1)
+        agg_t = torch.tensor(agg, dtype=torch.float64, device=self.device)
+        sep_t = torch.tensor(sep, dtype=torch.float64, device=self.device)
+        if tdist.is_initialized():  # average across ranks
+            tdist.all_reduce(agg_t)
+            tdist.all_reduce(sep_t)
+            agg_t /= dist.get_world_size()
+            sep_t /= dist.get_world_size()
+        rmse_map = dict(zip(val_dataset.variables, sep_t.cpu().numpy()))
+        selected = [v for v in (self.val_variables or val_dataset.variables) if v in rmse_map] or list(val_dataset.variables)
+        metrics = {"train/kimg": int(global_nimg / 1e3), "val/tick": cur_tick,
+                   **{f"val/rmse/{v}": [float(x) for x in rmse_map[v]] for v in selected}, "val/rmse": float(agg_t)}
+        dist.log0(json.dumps({k: metrics[k] for k in ("train/kimg", "val/tick", "val/rmse")}))
+        if val_stats_jsonl is not None:
+            val_stats_jsonl.write(json.dumps(metrics) + "\n")
+            val_stats_jsonl.flush()
+        return metrics
+
     # ------------------------------------------------------------------ loop
     def train(self, train_loader: Iterable, val_loader=None):
         it = iter(train_loader)
+        val_dataset, val_stats = None, None
+        if val_loader is not None:
+            val_dataset = val_loader.sampler.dataset
+            val_loader = iter(val_loader)
+            if dist.get_rank() == 0:
+                val_stats = open(os.path.join(os.getcwd(), "val_stats.jsonl"), "at")
         world = dist.get_world_size()
         global_nimg = self.resume_kimg * 1000
         tick_start_nimg, cur_tick, i = global_nimg, 0, 0
@@ -200,6 +232,8 @@ class Trainer:
             done = global_nimg >= self.total_kimg * 1000
             if not done and cur_tick != 0 and global_nimg < tick_start_nimg + self.kimg_per_tick * 1000:
                 continue
+            if self.val_ticks is not None and val_loader is not None and cur_tick % self.val_ticks == 0:  # trainer.py:411-418
+                self._val_step(val_loader, val_dataset, cur_tick, global_nimg, val_stats)
             torch.cuda.synchronize()
             now = time.perf_counter()
             lv = loss.clone()

@@ -45,12 +45,16 @@ def test_train_then_generate_cli(tmp_path):
     assert cfg2["loss"]["_target_"].endswith("CRPSLoss") and cfg2["finetune"]["name"] == "multistep"
     # sCM training (forward-mode tangent through the network) distilling from the trigflow run's EMA weights
     run(["swift_amd.train", "experiment=era5-swinv2-1.4-scm", f"distill={rdir}", "loss.distillation=true",
-         "loss.tangent_warmup_kimg=1"] + [o for o in small if o != "optimizer=adamw"], cwd=str(tmp_path),
+         "loss.tangent_warmup_kimg=1", "trainer.val_target_interval=4", "data.val_local_batch_size=2"] +
+        [o for o in small if o not in ("optimizer=adamw", "trainer.val_ticks=null")] + ["trainer.val_ticks=1"], cwd=str(tmp_path),
         env={"HYDRA_RUN_ID": "002"})  # the experiment's own optimiser: MuonWithAuxAdam
     rdir3 = tmp_path / "results" / "era5-swinv2-1.4-scm" / "002"
     cfg3 = yaml.safe_load(open(rdir3 / ".hydra" / "config.yaml"))
     assert cfg3["loss"]["_target_"].endswith("SCMLoss") and cfg3["loss"]["distillation"] is True
     assert cfg3["optimizer"]["_target_"].endswith("MuonWithAuxAdam")
+    # ... with the in-training validation rollout switched on (4 six-hour steps, dpm solver on the EMA weights)
+    val = [yaml.safe_load(l) for l in open(rdir3 / "val_stats.jsonl")]
+    assert val and np.isfinite(val[0]["val/rmse"]) and len(val[0]["val/rmse/2m_temperature"]) == 2
     lines3 = [yaml.safe_load(l) for l in open(rdir3 / "stats.jsonl")]
     assert len(lines3) >= 2 and all(np.isfinite(l["train/loss"]) for l in lines3)
     assert sorted(os.listdir(rdir3 / "checkpoints"))

@@ -10,6 +10,7 @@ Tolerances (relative L2):
 """
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -103,6 +104,44 @@ def test_samplers_vs_oracle(dev, dtype, tol):
     e = rel_l2(y.cpu(), ref)
     print(f"dpm_solver_2s num_steps=3 {dtype}: rel-L2 {e:.3e}")
     assert e < tol * 3
+
+
+def test_dpm_solver_and_validation_rollout_vs_oracle(dev):
+    """dpm_solver (diffusion.py:289-353) and RMSE_rollout (training/validate.py:23-127) on the fp32 engine against their
+    CPU restatements (which tests/test_oracle_golden.py pins to the reference's own functions)."""
+    from oracle import rollout as oroll
+    from oracle import sampler as osamp
+    from oracle import validate as oval
+    from swift_amd.data.era5 import SyntheticERA5RollOutDataset
+    from swift_amd.generating.factory import sampler_factory
+    from swift_amd.training.validate import RMSE_rollout
+    net, onet = build(SMALLB, 9, dev)
+    B = 2
+    cond, lat = det_normal((B, 72, 64, 64), 9, "cond"), det_normal((B, 69, 64, 64), 9, "lat")
+    kw = dict(sigma_min=0.02, sigma_max=200.0, auxiliary=0.6)
+    for pp in (True, False):
+        y = sampler_factory("dpm", net, num_steps=4, use_pp=pp, **kw)(cond.to(dev), latents=lat.to(dev))
+        e = rel_l2(y.cpu(), osamp.dpm_solver(onet, lat, cond, num_steps=4, use_pp=pp, **kw))
+        print(f"dpm_solver num_steps=4 use_pp={pp}: rel-L2 {e:.3e}")
+        assert e < 3e-4
+    names = [f"v{i}" for i in range(69)]
+    ds = SyntheticERA5RollOutDataset(8, names, ["f0", "f1", "f2"], img_resolution=(64, 64), length=40, seed=9, random_stats=True)
+    items = [ds[0], ds[5]]
+    X0, TS, idx = torch.stack([i[0] for i in items]), torch.stack([i[1] for i in items]), [0, 5]
+    assert TS.shape == (2, 3, 69, 64, 64) and torch.equal(TS[0, 0], ds._fields(1, "state", 69)) \
+        and torch.equal(TS[0, 2], ds._fields(8, "state", 69))
+    g = torch.Generator(device=dev).manual_seed(5)
+    lats = [torch.randn((B, 69, 64, 64), generator=g, device=dev) for _ in range(8)]
+    g = torch.Generator(device=dev).manual_seed(5)
+    agg, sep = RMSE_rollout(sampler_factory("dpm", net, num_steps=2, **kw), iter([(X0, TS, idx)]), ds, 8, dev, rng=g,
+                            num_batches=1)
+    stats = oroll.Stats(ds.x_means, ds.x_stds, {6: ds.t_stds[6]}, n_vars=69, n_forc=3)
+    it = iter(lats)
+    ragg, rsep = oval.rmse_rollout(lambda c: osamp.dpm_solver(onet, next(it).cpu(), c, num_steps=2, **kw), stats, X0, TS,
+                                   lambda i: torch.stack([ds.get_forcings(j + i) for j in idx], 0), ds.get_lat_lon()[0], 8)
+    print(f"validation rollout (8 steps): aggregate RMSE {agg:.6f} vs oracle {ragg:.6f}")
+    assert agg == pytest.approx(ragg, rel=2e-4)
+    np.testing.assert_allclose(sep, rsep, rtol=1e-3)
 
 
 def test_sampler_draws_like_reference(dev):

@@ -366,7 +366,50 @@ def fx_muon_tiny():
     save("muon_tiny", **out)
 
 
-ALL = dict(muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
+@torch.no_grad()
+def fx_val_tiny():
+    """dpm_solver (diffusion.py:289-353) alone, and the reference's RMSE_rollout (training/validate.py:23-127) driven by
+    its own "dpm" and "scm" samplers on the fake dataset.  validate.py needs three more import-time stubs (mpi4py,
+    torchinfo, swift.utils.io -- none of them is touched by RMSE_rollout)."""
+    ti = types.ModuleType("torchinfo")
+    ti.summary = lambda *a, **k: None
+    sys.modules["torchinfo"] = ti
+    sys.modules["swift.utils.io"] = types.ModuleType("swift.utils.io")
+    mp = types.ModuleType("mpi4py")
+    mp.MPI = types.SimpleNamespace(COMM_WORLD=None)
+    sys.modules["mpi4py"] = mp
+    sys.modules["ezpz"].get_rank = lambda: 0
+    sys.modules["ezpz"].get_world_size = lambda: 1
+    from swift.generating.diffusion import DiffusionSampler
+    from swift.training.validate import RMSE_rollout
+    c, seed, interval = TINY, 8, 8   # 8 six-hour steps = 2 days -> columns [6h, day 1, day 2]
+    net, state = build_ref_net(c, seed)
+    B, nv, nf = 2, c["n_vars"], c["n_forc"]
+    cond = det_normal((B, nv + nf, *c["img"]), seed, "cond")
+    lat = det_normal((B, nv, *c["img"]), seed, "lat")
+    kw = dict(sigma_min=0.02, sigma_max=200.0, auxiliary=0.6)
+    out = {"dpm4": DiffusionSampler(net).dpm_solver(lat.clone(), condition=cond, num_steps=4, **kw),
+           "dpm4_noise": DiffusionSampler(net).dpm_solver(lat.clone(), condition=cond, num_steps=4, use_pp=False, **kw)}
+    bank = det_normal((B + interval + 4, nf, *c["img"]), seed, "forc", std=1.5, mean=0.5)
+    ds = FakeERA5(c, seed, bank)
+    lat_deg = np.linspace(-88.0, 88.0, c["img"][0]).astype(np.float32)
+    ds.get_lat_lon = lambda: (lat_deg, np.zeros(c["img"][1], dtype=np.float32))
+    idx = [0, 3]
+    X0 = det_normal((B, nv, *c["img"]), seed, "X0")
+    TS = det_normal((B, interval // 4 + 1, nv, *c["img"]), seed, "TS", std=2.0)  # unstandardised targets [6h, day1, day2]
+    for mode, skw in (("dpm", dict(num_steps=3)), ("scm", dict(num_steps=1))):
+        smp = sampler_factory(mode, net, **skw, **kw)
+        gen = torch.Generator().manual_seed(21)
+        agg, sep = RMSE_rollout(smp, iter([(X0.clone(), TS.clone(), idx)]), ds, interval, torch.device("cpu"), rng=gen,
+                                num_batches=1)
+        out[f"agg_{mode}"], out[f"sep_{mode}"] = np.float64(agg), sep
+    gen = torch.Generator().manual_seed(21)
+    out["latents"] = torch.stack([torch.randn((B, nv, *c["img"]), generator=gen) for _ in range(interval)], 0)
+    save("val_tiny", seed=seed, fingerprint=state_fingerprint(state), cond=cond, lat=lat, X0=X0, TS=TS, idx=np.array(idx),
+         bank=bank, lat_deg=lat_deg, x_mean=ds.x_means, x_std=ds.x_stds, t_std6=ds.t_stds[6], **out)
+
+
+ALL = dict(val_tiny=fx_val_tiny, muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
            samplers_tiny=fx_samplers_tiny, rollout_tiny=fx_rollout_tiny, losses_tiny=fx_losses_tiny,
            swiftb_step=fx_swiftb_step, weights_aux=fx_weights_aux)
 
