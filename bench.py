@@ -164,6 +164,15 @@ def main():
     dt = float(tmax.item())
 
     if rank == 0:
+        # per-launch fabric traffic of the two roofline kernels from the committed PMC passes (valid for the default workload)
+        traffic = {}
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            if pt.get("units_per_step") == B and a.dtype == "bf16":
+                traffic = pt
+        except OSError:
+            pass
         value = world * B * K / dt
         M = B * 64 * 128
         flop_launch = 2.0 * M * mlp2 * 1056  # algorithmic: K = 1056, not the padded 1088
@@ -189,7 +198,8 @@ def main():
             "e2e": {"tflops": FLOP_PER_EVAL * value / 1e12, "frac_of_dense_mfma_peak": FLOP_PER_EVAL * value / (peak * world)},
             "roofline": {"kernel": "gemm_kernel<bf16,bf16,SWIGLU> (w1 + SwiGLU)" if a.dtype == "bf16" else
                          "gemm_kernel<f32,f32,SWIGLU> (w1 + SwiGLU)", "bound": "mfma", "achieved": ach / 1e12,
-                         "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic.get("gemm_swiglu"),
+                         "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json)",
                          "launches": int(n_launch.value), "avg_launch_ms": avg_s * 1e3,
                          "flop_per_launch": flop_launch},
         }
@@ -201,7 +211,7 @@ def main():
             line["attention_roofline"] = {
                 "kernel": "attn_pipe_kernel (shifted-window attention, bf16, window-tiled q/k/v)", "bound": "hbm",
                 "achieved": att_bytes / att_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": att_bytes / att_s / 8e12,
-                "traffic": None, "launches": int(att_n.value), "avg_launch_ms": att_s * 1e3, "bytes_per_launch": att_bytes,
+                "traffic": traffic.get("attention"), "launches": int(att_n.value), "avg_launch_ms": att_s * 1e3, "bytes_per_launch": att_bytes,
                 "mfma_tflops": att_flop / att_s / 1e12, "mfma_frac": att_flop / att_s / PEAK_BF16}
         if world == 1 and a.cpu_steps > 0:
             line["cpu_baseline"] = cpu_baseline(state, a.cpu_steps)
