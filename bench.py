@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="(member, IC) units per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-steps", type=int, default=2, help="sample-steps of the CPU baseline (0 = skip)")
+    ap.add_argument("--solver", default="scm", choices=["scm", "2s", "dpm"],
+                    help="scm = BASELINE configs[1] (default, the metric's workload); 2s / dpm = configs[2], multi-step ODE sampler")
+    ap.add_argument("--num-steps", type=int, default=None, help="solver steps (default: 1 for scm, 20 for 2s, 8 for dpm)")
     a = ap.parse_args()
 
     from swift_amd import _lib, dist as sdist, ops
@@ -109,7 +112,9 @@ def main():
     net, state = build_net(dev, rank, world)
     ds = SyntheticERA5Dataset([f"v{i}" for i in range(NV)], [f"f{i}" for i in range(NF)], img_resolution=IMG, length=64,
                               seed=1234)
-    eng = RolloutEngine(net, ds, interval=6, solver="scm", denoise_dtype=dtype)
+    nsteps = a.num_steps or {"scm": 1, "2s": 20, "dpm": 8}[a.solver]
+    evals = {"scm": nsteps, "2s": 2 * nsteps - 1, "dpm": nsteps}[a.solver]  # network evaluations per sample-step
+    eng = RolloutEngine(net, ds, interval=6, solver=a.solver, denoise_dtype=dtype, num_steps=nsteps)
     # this rank's units: contiguous block of the flattened (member, IC) space
     units = [(u // 64, u % 64) for u in range(rank * B, rank * B + B)]
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -192,10 +197,13 @@ def main():
             "vs_baseline": None,
             "dtype": a.dtype,
             "data": "synthetic",
-            "config": {"workload": "Swift-B sCM 1-step sampler, 128x256x69 (BASELINE configs[1]): noise + fused network "
-                                   "eval + residual state update per step", "units_per_gpu_per_step": B,
+            "config": {"workload": ("Swift-B sCM 1-step sampler, 128x256x69 (BASELINE configs[1]): noise + fused network "
+                                    "eval + residual state update per step") if a.solver == "scm" and nsteps == 1 else
+                       f"Swift-B {a.solver} sampler, num_steps {nsteps} = {evals} network evaluations per sample-step, 128x256x69 "
+                       "(BASELINE configs[2])", "units_per_gpu_per_step": B,
                        "params": 225980976, "parallelism": f"units sharded over {world} GPU(s), no data-path collective"},
-            "e2e": {"tflops": FLOP_PER_EVAL * value / 1e12, "frac_of_dense_mfma_peak": FLOP_PER_EVAL * value / (peak * world)},
+            "e2e": {"tflops": FLOP_PER_EVAL * evals * value / 1e12,
+                    "frac_of_dense_mfma_peak": FLOP_PER_EVAL * evals * value / (peak * world)},
             "roofline": {"kernel": "gemm_kernel<bf16,bf16,SWIGLU> (w1 + SwiGLU)" if a.dtype == "bf16" else
                          "gemm_kernel<f32,f32,SWIGLU> (w1 + SwiGLU)", "bound": "mfma", "achieved": ach / 1e12,
                          "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic.get("gemm_swiglu"),
