@@ -202,10 +202,12 @@ int swiftk_swiglu_bwd(const void* h, int64_t ldh, const void* dout, int64_t ldo,
                       int dtype, void* stream);
 
 /* Backward of swiftk_modnorm_residual's norm branch: g = dL/d(out) fp32 [M, d] -> dy (dtype), and fp32 atomic sums
- * dgamma[d], dbeta[d], dmod[B, lddmod] (scale grads at [0,d), shift grads at [d,2d)); the residual branch is identity. */
+ * dgamma[d], dbeta[d], dmod[B, lddmod] (scale grads at [0,d), shift grads at [d,2d)); the residual branch is identity.
+ * row_stats: caller-provided scratch of 2*M floats (per-row mean and 1/std, handed from the row pass to the column pass). */
 int swiftk_modnorm_bwd(const void* y, int64_t ldy, const float* g, void* dy, int64_t lddy, const float* gamma,
                        const float* beta, const float* mod, int64_t ldmod, float* dgamma, float* dbeta, float* dmod,
-                       int64_t lddmod, int64_t M, int d, int64_t rows_per_sample, float eps, int dtype, void* stream);
+                       int64_t lddmod, float* row_stats, int64_t M, int d, int64_t rows_per_sample, float eps, int dtype,
+                       void* stream);
 
 /* Backward of SWIFTK_EPI_QKNORM: qkvh / dqkvh [M, ld] (normalised values and their gradients), rn [M, 3*heads] the
  * 1/max(|.|,1e-12) factors the epilogue stored through ep1 -> dqkv [M, ldo] (raw projections), dscale[heads] += . */

@@ -63,6 +63,43 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
     }
 }
 
+// bf16 fast path: 64x64 tiles, 16-B global loads and stores on both sides (every tile row is one 128-B line), the
+// transposition itself as 2-B LDS writes into a [64][72] image (144-B rows keep the 16-B read-back aligned).
+// Needs 16-B aligned bases and lds, ldd multiples of 8.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, int64_t lds, bf16_t* __restrict__ dst,
+                                                             int64_t ldd, int64_t rows, int64_t cols) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 72];
+    const int t = threadIdx.x, ch = t & 7, rr = t >> 3;  // 8 chunks x 32 rows per pass
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = rr + 32 * i;
+        const int64_t r = r0 + row, c = c0 + 8 * ch;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < rows && c + 8 <= cols) {
+            v = *reinterpret_cast<const uint4*>(src + r * lds + c);
+        } else if (r < rows) {
+            bf16_t e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = c + k < cols ? src[r * lds + c + k] : bf16_t(0);
+            v = *reinterpret_cast<uint4*>(e);
+        }
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[(8 * ch + k) * 72 + row] = e[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int col = rr + 32 * i;  // row of the transposed tile
+        const int64_t c = c0 + col, r = r0 + 8 * ch;
+        if (c < cols && r < ldd) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tile + col * 72 + 8 * ch);  // rows >= `rows` were zero-filled above
+            *reinterpret_cast<uint4*>(dst + c * ldd + r) = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ slab reduction
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int64_t ld_slab,
                                                            int64_t slab_stride, int nslabs, float* __restrict__ out,
@@ -108,102 +145,131 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ h
 // out = LN(y; gamma, beta) * (1 + sc_b) + sh_b,  upstream g = dL/dout (fp32 [M, d]).
 //   dy = rstd * (dn - mean(dn) - n * mean(dn * n)),  dn = g (1+sc) gamma,  n = (y - mu) rstd
 //   dgamma += sum_rows g (1+sc) n,  dbeta += sum_rows g (1+sc),  dsc_b += sum_rows g ln,  dsh_b += sum_rows g
-// One wave per chunk of ROWS_PER_WAVE rows of ONE sample; column sums live in registers and leave as fp32 atomics.
-template <typename T, int SLOTS>
-__global__ __launch_bounds__(256) void modnorm_bwd_kernel(const T* __restrict__ y, int64_t ldy, const float* __restrict__ g,
-                                                          T* __restrict__ dy, int64_t lddy, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const float* __restrict__ mod,
-                                                          int64_t ldmod, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                          float* __restrict__ dmod, int64_t lddmod, int64_t M, int d,
-                                                          int64_t rps, int rows_per_wave, float eps) {
+// Two streaming passes instead of one serial one: (A) one wave per row -- statistics, dy, and (mu, rstd) saved per row;
+// (B) column sums with a lane per four columns walking rows (no cross-lane reduction: the statistics are known), four
+// waves of a block on four row sub-ranges, combined in LDS, one atomic per column and output per block.
+template <typename T>
+__global__ __launch_bounds__(256) void modnorm_bwd_rows_kernel(const T* __restrict__ y, int64_t ldy, const float* __restrict__ g,
+                                                               T* __restrict__ dy, int64_t lddy, const float* __restrict__ gamma,
+                                                               const float* __restrict__ mod, int64_t ldmod,
+                                                               float* __restrict__ stats, int64_t M, int d, int64_t rps,
+                                                               float eps) {
+    constexpr int SLOTS = 6;  // d <= 1536
     const int lane = threadIdx.x & 63;
-    const int nc = d >> 2;  // float4 slots
-    const int64_t chunks_per_sample = (rps + rows_per_wave - 1) / rows_per_wave;
-    const int64_t nchunks = (M / rps) * chunks_per_sample;
-    for (int64_t ch = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ch < nchunks; ch += (int64_t)gridDim.x * 4) {
-        const int64_t b = ch / chunks_per_sample;
-        const int64_t r0 = b * rps + (ch - b * chunks_per_sample) * rows_per_wave;
-        const int64_t r1 = min(r0 + rows_per_wave, (b + 1) * rps);
-        const float* mrow = mod + b * ldmod;
-        float ga[SLOTS][4], be[SLOTS][4], sc[SLOTS][4];
-        float a_dg[SLOTS][4], a_db[SLOTS][4], a_ds[SLOTS][4], a_dh[SLOTS][4];
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nc = d >> 2;
+    const float* mrow = mod + (row / rps) * ldmod;
+    float v[SLOTS][4], dn[SLOTS][4];
+    float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < SLOTS; ++i) {
-            const int c = lane + 64 * i;
+    for (int i = 0; i < SLOTS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            float gg[4], ga[4], sc[4];
+            ld4<T>(y + row * ldy + 4 * c, v[i]);
+            ld4<float>(g + row * d + 4 * c, gg);
+            ld4<float>(gamma + 4 * c, ga);
+            ld4<float>(mrow + 4 * c, sc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dn[i][e] = gg[e] * (1.0f + sc[e]) * ga[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = dn[i][e] = 0.f;
+        }
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float inv_d = 1.0f / (float)d;
+    const float mean = wave_sum(sum) * inv_d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = (lane + 64 * i < nc) ? v[i][e] - mean : 0.f;
+            v[i][e] = t;
+            sq += t * t;
+        }
+    const float rstd = rsqrtf(wave_sum(sq) * inv_d + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[i][e] *= rstd;
+            s1 += dn[i][e];
+            s2 += dn[i][e] * v[i][e];
+        }
+    s1 = wave_sum(s1) * inv_d;
+    s2 = wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc)
+            st4<T>(dy + row * lddy + 4 * c, rstd * (dn[i][0] - s1 - v[i][0] * s2), rstd * (dn[i][1] - s1 - v[i][1] * s2),
+                   rstd * (dn[i][2] - s1 - v[i][2] * s2), rstd * (dn[i][3] - s1 - v[i][3] * s2));
+    }
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void modnorm_bwd_cols_kernel(const T* __restrict__ y, int64_t ldy, const float* __restrict__ g,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ mod, int64_t ldmod,
+                                                               const float* __restrict__ stats, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ dmod,
+                                                               int64_t lddmod, int d, int64_t rps, int rows_per_block) {
+    __shared__ float red[3][64][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;  // float4 column slot
+    const bool ok = c < (d >> 2);
+    const int64_t blocks_per_sample = (rps + rows_per_block - 1) / rows_per_block;
+    const int64_t b = blockIdx.y / blocks_per_sample;
+    const int64_t r0 = b * rps + (blockIdx.y - b * blocks_per_sample) * rows_per_block;
+    const int64_t r1 = min(r0 + rows_per_block, (b + 1) * rps);
+    float ga[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        ld4<float>(gamma + 4 * c, ga);
+        ld4<float>(beta + 4 * c, be);
+        ld4<float>(mod + b * ldmod + 4 * c, sc);
+    }
+    float acc[16];  // dg[4], db[4], ds[4], dh[4]
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    if (ok) {
+        for (int64_t row = r0 + wv; row < r1; row += 4) {
+            float v[4], gg[4];
+            ld4<T>(y + row * ldy + 4 * c, v);
+            ld4<float>(g + row * d + 4 * c, gg);
+            const float mean = stats[2 * row], rstd = stats[2 * row + 1];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bool ok = c < nc;
-                ga[i][e] = ok ? gamma[4 * c + e] : 0.f;
-                be[i][e] = ok ? beta[4 * c + e] : 0.f;
-                sc[i][e] = ok ? mrow[4 * c + e] : 0.f;
-                a_dg[i][e] = a_db[i][e] = a_ds[i][e] = a_dh[i][e] = 0.f;
+                const float n = (v[e] - mean) * rstd;
+                const float dl = gg[e] * (1.0f + sc[e]);
+                acc[e] += dl * n;
+                acc[4 + e] += dl;
+                acc[8 + e] += gg[e] * (n * ga[e] + be[e]);
+                acc[12 + e] += gg[e];
             }
         }
-        for (int64_t row = r0; row < r1; ++row) {
-            float v[SLOTS][4], gg[SLOTS][4];
-            float sum = 0.f;
+    }
+    if (wv > 0) {
 #pragma unroll
-            for (int i = 0; i < SLOTS; ++i) {
-                const int c = lane + 64 * i;
-                if (c < nc) {
-                    ld4<T>(y + row * ldy + 4 * c, v[i]);
-                    ld4<float>(g + row * d + 4 * c, gg[i]);
-                } else {
+        for (int k = 0; k < 16; ++k) red[wv - 1][lane][k] = acc[k];
+    }
+    __syncthreads();
+    if (wv == 0 && ok) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[i][e] = gg[i][e] = 0.f;
-                }
-                sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-            }
-            const float mean = wave_sum(sum) / (float)d;
-            float sq = 0.f;
+        for (int k = 0; k < 16; ++k) acc[k] += red[0][lane][k] + red[1][lane][k] + red[2][lane][k];
 #pragma unroll
-            for (int i = 0; i < SLOTS; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = (lane + 64 * i < nc) ? v[i][e] - mean : 0.f;
-                    v[i][e] = t;
-                    sq += t * t;
-                }
-            const float rstd = rsqrtf(wave_sum(sq) / (float)d + eps);
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < SLOTS; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float n = v[i][e] * rstd;
-                    const float dl = gg[i][e] * (1.0f + sc[i][e]);  // dL/d ln
-                    a_dg[i][e] += dl * n;
-                    a_db[i][e] += dl;
-                    a_ds[i][e] += gg[i][e] * (n * ga[i][e] + be[i][e]);
-                    a_dh[i][e] += gg[i][e];
-                    const float dn = dl * ga[i][e];
-                    v[i][e] = n;
-                    gg[i][e] = dn;
-                    s1 += dn;
-                    s2 += dn * n;
-                }
-            s1 = wave_sum(s1) / (float)d;
-            s2 = wave_sum(s2) / (float)d;
-#pragma unroll
-            for (int i = 0; i < SLOTS; ++i) {
-                const int c = lane + 64 * i;
-                if (c < nc)
-                    st4<T>(dy + row * lddy + 4 * c, rstd * (gg[i][0] - s1 - v[i][0] * s2), rstd * (gg[i][1] - s1 - v[i][1] * s2),
-                           rstd * (gg[i][2] - s1 - v[i][2] * s2), rstd * (gg[i][3] - s1 - v[i][3] * s2));
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < SLOTS; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nc) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    atomicAdd(dgamma + 4 * c + e, a_dg[i][e]);
-                    atomicAdd(dbeta + 4 * c + e, a_db[i][e]);
-                    atomicAdd(dmod + b * lddmod + 4 * c + e, a_ds[i][e]);
-                    atomicAdd(dmod + b * lddmod + d + 4 * c + e, a_dh[i][e]);
-                }
-            }
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(dgamma + 4 * c + e, acc[e]);
+            atomicAdd(dbeta + 4 * c + e, acc[4 + e]);
+            atomicAdd(dmod + b * lddmod + 4 * c + e, acc[8 + e]);
+            atomicAdd(dmod + b * lddmod + d + 4 * c + e, acc[12 + e]);
         }
     }
 }
@@ -460,6 +526,12 @@ extern "C" int swiftk_transpose(const void* src, int64_t lds, void* dst, int64_t
     if (!src || !dst || rows <= 0 || cols <= 0 || lds < cols || ldd < rows) return SWIFTK_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((ldd + 63) / 64));
+    if (dtype == SWIFTK_BF16 && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15) && !(lds & 7) && !(ldd & 7)) {
+        hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, st, static_cast<const bf16_t*>(src), lds,
+                           static_cast<bf16_t*>(dst), ldd, rows, cols);
+        SWIFTK_CHECK_LAUNCH();
+        return 0;
+    }
     DT_SWITCH(dtype,
               hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, st, static_cast<const bf16_t*>(src), lds,
                                  static_cast<bf16_t*>(dst), ldd, rows, cols),
@@ -508,22 +580,32 @@ extern "C" int swiftk_swiglu_bwd(const void* h, int64_t ldh, const void* dout, i
 
 extern "C" int swiftk_modnorm_bwd(const void* y, int64_t ldy, const float* g, void* dy, int64_t lddy, const float* gamma,
                                   const float* beta, const float* mod, int64_t ldmod, float* dgamma, float* dbeta, float* dmod,
-                                  int64_t lddmod, int64_t M, int d, int64_t rows_per_sample, float eps, int dtype,
-                                  void* stream) {
-    if (!y || !g || !dy || !gamma || !beta || !mod || !dgamma || !dbeta || !dmod || M <= 0 || rows_per_sample <= 0)
+                                  int64_t lddmod, float* row_stats, int64_t M, int d, int64_t rows_per_sample, float eps,
+                                  int dtype, void* stream) {
+    if (!y || !g || !dy || !gamma || !beta || !mod || !dgamma || !dbeta || !dmod || !row_stats || M <= 0 || rows_per_sample <= 0)
         return SWIFTK_EINVAL;
     if (d % 4 || d > 1536 || M % rows_per_sample) return SWIFTK_ESHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int rpw = 32;
-    const int64_t nchunks = (M / rows_per_sample) * ((rows_per_sample + rpw - 1) / rpw);
-    const int grid = grid_for(nchunks, 4, 256 * 8);
+    const unsigned grid_rows = (unsigned)((M + 3) / 4);
+    const int rpb = 256;
+    const dim3 grid_cols((unsigned)(((d >> 2) + 63) / 64), (unsigned)((M / rows_per_sample) * ((rows_per_sample + rpb - 1) / rpb)));
     DT_SWITCH(dtype,
-              hipLaunchKernelGGL((modnorm_bwd_kernel<bf16_t, 6>), dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(y),
-                                 ldy, g, static_cast<bf16_t*>(dy), lddy, gamma, beta, mod, ldmod, dgamma, dbeta, dmod, lddmod, M,
-                                 d, rows_per_sample, rpw, eps),
-              hipLaunchKernelGGL((modnorm_bwd_kernel<float, 6>), dim3(grid), dim3(256), 0, st, static_cast<const float*>(y), ldy,
-                                 g, static_cast<float*>(dy), lddy, gamma, beta, mod, ldmod, dgamma, dbeta, dmod, lddmod, M, d,
-                                 rows_per_sample, rpw, eps));
+              {
+                  hipLaunchKernelGGL(modnorm_bwd_rows_kernel<bf16_t>, dim3(grid_rows), dim3(256), 0, st,
+                                     static_cast<const bf16_t*>(y), ldy, g, static_cast<bf16_t*>(dy), lddy, gamma, mod, ldmod,
+                                     row_stats, M, d, rows_per_sample, eps);
+                  hipLaunchKernelGGL(modnorm_bwd_cols_kernel<bf16_t>, grid_cols, dim3(256), 0, st, static_cast<const bf16_t*>(y),
+                                     ldy, g, gamma, beta, mod, ldmod, row_stats, dgamma, dbeta, dmod, lddmod, d, rows_per_sample,
+                                     rpb);
+              },
+              {
+                  hipLaunchKernelGGL(modnorm_bwd_rows_kernel<float>, dim3(grid_rows), dim3(256), 0, st,
+                                     static_cast<const float*>(y), ldy, g, static_cast<float*>(dy), lddy, gamma, mod, ldmod,
+                                     row_stats, M, d, rows_per_sample, eps);
+                  hipLaunchKernelGGL(modnorm_bwd_cols_kernel<float>, grid_cols, dim3(256), 0, st, static_cast<const float*>(y),
+                                     ldy, g, gamma, beta, mod, ldmod, row_stats, dgamma, dbeta, dmod, lddmod, d, rows_per_sample,
+                                     rpb);
+              });
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

@@ -288,11 +288,13 @@ class SwinTrainEngine:
         return dins
 
     def _modnorm_bwd(self, y, g, dy, ln, mod_slice, dmod_slice, M, d, ntok):
+        if getattr(self, "_row_stats", None) is None or self._row_stats.numel() < 2 * M:
+            self._row_stats = torch.empty(2 * M, dtype=torch.float32, device=y.device)
         check(lib().swiftk_modnorm_bwd(y.data_ptr(), y.stride(0), g.data_ptr(), dy.data_ptr(), dy.stride(0),
                                        ln.weight.detach().float().data_ptr(), ln.bias.detach().float().data_ptr(),
                                        mod_slice.data_ptr(), mod_slice.stride(0), self._grad_buf(ln.weight).data_ptr(),
-                                       self._grad_buf(ln.bias).data_ptr(), dmod_slice.data_ptr(), dmod_slice.stride(0), M, d, ntok,
-                                       1e-6, BF16, _s()), "swiftk_modnorm_bwd")
+                                       self._grad_buf(ln.bias).data_ptr(), dmod_slice.data_ptr(), dmod_slice.stride(0),
+                                       self._row_stats.data_ptr(), M, d, ntok, 1e-6, BF16, _s()), "swiftk_modnorm_bwd")
 
     def _small_bwd(self, dz, x, lin, want_dx=True, w=None, dW=None, db=None):
         w = lin.weight.detach().float().contiguous() if w is None else w

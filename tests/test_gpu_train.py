@@ -40,6 +40,12 @@ def test_transpose_and_splitk_wgrad(dev):
     dy, x = rnd((M, N), 1).to(dev).to(BF), rnd((M, K), 2).to(dev).to(BF)
     dyt, xt = _transpose(dy, M, N), _transpose(x, M, K)
     assert torch.equal(dyt, dy.t().contiguous())
+    # ragged tile edges, zero-filled padding columns [rows, ldd), and a strided (column-sliced) source
+    src = rnd((1000, 300), 3).to(dev).to(BF)
+    tt = _transpose(src[:, 4:284], 1000, 276, ldd=1024)   # unaligned base -> generic kernel
+    assert torch.equal(tt[:, :1000], src[:, 4:280].t()) and float(tt[:, 1000:].float().abs().max()) == 0.0
+    tt = _transpose(src[:, 8:288], 1000, 276, ldd=1024)   # 16-B aligned base -> vector kernel
+    assert torch.equal(tt[:, :1000], src[:, 8:284].t()) and float(tt[:, 1000:].float().abs().max()) == 0.0
     ks = 4
     slabs = torch.empty(ks, N, K, dtype=torch.float32, device=dev)
     rc = L.swiftk_gemm_splitk(dyt.data_ptr(), M, xt.data_ptr(), M, slabs.data_ptr(), K, N * K, N, K, M, _lib.BF16, ks, s())
@@ -85,8 +91,8 @@ def test_modnorm_bwd(dev):
     dmod = torch.zeros(B, 3 * 2 * d, device=dev)
     dsl = dmod[:, 2 * d: 4 * d]
     rc = L.swiftk_modnorm_bwd(y.data_ptr(), d, g.data_ptr(), dy.data_ptr(), dy.stride(0), gamma.data_ptr(), beta.data_ptr(),
-                              msl.data_ptr(), msl.stride(0), dgam.data_ptr(), dbet.data_ptr(), dsl.data_ptr(), dsl.stride(0), M,
-                              d, rps, 1e-6, _lib.BF16, s())
+                              msl.data_ptr(), msl.stride(0), dgam.data_ptr(), dbet.data_ptr(), dsl.data_ptr(), dsl.stride(0),
+                              torch.empty(2 * M, device=dev).data_ptr(), M, d, rps, 1e-6, _lib.BF16, s())
     assert rc == 0
     yc = y.float().cpu().requires_grad_(True)
     gc, bc = gamma.cpu().requires_grad_(True), beta.cpu().requires_grad_(True)
