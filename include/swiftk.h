@@ -325,7 +325,7 @@ typedef struct swiftk_model {
     const float* mod_b;            /* [depth*2*2d]                              */
     const float* logvar_w;         /* [1, d] or NULL                            */
     const float* logvar_b;
-    const void* head_w;            /* [out_ch*p1*p2, kd] dtype (head.head.0.weight) */
+    const void* head_w;            /* [round_up(out_ch*p1*p2, 4), kd] dtype (head.head.0.weight, zero rows appended) */
     const swiftk_layer* layers_host; /* HOST array of `depth` entries           */
 } swiftk_model;
 

@@ -228,17 +228,18 @@ __global__ __launch_bounds__(NT) void attn_bf16_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ fp32
 
-constexpr int KSTR32 = 92;  // floats per K row (88 + 4): conflict-free ds_read_b128 over 16 rows
 constexpr int VSTR32 = 96;  // floats per V row
 
 template <int HD>
 __global__ __launch_bounds__(NT) void attn_f32_kernel(AttnArgs a) {
-    static_assert(HD % 8 == 0 && HD <= 88, "head_dim (fp32 path)");
+    static_assert(HD % 8 == 0 && HD <= 96, "head_dim (fp32 path)");
+    constexpr int KSTR32 = HD + 4;      // floats per K row: 16 consecutive rows land on 16 distinct 4-bank groups
+    constexpr int ISTR32 = KSTR32 > VSTR32 ? KSTR32 : VSTR32;
     constexpr int HALF = HD / 2;        // k-slot (kk, hh) <-> d = kk + HALF*hh
     constexpr int NQ = HALF / 4;        // float4 per half row
     constexpr int NF4 = HD / 4;
     constexpr int DB = (HD + 31) / 32;
-    __shared__ __attribute__((aligned(16))) float sKV[WTOK * VSTR32];  // K image (stride 92), later V image (stride 96)
+    __shared__ __attribute__((aligned(16))) float sKV[WTOK * ISTR32];  // K image (stride HD + 4), later V image (stride 96)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -408,6 +409,7 @@ extern "C" int swiftk_window_attention(const void* qkv, int64_t ldq, void* out, 
     }
     if (flags & SWIFTK_ATTN_TILED) return SWIFTK_ESHAPE;  // window-tiled input exists for the pipelined kernel only
     switch (head_dim) {
+        case 96: return launch_hd<96>(a, B, dtype, st);
         case 88: return launch_hd<88>(a, B, dtype, st);
         case 80: return launch_hd<80>(a, B, dtype, st);
         case 64: return launch_hd<64>(a, B, dtype, st);

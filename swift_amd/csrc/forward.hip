@@ -29,7 +29,7 @@ bool model_ok(const swiftk_model* m) {
     if (m->H % m->p1 || m->W % m->p2) return false;
     if (m->wh != 16 || m->ww != 16) return false;
     if ((m->H / m->p1) % 16 || (m->W / m->p2) % 16) return false;
-    if (m->dim % 4 || m->mlp % 2 || (m->out_ch * m->p1 * m->p2) % 4) return false;
+    if (m->dim % 4 || m->mlp % 2) return false;
     return true;
 }
 
@@ -49,7 +49,7 @@ Layout make_layout(const swiftk_model* m, int B) {
     L.att = o; o += al(M * m->kd * es);
     L.y = o; o += al(M * d * es);
     L.hmid = o; o += al(M * m->kmlp * es);
-    L.tok = o; o += al(M * (int64_t)m->out_ch * m->p1 * m->p2 * 4);
+    L.tok = o; o += al(M * (int64_t)((m->out_ch * m->p1 * m->p2 + 3) & ~3) * 4);
     L.total = o;
     return L;
 }
@@ -154,9 +154,10 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
                                     ntok, 1e-6f, dt, stream));
     }
 
-    const int po = m->out_ch * m->p1 * m->p2;
-    RUN(swiftk_gemm(xT, m->kd, m->head_w, m->kd, tok, po, M, po, kdv, dt, SWIFTK_F32, SWIFTK_EPI_NONE, nullptr, nullptr, 0,
+    // the head's output width rounded up to the GEMM's N granularity (head_w carries zero rows there: 69 -> 72 for 1x1 patches)
+    const int po4 = (m->out_ch * m->p1 * m->p2 + 3) & ~3;
+    RUN(swiftk_gemm(xT, m->kd, m->head_w, m->kd, tok, po4, M, po4, kdv, dt, SWIFTK_F32, SWIFTK_EPI_NONE, nullptr, nullptr, 0,
                     stream));
-    RUN(swiftk_unpatchify_affine(tok, po, xt, alpha, beta, out, B, m->out_ch, m->H, m->W, m->p1, m->p2, stream));
+    RUN(swiftk_unpatchify_affine(tok, po4, xt, alpha, beta, out, B, m->out_ch, m->H, m->W, m->p1, m->p2, stream));
     return 0;
 }

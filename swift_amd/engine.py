@@ -46,7 +46,10 @@ class SwinEngine:
         dt = self.dtype
         d, heads, depth, mlp = m.dim, m.heads, m.depth, m.mlp_dim
         p1, p2 = m.patch_size
-        kd, kmlp, kpe = ops.k_pad(dt, d), ops.k_pad(dt, mlp), ops.k_pad(dt, m.in_channels * p1 * p2)
+        # int(8/3 * dim) is odd for some widths (1280 -> 3413): one zero (gate, up) row pair makes w1's N a multiple of 4;
+        # the extra SwiGLU column is silu(0) * 0 = 0 and lands in w2's zero K padding
+        mlp_e = mlp + (mlp & 1)
+        kd, kmlp, kpe = ops.k_pad(dt, d), ops.k_pad(dt, mlp_e), ops.k_pad(dt, m.in_channels * p1 * p2)
         keep = []
 
         def f32(t):
@@ -64,6 +67,8 @@ class SwinEngine:
         for i, (att, ff) in enumerate(m.transformer.layers):
             w1 = ff.w1.weight.detach()
             w1i = w1.view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)  # rows: gate_0, up_0, gate_1, up_1, ...
+            if mlp_e != mlp:
+                w1i = torch.cat([w1i, w1i.new_zeros(2, d)], 0)
             layers[i].qkv_w = gemm_w(att.to_qkv.weight, kd)
             layers[i].wo_w = gemm_w(att.wo.weight, kd)
             layers[i].w1_w = gemm_w(w1i, kd)
@@ -82,7 +87,7 @@ class SwinEngine:
         mo.H, mo.W = m.image_size
         mo.p1, mo.p2 = p1, p2
         mo.in_ch, mo.out_ch = m.in_channels, m.out_channels
-        mo.depth, mo.dim, mo.heads, mo.mlp = depth, d, heads, mlp
+        mo.depth, mo.dim, mo.heads, mo.mlp = depth, d, heads, mlp_e
         mo.wh, mo.ww = m.window_size
         mo.sh, mo.sw = m.shift_size
         mo.aux_dim = m.auxiliary_dim
@@ -100,7 +105,10 @@ class SwinEngine:
         mo.mod_w, mo.mod_b = f32(torch.cat(mods_w, 0)), f32(torch.cat(mods_b, 0))
         if m.logvar_embed is not None:
             mo.logvar_w, mo.logvar_b = f32(m.logvar_embed.weight), f32(m.logvar_embed.bias)
-        mo.head_w = gemm_w(m.head.head[0].weight, kd)
+        hw = m.head.head[0].weight.detach()
+        if hw.shape[0] % 4:  # GEMM N granularity: zero rows (1x1 patches: 69 -> 72 output columns, the extra ones unused)
+            hw = torch.cat([hw, hw.new_zeros(4 - hw.shape[0] % 4, hw.shape[1])], 0)
+        mo.head_w = gemm_w(hw, kd)
         mo.layers_host = C.cast(layers, C.POINTER(Layer))
         keep.append(layers)
         self.model, self._keep, self._stamp = mo, keep, stamp

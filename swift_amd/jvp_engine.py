@@ -68,7 +68,10 @@ class SwinJvpEngine:
             mods_w += [att.norm.modulation.weight.detach(), ff.norm.modulation.weight.detach()]
             mods_b += [att.norm.modulation.bias.detach(), ff.norm.modulation.bias.detach()]
         self.pe = cast(m.patch_embed.emb.weight, self.kpe)
-        self.head = cast(m.head.head[0].weight, self.kd)
+        hw = m.head.head[0].weight.detach()
+        if hw.shape[0] % 4:  # GEMM N granularity (1x1 patches: 69 -> 72 output columns, the zero ones unused)
+            hw = torch.cat([hw, hw.new_zeros(4 - hw.shape[0] % 4, hw.shape[1])], 0)
+        self.head = cast(hw, self.kd)
         self.mod_w, self.mod_b = torch.cat(mods_w, 0).float().contiguous(), torch.cat(mods_b, 0).float().contiguous()
         half = d // 2
         self.freqs = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32) / half).to(self.mod_w.device)
@@ -156,7 +159,7 @@ class SwinJvpEngine:
                                       HM.data_ptr() + M * self.kmlp * es, self.kmlp, M, mlp, tc, _s()), "swiftk_swiglu_jvp")
             _gemm(HM, W["w2"], Y)
             modnorm(2 * i + 1, W["g2"], W["b2"])
-        po = m.out_channels * m.patch_size[0] * m.patch_size[1]
-        tok = torch.empty(M, po, dtype=torch.float32, device=dev)
+        po4 = self.head.shape[0]
+        tok = torch.empty(M, po4, dtype=torch.float32, device=dev)
         _gemm(XT[M:], self.head, tok)
-        return ops.unpatchify_affine(tok.view(B, ntok, po), (B, m.out_channels, *m.image_size), m.patch_size)
+        return ops.unpatchify_affine(tok.view(B, ntok, po4), (B, m.out_channels, *m.image_size), m.patch_size)

@@ -80,7 +80,10 @@ class SwinTrainEngine:
                 scale=att.scale.detach().reshape(-1).float().contiguous()))
         self.pe = cast(m.patch_embed.emb.weight, self.kpe)
         self.pe_t = tr(m.patch_embed.emb.weight, self.kd)
-        self.head = cast(m.head.head[0].weight, self.kd)
+        hw = m.head.head[0].weight.detach()
+        if hw.shape[0] % 4:  # GEMM N granularity (1x1 patches: 69 -> 72 output columns, the zero ones unused)
+            hw = torch.cat([hw, hw.new_zeros(4 - hw.shape[0] % 4, hw.shape[1])], 0)
+        self.head = cast(hw, self.kd)
         self.head_t = tr(m.head.head[0].weight, self.kpo)
         mods_w, mods_b = [], []
         for att, ff in m.transformer.layers:
@@ -184,9 +187,10 @@ class SwinTrainEngine:
             xT = xT_out
         ctx["xT_final"] = xT
         po = m.out_channels * m.patch_size[0] * m.patch_size[1]
-        tok = torch.empty(M, po, dtype=torch.float32, device=dev)
+        po4 = self.head.shape[0]
+        tok = torch.empty(M, po4, dtype=torch.float32, device=dev)
         _gemm(xT, self.head, tok)
-        out = ops.unpatchify_affine(tok.view(B, ntok, po), (B, m.out_channels, *m.image_size), m.patch_size)
+        out = ops.unpatchify_affine(tok.view(B, ntok, po4), (B, m.out_channels, *m.image_size), m.patch_size)
         return (out, logvar, ctx) if want_logvar else (out, ctx)
 
     # ------------------------------------------------------------------ backward

@@ -66,3 +66,23 @@ def test_train_then_generate_cli(tmp_path):
     assert a.shape == (3, 2, 4, 69, 64, 64) and np.isfinite(a).all()
     assert np.abs(a[:, 0] - a[:, 1])[:, 1:].max() > 0  # members differ after the first step, share the initial state
     assert np.array_equal(a[:, 0, 0], a[:, 1, 0])
+
+
+def test_train_cli_5p6deg_one_by_one_patches(tmp_path):
+    """experiment=era5-swinv2-5.6-scm (1x1 patches on the 32x64 grid, head width 69): sCM training + validation run."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    run(["swift_amd.train", "experiment=era5-swinv2-5.6-scm", "data=era5-synthetic-5.6", "data.dataset.length=48",
+         "data.data_workers=0", "model.depth=2", "trainer.total_kimg=0.008", "trainer.kimg_per_tick=0.004",
+         "trainer.checkpoint_ticks=1", "trainer.lr_rampup_kimg=0", "trainer.val_ticks=1", "trainer.val_target_interval=4",
+         "data.val_local_batch_size=2", "data.batch_size=2", "loss.tangent_warmup_kimg=1"], cwd=str(tmp_path))
+    rdir = tmp_path / "results" / "era5-swinv2-5.6-scm" / "000"
+    lines = [yaml.safe_load(l) for l in open(rdir / "stats.jsonl")]
+    assert len(lines) >= 2 and all(np.isfinite(l["train/loss"]) for l in lines)
+    val = [yaml.safe_load(l) for l in open(rdir / "val_stats.jsonl")]
+    assert val and np.isfinite(val[0]["val/rmse"])
+    run(["swift_amd.generate", "--input", str(rdir), "--members", "2", "--steps", "2", "--samples", "2", "--batch", "4",
+         "--dump", "numpy"], cwd=str(tmp_path))
+    a = np.load(rdir / "output" / "latest" / "output-2i-2s-2m-6h.npy")
+    assert a.shape == (2, 2, 3, 69, 32, 64) and np.isfinite(a).all()

@@ -69,6 +69,30 @@ def test_forward_vs_reference_golden(dev):
     assert e16 < 1.25 * float(g["bf16_autocast_rel"])
 
 
+@pytest.mark.parametrize("name,c", [
+    # reference experiment/era5-swinv2-5.6-scm.yaml: 1x1 patches on the 32x64 grid (head width 69: not a multiple of 4)
+    ("5.6deg-1x1-patches", dict(img=(32, 64), n_vars=69, n_forc=3, window=(16, 16), shift=(8, 8), patch=(1, 1), dim=1056,
+                                heads=12, depth=2)),
+    # the larger variants in experiment/era5-swinv2-1.4-scm.yaml's comments: head_dim 80 (1280/16) and 96 (1536/16)
+    ("head_dim-80", dict(img=(64, 64), n_vars=69, n_forc=3, window=(16, 16), shift=(8, 8), patch=(2, 2), dim=320, heads=4,
+                         depth=2)),
+    ("head_dim-96", dict(img=(64, 64), n_vars=69, n_forc=3, window=(16, 16), shift=(8, 8), patch=(2, 2), dim=384, heads=4,
+                         depth=2)),
+])
+def test_forward_other_swift_variants_vs_oracle(dev, name, c):
+    net, onet = build(c, 12, dev)
+    x, cond = det_normal((2, 69, *c["img"]), 12, "x"), det_normal((2, 72, *c["img"]), 12, "cond")
+    t = torch.tensor([0.4, 1.3])
+    with torch.no_grad():
+        y = net(x.to(dev), t.to(dev), cond.to(dev), 0.6)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            yb = net(x.to(dev), t.to(dev), cond.to(dev), 0.6)
+        yo = onet(x, t, cond, 0.6)
+    e32, e16 = rel_l2(y.cpu(), yo), rel_l2(yb.cpu(), yo)
+    print(f"{name}: fp32 rel-L2 {e32:.3e}, bf16 rel-L2 {e16:.3e}")
+    assert e32 < FP32_TOL and e16 < BF16_TOL
+
+
 def test_forward_logvar_and_split_sources(dev):
     net, onet = build(SMALLB, 8, dev, logvar=True)
     x, cond = det_normal((2, 69, 64, 64), 8, "x"), det_normal((2, 72, 64, 64), 8, "cond")
