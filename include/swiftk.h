@@ -263,6 +263,11 @@ int swiftk_scm_target(const float* F, const float* dxt, const float* xt_over_sd,
  * slice).  The caller zero-fills sq (1 + C floats), divides by the counts and takes the roots. */
 int swiftk_rmse_sums(const float* y, const float* t, int64_t t_batch_stride, const float* w_lat, float* sq, int B, int C, int H,
                      int W, void* stream);
+/* Ensemble evaluation sums (eval/metrics.py:39-134), pred [B, N, V, H, W], y [B, V, H, W], out [B, V, 4] (zero-filled by
+ * the caller): per (sample, variable) the latitude-weighted grid sums of (ens-mean - y)^2, sum_n |x_n - y|,
+ * sum_{n,n'} |x_n - x_n'| and the unbiased member variance; 2 <= N <= 64.  RMSE / CRPS / spread-skill follow on the host. */
+int swiftk_ensemble_sums(const float* pred, const float* y, const float* w_lat, float* out, int B, int N, int V, int H, int W,
+                         void* stream);
 /* Almost-fair CRPS over m members (loss.py:343-371,445): *loss += 1/(B H W) sum w_var[c] w_lat[h] crps; dpreds optional. */
 int swiftk_crps_loss(const float* preds, const float* target, const float* w_var, const float* w_lat, float* loss,
                      float* dpreds, int m, int B, int C, int H, int W, float alpha, float gscale, void* stream);

@@ -516,6 +516,59 @@ __global__ __launch_bounds__(256) void rmse_sums_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------ ensemble metric sums
+// Per (sample b, variable v), over the grid with latitude weights (eval/metrics.py:39-134):
+//   out[b][v][0] = sum w (mean_n x - y)^2          (ensemble-mean RMSE)
+//   out[b][v][1] = sum_n sum w |x_n - y|           (CRPS skill term)
+//   out[b][v][2] = sum_{n,n'} sum w |x_n - x_n'|   (CRPS spread term)
+//   out[b][v][3] = sum w var_n(x), unbiased        (spread of the spread/skill ratio)
+// One block per (b, v, chunk of the grid); the N member values of a grid point live in registers (N <= 64).
+template <int NMAX>
+__global__ __launch_bounds__(256) void ensemble_sums_kernel(const float* __restrict__ pred, const float* __restrict__ y,
+                                                            const float* __restrict__ w_lat, float* __restrict__ out, int N,
+                                                            int V, int H, int W) {
+    __shared__ float red[4][4];
+    const int bv = blockIdx.y, b = bv / V, v = bv - b * V;
+    const int64_t hw = (int64_t)H * W;
+    const float* p0 = pred + ((int64_t)b * N * V + v) * hw;  // member stride V*hw
+    const float* yy = y + (int64_t)bv * hw;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+        const float w = w_lat[i / W], t = yy[i];
+        float x[NMAX];
+        float mean = 0.f;
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) {
+            x[n] = n < N ? p0[(int64_t)n * V * hw + i] : 0.f;
+            mean += x[n];
+        }
+        mean /= (float)N;
+        float e = 0.f, sp = 0.f, var = 0.f;
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) {
+            if (n < N) {
+                e += fabsf(x[n] - t);
+                var += (x[n] - mean) * (x[n] - mean);
+#pragma unroll
+                for (int k = 0; k < NMAX; ++k)
+                    if (k < n) sp += fabsf(x[n] - x[k]);
+            }
+        }
+        a0 += w * (mean - t) * (mean - t);
+        a1 += w * e;
+        a2 += w * 2.0f * sp;  // both orders of every pair
+        a3 += w * var / (float)(N - 1);
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = threadIdx.x >> 6;
+        red[0][wv] = a0; red[1][wv] = a1; red[2][wv] = a2; red[3][wv] = a3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(out + (int64_t)bv * 4 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] +
+                                                                           red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
 }  // namespace
 
 #define DT_SWITCH(dtype, CALL_BF16, CALL_F32) \
@@ -720,6 +773,22 @@ extern "C" int swiftk_rmse_sums(const float* y, const float* t, int64_t t_batch_
     const dim3 grid((unsigned)grid_for((int64_t)B * H * W, 256, 64), (unsigned)C);
     hipLaunchKernelGGL(rmse_sums_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), y, t, t_batch_stride, w_lat, sq, B,
                        C, H, W);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_ensemble_sums(const float* pred, const float* y, const float* w_lat, float* out, int B, int N, int V, int H,
+                                    int W, void* stream) {
+    if (!pred || !y || !w_lat || !out || B <= 0 || N < 2 || V <= 0 || H <= 0 || W <= 0) return SWIFTK_EINVAL;
+    if (N > 64) return SWIFTK_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)grid_for((int64_t)H * W, 256, 32), (unsigned)(B * V));
+    if (N <= 8)
+        hipLaunchKernelGGL(ensemble_sums_kernel<8>, grid, dim3(256), 0, st, pred, y, w_lat, out, N, V, H, W);
+    else if (N <= 16)
+        hipLaunchKernelGGL(ensemble_sums_kernel<16>, grid, dim3(256), 0, st, pred, y, w_lat, out, N, V, H, W);
+    else
+        hipLaunchKernelGGL(ensemble_sums_kernel<64>, grid, dim3(256), 0, st, pred, y, w_lat, out, N, V, H, W);
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

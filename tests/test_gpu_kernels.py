@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -300,3 +300,26 @@ def test_window_tiled_qkv_path(dev, shift, B):
     ref[:, idx.reshape(-1)] = ow.permute(0, 2, 1, 3).reshape(B, n, -1)
     assert torch.isfinite(out_t.float()).all()
     assert rel_l2(out_t.float().cpu(), ref) < 1.2e-2
+
+
+def test_ensemble_metrics_vs_reference_golden(dev):
+    """swiftk_ensemble_sums -> RMSE / CRPS / spread-skill against the reference's eval/metrics.py functions (golden)."""
+    from swift_amd.eval.metrics import all_metrics, lat_weighted_crps
+    g = load_golden("metrics_tiny")
+    pred, y = torch.from_numpy(g["pred"]).to(dev), torch.from_numpy(g["y"]).to(dev)
+    names = [f"v{i}" for i in range(4)]
+    got = all_metrics(pred, y, names, g["lat"], "6h")
+    ref = dict(zip([str(k) for k in g["keys"]], g["values"]))
+    assert set(got) == set(ref)
+    for k, v in ref.items():
+        assert float(got[k]) == pytest.approx(v, rel=5e-5), k
+    assert set(lat_weighted_crps(pred, y, names, g["lat"], "6h")) == {f"crps_v{i}_6h" for i in range(4)}
+    # 12 members (the rollout's ensemble size) against the fp64 formulas
+    from oracle import metrics as omet
+    p12, y12 = rnd((2, 12, 3, 32, 64), 70).to(dev), rnd((2, 3, 32, 64), 71).to(dev)
+    lat = np.linspace(-88, 88, 32)
+    got = all_metrics(p12, y12, ["a", "b", "c"], lat, "x")
+    for name, fn in (("rmse", omet.rmse), ("crps", omet.crps), ("ssr", omet.spread_skill_ratio)):
+        r = fn(p12.cpu().double(), y12.cpu().double(), lat)
+        for i, v in enumerate("abc"):
+            assert float(got[f"{name}_{v}_x"]) == pytest.approx(float(r[i]), rel=5e-5)

@@ -409,7 +409,24 @@ def fx_val_tiny():
          bank=bank, lat_deg=lat_deg, x_mean=ds.x_means, x_std=ds.x_stds, t_std6=ds.t_stds[6], **out)
 
 
-ALL = dict(val_tiny=fx_val_tiny, muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
+@torch.no_grad()
+def fx_metrics_tiny():
+    """The reference's offline ensemble metrics (eval/metrics.py:39-134) on a seeded 5-member ensemble (xarray stubbed:
+    only its main() touches it)."""
+    sys.modules.setdefault("xarray", types.ModuleType("xarray"))
+    from swift.eval.metrics import lat_weighted_crps, lat_weighted_rmse, lat_weighted_spread_skill_ratio
+    B, N, V, H, W = 3, 5, 4, 16, 32
+    y = det_normal((B, V, H, W), 91, "y")
+    pred = y[:, None] * 0.8 + det_normal((B, N, V, H, W), 91, "p") * 0.5
+    lat = np.linspace(-87.1875, 87.1875, H).astype(np.float64)
+    names = [f"v{i}" for i in range(V)]
+    out = {}
+    for fn in (lat_weighted_rmse, lat_weighted_crps, lat_weighted_spread_skill_ratio):
+        out.update({k: float(v) for k, v in fn(pred, y, names, lat, "6h").items()})
+    save("metrics_tiny", pred=pred, y=y, lat=lat, keys=np.array(sorted(out)), values=np.array([out[k] for k in sorted(out)]))
+
+
+ALL = dict(metrics_tiny=fx_metrics_tiny, val_tiny=fx_val_tiny, muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
            samplers_tiny=fx_samplers_tiny, rollout_tiny=fx_rollout_tiny, losses_tiny=fx_losses_tiny,
            swiftb_step=fx_swiftb_step, weights_aux=fx_weights_aux)
 
