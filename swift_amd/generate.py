@@ -80,18 +80,47 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
     mine = dist.shard_units(members * n_ic, rank, world)  # unit u = member * n_ic + ic
     nv = len(dataset.variables)
     done = 0
-    for s in range(mine.start, mine.stop, args.batch):
+    # Output streaming (the reference copies every step to the host synchronously, generate.py:129): the trajectory of a
+    # batch stays on the device while it is rolled out; its device->host copy then runs on a side stream into one of two
+    # pinned buffers while the NEXT batch computes, and the memmap write of batch k-1 happens on the host meanwhile.
+    copy_stream = torch.cuda.Stream(device=device)
+    pinned = [None, None]
+    pending = None  # (copy-done event, pinned buffer view, units)
+
+    def flush(p):
+        ev, host, us = p
+        ev.synchronize()
+        h = host.numpy()
+        for k, (m, ic) in enumerate(us):
+            store[ic, m] = h[:, k]          # buffer is step-major [steps+1, B, ...]
+        store.flush()
+
+    for bi, s in enumerate(range(mine.start, mine.stop, args.batch)):
         units = [(u // n_ic, u % n_ic) for u in range(s, min(s + args.batch, mine.stop))]
         ics = [indices[ic] for _, ic in units]
         X0 = torch.stack([dataset[int(j)][0][0][:nv] for j in ics], 0).to(device, non_blocking=True)
         forc = engine.stage_forcings(ics, steps, device)
-        traj = engine.run(X0, forc, steps, seeds=[unit_seed(m, indices[ic]) for m, ic in units])
-        host = traj.cpu().numpy()  # one D2H per batch instead of one per step (generate.py:129)
-        for k, (m, ic) in enumerate(units):
-            store[ic, m] = host[k]
-        store.flush()
+        traj = engine.run(X0, forc, steps, seeds=[unit_seed(m, indices[ic]) for m, ic in units])  # [B, steps+1, ...] view
+        dev_buf = traj.transpose(0, 1)      # the contiguous step-major buffer behind it
+        ready = torch.cuda.Event()
+        ready.record()
+        slot = bi & 1
+        if pinned[slot] is None or pinned[slot].shape[1] < dev_buf.shape[1]:
+            pinned[slot] = torch.empty(dev_buf.shape, dtype=torch.float32, pin_memory=True)
+        host = pinned[slot][:, :dev_buf.shape[1]]
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ready)
+            host.copy_(dev_buf, non_blocking=True)
+            dev_buf.record_stream(copy_stream)
+            ev.record(copy_stream)
+        if pending is not None:
+            flush(pending)                  # host-side write of the previous batch, under this batch's kernels
+        pending = (ev, host, units)
         done += len(units)
         dist.log0(f"rank 0: {done}/{len(mine)} units")
+    if pending is not None:
+        flush(pending)
 
 
 def main(args):
