@@ -41,7 +41,7 @@ parser.add_argument("--samples", type=int, default=-1, help="Number of samples u
 parser.add_argument("--interval", type=int, default=6, choices=[6, 12, 24], help="Interval in hours")
 parser.add_argument("--dump", type=str, default="zarr", choices=["zarr", "numpy"], help="Output format")
 # additive
-parser.add_argument("--solver", type=str, default="scm", choices=["scm", "2s"])
+parser.add_argument("--solver", type=str, default="scm", choices=["scm", "2s", "dpm"])
 parser.add_argument("--num-steps", type=int, default=1, help="solver steps per forecast step")
 parser.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16"], help="GEMM operand type")
 parser.add_argument("--synthetic", action="store_true", help="random-init weights + synthetic data (no run dir needed)")
@@ -83,23 +83,42 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
     # Output streaming (the reference copies every step to the host synchronously, generate.py:129): the trajectory of a
     # batch stays on the device while it is rolled out; its device->host copy then runs on a side stream into one of two
     # pinned buffers while the NEXT batch computes, and the memmap write of batch k-1 happens on the host meanwhile.
+    from concurrent.futures import ThreadPoolExecutor
+    writer = ThreadPoolExecutor(max_workers=1)
     copy_stream = torch.cuda.Stream(device=device)
     pinned = [None, None]
     pending = None  # (copy-done event, pinned buffer view, units)
 
+    t_host = [0.0, 0.0]  # seconds in input staging / output writes (host side)
+
     def flush(p):
         ev, host, us = p
         ev.synchronize()
+        t1 = time.time()
         h = host.numpy()
         for k, (m, ic) in enumerate(us):
             store[ic, m] = h[:, k]          # buffer is step-major [steps+1, B, ...]
         store.flush()
+        t_host[1] += time.time() - t1
 
-    for bi, s in enumerate(range(mine.start, mine.stop, args.batch)):
+    def stage(s):
+        """Host-side inputs of the batch starting at unit s (pinned tensors; runs on the reader thread, one batch ahead)."""
+        t1 = time.time()
         units = [(u // n_ic, u % n_ic) for u in range(s, min(s + args.batch, mine.stop))]
         ics = [indices[ic] for _, ic in units]
-        X0 = torch.stack([dataset[int(j)][0][0][:nv] for j in ics], 0).to(device, non_blocking=True)
-        forc = engine.stage_forcings(ics, steps, device)
+        x0 = {int(j): dataset[int(j)][0][0][:nv] for j in set(ics)}
+        X0 = torch.stack([x0[int(j)] for j in ics], 0).pin_memory()
+        forc = engine.stage_forcings(ics, steps, "cpu").pin_memory()
+        t_host[0] += time.time() - t1
+        return units, X0, forc
+
+    reader = ThreadPoolExecutor(max_workers=1)
+    starts = list(range(mine.start, mine.stop, args.batch))
+    nxt = reader.submit(stage, starts[0]) if starts else None
+    for bi, s in enumerate(starts):
+        units, X0, forc = nxt.result()
+        nxt = reader.submit(stage, starts[bi + 1]) if bi + 1 < len(starts) else None
+        X0, forc = X0.to(device, non_blocking=True), forc.to(device, non_blocking=True)
         traj = engine.run(X0, forc, steps, seeds=[unit_seed(m, indices[ic]) for m, ic in units])  # [B, steps+1, ...] view
         dev_buf = traj.transpose(0, 1)      # the contiguous step-major buffer behind it
         ready = torch.cuda.Event()
@@ -115,12 +134,15 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
             dev_buf.record_stream(copy_stream)
             ev.record(copy_stream)
         if pending is not None:
-            flush(pending)                  # host-side write of the previous batch, under this batch's kernels
-        pending = (ev, host, units)
+            pending.result()                # the writer thread is done with the other pinned buffer
+        pending = writer.submit(flush, (ev, host, units))  # host-side write under the next batch's staging + kernels
         done += len(units)
         dist.log0(f"rank 0: {done}/{len(mine)} units")
     if pending is not None:
-        flush(pending)
+        pending.result()
+    writer.shutdown()
+    reader.shutdown()
+    dist.log0(f"host side: {t_host[0]:.2f} s staging inputs, {t_host[1]:.2f} s writing outputs")
 
 
 def main(args):
@@ -182,7 +204,10 @@ def main(args):
     rollout_and_save(engine, dataset, indices, args.members, args.steps, ofile, device, args)
     torch.cuda.synchronize()
     dist.barrier()
-    dist.log0(f"Done! Took {time.time() - t0:.3f} seconds.")
+    el = time.time() - t0
+    n = len(indices) * args.members * args.steps
+    dist.log0(f"Done! Took {el:.3f} seconds: {n} sample-steps, {n / el:.1f} sample-steps/s including forcing staging and output "
+              f"streaming to {os.path.basename(ofile)}.")
     if tdist.is_initialized():
         tdist.destroy_process_group()
     dist.log0(f"Output saved to: {ofile}")

@@ -50,10 +50,12 @@ class RolloutEngine:
     def stage_forcings(self, ic_indices: Sequence[int], steps: int, device) -> torch.Tensor:
         """Standardised forcings [steps, B, n_forc, H, W] on the device (file index j + i*interval//6)."""
         rows = []
+        uniq = sorted(set(int(j) for j in ic_indices))  # members of one IC share its forcings: read each file once
+        pos = torch.tensor([uniq.index(int(j)) for j in ic_indices])
         for i in range(steps):
-            f = torch.stack([self.dataset.get_forcings(int(j) + int(i * self.interval // 6)) for j in ic_indices], 0)
+            f = torch.stack([self.dataset.get_forcings(j + int(i * self.interval // 6)) for j in uniq], 0)
             rows.append(self.dataset.standardize_x(f))
-        return torch.stack(rows, 0).to(device, non_blocking=True)
+        return torch.stack(rows, 0)[:, pos].contiguous().to(device, non_blocking=True)
 
     @torch.no_grad()
     def run(self, X0: torch.Tensor, forcings: torch.Tensor, steps: int, *, seeds: Optional[Sequence[int]] = None,
