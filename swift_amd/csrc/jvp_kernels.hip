@@ -4,8 +4,9 @@
 // The network's linear maps carry the tangent as extra rows of the same GEMM (primal rows 0..M-1, tangent rows M..2M-1,
 // gemm.hip unchanged); what lives here are the tangent rules of the non-linear steps:
 //   time embedding, SiLU, q/k L2-normalisation, windowed softmax attention, LayerNorm + modulation, SwiGLU,
-// and the loss-side target construction.  All arithmetic is fp32 (bf16 only as storage), the attention products run on
-// the fp32 matrix pipe (v_mfma_f32_16x16x4_f32): this path exists for exactness first, it is not on the forecast path.
+// and the loss-side target construction.  Element-wise arithmetic and statistics are fp32 (bf16 only as storage).  The
+// attention products run on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32) for fp32 operands -- the parity configuration --
+// and on the bf16 pipe (v_mfma_f32_16x16x32_bf16) for bf16 operands, as the reference's autocast does.
 #include "common.h"
 
 namespace {
@@ -369,6 +370,156 @@ __global__ __launch_bounds__(512) void attn_jvp_kernel(AttnJvpArgs a) {
     }
 }
 
+// bf16 operands: the same tangent on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, fp32 accumulation) -- what the
+// reference computes under the trainer's autocast, where q k^T, dq k^T + q dk^T, P v, dP v and P dv are bf16 matmuls.
+// K / dK images (208-B rows) are resident together for the score products, then V / dV images (192-B rows) for the value
+// products; V^T fragments come from the row-major images through ds_read_b64_tr_b16, with the k-slots of a 32-key step
+// ordered to match the S^T accumulator registers of two 16-key blocks: slot (g, j) <-> key 16 (2p + j/4) + 4 g + j%4.
+constexpr int JK = 208, JV = 192;
+
+__global__ __launch_bounds__(512) void attn_jvp_bf16_kernel(AttnJvpArgs a) {
+    __shared__ __attribute__((aligned(16))) char img[2 * 256 * JK];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qh = blockIdx.x & 1;
+    const int item = blockIdx.x >> 1;
+    const int head = item % a.heads;
+    const int w = (item / a.heads) % a.nw;
+    const int b = item / (a.heads * a.nw);
+    const int64_t tok0 = (int64_t)b * a.gh * a.gw;
+    const bf16_t* qkv = static_cast<const bf16_t*>(a.qkv);
+    const bf16_t* dqkv = static_cast<const bf16_t*>(a.dqkv);
+    const int l16 = lane & 15, g = lane >> 4;
+
+    // both images of `part` (1 = k, 2 = v): primal at img, tangent at img + 256 * stride; coalesced 16-B chunks
+    auto fill = [&](int part, int stride) {
+        for (int c = tid; c < 2 * 256 * 12; c += 512) {
+            const int tan = c >= 256 * 12;
+            const int cc0 = c - tan * 256 * 12;
+            const int row = cc0 / 12, cc = cc0 - row * 12;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (cc < 11) {
+                const bf16_t* src = (tan ? dqkv : qkv) + (tok0 + jvp_window_token(a, w, row)) * a.ldq + (head * 3 + part) * 88;
+                v = *reinterpret_cast<const uint4*>(src + 8 * cc);
+            }
+            *reinterpret_cast<uint4*>(img + (tan * 256 + row) * stride + cc * 16) = v;
+        }
+    };
+
+    // q / dq fragments of query row qh*128 + wv*16 + l16: 8 bf16 at d = 32 ks + 8 g (zero beyond d = 88)
+    uint4 qf[3], dqf[3];
+    {
+        const int64_t r = (tok0 + jvp_window_token(a, w, qh * 128 + wv * 16 + l16)) * a.ldq + head * 3 * 88;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int d = 32 * ks + 8 * g;
+            qf[ks] = d < 88 ? *reinterpret_cast<const uint4*>(qkv + r + d) : make_uint4(0, 0, 0, 0);
+            dqf[ks] = d < 88 ? *reinterpret_cast<const uint4*>(dqkv + r + d) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    fill(1, JK);
+    __syncthreads();
+
+    f32x4 s[16], ds[16];
+    const char* sK = img;
+    const char* sdK = img + 256 * JK;
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk) {
+        s[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ds[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int off = (blk * 16 + l16) * JK + (32 * ks + 8 * g) * 2;
+            const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sK + off));
+            const bf16x8 dkf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sdK + off));
+            s[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, __builtin_bit_cast(bf16x8, qf[ks]), s[blk], 0, 0, 0);
+            ds[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, __builtin_bit_cast(bf16x8, dqf[ks]), ds[blk], 0, 0, 0);
+            ds[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dkf, __builtin_bit_cast(bf16x8, qf[ks]), ds[blk], 0, 0, 0);
+        }
+    }
+
+    float mx = -INFINITY;
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[blk][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float l = 0.f, rs = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = __expf(s[blk][r] - mx);
+            const float wgt = e * ds[blk][r];
+            s[blk][r] = e;
+            ds[blk][r] = wgt;
+            l += e;
+            rs += wgt;
+        }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+
+    __syncthreads();
+    fill(2, JV);
+    __syncthreads();
+    f32x4 o[6], u[6], tt[6];
+#pragma unroll
+    for (int db = 0; db < 6; ++db) {
+        o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tt[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const char* sV = img;
+    const char* sdV = img + 256 * JV;
+    // transposed-read address of this lane inside a 4-row x 16-column block: row l16 >> 2, columns 4 (l16 & 3) ..
+    const int troff = (4 * g + (l16 >> 2)) * JV + 4 * (l16 & 3) * 2;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        uint4 pf, wf;
+        pf.x = pack_bf16(s[2 * p][0], s[2 * p][1]);
+        pf.y = pack_bf16(s[2 * p][2], s[2 * p][3]);
+        pf.z = pack_bf16(s[2 * p + 1][0], s[2 * p + 1][1]);
+        pf.w = pack_bf16(s[2 * p + 1][2], s[2 * p + 1][3]);
+        wf.x = pack_bf16(ds[2 * p][0], ds[2 * p][1]);
+        wf.y = pack_bf16(ds[2 * p][2], ds[2 * p][3]);
+        wf.z = pack_bf16(ds[2 * p + 1][0], ds[2 * p + 1][1]);
+        wf.w = pack_bf16(ds[2 * p + 1][2], ds[2 * p + 1][3]);
+        const int rb = 32 * p * JV + troff;
+#pragma unroll
+        for (int db = 0; db < 6; ++db) {
+            typedef __attribute__((address_space(3))) s16x4* lds4;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(sV + rb + db * 32));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(sV + rb + 16 * JV + db * 32));
+            const s16x4 dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(sdV + rb + db * 32));
+            const s16x4 dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(sdV + rb + 16 * JV + db * 32));
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            const bf16x8 dvf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(dlo, dhi, 0, 1, 2, 3, 4, 5, 6, 7));
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pf), o[db], 0, 0, 0);
+            u[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, wf), u[db], 0, 0, 0);
+            tt[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dvf, __builtin_bit_cast(bf16x8, pf), tt[db], 0, 0, 0);
+        }
+    }
+
+    const float rl = 1.0f / l, rr = rs * rl;
+    const int64_t orow = (tok0 + jvp_window_token(a, w, qh * 128 + wv * 16 + l16)) * a.ldo + head * 88;
+    bf16_t* po = static_cast<bf16_t*>(a.out) + orow;
+    bf16_t* pdo = static_cast<bf16_t*>(a.dout) + orow;
+#pragma unroll
+    for (int db = 0; db < 6; ++db) {
+        const int d = 16 * db + 4 * g;
+        if (d < 88) {
+            *reinterpret_cast<uint2*>(po + d) = make_uint2(pack_bf16(o[db][0] * rl, o[db][1] * rl), pack_bf16(o[db][2] * rl, o[db][3] * rl));
+            float dv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dv[r] = (u[db][r] + tt[db][r] - rr * o[db][r]) * rl;
+            *reinterpret_cast<uint2*>(pdo + d) = make_uint2(pack_bf16(dv[0], dv[1]), pack_bf16(dv[2], dv[3]));
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------- sCM target (loss.py:236-247)
 // g = -cos^2 t (sd F - dxt) - r (cos t sin t x_t + sd dF);  g /= (rms_sample(g) + 0.1);  target = F + g
 // (the loss kernel then sees (F - target)^2 = g^2 with gradient -2 w g through F only, as Fx - Fx.detach() - g does)
@@ -483,7 +634,8 @@ extern "C" int swiftk_window_attention_jvp(const void* qkv, const void* dqkv, in
     AttnJvpArgs a{qkv, dqkv, out, dout, ldq, ldo, gh, gw, heads, shift_h, shift_w, gw / 16, (gh / 16) * (gw / 16)};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = B * a.nw * heads * 2;
-    DT_SWITCH(dtype, hipLaunchKernelGGL(attn_jvp_kernel<bf16_t>, dim3(grid), dim3(512), 0, st, a),
+    if (dtype == SWIFTK_BF16 && ((uintptr_t)out & 7 || (uintptr_t)dout & 7 || (ldo & 3))) return SWIFTK_EALIGN;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(attn_jvp_bf16_kernel, dim3(grid), dim3(512), 0, st, a),
               hipLaunchKernelGGL(attn_jvp_kernel<float>, dim3(grid), dim3(512), 0, st, a));
     SWIFTK_CHECK_LAUNCH();
     return 0;
