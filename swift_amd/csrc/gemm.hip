@@ -469,6 +469,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 constexpr int COLS = (EPI == SWIFTK_EPI_SWIGLU) ? 88 : 176;  // output columns of the wave tile
                 constexpr int CPR = COLS / 8;                                  // 16-B chunks per row
                 constexpr int RSTR = COLS * 2 + 16;                            // padded slab row stride (bytes)
+                // the slabs overlay operand bytes of the stage just consumed: every wave must be done READING that stage
+                // (its last fragments were consumed by MFMAs it has already issued) before any wave writes a slab
+                __builtin_amdgcn_s_barrier();
                 char* slab = const_cast<char*>(s) + wv * (16 * RSTR);
                 const int g4 = lane >> 4;
                 const int elane = lane;
