@@ -162,7 +162,8 @@ int swiftk_axpby(float* out, float a, const float* x, float b, const float* y, i
 int swiftk_profile_gemm(int epilogue, int64_t N);
 /* Tuning knobs (A/B measurements only): key 0 = GEMM variant (0 one tile per workgroup, 1 persistent pipeline),
  * key 1 = tile rows per group of the persistent tile order, key 2 = persistent grid size, keys 3 / 4 = ablation
- * bits of the GEMM / attention kernels (timing experiments; results are wrong while set). */
+ * bits of the GEMM / attention kernels (timing experiments; results are wrong while set), key 5 = window-tiled q/k/v in
+ * swiftk_swinv2_forward (1), key 6 = non-temporal residual-stream accesses in swiftk_modnorm_residual (1). */
 int swiftk_set_tuning(int key, int value);
 int swiftk_profile_collect(double* total_ms_host, int64_t* launches_host);
 

@@ -3,6 +3,8 @@
 // time-embedding MLP, the rollout state update and operand casts.
 #include "common.h"
 
+int g_modnorm_nt = 1;  // tuning key 6: stream the fp32 residual with non-temporal loads / stores
+
 namespace {
 
 // --------------------------------------------------------------------------------- modnorm + residual
@@ -40,11 +42,26 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
         make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
 }
 
+// streaming (non-temporal) forms for the fp32 residual stream: read once, written once, not needed again for a whole
+// GEMM + attention -- keeping it out of the way leaves L2 / Infinity Cache to the operand copy the next GEMM reads
+__device__ __forceinline__ void load8_nt(const float* p, float (&v)[8]) {
+    typedef __attribute__((ext_vector_type(4))) float v4;
+    const v4 a = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+    const v4 b = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p + 4));
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+__device__ __forceinline__ void store8_nt(float* p, const float (&v)[8]) {
+    typedef __attribute__((ext_vector_type(4))) float v4;
+    __builtin_nontemporal_store(v4{v[0], v[1], v[2], v[3]}, reinterpret_cast<v4*>(p));
+    __builtin_nontemporal_store(v4{v[4], v[5], v[6], v[7]}, reinterpret_cast<v4*>(p + 4));
+}
+
 template <typename T, int SLOTS>
 __global__ __launch_bounds__(256) void modnorm_kernel(const T* __restrict__ y, int64_t ldy, float* __restrict__ x,
                                                       T* __restrict__ xc, int64_t ldc, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ mod,
-                                                      int64_t ldmod, int64_t M, int d, int64_t rps, float eps) {
+                                                      int64_t ldmod, int64_t M, int d, int64_t rps, float eps, int nt_x) {
+    const bool NT_X = nt_x != 0;
     const int lane = threadIdx.x & 63;
     const int nc = d >> 3;  // 8-channel slots per row
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -56,7 +73,7 @@ __global__ __launch_bounds__(256) void modnorm_kernel(const T* __restrict__ y, i
             const int c = lane + 64 * i;
             if (c < nc) {
                 load8<T>(y + row * ldy + 8 * c, v[i]);
-                load8<float>(x + row * d + 8 * c, xr[i]);
+                if (NT_X) load8_nt(x + row * d + 8 * c, xr[i]); else load8<float>(x + row * d + 8 * c, xr[i]);
             }
         }
         float sum = 0.f;
@@ -88,7 +105,7 @@ __global__ __launch_bounds__(256) void modnorm_kernel(const T* __restrict__ y, i
                 load8<float>(mrow + d + 8 * c, sh);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) xr[i][e] += (v[i][e] * rstd * g[e] + bt[e]) * (1.0f + sc[e]) + sh[e];
-                store8<float>(x + row * d + 8 * c, xr[i]);
+                if (NT_X) store8_nt(x + row * d + 8 * c, xr[i]); else store8<float>(x + row * d + 8 * c, xr[i]);
                 if (xc) store8<T>(xc + row * ldc + 8 * c, xr[i]);
             }
         }
@@ -278,7 +295,7 @@ extern "C" int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, voi
     const bool small = d <= 3 * 512;  // three 8-channel slots per lane cover d <= 1536 with fewer registers
 #define SWIFTK_MODNORM(TT, SL)                                                                                             \
     hipLaunchKernelGGL((modnorm_kernel<TT, SL>), dim3(grid), dim3(256), 0, st, static_cast<const TT*>(y), ldy, x,            \
-                       static_cast<TT*>(xcopy), ldc, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps)
+                       static_cast<TT*>(xcopy), ldc, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps, g_modnorm_nt)
     if (dtype == SWIFTK_BF16) {
         if (small) SWIFTK_MODNORM(bf16_t, 3); else SWIFTK_MODNORM(bf16_t, 4);
     } else if (dtype == SWIFTK_F32) {

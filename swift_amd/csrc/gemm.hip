@@ -644,6 +644,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 3: g_dbg = value; return 0;
         case 4: g_attn_dbg = value; return 0;
         case 5: g_fwd_tiled = value; return 0;
+        case 6: g_modnorm_nt = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
