@@ -147,6 +147,51 @@ __global__ __launch_bounds__(256) void patchify_kernel(PatchArgs a, T* __restric
     }
 }
 
+// Tiled form: one block per (sample, grid row, 16 consecutive tokens).  The C x p1 x (16 p2) source pixels of those tokens
+// are read as whole 128-B row segments (float4 per thread, channel scale applied) into an LDS tile, then every thread
+// assembles 16-B chunks of the output rows ((p1 p2 c) order, c fastest) from it: coalesced on both sides, where the
+// element-per-thread form above gathers one cache line per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_tiled_kernel(PatchArgs a, T* __restrict__ A, int rs) {
+    extern __shared__ __attribute__((aligned(16))) float ptile[];
+    const int tid = threadIdx.x;
+    const int gxb = blockIdx.x, gy = blockIdx.y, b = blockIdx.z;
+    const int q4 = (16 * a.p2) >> 2;  // float4 per tile row
+    const int nload = a.C * a.p1 * q4;
+    for (int i = tid; i < nload; i += 256) {
+        const int q = i % q4, r = i / q4;
+        const int i1 = r % a.p1, c = r / a.p1;
+        const int s = c >= a.c0[2] ? 2 : (c >= a.c0[1] ? 1 : 0);
+        const float* src = a.src[s] + (((int64_t)b * a.cn[s] + (c - a.c0[s])) * a.H + (gy * a.p1 + i1)) * a.W + gxb * 16 * a.p2 + 4 * q;
+        float4 v = *reinterpret_cast<const float4*>(src);
+        const float sc = a.sc[s];
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        *reinterpret_cast<float4*>(ptile + r * rs + 4 * q) = v;
+    }
+    __syncthreads();
+    const int F = a.p1 * a.p2 * a.C;
+    const int cpr = (int)(a.lda >> 3);  // 8-element chunks per output row
+    const int64_t tok0 = ((int64_t)b * a.gh + gy) * a.gw + gxb * 16;
+    for (int i = tid; i < 16 * cpr; i += 256) {
+        const int tk = i / cpr, fc = i - tk * cpr;
+        float v[8];
+        int f = 8 * fc;
+        int pp = f / a.C, c = f - pp * a.C;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float val = 0.f;
+            if (f < F) {
+                const int i1 = pp / a.p2, i2 = pp - i1 * a.p2;
+                val = ptile[(c * a.p1 + i1) * rs + tk * a.p2 + i2];
+            }
+            v[e] = val;
+            ++f;
+            if (++c == a.C) { c = 0; ++pp; }
+        }
+        store8<T>(A + (tok0 + tk) * a.lda + 8 * fc, v);
+    }
+}
+
 // --------------------------------------------------------------------------------- un-patchify (+ sampler affine)
 __global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ tok, int64_t ldt,
                                                          const float* __restrict__ xt, const float* __restrict__ alpha,
@@ -325,6 +370,20 @@ extern "C" int swiftk_patchify(const float* src0, int c0, float s0, const float*
     a.lda = lda;
     if (lda < (int64_t)p1 * p2 * a.C) return SWIFTK_ESHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // tiled form where its alignment assumptions hold (16-token runs, float4 source segments, 16-B output chunks)
+    const int rs = 16 * p2 + 4;
+    const size_t tile_bytes = (size_t)a.C * p1 * rs * sizeof(float);
+    bool aligned = !(a.gw & 15) && !((16 * p2) & 3) && !(W & 3) && !(lda & 7) && !((uintptr_t)A & 15) && tile_bytes <= 64 * 1024;
+    for (int k = 0; k < 3; ++k) aligned = aligned && !((uintptr_t)a.src[k] & 15);
+    if (aligned && (dtype == SWIFTK_BF16 || dtype == SWIFTK_F32)) {
+        const dim3 grid(a.gw / 16, a.gh, B);
+        if (dtype == SWIFTK_BF16)
+            hipLaunchKernelGGL(patchify_tiled_kernel<bf16_t>, grid, dim3(256), tile_bytes, st, a, static_cast<bf16_t*>(A), rs);
+        else
+            hipLaunchKernelGGL(patchify_tiled_kernel<float>, grid, dim3(256), tile_bytes, st, a, static_cast<float*>(A), rs);
+        SWIFTK_CHECK_LAUNCH();
+        return 0;
+    }
     const int grid = grid_for((int64_t)B * a.gh * a.gw * lda);
     if (dtype == SWIFTK_BF16)
         hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a, static_cast<bf16_t*>(A));
