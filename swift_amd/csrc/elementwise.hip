@@ -236,6 +236,64 @@ __global__ void temb_kernel(const float* __restrict__ t, const float* __restrict
     emb[i] = v;
 }
 
+// --------------------------------------------------------------------------------- small-batch linear, x in LDS
+// The 24 modulation Linears as one [50688, 1056] matrix dominate this op: every weight row is read once from HBM, but
+// with one wave per output feature the 8 x-rows were re-read from L1/L2 by each of the 50k waves (8x the weight bytes).
+// Here a block stages its x rows in LDS once and its four waves walk output features against that copy.
+template <int BB>
+__global__ __launch_bounds__(256) void linear_small_lds_kernel(const float* __restrict__ x, int64_t ldx,
+                                                               const float* __restrict__ W, int64_t ldw,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               int64_t ldo, int B, int N, int K, int act) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [BB][K]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int k4 = K >> 2;
+    for (int b0 = 0; b0 < B; b0 += BB) {
+        const int nb = min(BB, B - b0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb * k4; i += 256) {
+            const int j = i / k4, c = i - j * k4;
+            *reinterpret_cast<float4*>(xs + j * K + 4 * c) = *reinterpret_cast<const float4*>(x + (int64_t)(b0 + j) * ldx + 4 * c);
+        }
+        __syncthreads();
+        for (int n = blockIdx.x * 4 + wv; n < N; n += gridDim.x * 4) {
+            float acc[BB];
+#pragma unroll
+            for (int j = 0; j < BB; ++j) acc[j] = 0.f;
+            for (int c0 = 0; c0 < k4; c0 += 5 * 64) {  // five 16-B loads of the weight row in flight per lane
+                float4 w[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int c = c0 + lane + 64 * u;
+                    w[u] = c < k4 ? *reinterpret_cast<const float4*>(W + (int64_t)n * ldw + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int c = c0 + lane + 64 * u;
+                    if (c < k4) {
+#pragma unroll
+                        for (int j = 0; j < BB; ++j) {
+                            if (j < nb) {
+                                const float4 xv = *reinterpret_cast<const float4*>(xs + j * K + 4 * c);
+                                acc[j] += (w[u].x * xv.x + w[u].y * xv.y) + (w[u].z * xv.z + w[u].w * xv.w);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < BB; ++j) {
+                const float s = wave_sum(acc[j]);
+                if (lane == 0 && j < nb) {
+                    float v = s + (bias ? bias[n] : 0.f);
+                    if (act == 1) v = v / (1.0f + expf(-v));
+                    out[(int64_t)(b0 + j) * ldo + n] = v;
+                }
+            }
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------- small-batch linear
 // One wave per output feature n, lanes stride over K in float4; x rows are tiny and stay in L1/L2.
 template <int BB>
@@ -422,6 +480,13 @@ extern "C" int swiftk_linear_small(const float* x, int64_t ldx, const float* W, 
     if (!x || !W || !out || B <= 0 || N <= 0 || K <= 0) return SWIFTK_EINVAL;
     if (B > 64) return SWIFTK_ESHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)W & 15) || (ldx % 4) || (ldw % 4)) return SWIFTK_EALIGN;
+    if (K % 4 == 0 && (size_t)8 * K * sizeof(float) <= 60 * 1024 && N >= 4096) {  // wide outputs: x staged in LDS
+        const int grid = (N + 3) / 4 < 2048 ? (N + 3) / 4 : 2048;
+        hipLaunchKernelGGL(linear_small_lds_kernel<8>, dim3(grid), dim3(256), (size_t)8 * K * sizeof(float),
+                           static_cast<hipStream_t>(stream), x, ldx, W, ldw, bias, out, ldo, B, N, K, act);
+        SWIFTK_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(linear_small_kernel<8>, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, W,
                        ldw, bias, out, ldo, B, N, K, act);
     SWIFTK_CHECK_LAUNCH();
