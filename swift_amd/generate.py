@@ -85,7 +85,8 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
     # pinned buffers while the NEXT batch computes, and the memmap write of batch k-1 happens on the host meanwhile.
     from concurrent.futures import ThreadPoolExecutor
     writer = ThreadPoolExecutor(max_workers=1)
-    copy_stream = torch.cuda.Stream(device=device)
+    on_gpu = torch.device(device).type == "cuda"   # (the host-logic tests drive this loop with a CPU stand-in engine)
+    copy_stream = torch.cuda.Stream(device=device) if on_gpu else None
     pinned = [None, None]
     pending = None  # (copy-done event, pinned buffer view, units)
 
@@ -93,7 +94,8 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
 
     def flush(p):
         ev, host, us = p
-        ev.synchronize()
+        if ev is not None:
+            ev.synchronize()
         t1 = time.time()
         h = host.numpy()
         for k, (m, ic) in enumerate(us):
@@ -107,8 +109,10 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
         units = [(u // n_ic, u % n_ic) for u in range(s, min(s + args.batch, mine.stop))]
         ics = [indices[ic] for _, ic in units]
         x0 = {int(j): dataset[int(j)][0][0][:nv] for j in set(ics)}
-        X0 = torch.stack([x0[int(j)] for j in ics], 0).pin_memory()
-        forc = engine.stage_forcings(ics, steps, "cpu").pin_memory()
+        X0 = torch.stack([x0[int(j)] for j in ics], 0)
+        forc = engine.stage_forcings(ics, steps, "cpu")
+        if on_gpu:
+            X0, forc = X0.pin_memory(), forc.pin_memory()
         t_host[0] += time.time() - t1
         return units, X0, forc
 
@@ -121,18 +125,21 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
         X0, forc = X0.to(device, non_blocking=True), forc.to(device, non_blocking=True)
         traj = engine.run(X0, forc, steps, seeds=[unit_seed(m, indices[ic]) for m, ic in units])  # [B, steps+1, ...] view
         dev_buf = traj.transpose(0, 1)      # the contiguous step-major buffer behind it
-        ready = torch.cuda.Event()
-        ready.record()
-        slot = bi & 1
-        if pinned[slot] is None or pinned[slot].shape[1] < dev_buf.shape[1]:
-            pinned[slot] = torch.empty(dev_buf.shape, dtype=torch.float32, pin_memory=True)
-        host = pinned[slot][:, :dev_buf.shape[1]]
-        ev = torch.cuda.Event()
-        with torch.cuda.stream(copy_stream):
-            copy_stream.wait_event(ready)
-            host.copy_(dev_buf, non_blocking=True)
-            dev_buf.record_stream(copy_stream)
-            ev.record(copy_stream)
+        if on_gpu:
+            ready = torch.cuda.Event()
+            ready.record()
+            slot = bi & 1
+            if pinned[slot] is None or pinned[slot].shape[1] < dev_buf.shape[1]:
+                pinned[slot] = torch.empty(dev_buf.shape, dtype=torch.float32, pin_memory=True)
+            host = pinned[slot][:, :dev_buf.shape[1]]
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                host.copy_(dev_buf, non_blocking=True)
+                dev_buf.record_stream(copy_stream)
+                ev.record(copy_stream)
+        else:
+            host, ev = dev_buf.contiguous(), None
         if pending is not None:
             pending.result()                # the writer thread is done with the other pinned buffer
         pending = writer.submit(flush, (ev, host, units))  # host-side write under the next batch's staging + kernels
