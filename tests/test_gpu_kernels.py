@@ -5,6 +5,7 @@ Tolerances (relative L2 unless noted):
   bf16 kernels   operands rounded to bf16 (2^-9 relative), fp32 accumulation: 6e-3 per GEMM-like op
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -323,3 +324,13 @@ def test_ensemble_metrics_vs_reference_golden(dev):
         r = fn(p12.cpu().double(), y12.cpu().double(), lat)
         for i, v in enumerate("abc"):
             assert float(got[f"{name}_{v}_x"]) == pytest.approx(float(r[i]), rel=5e-5)
+
+
+def test_race_screen_pipelined_kernels(dev):
+    """tools/stress.py in short form: the LDS-DMA pipelined kernels (counted-vmcnt hand-overs, LDS overlays) must give
+    bit-identical results run after run, also with competing HBM traffic on a second stream."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "stress.py"), "12"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RACE SCREEN: CLEAN" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

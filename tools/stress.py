@@ -1,0 +1,63 @@
+"""Race screen: repeat the pipelined kernels on fixed inputs and require bit-identical outputs every time (a missed
+hand-over -- counted vmcnt, barrier placement, LDS overlays -- shows up as run-to-run differences long before it shows up
+as a parity failure).  python tools/stress.py [rounds]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import math
+
+import torch
+
+from swift_amd import _lib, ops
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    heads, gh, gw = 12, 64, 128
+    bad = 0
+    for B in (1, 3, 8):
+        M = B * gh * gw
+        a = torch.randn(M, 1088, device=dev).to(torch.bfloat16)
+        a[:, 1056:] = 0
+        wq = (torch.randn(3168, 1088, device=dev) * 0.03).to(torch.bfloat16)
+        w1 = (torch.randn(5632, 1088, device=dev) * 0.03).to(torch.bfloat16)
+        scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 48.0])).to(dev)
+        ref = {}
+        side = torch.cuda.Stream()
+        src = torch.empty(256 * 1024 * 1024, device=dev, dtype=torch.uint8)
+        dst = torch.empty_like(src)
+        for it in range(rounds):
+            # competing HBM traffic on a second stream (two rounds in three) changes DMA latencies under the kernels
+            junk = None
+            if it % 3:
+                with torch.cuda.stream(side):
+                    for _ in range(1 + it % 4):
+                        dst.copy_(src, non_blocking=True)
+            sh = (8, 8) if it & 1 else (0, 0)
+            ct = ops.gemm_qkv_tiled(a, wq, scale, B, (gh, gw), heads, sh, k=1056)
+            ot = ops.window_attention_tiled(ct, scale, (gh, gw), heads, sh)
+            c = ops.gemm(a, wq, epilogue=ops.EPI_QKNORM, bias=scale)
+            orm = ops.window_attention(c.view(B, gh * gw, -1), scale, (gh, gw), heads, sh, flags=ops.ATTN_PRENORM)
+            h = ops.gemm(a, w1, epilogue=ops.EPI_SWIGLU)
+            outs = dict(ct=ct, ot=ot, c=c, orm=orm, h=h)
+            for k, v in outs.items():
+                key = (k, sh)
+                if key not in ref:
+                    ref[key] = v.clone()
+                elif not torch.equal(ref[key], v):
+                    bad += 1
+                    d = (ref[key].float() - v.float()).abs()
+                    print(f"B={B} round {it} {k} shift {sh}: {int((d > 0).sum())} elements differ, max {float(d.max()):.3e}", flush=True)
+            if not torch.equal(ot, orm):
+                bad += 1
+                print(f"B={B} round {it}: tiled and row-major attention differ", flush=True)
+            del junk
+        print(f"B={B}: {rounds} rounds done", flush=True)
+    print("RACE SCREEN:", "CLEAN" if bad == 0 else f"{bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+main()
