@@ -374,23 +374,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 #pragma unroll
     for (int p = 0; p < 10; ++p) issue_piece(lds0, (uint32_t)kt * ROWB, p);
     int par = 0;
-    // vector stores one wave issues per fully-interior tile epilogue (edge tiles may skip some: they wait for all)
-    constexpr int EPI_STORES = (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS)
-                                   ? MI * ((16 * ((EPI == SWIFTK_EPI_SWIGLU ? 88 : 176) / 8) + 63) / 64)
-                                   : MI * NI;
-    bool stores_pending = false;
     for (;;) {
         // own DMA of the stage about to be read has landed; after the barrier every wave's has, and every wave is
         // done reading the other stage (its fragment reads were consumed by MFMAs before it got here)
-        // Right after an epilogue the wave's youngest VMEM operations are that tile's output stores; the DMA of this
-        // stage is older (VMEM retires in issue order), so a counted wait lets the stores drain behind the first
-        // k-tile's MFMAs instead of stalling every CU on the chip-wide write burst.
-        if (stores_pending) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EPI_STORES) : "memory");
-            stores_pending = false;
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(g.dbg & 2)) __builtin_amdgcn_s_barrier();
         const char* s = smem + par * STAGE;
         const uint32_t fill = lds0 + (par ^ 1) * STAGE;
@@ -456,7 +443,6 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             int tm, tn;
             it.coords(tile / ksplit, tm, tn);
             const int m0 = tm * BM, n0 = tn * BN;
-            stores_pending = !(g.dbg & 8) && m0 + BM <= g.M && n0 + BN <= g.N;
             if constexpr (EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED)
                 qknorm_tile(acc, lane, n0 + wn * 176, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / 88);
             OutT* C = reinterpret_cast<OutT*>(g.C) + (int64_t)(tile % ksplit) * g.c_split;
