@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="(member, IC) units per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-steps", type=int, default=2, help="sample-steps of the CPU baseline (0 = skip)")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one HIP graph (pays off below ~8 units per step)")
     ap.add_argument("--solver", default="scm", choices=["scm", "2s", "dpm"],
                     help="scm = BASELINE configs[1] (default, the metric's workload); 2s / dpm = configs[2], multi-step ODE sampler")
     ap.add_argument("--num-steps", type=int, default=None, help="solver steps (default: 1 for scm, 20 for 2s, 8 for dpm)")
@@ -131,6 +132,14 @@ def main():
         Y = eng.sampler((X, forc[0]), latents=z)
         ops.rollout_update(X, Y, mx, sx, st, phys=phys)
 
+    if a.graph:  # noise stays outside the graph (per-unit generators); everything else of the step is one replay
+        graph = eng.capture_step(X, forc[0], z, phys)
+
+        def step():  # noqa: F811
+            for b, gg in enumerate(gens):
+                z[b].normal_(generator=gg)
+            graph.replay()
+
     def sync():
         torch.cuda.synchronize()
         if world > 1:
@@ -140,7 +149,8 @@ def main():
     for _ in range(W):
         step()
     mlp2 = 2 * int(8 / 3.0 * 1056)
-    lib.swiftk_profile_gemm(_lib.EPI_SWIGLU, mlp2)
+    if not a.graph:  # the per-launch event pairs of the roofline leg cannot be recorded inside a replayed graph
+        lib.swiftk_profile_gemm(_lib.EPI_SWIGLU, mlp2)
     sync()
     t0 = time.perf_counter()
     for _ in range(K):
@@ -155,7 +165,7 @@ def main():
     # second roofline leg, outside the timed region: the window-attention kernel (north_star's named kernel) over two
     # more steps, HIP events on its launch stream
     att_ms, att_n = ctypes.c_double(0), ctypes.c_int64(0)
-    if a.dtype == "bf16":
+    if a.dtype == "bf16" and not a.graph:
         lib.swiftk_profile_gemm(_lib.PROF_ATTENTION, 0)
         for _ in range(2):
             step()
@@ -200,7 +210,7 @@ def main():
             "config": {"workload": ("Swift-B sCM 1-step sampler, 128x256x69 (BASELINE configs[1]): noise + fused network "
                                     "eval + residual state update per step") if a.solver == "scm" and nsteps == 1 else
                        f"Swift-B {a.solver} sampler, num_steps {nsteps} = {evals} network evaluations per sample-step, 128x256x69 "
-                       "(BASELINE configs[2])", "units_per_gpu_per_step": B,
+                       "(BASELINE configs[2])", "units_per_gpu_per_step": B, "hip_graph": bool(a.graph),
                        "params": 225980976, "parallelism": f"units sharded over {world} GPU(s), no data-path collective"},
             "e2e": {"tflops": FLOP_PER_EVAL * evals * value / 1e12,
                     "frac_of_dense_mfma_peak": FLOP_PER_EVAL * evals * value / (peak * world)},

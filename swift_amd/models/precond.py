@@ -30,7 +30,10 @@ def _process_auxiliary(auxiliary, auxiliary_dim, batch_size, device):
     if auxiliary is None:
         return torch.zeros([1, auxiliary_dim], device=device)
     if not isinstance(auxiliary, torch.Tensor):
-        auxiliary = torch.tensor(auxiliary, device=device)
+        if isinstance(auxiliary, (int, float)):  # a fill kernel instead of a pageable host->device copy: graph-capturable
+            auxiliary = torch.full((), float(auxiliary), dtype=torch.float32, device=device)
+        else:
+            auxiliary = torch.tensor(auxiliary, device=device)
     if auxiliary.dim() == 0 or (auxiliary.dim() == 1 and auxiliary.size(0) == 1):
         auxiliary = auxiliary.repeat(batch_size)
     return auxiliary.reshape(-1, auxiliary_dim)

@@ -58,6 +58,29 @@ class RolloutEngine:
         return torch.stack(rows, 0)[:, pos].contiguous().to(device, non_blocking=True)
 
     @torch.no_grad()
+    def capture_step(self, X: torch.Tensor, forc: torch.Tensor, z: torch.Tensor, phys: torch.Tensor) -> "torch.cuda.CUDAGraph":
+        """One forecast step (sampler + residual state update) recorded as a HIP graph over the caller's static tensors:
+        replaying it advances ``X`` in place from the noise currently in ``z`` and the forcings in ``forc``.  For the
+        launch-bound regime (a few units per step: ~100 launches per network evaluation against ~5 ms of kernels);
+        at 8+ units per step the launch queue already runs ahead of the kernels."""
+        mx, sx, st = self.stats(X.device)
+        side = torch.cuda.Stream(device=X.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up outside the capture: operand preparation, workspace allocation
+            keep = X.clone()
+            for _ in range(2):
+                Y = self.sampler((X, forc), latents=z)
+                ops.rollout_update(X, Y, mx, sx, st, phys=phys)
+            X.copy_(keep)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            Y = self.sampler((X, forc), latents=z)
+            ops.rollout_update(X, Y, mx, sx, st, phys=phys)
+        X.copy_(keep)
+        return graph
+
+    @torch.no_grad()
     def run(self, X0: torch.Tensor, forcings: torch.Tensor, steps: int, *, seeds: Optional[Sequence[int]] = None,
             latents: Optional[Callable[[int], torch.Tensor]] = None, out: Optional[torch.Tensor] = None,
             keep_trajectory: bool = True) -> torch.Tensor:
