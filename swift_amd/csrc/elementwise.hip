@@ -394,7 +394,7 @@ extern "C" int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, voi
         ((uintptr_t)mod & 15) || (ldmod % 4) || (xcopy && (((uintptr_t)xcopy & 15) || (ldc * es) % 16)))
         return SWIFTK_EALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int grid = grid_for(M, 4, 256 * 32);
+    const int grid = grid_for(M, 4, 1 << 20);  // one row per wave (a capped, looping grid measured 6 % slower)
     const bool small = d <= 3 * 512;  // three 8-channel slots per lane cover d <= 1536 with fewer registers
 #define SWIFTK_MODNORM(TT, SL)                                                                                             \
     hipLaunchKernelGGL((modnorm_kernel<TT, SL>), dim3(grid), dim3(256), 0, st, static_cast<const TT*>(y), ldy, x,            \
