@@ -374,11 +374,24 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 #pragma unroll
     for (int p = 0; p < 10; ++p) issue_piece(lds0, (uint32_t)kt * ROWB, p);
     int par = 0;
+    // dbg bit 32 (timing experiment, EPI_NONE only): wave 0 of every 32nd workgroup logs s_memtime at five points of each tile
+    // into the buffer passed as ep1 -- [wg/32][tile][5] uint64: loop top of the first k-step, last MFMA issued, epilogue
+    // barrier passed, stores issued, next loop top passed
+    unsigned long long* tlog = nullptr;
+    int tl_i = 0;
+    if ((g.dbg & 32) && wv == 0 && lane == 0 && (blockIdx.x & 31) == 0)
+        tlog = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.ep1)) + (blockIdx.x >> 5) * 5 * 64;
+    bool first_k = true;
     for (;;) {
         // own DMA of the stage about to be read has landed; after the barrier every wave's has, and every wave is
         // done reading the other stage (its fragment reads were consumed by MFMAs before it got here)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(g.dbg & 2)) __builtin_amdgcn_s_barrier();
+        if (tlog && first_k) {
+            if (tl_i > 0) tlog[(tl_i - 1) * 5 + 4] = __builtin_amdgcn_s_memtime();
+            tlog[tl_i * 5 + 0] = __builtin_amdgcn_s_memtime();
+        }
+        first_k = false;
         const char* s = smem + par * STAGE;
         const uint32_t fill = lds0 + (par ^ 1) * STAGE;
         const bool last_k = (kt + 1 == nk);
@@ -431,6 +444,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             continue;
         }
         // ---- epilogue of `tile`: lane holds C[m][nb .. nb+3] for m = ..+r16, nb = ..+4*(lane>>4) ----
+        if (tlog) tlog[tl_i * 5 + 1] = __builtin_amdgcn_s_memtime();
+        first_k = true;
         if (g.dbg & 4) {  // tuning experiment: drop the epilogue (keeps the accumulators live through a fake use)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -458,6 +473,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 // the slabs overlay operand bytes of the stage just consumed: every wave must be done READING that stage
                 // (its last fragments were consumed by MFMAs it has already issued) before any wave writes a slab
                 __builtin_amdgcn_s_barrier();
+                if (tlog) tlog[tl_i * 5 + 2] = __builtin_amdgcn_s_memtime();
                 char* slab = const_cast<char*>(s) + wv * (16 * RSTR);
                 const int g4 = lane >> 4;
                 const int elane = lane;
@@ -549,6 +565,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                     }
                 }
             }
+        }
+        if (tlog) {
+            tlog[tl_i * 5 + 3] = __builtin_amdgcn_s_memtime();
+            ++tl_i;
         }
         tile += stride;
         if (tile >= ntiles) break;
