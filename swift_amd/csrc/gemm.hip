@@ -375,21 +375,32 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     for (int p = 0; p < 10; ++p) issue_piece(lds0, (uint32_t)kt * ROWB, p);
     int par = 0;
     // dbg bit 32 (timing experiment, EPI_NONE only): wave 0 of every 32nd workgroup logs s_memtime at five points of each tile
-    // into the buffer passed as ep1 -- [wg/32][tile][5] uint64: loop top of the first k-step, last MFMA issued, epilogue
-    // barrier passed, stores issued, next loop top passed
+    // into the buffer passed as ep1 -- [wg/32][tile][8] uint64: loop top of the first k-step, last MFMA issued, epilogue
+    // barrier passed, stores issued, next loop top passed, sum of the k-steps' vmcnt(0) waits, sum of their barrier waits
     unsigned long long* tlog = nullptr;
     int tl_i = 0;
     if ((g.dbg & 32) && wv == 0 && lane == 0 && (blockIdx.x & 31) == 0)
-        tlog = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.ep1)) + (blockIdx.x >> 5) * 5 * 64;
+        tlog = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.ep1)) + (blockIdx.x >> 5) * 8 * 64;
     bool first_k = true;
     for (;;) {
         // own DMA of the stage about to be read has landed; after the barrier every wave's has, and every wave is
         // done reading the other stage (its fragment reads were consumed by MFMAs before it got here)
+        unsigned long long ts0 = 0, ts1 = 0;
+        if (tlog) ts0 = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tlog) ts1 = __builtin_amdgcn_s_memtime();
         if (!(g.dbg & 2)) __builtin_amdgcn_s_barrier();
-        if (tlog && first_k) {
-            if (tl_i > 0) tlog[(tl_i - 1) * 5 + 4] = __builtin_amdgcn_s_memtime();
-            tlog[tl_i * 5 + 0] = __builtin_amdgcn_s_memtime();
+        if (tlog) {
+            const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+            if (first_k) {
+                if (tl_i > 0) tlog[(tl_i - 1) * 8 + 4] = ts2;
+                tlog[tl_i * 8 + 0] = ts2;
+                tlog[tl_i * 8 + 5] = 0;
+                tlog[tl_i * 8 + 6] = 0;
+            } else {  // waits of the k-steps inside the tile: own DMA, then the other waves
+                tlog[tl_i * 8 + 5] += ts1 - ts0;
+                tlog[tl_i * 8 + 6] += ts2 - ts1;
+            }
         }
         first_k = false;
         const char* s = smem + par * STAGE;
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             continue;
         }
         // ---- epilogue of `tile`: lane holds C[m][nb .. nb+3] for m = ..+r16, nb = ..+4*(lane>>4) ----
-        if (tlog) tlog[tl_i * 5 + 1] = __builtin_amdgcn_s_memtime();
+        if (tlog) tlog[tl_i * 8 + 1] = __builtin_amdgcn_s_memtime();
         first_k = true;
         if (g.dbg & 4) {  // tuning experiment: drop the epilogue (keeps the accumulators live through a fake use)
 #pragma unroll
@@ -473,7 +484,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 // the slabs overlay operand bytes of the stage just consumed: every wave must be done READING that stage
                 // (its last fragments were consumed by MFMAs it has already issued) before any wave writes a slab
                 __builtin_amdgcn_s_barrier();
-                if (tlog) tlog[tl_i * 5 + 2] = __builtin_amdgcn_s_memtime();
+                if (tlog) tlog[tl_i * 8 + 2] = __builtin_amdgcn_s_memtime();
                 char* slab = const_cast<char*>(s) + wv * (16 * RSTR);
                 const int g4 = lane >> 4;
                 const int elane = lane;
@@ -567,7 +578,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             }
         }
         if (tlog) {
-            tlog[tl_i * 5 + 3] = __builtin_amdgcn_s_memtime();
+            tlog[tl_i * 8 + 3] = __builtin_amdgcn_s_memtime();
             ++tl_i;
         }
         tile += stride;
