@@ -86,3 +86,27 @@ def test_train_cli_5p6deg_one_by_one_patches(tmp_path):
          "--dump", "numpy"], cwd=str(tmp_path))
     a = np.load(rdir / "output" / "latest" / "output-2i-2s-2m-6h.npy")
     assert a.shape == (2, 2, 3, 69, 32, 64) and np.isfinite(a).all()
+
+
+def test_bench_contract_line(tmp_path):
+    """bench.py prints ONE JSON line with the driver's keys, the two roofline objects and (when asked) the CPU baseline."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    e = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-steps", "0"],
+                       cwd=str(tmp_path), env=e, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"]
+    for r in (d["roofline"], d["attention_roofline"]):
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r)
+        assert 0.05 < r["frac"] < 1.0 and r["achieved"] == pytest.approx(r["frac"] * r["peak"], rel=1e-6)
+    assert d["value"] == pytest.approx(8 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-3)
