@@ -121,22 +121,25 @@ WORKER = textwrap.dedent("""
 """)
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(400)
 def test_generate_sharding_world2_gloo_equals_world1(tmp_path):
-    """(member, IC) units sharded over 2 gloo ranks write the same npy as one rank (SURVEY.md section 4 item v)."""
+    """(member, IC) units sharded over 2 and over 4 gloo ranks write the same npy as one rank (SURVEY.md section 4 item v:
+    15 units over 4 ranks = blocks of 4, 4, 4, 3 -- uneven shards, partial batches)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    one = str(tmp_path / "one.npy")
     subprocess.run([sys.executable, str(script), one], check=True, env={**env, "WORLD_SIZE": "1", "RANK": "0"}, timeout=200)
-    port = str(29600 + os.getpid() % 300)
-    procs = [subprocess.Popen([sys.executable, str(script), two],
-                              env={**env, "WORLD_SIZE": "2", "RANK": str(r), "LOCAL_RANK": str(r), "MASTER_PORT": port})
-             for r in range(2)]
-    assert [p.wait(timeout=200) for p in procs] == [0, 0]
-    a, b = np.load(one), np.load(two)
+    a = np.load(one)
     assert a.shape == (5, 3, 3, 3, 4, 8) and np.isfinite(a).all() and np.abs(a).sum() > 0
-    np.testing.assert_array_equal(a, b)
+    for world in (2, 4):
+        out = str(tmp_path / f"w{world}.npy")
+        port = str(29600 + (os.getpid() + world) % 300)
+        procs = [subprocess.Popen([sys.executable, str(script), out],
+                                  env={**env, "WORLD_SIZE": str(world), "RANK": str(r), "LOCAL_RANK": str(r), "MASTER_PORT": port})
+                 for r in range(world)]
+        assert [p.wait(timeout=200) for p in procs] == [0] * world
+        np.testing.assert_array_equal(a, np.load(out))
 
 
 DDP_WORKER = textwrap.dedent("""
