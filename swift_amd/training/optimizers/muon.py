@@ -2,8 +2,9 @@
 
 Same constructor contract (param groups flagged ``use_muon``; same defaults and key check), same update rule:
 Nesterov momentum -> quintic Newton-Schulz orthogonalisation in bf16 (5 iterations) -> ``sqrt(max(1, rows/cols))`` rescale ->
-decoupled weight decay -> step; AdamW-style update for the non-Muon groups; round-robin parameter ownership across ranks
-with an all-gather of the updated parameters (RCCL over xGMI), as the reference does.
+decoupled weight decay -> step; AdamW-style update for the non-Muon groups; round-robin parameter ownership across ranks as
+in the reference, the updated parameters travelling by broadcast from their owner (RCCL over xGMI; shape-agnostic, where
+the reference's per-round all-gather needs equal shapes within a round).
 
 The three products of every Newton-Schulz iteration (``X X^T``, ``A A``, ``B X`` -- all the FLOPs of the optimiser: 5 x 3
 GEMMs on up to 5632 x 1056 matrices per parameter) run on ``swiftk_gemm`` (bf16 MFMA, bf16 results like the reference's bf16
@@ -123,7 +124,6 @@ class MuonWithAuxAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             if group["use_muon"]:
                 params = group["params"]
-                pad = params + [torch.empty_like(params[-1])] * (world - len(params) % world) if multi else params
                 for base in range(0, len(params), world):
                     if base + rank < len(params):
                         p = params[base + rank]
@@ -136,7 +136,12 @@ class MuonWithAuxAdam(torch.optim.Optimizer):
                         p.mul_(1 - group["lr"] * group["weight_decay"])
                         p.add_(update.reshape(p.shape).to(p.dtype), alpha=-group["lr"])
                     if multi:
-                        dist.all_gather(pad[base: base + world], pad[base + rank])
+                        # the reference all-gathers the round's parameters (muon.py:234-237), which needs one shape per
+                        # round; rounds here may mix shapes (12 x w1 then 12 x to_qkv on 8 ranks), so every parameter of
+                        # the round is broadcast from the rank that owns it
+                        for r in range(world):
+                            if base + r < len(params):
+                                dist.broadcast(params[base + r].data, src=r)
             else:
                 for p in group["params"]:
                     if p.grad is None:

@@ -183,6 +183,49 @@ def test_gradient_allreduce_world2_equals_single_process(tmp_path):
     assert a.abs().sum() > 0 and torch.allclose(a, b, rtol=1e-5, atol=1e-7)
 
 
+MUON_WORKER = textwrap.dedent("""
+    import os, sys, torch
+    sys.path.insert(0, %(root)r)
+    from swift_amd import dist
+    from swift_amd.training.optimizers import muon as pm
+    from oracle import muon as om          # CPU stand-in for the GEMM-backed orthogonaliser (no GPU in this test)
+    pm.zeropower_via_newtonschulz5 = lambda G, steps=5: om.newton_schulz5(G, steps)
+    dist.setup_torch(backend="gloo")
+    g = torch.Generator().manual_seed(3)
+    shapes = [(24, 16), (16, 40), (32, 32), (8, 48), (40, 8), (12,), (5, 3)]
+    params = [torch.nn.Parameter(torch.randn(*sh, generator=g) * 0.05) for sh in shapes]
+    opt = pm.MuonWithAuxAdam([dict(params=params[:5], use_muon=True, lr=0.02, weight_decay=0.01),
+                              dict(params=params[5:], use_muon=False, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-10)])
+    for st in range(3):
+        for p in params:
+            p.grad = torch.randn(p.shape, generator=g)      # identical on every rank (as after the gradient all-reduce)
+        opt.step()
+    if dist.get_rank() == 0:
+        torch.save([p.detach().clone() for p in params], sys.argv[1])
+    dist.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+""")
+
+
+@pytest.mark.timeout(300)
+def test_muon_round_robin_world2_equals_single_process(tmp_path):
+    """MuonWithAuxAdam's parameter ownership (rank r updates parameters r, r + world, ... and all-gathers them, muon.py:215-238):
+    two gloo ranks end with the parameters of one process.  5 Muon parameters on 2 ranks = an uneven last round."""
+    script = tmp_path / "muon_worker.py"
+    script.write_text(MUON_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    one, two = str(tmp_path / "m1.pt"), str(tmp_path / "m2.pt")
+    subprocess.run([sys.executable, str(script), one], check=True, env={**env, "WORLD_SIZE": "1", "RANK": "0"}, timeout=200)
+    port = str(29800 + os.getpid() % 90)
+    procs = [subprocess.Popen([sys.executable, str(script), two],
+                              env={**env, "WORLD_SIZE": "2", "RANK": str(r), "LOCAL_RANK": str(r), "MASTER_PORT": port})
+             for r in range(2)]
+    assert [p.wait(timeout=200) for p in procs] == [0, 0]
+    a, b = torch.load(one), torch.load(two)
+    assert len(a) == 7 and all(torch.equal(x, y) for x, y in zip(a, b))
+
+
 def test_lr_schedule_and_param_groups():
     """trainer.py:201-217 and train.py:275-286 on a CPU-only stand-in (no kernels involved)."""
     from swift_amd.train import adamw_param_groups
