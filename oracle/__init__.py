@@ -5,7 +5,7 @@ consistency-model forecast path.  It exists so that the HIP path in
 ``swift_amd/`` can be checked against the reference's arithmetic on a machine
 where the reference's Python cannot travel (the GPU box).
 
-Rules (enforced by tests/test_layout.py):
+Rules (enforced by tests/test_abi_and_layout.py):
   * only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
     ``cpu_baseline`` leg may import anything from here;
   * nothing under ``swift_amd/`` imports it -- the product path fails loudly
