@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8); ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--iters", type=int, default=2); ap.add_argument("--depth", type=int, default=12)
 ap.add_argument("--loss", default="crps", choices=["crps", "scm"])
+ap.add_argument("--opt", default="adamw", choices=["adamw", "muon"])
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 names = ["2m_temperature", "10m_u_component_of_wind", "10m_v_component_of_wind", "mean_sea_level_pressure"]
@@ -27,7 +28,14 @@ net = PassPrecond(mcfg, img_resolution=[128, 256], img_channels=69, condition_ch
 net.load_state_dict(swinv2_state(grid=(64, 128), in_channels=141, out_channels=69, patch_size=(2, 2), depth=a.depth, dim=1056,
                                  heads=12, seed=1))
 net = net.to(dev).train().requires_grad_(True)
-opt = torch.optim.AdamW(adamw_param_groups(net, 1e-5), lr=1e-5, betas=(0.9, 0.95), eps=1e-6)
+if a.opt == "muon":  # the sCM experiment's optimiser (train.py:286-309 parameter split)
+    from swift_amd.training.optimizers.muon import MuonWithAuxAdam
+    mp = [p for n, p in net.named_parameters() if p.ndim >= 2 and "transformer" in n]
+    ap_ = [p for n, p in net.named_parameters() if not (p.ndim >= 2 and "transformer" in n)]
+    opt = MuonWithAuxAdam([dict(params=mp, use_muon=True, lr=0.02, weight_decay=0.01),
+                           dict(params=ap_, use_muon=False, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-10)])
+else:
+    opt = torch.optim.AdamW(adamw_param_groups(net, 1e-5), lr=1e-5, betas=(0.9, 0.95), eps=1e-6)
 loss_fn = (CRPSLoss(ds, 1.0, 2, 1.0) if a.loss == "crps" else
            SCMLoss(ds, dict(dist="loguniform", sigma_min=0.02, sigma_max=200.0), 1.0, tangent_warmup_kimg=1)).to(dev)
 tr = Trainer(net, opt, loss_fn, total_kimg=1, lr_rampup_kimg=0, lr_min_factor=1.0, device=dev,
