@@ -26,8 +26,29 @@ def _s():
     return torch.cuda.current_stream().cuda_stream
 
 
+_SLABS = {}
+
+
 def _gemm_bf16(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, n: int, k: int) -> torch.Tensor:
-    """out[:, :n] = a[:, :k] @ w[:n, :k]^T (bf16 operands with zero K padding, bf16 result)."""
+    """out[:, :n] = a[:, :k] @ w[:n, :k]^T (bf16 operands with zero K padding, bf16 result).
+
+    The products of the orthogonaliser have few output tiles (1056 x 1056 = 15 tiles of 256 x 352 on 256 CUs) and long
+    contractions, so they go through the split-K form of the GEMM (k-ranges into fp32 slabs, summed by
+    ``swiftk_reduce_slabs``) whenever that fills more of the chip; the sum is rounded to bf16 once, like a bf16 matmul."""
+    m = a.shape[0]
+    tiles = ((m + 255) // 256) * ((n + 351) // 352)
+    ks = max(1, min(32, 256 // tiles, k // 128))
+    if ks > 1 and n % 8 == 0 and m % 8 == 0:
+        need = ks * m * n
+        dev = a.device
+        if dev not in _SLABS or _SLABS[dev].numel() < need + m * n:
+            _SLABS[dev] = torch.empty(need + m * n, dtype=torch.float32, device=dev)
+        slabs, acc = _SLABS[dev][:need], _SLABS[dev][need:need + m * n].view(m, n)
+        check(lib().swiftk_gemm_splitk(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), slabs.data_ptr(), n, m * n, m, n, k,
+                                       ops.dtype_code(_BF), ks, _s()), "swiftk_gemm_splitk")
+        check(lib().swiftk_reduce_slabs(slabs.data_ptr(), n, m * n, ks, acc.data_ptr(), n, m, n, 0, _s()), "swiftk_reduce_slabs")
+        out[:, :n] = acc
+        return out
     check(lib().swiftk_gemm(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), a.shape[0], n,
                             k, ops.dtype_code(_BF), ops.dtype_code(_BF), EPI_NONE, None, None, 0, _s()), "swiftk_gemm")
     return out
