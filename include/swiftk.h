@@ -54,6 +54,9 @@ extern "C" {
                                   of the grid rolled by (shift_h, shift_w); needs PRENORM, bf16, head_dim 88; ldq unused */
 #define SWIFTK_ATTN_NO_PIPE 2  /* tuning: keep the one-workgroup-per-item kernel even where the pipelined one applies */
 
+/* Most (member, IC) units one swiftk_swinv2_forward call takes (BASELINE configs[3] puts 96 on a GPU). */
+#define SWIFTK_MAX_UNITS 256
+
 int swiftk_version(void);
 
 /* Round `k` up to the K granularity of the GEMM for `dtype` (64 bf16 / 32 fp32 elements = 128 B). */
@@ -128,7 +131,7 @@ int swiftk_timestep_embed(const float* t, const float* aux, const float* freqs, 
                           float* emb, int B, int d, int aux_dim, float timestep_weight, void* stream);
 
 /*
- * Small-batch fp32 linear: out[b][n] = act(x[b][:] . W[n][:] + bias[n]), B <= 64.
+ * Small-batch fp32 linear: out[b][n] = act(x[b][:] . W[n][:] + bias[n]) (any B; rows are walked 8 at a time).
  * act: 0 none, 1 SiLU.  Replaces swinv2.py:74 (LatentEmbedding), :85
  * (all modulation Linears, concatenated along n), :327 (logvar).
  */
@@ -142,6 +145,14 @@ int swiftk_linear_small(const float* x, int64_t ldx, const float* W, int64_t ldw
  */
 int swiftk_rollout_update(float* xstd, const float* y, float* phys, const float* mx, const float* sx, const float* st,
                           int B, int C, int64_t hw, void* stream);
+
+/*
+ * Output collection (the reference writes every rank's slice to a shared store,
+ * generate.py:139-152, and has no collective): out[b] = fp64 sum of unit b's n fp32 values, added in a
+ * fixed order -- bit-identical for a unit whatever rank or batch slot computed it, so ranks can
+ * all-gather B doubles per step instead of 9 MB per unit.  scratch: 32*B doubles.
+ */
+int swiftk_unit_checksum(const float* x, double* out, double* scratch, int B, int64_t n, void* stream);
 
 /*
  * out = a*x + b*y (fp32, out may alias x or y): the samplers' state arithmetic between network

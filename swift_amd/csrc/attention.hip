@@ -408,11 +408,15 @@ extern "C" int swiftk_window_attention(const void* qkv, int64_t ldq, void* out, 
         return rc;
     }
     if (flags & SWIFTK_ATTN_TILED) return SWIFTK_ESHAPE;  // window-tiled input exists for the pipelined kernel only
+    const bool timed = swiftk_prof_begin(SWIFTK_PROF_ATTENTION, 0, st);  // bench.py's attention leg (fp32 engine)
+    int rc;
     switch (head_dim) {
-        case 96: return launch_hd<96>(a, B, dtype, st);
-        case 88: return launch_hd<88>(a, B, dtype, st);
-        case 80: return launch_hd<80>(a, B, dtype, st);
-        case 64: return launch_hd<64>(a, B, dtype, st);
-        default: return SWIFTK_ESHAPE;
+        case 96: rc = launch_hd<96>(a, B, dtype, st); break;
+        case 88: rc = launch_hd<88>(a, B, dtype, st); break;
+        case 80: rc = launch_hd<80>(a, B, dtype, st); break;
+        case 64: rc = launch_hd<64>(a, B, dtype, st); break;
+        default: rc = SWIFTK_ESHAPE;
     }
+    if (timed) swiftk_prof_end(st);
+    return rc;
 }

@@ -236,6 +236,37 @@ __global__ void temb_kernel(const float* __restrict__ t, const float* __restrict
     emb[i] = v;
 }
 
+// --------------------------------------------------------------------------------- per-unit checksum
+// Order-fixed fp64 sum of every unit's [n] fp32 values: PARTS blocks per unit write partials, block 0..B-1 of the second
+// launch adds them in index order -- the same bits for the same unit whatever rank or batch slot it ran in.
+constexpr int CK_PARTS = 32;
+__global__ __launch_bounds__(256) void checksum_part_kernel(const float* __restrict__ x, double* __restrict__ part, int64_t n) {
+    __shared__ double red[256];
+    const int u = blockIdx.y, p = blockIdx.x;
+    const int64_t n4 = n >> 2, per = (n4 + CK_PARTS - 1) / CK_PARTS;
+    const int64_t lo = p * per, hi = min(n4, lo + per);
+    const float4* src = reinterpret_cast<const float4*>(x + (int64_t)u * n);
+    double acc = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const float4 v = src[i];
+        acc += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[u * CK_PARTS + p] = red[0];
+}
+__global__ void checksum_final_kernel(const double* __restrict__ part, double* __restrict__ out, int B) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= B) return;
+    double s = 0.0;
+    for (int p = 0; p < CK_PARTS; ++p) s += part[u * CK_PARTS + p];
+    out[u] = s;
+}
+
 // --------------------------------------------------------------------------------- small-batch linear, x in LDS
 // The 24 modulation Linears as one [50688, 1056] matrix dominate this op: every weight row is read once from HBM, but
 // with one wave per output feature the 8 x-rows were re-read from L1/L2 by each of the 50k waves (8x the weight bytes).
@@ -478,7 +509,6 @@ extern "C" int swiftk_timestep_embed(const float* t, const float* aux, const flo
 extern "C" int swiftk_linear_small(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* out,
                                    int64_t ldo, int B, int N, int K, int act, void* stream) {
     if (!x || !W || !out || B <= 0 || N <= 0 || K <= 0) return SWIFTK_EINVAL;
-    if (B > 64) return SWIFTK_ESHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)W & 15) || (ldx % 4) || (ldw % 4)) return SWIFTK_EALIGN;
     if (K % 4 == 0 && (size_t)8 * K * sizeof(float) <= 60 * 1024 && N >= 4096) {  // wide outputs: x staged in LDS
         const int grid = (N + 3) / 4 < 2048 ? (N + 3) / 4 : 2048;
@@ -531,4 +561,15 @@ extern "C" int swiftk_axpby(float* out, float a, const float* x, float b, const 
     return 0;
 }
 
-extern "C" int swiftk_version(void) { return 1; }
+extern "C" int swiftk_unit_checksum(const float* x, double* out, double* scratch, int B, int64_t n, void* stream) {
+    if (!x || !out || !scratch || B <= 0 || n <= 0) return SWIFTK_EINVAL;
+    if (n % 4) return SWIFTK_ESHAPE;
+    if ((uintptr_t)x & 15) return SWIFTK_EALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(checksum_part_kernel, dim3(CK_PARTS, B), dim3(256), 0, st, x, scratch, n);
+    hipLaunchKernelGGL(checksum_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, scratch, out, B);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_version(void) { return 2; }

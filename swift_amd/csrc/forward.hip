@@ -74,7 +74,7 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     if (!model_ok(m)) return SWIFTK_ESHAPE;
     if (!src0 || !t || !out || !workspace || B <= 0) return SWIFTK_EINVAL;
     if (c0 + c1 + c2 != m->in_ch) return SWIFTK_ESHAPE;
-    if (B > 64) return SWIFTK_ESHAPE;
+    if (B > SWIFTK_MAX_UNITS) return SWIFTK_ESHAPE;  // M = B * tokens rows must stay below 2^30 (int tile coordinates)
     if ((uintptr_t)workspace & 255) return SWIFTK_EALIGN;
     const Layout L = make_layout(m, B);
     if (workspace_bytes < L.total) return SWIFTK_EWORKSPACE;

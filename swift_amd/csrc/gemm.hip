@@ -37,6 +37,21 @@ constexpr int MI = 4, NI = 11;
 
 constexpr int EPI_QKNORM_TILED = 4;  // internal: SWIFTK_EPI_QKNORM with the window-tiled store (swiftk_gemm_qkv_tiled)
 
+// Build-time switches.  SWIFTK_GEMM_INSTR = 1 compiles the timing experiments (tuning key 3: ablation bits, s_memtime
+// timeline) into the persistent kernel -- `make variant EXTRA=-DSWIFTK_GEMM_INSTR=1`, never into libswiftk.so.
+#ifndef SWIFTK_GEMM_INSTR
+#define SWIFTK_GEMM_INSTR 0
+#endif
+#ifndef SWIFTK_X_VMCNT
+#define SWIFTK_X_VMCNT 1
+#endif
+#ifndef SWIFTK_X_PRIO
+#define SWIFTK_X_PRIO 1
+#endif
+#ifndef SWIFTK_X_PF2
+#define SWIFTK_X_PF2 1
+#endif
+
 struct GemmArgs {
     const char* A;
     const char* W;
@@ -351,6 +366,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             dma_piece_fast(sa + (wv * 4 + p) * 1024, abase[p], ((p & 1) ? va_odd : va_even) + koff);
         } else {
             const int i = p - 4;
+            // W has 44 pieces for 8 waves: the sixth one exists for waves 0-3 only (a wave-uniform branch around the asm; the
+            // EXEC-mask form needs an SGPR operand and hipcc hands inline asm a VGPR for it at this SGPR pressure)
             if (i < 5 || wv < 4) dma_piece_fast(sa + A_BYTES + (wv + 8 * i) * 1024, wbase[i], vb + koff);
         }
     };
@@ -377,17 +394,28 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     // dbg bit 32 (timing experiment, EPI_NONE only): wave 0 of every 32nd workgroup logs s_memtime at five points of each tile
     // into the buffer passed as ep1 -- [wg/32][tile][8] uint64: loop top of the first k-step, last MFMA issued, epilogue
     // barrier passed, stores issued, next loop top passed, sum of the k-steps' vmcnt(0) waits, sum of their barrier waits
+#if SWIFTK_GEMM_INSTR
     unsigned long long* tlog = nullptr;
     int tl_i = 0;
     if ((g.dbg & 32) && wv == 0 && lane == 0 && (blockIdx.x & 31) == 0)
         tlog = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.ep1)) + (blockIdx.x >> 5) * 8 * 64;
     bool first_k = true;
+#endif
+#if SWIFTK_X_PRIO
+    // the second-dispatched half of the workgroup loses every issue arbitration against its SIMD partner; one static
+    // priority for that half, no per-segment flips (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (;;) {
-        // own DMA of the stage about to be read has landed; after the barrier every wave's has, and every wave is
-        // done reading the other stage (its fragment reads were consumed by MFMAs before it got here)
+        // (waited at the bottom of the previous trip) own DMA of the stage about to be read has landed; after the
+        // barrier every wave's has, and every wave is done reading the other stage (its fragment reads were consumed
+        // by MFMAs before it got here)
+#if SWIFTK_GEMM_INSTR
         unsigned long long ts0 = 0, ts1 = 0;
-        if (tlog) ts0 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tlog) ts0 = ts1 = __builtin_amdgcn_s_memtime();
+#endif
+#if SWIFTK_GEMM_INSTR
         if (tlog) ts1 = __builtin_amdgcn_s_memtime();
         if (!(g.dbg & 2)) __builtin_amdgcn_s_barrier();
         if (tlog) {
@@ -403,6 +431,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             }
         }
         first_k = false;
+#else
+        __builtin_amdgcn_s_barrier();
+#endif
         const char* s = smem + par * STAGE;
         const uint32_t fill = lds0 + (par ^ 1) * STAGE;
         const bool last_k = (kt + 1 == nk);
@@ -413,48 +444,52 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             if (ntile < ntiles) set_sources(ntile);
             koff = (uint32_t)k_begin(ntile < ntiles ? ntile : tile) * ROWB;
         }
-        // one k-tile = 22 steps of 4 MFMAs (one W fragment x four activation fragments); the fragment of step
-        // i+1 is requested before the MFMAs of step i issue, and one DMA piece of the next stage follows every
-        // second step, so LDS latency and DMA issue hide behind the matrix pipe instead of bunching up
+        // One k-tile = 22 steps of 4 MFMAs (one W fragment x four activation fragments), written as straight-line code:
+        // the fragment of step i+1 is requested before the MFMAs of step i issue, one DMA piece of the next stage follows
+        // each of the first ten steps, and the only control flow is ONE branch around the second k-half (K = 1056 is 16.5
+        // k-tiles: the last k-tile of the K range carries data in its first half only; its second half meets zero pad
+        // columns, so those 44 MFMAs are skipped -- 3 % of the GEMM).  Branches between the MFMA groups make hipcc
+        // shuffle and spill accumulators (297 v_mov + 27 spilled dwords per k-tile in the SwiGLU build).
         {
-            uint4 xf[MI], xg[MI];
+            uint4 xf[MI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch0);
-            uint4 wf = *reinterpret_cast<const uint4*>(s + woff + ch0);
+            auto k_half = [&](const int ch, const bool with_dma) {
+                uint4 wf = *reinterpret_cast<const uint4*>(s + woff + ch);
+#if SWIFTK_X_PF2
+                uint4 wf1 = *reinterpret_cast<const uint4*>(s + woff + 16 * ROWB + ch);  // W fragments run two steps ahead
+#endif
 #pragma unroll
-            for (int step = 0; step < 2 * NI; ++step) {
-                const int ks = step / NI, j = step - ks * NI;
-                uint4 wn_ = wf;
-                if (step + 1 < 2 * NI) {
-                    const int ks1 = (step + 1) / NI, j1 = (step + 1) - ks1 * NI;
-                    wn_ = *reinterpret_cast<const uint4*>(s + woff + j1 * 16 * ROWB + (ks1 ? ch1 : ch0));
-                }
-                if (step == NI - 2) {
+                for (int j = 0; j < NI; ++j) {
+#if SWIFTK_X_PF2
+                    uint4 wn_ = wf1;
+                    if (j + 2 < NI) wf1 = *reinterpret_cast<const uint4*>(s + woff + (j + 2) * 16 * ROWB + ch);
+#else
+                    uint4 wn_ = wf;
+                    if (j + 1 < NI) wn_ = *reinterpret_cast<const uint4*>(s + woff + (j + 1) * 16 * ROWB + ch);
+#endif
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) xg[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch1);
+                    for (int i = 0; i < MI; ++i) mma_chunk<T>(acc[i][j], wf, xf[i]);
+                    if (with_dma && j < 10) issue_piece(fill, koff, j);
+                    wf = wn_;
                 }
-                // K = 1056 is 16.5 k-tiles: the last k-tile of the K range carries data only in its first half
-                // (ks = 0); its second half meets zero pad columns, so those 44 MFMAs are skipped (3 % of the GEMM)
-                if (step < NI || !half) {
+            };
+            k_half(ch0, true);
+            if (!half) {
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) mma_chunk<T>(acc[i][j], wf, ks ? xg[i] : xf[i]);
-                }
-                if (!(g.dbg & 1)) {
-                    if (half) {
-                        if (step < 10) issue_piece(fill, koff, step);
-                    } else if ((step & 1) && (step >> 1) < 10) {
-                        issue_piece(fill, koff, step >> 1);
-                    }
-                }
-                wf = wn_;
+                for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch1);
+                k_half(ch1, false);
             }
         }
         par ^= 1;
         if (!last_k) {
             ++kt;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             continue;
         }
+        bool interior = false;
         // ---- epilogue of `tile`: lane holds C[m][nb .. nb+3] for m = ..+r16, nb = ..+4*(lane>>4) ----
+#if SWIFTK_GEMM_INSTR
         if (tlog) tlog[tl_i * 8 + 1] = __builtin_amdgcn_s_memtime();
         first_k = true;
         if (g.dbg & 4) {  // tuning experiment: drop the epilogue (keeps the accumulators live through a fake use)
@@ -465,7 +500,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                     asm volatile("" ::"v"(acc[i][j]));
                     acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-        } else {
+        } else
+#endif
+        {
             int tm, tn;
             it.coords(tile / ksplit, tm, tn);
             const int m0 = tm * BM, n0 = tn * BN;
@@ -484,10 +521,21 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 // the slabs overlay operand bytes of the stage just consumed: every wave must be done READING that stage
                 // (its last fragments were consumed by MFMAs it has already issued) before any wave writes a slab
                 __builtin_amdgcn_s_barrier();
+#if SWIFTK_GEMM_INSTR
                 if (tlog) tlog[tl_i * 8 + 2] = __builtin_amdgcn_s_memtime();
+#endif
+#if SWIFTK_X_VMCNT
+                // interior tile: every lane group of every store below is live, so the wave issues exactly 24 (12 with
+                // SwiGLU) global stores after its last DMA piece -- the count the next loop trip leaves outstanding
+                interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+#endif
                 char* slab = const_cast<char*>(s) + wv * (16 * RSTR);
-                const int g4 = lane >> 4;
-                const int elane = lane;
+                // lane-derived epilogue addresses are rebuilt from an opaque copy of the lane id: left visible, hipcc
+                // hoists ~40 loop-invariant epilogue VGPRs above the k-loop and spills them inside it
+                int elane = lane;
+                asm volatile("" : "+v"(elane));
+                const int g4 = elane >> 4;
+                const int r16 = elane & 15;
                 const int ncol0 = (EPI == SWIFTK_EPI_SWIGLU ? (n0 >> 1) : n0) + wn * COLS;
                 const int nout = EPI == SWIFTK_EPI_SWIGLU ? (g.N >> 1) : g.N;
 #pragma unroll
@@ -577,14 +625,25 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 }
             }
         }
+#if SWIFTK_GEMM_INSTR
         if (tlog) {
             tlog[tl_i * 8 + 3] = __builtin_amdgcn_s_memtime();
             ++tl_i;
         }
+#endif
         tile += stride;
         if (tile >= ntiles) break;
         kt = k_begin(tile);
         nk = k_end(tile);
+        // VMEM retires in issue order: the DMA pieces of the next tile's first stage are older than this tile's epilogue
+        // stores, so leaving exactly those stores outstanding is enough (no store drain in front of a tile)
+        if (interior) {
+            if constexpr (sizeof(OutT) == 2 && EPI == SWIFTK_EPI_SWIGLU) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing dummy DMA must not outlive the LDS allocation
 }

@@ -197,3 +197,16 @@ def axpby(a: float, x: torch.Tensor, b: float, y: torch.Tensor, out: Optional[to
     check(lib().swiftk_axpby(out.data_ptr(), float(a), x.data_ptr(), float(b), y.data_ptr(), x.numel(), _stream()),
           "swiftk_axpby")
     return out
+
+
+def unit_checksum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp64 sum of every unit of x [B, ...] fp32 in a fixed order (bit-stable across ranks and batch slots) -> [B] fp64."""
+    _dev(x, out)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    B = x.shape[0]
+    if out is None:
+        out = torch.empty(B, dtype=torch.float64, device=x.device)
+    scratch = torch.empty(32 * B, dtype=torch.float64, device=x.device)
+    check(lib().swiftk_unit_checksum(x.data_ptr(), out.data_ptr(), scratch.data_ptr(), B, x.numel() // B, _stream()),
+          "swiftk_unit_checksum")
+    return out

@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""A/B of GEMM builds in ONE process (cdna_hip_programming.md rule 24): every lib in swift_amd/csrc/variants/ plus the
+product lib runs the Swift-B GEMM shapes in interleaved rounds; outputs are compared bit-for-bit with the first lib's.
+
+  python tools/gemm_ab.py [units] [rounds] [name ...]      (names: product, r01, novm, prio, ...; default: all found)
+"""
+import ctypes as C
+import glob
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from swift_amd import _lib  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+want = sys.argv[3:]
+paths = {"product": os.path.join(ROOT, "swift_amd", "csrc", "libswiftk.so")}
+for p in sorted(glob.glob(os.path.join(ROOT, "swift_amd", "csrc", "variants", "libswiftk_*.so"))):
+    paths[os.path.basename(p)[len("libswiftk_"):-3]] = p
+if want:
+    paths = {k: v for k, v in paths.items() if k in want}
+libs = {}
+for name, p in paths.items():
+    h = C.CDLL(p)
+    for fn in ("swiftk_gemm", "swiftk_gemm_qkv_tiled"):
+        getattr(h, fn).argtypes, getattr(h, fn).restype = _lib._SIGS[fn]
+    libs[name] = h
+names = list(libs)
+dev = torch.device("cuda")
+M = B * 8192
+st = lambda: torch.cuda.current_stream().cuda_stream
+torch.manual_seed(0)
+scale = torch.full((12,), 2.3, device=dev)
+shapes = [("qkv_tiled", 3168, 1088, 1056, "tiled"), ("wo", 1056, 1088, 1056, _lib.EPI_NONE),
+          ("w1+swiglu", 5632, 1088, 1056, _lib.EPI_SWIGLU), ("w2", 1056, 2816, 2816, _lib.EPI_NONE)]
+for sname, N, K, Kalg, epi in shapes:
+    a = torch.randn(M, K, device=dev).bfloat16()
+    if K > Kalg:
+        a[:, Kalg:] = 0
+    w = (torch.randn(N, K, device=dev) * 0.03).bfloat16()
+    if K > Kalg:
+        w[:, Kalg:] = 0
+    ncol = N // 2 if epi == _lib.EPI_SWIGLU else N
+    outs = {n: torch.zeros(M, ncol, dtype=torch.bfloat16, device=dev) for n in names}
+
+    def run(n):
+        h, o = libs[n], outs[n]
+        if epi == "tiled":
+            rc = h.swiftk_gemm_qkv_tiled(a.data_ptr(), K, w.data_ptr(), K, o.data_ptr(), Kalg, scale.data_ptr(), B, 64, 128, 12,
+                                         8, 8, st())
+        else:
+            rc = h.swiftk_gemm(a.data_ptr(), K, w.data_ptr(), K, o.data_ptr(), ncol, M, N, Kalg, _lib.BF16, _lib.BF16, epi, None,
+                               None, 0, st())
+        assert rc == 0, (n, sname, rc)
+
+    res = {n: [] for n in names}
+    for rnd in range(ROUNDS):
+        for n in (names if rnd % 2 == 0 else names[::-1]):
+            run(n)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(6):
+                run(n)
+            e1.record()
+            torch.cuda.synchronize()
+            res[n].append(e0.elapsed_time(e1) / 6)
+    ref = outs[names[0]]
+    flop = 2.0 * M * N * Kalg
+    for n in names:
+        same = bool(torch.equal(outs[n].view(torch.int16), ref.view(torch.int16)))
+        t = sorted(res[n])
+        print(f"{sname:10s} {n:10s} median {t[len(t) // 2] * 1e3:8.1f} us  min {t[0] * 1e3:8.1f} us  "
+              f"{flop / t[len(t) // 2] / 1e9:7.1f} TFLOP/s  bit-equal-to-{names[0]}: {same}", flush=True)
