@@ -105,7 +105,7 @@ def _load_yaml(path):
     with open(path) as f:
         text = f.read()
     pkg = _PKG_RE.search(text)
-    return (yaml.safe_load(text) or {}), (pkg.group(1) if pkg else None)
+    return (_yaml_load(text) or {}), (pkg.group(1) if pkg else None)
 
 
 def _merge(dst: dict, src: dict):
@@ -158,13 +158,22 @@ def _compose_file(config_dir, group, name, root, choices, pkg_path=None):
             _compose_file(config_dir, group, k, root, choices, pkg_path=here)  # plain file of the same group
             continue
         sub = (k if k.startswith("/") else (group.strip("/") + "/" + k if group.strip("/") else k)).strip("/")
-        choice = choices.get(sub, v)
+        child_pkg = (here + "/" if here else "") + k.strip("/")
+        choice = choices.get(_choice_key(sub, child_pkg), v)
         if choice is None or choice == "null":
             continue
-        child_pkg = (here + "/" if here else "") + k.strip("/")
         _compose_file(config_dir, sub, choice, root, choices, pkg_path=child_pkg)
     if not self_done:
         _place(root, here, body)
+
+
+def _choice_key(group: str, pkg: str) -> str:
+    """Hydra keys a defaults entry by group AND destination package (``get_override_key``): ``override /optimizer: muon`` or
+    a command-line ``optimizer=x`` reaches the entry packaged at ``optimizer`` only; the ``/optimizer: adamw`` that
+    ``finetune/multistep.yaml`` packages at ``finetune.optimizer`` keeps its own default unless addressed as
+    ``optimizer@finetune.optimizer=x``."""
+    group, pkg = group.strip("/"), pkg.strip("/")
+    return group if pkg == group else f"{group}@{pkg.replace('/', '.')}"
 
 
 def _collect_overrides(config_dir, group, name, choices):
@@ -182,11 +191,26 @@ def _collect_overrides(config_dir, group, name, choices):
                 _collect_overrides(config_dir, sub, choices.get(sub, v), choices)
 
 
+class _Loader(yaml.SafeLoader):
+    """SafeLoader with the YAML 1.2 float grammar: PyYAML (YAML 1.1) reads ``1e-4`` / ``3e-4`` as strings, Hydra reads floats."""
+
+
+_Loader.add_implicit_resolver(
+    "tag:yaml.org,2002:float",
+    re.compile(r"^[-+]?(?:(?:[0-9][0-9_]*)?\.[0-9_]+(?:[eE][-+]?[0-9]+)?|[0-9][0-9_]*\.?(?:[eE][-+]?[0-9]+)|\.(?:inf|Inf|INF)|"
+               r"[-+]\.(?:inf|Inf|INF)|\.(?:nan|NaN|NAN))$"),
+    list("-+0123456789."))
+
+
+def _yaml_load(text):
+    return yaml.load(text, Loader=_Loader)
+
+
 def _parse_value(s: str):
     if len(s) > 1 and s.isdigit() and s[0] == "0":  # run ids like 000 / 001 stay strings (resume=000)
         return s
     try:
-        return yaml.safe_load(s)
+        return _yaml_load(s)
     except yaml.YAMLError:
         return s
 
@@ -224,7 +248,7 @@ def compose(config_dir: str, config_name: str = "train", overrides=()) -> Cfg:
     for o in overrides:
         k, _, v = o.partition("=")
         k = k.lstrip("+")
-        if os.path.isdir(os.path.join(config_dir, k)):
+        if os.path.isdir(os.path.join(config_dir, k.partition("@")[0])):
             choices[k] = v
         else:
             values.append((k, v))
@@ -248,7 +272,7 @@ def compose(config_dir: str, config_name: str = "train", overrides=()) -> Cfg:
 def load_saved(path: str) -> Cfg:
     """Load a composed ``.hydra/config.yaml`` (what generate.py:161 and train.py:57 read back)."""
     with open(path) as f:
-        return Cfg(yaml.safe_load(f))
+        return Cfg(_yaml_load(f.read()))
 
 
 def to_yaml(cfg) -> str:

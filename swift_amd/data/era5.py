@@ -152,6 +152,14 @@ class ERA5Dataset(_ERA5Base):
         return (np.load(os.path.join(self.root, "lat.npy")).astype(np.float32),
                 np.load(os.path.join(self.root, "lon.npy")).astype(np.float32))
 
+    def get_time(self, idx: int) -> np.datetime64:
+        """data/era5.py:177-181."""
+        import h5py
+        with h5py.File(self.files[idx], "r") as f:
+            timestamp = f["input"]["time"][()]
+            assert isinstance(timestamp, bytes)
+            return np.datetime64(timestamp.decode("utf-8"))
+
     def __len__(self):
         return len(self.files[: -(max(self.intervals) * 1 // 6)])
 
@@ -207,6 +215,13 @@ class SyntheticERA5Dataset(_ERA5Base):
     def _fields(self, idx: int, kind: str, n: int) -> torch.Tensor:
         return det_normal((n, self._shape[1], self._shape[2]), self.seed, f"{kind}{int(idx)}")
 
+    def get_lat_lon(self):
+        H, W = self._shape[1], self._shape[2]
+        return np.linspace(-90.0, 90.0, H, dtype=np.float32), np.linspace(0.0, 360.0, W, endpoint=False, dtype=np.float32)
+
+    def get_time(self, idx: int) -> np.datetime64:
+        return np.datetime64("2020-01-01T00:00:00") + np.timedelta64(6 * int(idx), "h")
+
     def get_forcings(self, idx: int) -> torch.Tensor:
         return self._fields(idx, "forc", len(self.forcings))
 
@@ -244,10 +259,6 @@ class SyntheticERA5RollOutDataset(SyntheticERA5Dataset):
 
     def __len__(self):
         return self.length - self.interval
-
-    def get_lat_lon(self):
-        H, W = self._shape[1], self._shape[2]
-        return np.linspace(-90.0, 90.0, H, dtype=np.float32), np.linspace(0.0, 360.0, W, endpoint=False, dtype=np.float32)
 
     def __getitem__(self, idx: int):
         idx = int(idx)

@@ -63,6 +63,38 @@ def setup_torch(backend: Optional[str] = None, timeout_s: int = 1800) -> int:
     return get_rank()
 
 
+def maybe_launch_ranks(n_gpus: Optional[int], module: str) -> None:
+    """``python -m <module> ... --gpus N`` from a bare shell: start N rank processes (one per GPU, the reference's launch
+    contract: scripts/aurora-general.sh:74-91) and exit with their worst code.  Returns immediately inside a rank (WORLD_SIZE
+    set by this function, torchrun or MPI) or when ``n_gpus`` is None / 1.  Must run before anything touches the GPU: the
+    children are fresh interpreters, and this process never initialises the device."""
+    import socket
+    import subprocess
+    import sys
+    if not n_gpus or n_gpus <= 1 or any(k in os.environ for k in ("WORLD_SIZE", "PMI_SIZE", "OMPI_COMM_WORLD_SIZE")):
+        if n_gpus and get_world_size() not in (1, n_gpus):
+            raise SystemExit(f"--gpus {n_gpus} but launched with {get_world_size()} rank(s)")
+        return
+    have = torch.cuda.device_count()  # counting devices does not initialise the GPU runtime
+    if 0 < have < n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} but this node exposes {have} GPU(s)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    run_id = os.environ.get("HYDRA_RUN_ID")
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if run_id is not None:
+            env["HYDRA_RUN_ID"] = run_id
+        procs.append(subprocess.Popen([sys.executable, "-m", module, *sys.argv[1:]], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    raise SystemExit(rc)
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

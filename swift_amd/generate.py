@@ -8,13 +8,17 @@ reads ``RUN/.hydra/config.yaml`` (the saved composed config, generate.py:161) an
 ``RUN/output/<ckpt>/output-{n}i-{steps}s-{members}m-{interval}h.npy`` with shape
 (samples, members, steps+1, C, H, W) float32 (utils/io.py:237-259).
 
-MI355X-first differences: the flattened member x IC space is sharded in
-contiguous blocks over ranks (the reference shards members only, generate.py:79-81, which caps
-12 members at 6x on 8 GPUs); rank 0 loads the checkpoint and broadcasts the weights over RCCL;
-each rank rolls its units on the device (``RolloutEngine``) and writes its own slices of the
-shared memmap; a barrier closes the job.  Additive flags: ``--solver``, ``--num-steps``,
-``--dtype``, ``--synthetic`` (random-init weights + synthetic fields when no run directory exists).
-zarr output needs the ``zarr`` package, which this image lacks: ``--dump zarr`` raises.
+MI355X-first differences: the flattened IC-major (IC, member) space is
+sharded in contiguous blocks over ranks (the reference shards members only, generate.py:79-81,
+which caps 12 members at 6x on 8 GPUs) -- an IC's members sit next to each other, so a batch
+reads each IC's state and forcing files once; rank 0 loads the checkpoint and broadcasts the
+weights over RCCL; each rank rolls its units on the device (``RolloutEngine``) and writes its
+own slices of the shared store (npy memmap, or one zarr chunk file per unit and variable:
+``utils/zarrlite.py``); a barrier closes the job.  Additive flags: ``--solver``, ``--num-steps``,
+``--dtype``, ``--synthetic`` (random-init weights + synthetic fields when no run directory
+exists), ``--metrics`` (ensemble RMSE / CRPS / spread-skill against the dataset's own fields,
+reduced per rank on the device and all-gathered: eval/metrics.py:39-134 without the round trip
+through the store) and ``--gpus N`` (start the N ranks from a bare ``python -m`` call).
 """
 from __future__ import annotations
 
@@ -45,6 +49,8 @@ parser.add_argument("--solver", type=str, default="scm", choices=["scm", "2s", "
 parser.add_argument("--num-steps", type=int, default=1, help="solver steps per forecast step")
 parser.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16"], help="GEMM operand type")
 parser.add_argument("--synthetic", action="store_true", help="random-init weights + synthetic data (no run dir needed)")
+parser.add_argument("--metrics", action="store_true", help="ensemble metrics vs the dataset's fields -> evaluation_metrics.json")
+parser.add_argument("--gpus", type=int, default=None, help="start this many ranks (one per GPU) when not launched by torchrun/mpiexec")
 
 
 def get_ckpt_num(fpath: str) -> int:
@@ -70,19 +76,44 @@ def select_indices(n_dataset: int, samples: int, steps: int, interval: int):
     return np.linspace(0, n_dataset - 1 - (steps * interval // 6), num=samples, dtype=int).tolist()  # generate.py:179-184
 
 
+def create_empty_zarr(ofile, dataset, indices, members, steps, interval):
+    """utils/io.py:161-235 through the stdlib writer (no zarr / xarray in this image)."""
+    from .utils import zarrlite
+    lat, lon = dataset.get_lat_lon()
+    times = np.array([dataset.get_time(int(i)) for i in indices], dtype="datetime64[ns]")
+    zarrlite.create_forecast_store(ofile, list(dataset.variables), times, lat, lon, members, steps, interval=interval, batch=1)
+
+
+def unit_of(u: int, members: int):
+    """Flattened unit id -> (member, position of its IC in ``indices``); IC-major, so an IC's members are adjacent."""
+    return u % members, u // members
+
+
 def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, steps: int, ofile: str, device, args):
     """generate.py:48-154 with (member, IC) units instead of members as the sharded work item."""
-    if args.dump != "numpy":
-        raise NotImplementedError("zarr output needs the zarr package; use --dump numpy")
-    store = np.lib.format.open_memmap(ofile, mode="r+")
+    dump = getattr(args, "dump", "numpy")
+    if dump == "numpy":
+        store = np.lib.format.open_memmap(ofile, mode="r+")
+    else:
+        from .utils import zarrlite
+        var_channels = zarrlite.variable_channels(list(dataset.variables))
     rank, world = dist.get_rank(), dist.get_world_size()
     n_ic = len(indices)
-    mine = dist.shard_units(members * n_ic, rank, world)  # unit u = member * n_ic + ic
+    want_metrics = bool(getattr(args, "metrics", False))
+    batch = int(args.batch)
+    if want_metrics:  # an IC's members must meet in one batch: whole ICs per rank and per batch
+        batch = max(members, batch // members * members)
+        ic_range = dist.shard_units(n_ic, rank, world)
+        mine = range(ic_range.start * members, ic_range.stop * members)
+    else:
+        mine = dist.shard_units(members * n_ic, rank, world)  # unit u = ic * members + member
     nv = len(dataset.variables)
+    interval = engine.interval
     done = 0
+    metric_sums = {}  # IC position -> [steps, nv, 4] float64 (swiftk_ensemble_sums rows)
     # Output streaming (the reference copies every step to the host synchronously, generate.py:129): the trajectory of a
     # batch stays on the device while it is rolled out; its device->host copy then runs on a side stream into one of two
-    # pinned buffers while the NEXT batch computes, and the memmap write of batch k-1 happens on the host meanwhile.
+    # pinned buffers while the NEXT batch computes, and the store write of batch k-1 happens on the host meanwhile.
     from concurrent.futures import ThreadPoolExecutor
     writer = ThreadPoolExecutor(max_workers=1)
     on_gpu = torch.device(device).type == "cuda"   # (the host-logic tests drive this loop with a CPU stand-in engine)
@@ -98,40 +129,65 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
             ev.synchronize()
         t1 = time.time()
         h = host.numpy()
-        for k, (m, ic) in enumerate(us):
-            store[ic, m] = h[:, k]          # buffer is step-major [steps+1, B, ...]
-        store.flush()
+        for k, (m, ic) in enumerate(us):    # buffer is step-major [steps+1, B, ...]
+            if dump == "numpy":
+                store[ic, m] = h[:, k]
+            else:
+                zarrlite.write_unit(ofile, var_channels, ic, m, h[:, k])
+        if dump == "numpy":
+            store.flush()
         t_host[1] += time.time() - t1
 
     def stage(s):
         """Host-side inputs of the batch starting at unit s (pinned tensors; runs on the reader thread, one batch ahead)."""
         t1 = time.time()
-        units = [(u // n_ic, u % n_ic) for u in range(s, min(s + args.batch, mine.stop))]
+        units = [unit_of(u, members) for u in range(s, min(s + batch, mine.stop))]
         ics = [indices[ic] for _, ic in units]
         x0 = {int(j): dataset[int(j)][0][0][:nv] for j in set(ics)}
         X0 = torch.stack([x0[int(j)] for j in ics], 0)
         forc = engine.stage_forcings(ics, steps, "cpu")
+        truth = None
+        if want_metrics:  # verifying fields of every lead step, physical units, one copy per IC of the batch
+            uniq = sorted(set(ic for _, ic in units))
+            truth = torch.stack([torch.stack([dataset.unstandardize_x(dataset[int(indices[ic]) + (i + 1) * interval // 6][0][0][:nv])
+                                              for i in range(steps)], 0) for ic in uniq], 0)
         if on_gpu:
             X0, forc = X0.pin_memory(), forc.pin_memory()
+            truth = None if truth is None else truth.pin_memory()
         t_host[0] += time.time() - t1
-        return units, X0, forc
+        return units, X0, forc, truth
+
+    def batch_metrics(units, dev_buf, truth):
+        """Per IC of the batch: swiftk_ensemble_sums of its members against the verifying fields at every lead step."""
+        from .eval.metrics import ensemble_sums
+        lat = dataset.get_lat_lon()[0]
+        uniq = sorted(set(ic for _, ic in units))
+        for k, ic in enumerate(uniq):
+            slots = [b for b, (_, i) in enumerate(units) if i == ic]
+            assert len(slots) == members and slots == list(range(slots[0], slots[0] + members))
+            pred = dev_buf[1:, slots[0]:slots[0] + members].contiguous()       # [steps, members, nv, H, W]
+            metric_sums[ic] = ensemble_sums(pred, truth[k].to(pred.device, non_blocking=True), lat).double().cpu()
 
     reader = ThreadPoolExecutor(max_workers=1)
-    starts = list(range(mine.start, mine.stop, args.batch))
+    starts = list(range(mine.start, mine.stop, batch))
     nxt = reader.submit(stage, starts[0]) if starts else None
     for bi, s in enumerate(starts):
-        units, X0, forc = nxt.result()
+        units, X0, forc, truth = nxt.result()
         nxt = reader.submit(stage, starts[bi + 1]) if bi + 1 < len(starts) else None
         X0, forc = X0.to(device, non_blocking=True), forc.to(device, non_blocking=True)
         traj = engine.run(X0, forc, steps, seeds=[unit_seed(m, indices[ic]) for m, ic in units])  # [B, steps+1, ...] view
         dev_buf = traj.transpose(0, 1)      # the contiguous step-major buffer behind it
+        if want_metrics:
+            batch_metrics(units, dev_buf, truth)
         if on_gpu:
             ready = torch.cuda.Event()
             ready.record()
             slot = bi & 1
-            if pinned[slot] is None or pinned[slot].shape[1] < dev_buf.shape[1]:
-                pinned[slot] = torch.empty(dev_buf.shape, dtype=torch.float32, pin_memory=True)
-            host = pinned[slot][:, :dev_buf.shape[1]]
+            # flat pinned staging viewed with THIS batch's shape: the destination of the async copy is always contiguous
+            # (a [:, :B] view of a larger step-major buffer would send the last, smaller batch through pageable staging)
+            if pinned[slot] is None or pinned[slot].numel() < dev_buf.numel():
+                pinned[slot] = torch.empty(dev_buf.numel(), dtype=torch.float32, pin_memory=True)
+            host = pinned[slot][:dev_buf.numel()].view(dev_buf.shape)
             ev = torch.cuda.Event()
             with torch.cuda.stream(copy_stream):
                 copy_stream.wait_event(ready)
@@ -150,6 +206,44 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
     writer.shutdown()
     reader.shutdown()
     dist.log0(f"host side: {t_host[0]:.2f} s staging inputs, {t_host[1]:.2f} s writing outputs")
+    if want_metrics:
+        return collect_metrics(metric_sums, n_ic, steps, nv, members, dataset, interval, device, os.path.dirname(ofile))
+    return None
+
+
+def collect_metrics(metric_sums, n_ic, steps, nv, members, dataset, interval, device, odir):
+    """Output collection over RCCL: every rank contributes the ensemble sums of its ICs ([n_ic, steps, nv, 4], zeros
+    elsewhere), one all-gather, rank 0 turns them into the reference's metric names (eval/metrics.py:39-134)."""
+    import json
+    local = torch.zeros(n_ic, steps, nv, 4, dtype=torch.float64)
+    for ic, v in metric_sums.items():
+        local[ic] = v
+    if tdist.is_available() and tdist.is_initialized() and dist.get_world_size() > 1:
+        on_gpu = torch.device(device).type == "cuda"
+        buf = local.to(device) if on_gpu else local
+        parts = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
+        tdist.all_gather(parts, buf)
+        total = torch.stack(parts, 0).sum(0).cpu()
+    else:
+        total = local
+    if dist.get_rank() != 0:
+        return None
+    H, W = dataset.img_resolution
+    hw, N = H * W, members
+    res = {}
+    for j in range(steps):
+        s = total[:, j]                                                   # [n_ic, nv, 4]
+        rmse = torch.sqrt(s[..., 0] / hw).mean(0)
+        crps = s[..., 1].sum(0) / (n_ic * N * hw) - (s[..., 2] / hw / (2 * N * (N - 1))).mean(0)
+        ssr = torch.sqrt(s[..., 3] / hw).mean(0) / rmse
+        for i, v in enumerate(dataset.variables):
+            tag = f"{(j + 1) * interval}h"
+            res[f"rmse_{v}_{tag}"], res[f"crps_{v}_{tag}"], res[f"ssr_{v}_{tag}"] = float(rmse[i]), float(crps[i]), float(ssr[i])
+    path = os.path.join(odir, "evaluation_metrics.json")
+    with open(path, "w") as f:
+        json.dump(res, f, indent=1)
+    dist.log0(f"ensemble metrics of {n_ic} ICs x {members} members gathered from {dist.get_world_size()} rank(s): {path}")
+    return res
 
 
 def main(args):
@@ -199,9 +293,13 @@ def main(args):
     odir = os.path.join(args.input, "output", ckpt_basename)
     dist.run_on_rank0(os.makedirs, odir, exist_ok=True)
     filename = f"output-{len(indices)}i-{args.steps}s-{args.members}m-{args.interval}h"
-    ofile = os.path.join(odir, f"{filename}.npy")
-    dist.run_on_rank0(create_empty_numpy, ofile, len(indices), dataset.n_target_channels, dataset.img_resolution,
-                      args.members, args.steps)
+    if args.dump == "numpy":
+        ofile = os.path.join(odir, f"{filename}.npy")
+        dist.run_on_rank0(create_empty_numpy, ofile, len(indices), dataset.n_target_channels, dataset.img_resolution,
+                          args.members, args.steps)
+    else:  # zarr (the reference's default, generate.py:41-43)
+        ofile = os.path.join(odir, f"{filename}.zarr")
+        dist.run_on_rank0(create_empty_zarr, ofile, dataset, indices, args.members, args.steps, args.interval)
 
     solver_kwargs = dict(num_steps=args.num_steps, sigma_min=0.02, sigma_max=200.0, auxiliary=args.interval / 10.0)
     engine = RolloutEngine(net, dataset, interval=args.interval, solver=args.solver,
@@ -215,6 +313,9 @@ def main(args):
     n = len(indices) * args.members * args.steps
     dist.log0(f"Done! Took {el:.3f} seconds: {n} sample-steps, {n / el:.1f} sample-steps/s including forcing staging and output "
               f"streaming to {os.path.basename(ofile)}.")
+    if args.dump == "zarr" and dist.get_rank() == 0:  # generate.py:281-285
+        from .utils import zarrlite
+        zarrlite.consolidate(ofile)
     if tdist.is_initialized():
         tdist.destroy_process_group()
     dist.log0(f"Output saved to: {ofile}")
@@ -222,4 +323,6 @@ def main(args):
 
 
 if __name__ == "__main__":
-    main(parser.parse_args())
+    _args = parser.parse_args()
+    dist.maybe_launch_ranks(_args.gpus, "swift_amd.generate")  # before anything touches the GPU; returns in the ranks
+    main(_args)

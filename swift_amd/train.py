@@ -85,9 +85,42 @@ def adamw_param_groups(net, weight_decay: float):
     return [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
 
 
+def apply_distill_flag(cfg: Cfg) -> Cfg:
+    """train.py:318-319: with a teacher run (``distill=<run dir>``) SCMLoss does consistency distillation -- the teacher's
+    velocity replaces the analytic dx_t/dt -- instead of consistency training."""
+    if str(cfg.loss._target_).endswith("SCMLoss") and cfg.get("distill") is not None:
+        cfg.loss.distillation = True
+    return cfg
+
+
+def shared_run_id() -> str:
+    """HYDRA_RUN_ID names the run directory and seeds the samplers (train.py:154): every rank must hold the same one.  The
+    reference's launch scripts export it (scripts/aurora-general.sh:85); under a plain torchrun it is unset, and per-rank
+    clocks can straddle a second -- so rank 0's id is broadcast once the process group is up."""
+    rid = os.environ.get("HYDRA_RUN_ID")
+    if dist.get_world_size() > 1:
+        dist.setup_torch()
+        box = [rid or datetime.now().strftime("%Y%m%d_%H%M%S")]
+        tdist.broadcast_object_list(box, src=0)
+        rid = box[0]
+    rid = rid or datetime.now().strftime("%Y%m%d_%H%M%S")
+    os.environ["HYDRA_RUN_ID"] = rid
+    return rid
+
+
 def main(overrides=None):
-    os.environ.setdefault("HYDRA_RUN_ID", datetime.now().strftime("%Y%m%d_%H%M%S"))
-    cfg = compose(CONFIG_DIR, "train", list(sys.argv[1:] if overrides is None else overrides))
+    argv = list(sys.argv[1:] if overrides is None else overrides)
+    gpus = None
+    for a in list(argv):  # additive: `--gpus N` / `--gpus=N` starts the N ranks from a bare `python -m swift_amd.train`
+        if a.startswith("--gpus"):
+            i = argv.index(a)
+            gpus = int(a.split("=", 1)[1]) if "=" in a else int(argv[i + 1])
+            del argv[i:i + (1 if "=" in a else 2)]
+    if overrides is None and gpus:
+        os.environ.setdefault("HYDRA_RUN_ID", datetime.now().strftime("%Y%m%d_%H%M%S"))  # inherited by every rank
+        dist.maybe_launch_ranks(gpus, "swift_amd.train")
+    shared_run_id()
+    cfg = compose(CONFIG_DIR, "train", argv)
     run_dir = cfg.hydra.run.dir
     os.makedirs(os.path.join(run_dir, ".hydra"), exist_ok=True)
     os.chdir(run_dir)  # hydra.job.chdir: true
@@ -149,6 +182,7 @@ def main(overrides=None):
         optimizer = instantiate(dict(_target_=target), params, _convert_="object")
     if not target.endswith("MuonWithAuxAdam"):
         optimizer = instantiate(cfg.optimizer, params, _convert_="object")
+    apply_distill_flag(cfg)
     loss_fn = instantiate(cfg.loss, dataset=dataset, _convert_="object").to(device)
     trainer_cfg = {k: v for k, v in cfg.trainer.items()}
     trainer = instantiate(trainer_cfg, net=net, optimizer=optimizer, loss_fn=loss_fn, amp_type=cfg.system.torch.amp_type,

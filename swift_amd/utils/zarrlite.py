@@ -1,0 +1,182 @@
+"""Zarr v2 directory stores written (and read back) with the standard library + numpy.
+
+The reference's default output of ``swift.generate`` is a zarr group created by
+``utils/io.py:161-235`` (``fast_create_empty_zarr``) and filled per (sample, member) in
+``generate.py:141-152``; this image has neither ``zarr`` nor ``xarray``, and the format is
+simple enough not to need them: a store is a directory, a group is ``.zgroup`` + ``.zattrs``
+JSON, an array is ``<name>/.zarray`` + ``.zattrs`` JSON plus one file per chunk named by the
+dot-joined chunk index holding the chunk's C-order bytes (``compressor: null``).  xarray's
+conventions are kept (``_ARRAY_DIMENSIONS`` attributes, CF-encoded time coordinates,
+consolidated ``.zmetadata``), so ``xr.open_zarr(path, decode_timedelta=True)`` and
+``zarr.open_group(path)`` read these stores where those packages exist.
+
+Layout written by :func:`create_forecast_store` (identical to the reference's):
+one array per variable, dims ``(time, number, prediction_timedelta, [level,] latitude, longitude)``
+float32, chunks ``(batch, 1, steps + 1, [levels,] lat, lon)`` -- with ``batch = 1`` the whole
+trajectory of one (initial condition, member) unit is exactly one chunk file per variable,
+so ranks write disjoint files and never read-modify-write.
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+from collections import defaultdict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def compress_variables(variables: Sequence[str]) -> Dict[str, List[int]]:
+    """``name_<level>`` channels grouped per variable, in order of appearance (utils/io.py:73-82)."""
+    out: Dict[str, List[int]] = defaultdict(list)
+    for var in variables:
+        m = re.match(r"^(.*)_(\d+)$", var)
+        if m:
+            out[m.group(1)].append(int(m.group(2)))
+        else:
+            out[var] = []
+    return dict(out)
+
+
+def variable_channels(variables: Sequence[str]) -> Dict[str, List[int]]:
+    """Channel indices of each store variable (generate.py:62-72)."""
+    res, k = {}, 0
+    for var, levels in compress_variables(variables).items():
+        n = max(len(levels), 1)
+        res[var] = list(range(k, k + n))
+        k += n
+    return res
+
+
+def _dump(path: str, obj) -> None:
+    with open(path, "w") as f:
+        json.dump(obj, f, indent=1)
+
+
+def _dtype_str(dt: np.dtype) -> str:
+    dt = np.dtype(dt)
+    return dt.str if dt.byteorder != "|" else "|" + dt.str[1:]
+
+
+def create_group(path: str, attrs: Optional[dict] = None) -> None:
+    os.makedirs(path, exist_ok=True)
+    _dump(os.path.join(path, ".zgroup"), {"zarr_format": 2})
+    _dump(os.path.join(path, ".zattrs"), attrs or {})
+
+
+def create_array(root: str, name: str, shape: Sequence[int], chunks: Sequence[int], dtype, dims: Sequence[str],
+                 fill_value=0.0, attrs: Optional[dict] = None) -> None:
+    d = os.path.join(root, name)
+    os.makedirs(d, exist_ok=True)
+    _dump(os.path.join(d, ".zarray"), {"zarr_format": 2, "shape": [int(s) for s in shape], "chunks": [int(c) for c in chunks],
+                                        "dtype": _dtype_str(dtype), "compressor": None, "fill_value": fill_value,
+                                        "order": "C", "filters": None})
+    _dump(os.path.join(d, ".zattrs"), {"_ARRAY_DIMENSIONS": list(dims), **(attrs or {})})
+
+
+def write_chunk(root: str, name: str, index: Sequence[int], data: np.ndarray) -> None:
+    """Write one WHOLE chunk (``data.shape`` == the array's chunk shape; edge chunks are padded by the caller)."""
+    with open(os.path.join(root, name, ".zarray")) as f:
+        meta = json.load(f)
+    assert tuple(data.shape) == tuple(meta["chunks"]), (data.shape, meta["chunks"])
+    data = np.ascontiguousarray(data, dtype=np.dtype(meta["dtype"]))
+    tmp = os.path.join(root, name, "." + ".".join(str(int(i)) for i in index) + f".{os.getpid()}.tmp")
+    with open(tmp, "wb") as f:
+        f.write(data.tobytes())
+    os.replace(tmp, os.path.join(root, name, ".".join(str(int(i)) for i in index)))
+
+
+def write_full(root: str, name: str, data: np.ndarray, dims: Sequence[str], attrs: Optional[dict] = None) -> None:
+    """A small array (coordinates) as a single chunk."""
+    data = np.asarray(data)
+    fill = "NaN" if data.dtype.kind == "f" else 0
+    create_array(root, name, data.shape, data.shape if data.size else (1,) * data.ndim, data.dtype, dims, fill_value=fill, attrs=attrs)
+    if data.size:
+        write_chunk(root, name, (0,) * data.ndim, data)
+
+
+def consolidate(root: str) -> None:
+    """``.zmetadata`` (zarr.convenience.consolidate_metadata, generate.py:281-285)."""
+    meta = {}
+    for dirpath, _dirs, files in os.walk(root):
+        for fn in files:
+            if fn in (".zgroup", ".zarray", ".zattrs"):
+                key = os.path.relpath(os.path.join(dirpath, fn), root).replace(os.sep, "/")
+                with open(os.path.join(dirpath, fn)) as f:
+                    meta[key] = json.load(f)
+    _dump(os.path.join(root, ".zmetadata"), {"zarr_consolidated_format": 1, "metadata": dict(sorted(meta.items()))})
+
+
+def create_forecast_store(ofile: str, variables: Sequence[str], times: np.ndarray, lat: np.ndarray, lon: np.ndarray, members: int,
+                          steps: int, interval: int = 6, batch: int = 1) -> Dict[str, List[int]]:
+    """Empty forecast store with the reference's structure (utils/io.py:161-235); returns {variable: channel indices}."""
+    create_group(ofile)
+    n = len(times)
+    t_ns = np.asarray(times, dtype="datetime64[ns]").astype(np.int64)
+    write_full(ofile, "time", t_ns, ["time"], {"units": "nanoseconds since 1970-01-01", "calendar": "proleptic_gregorian"})
+    td = (np.arange(steps + 1, dtype=np.int64) * interval * 3_600_000_000_000)
+    write_full(ofile, "prediction_timedelta", td, ["prediction_timedelta"], {"units": "nanoseconds", "dtype": "timedelta64[ns]"})
+    write_full(ofile, "latitude", np.asarray(lat, np.float32), ["latitude"])
+    write_full(ofile, "longitude", np.asarray(lon, np.float32), ["longitude"])
+    write_full(ofile, "number", np.arange(members, dtype=np.int64), ["number"])
+    comp = compress_variables(variables)
+    if any(len(lv) for lv in comp.values()):
+        write_full(ofile, "level", np.arange(max(len(lv) for lv in comp.values()), dtype=np.int64), ["level"])
+    n_lat, n_lon = len(lat), len(lon)
+    for var, levels in comp.items():
+        if levels:
+            shape, chunks = (n, members, steps + 1, len(levels), n_lat, n_lon), (batch, 1, steps + 1, len(levels), n_lat, n_lon)
+            dims = ["time", "number", "prediction_timedelta", "level", "latitude", "longitude"]
+        else:
+            shape, chunks = (n, members, steps + 1, n_lat, n_lon), (batch, 1, steps + 1, n_lat, n_lon)
+            dims = ["time", "number", "prediction_timedelta", "latitude", "longitude"]
+        create_array(ofile, var, shape, chunks, np.float32, dims, fill_value=0.0)
+    return variable_channels(variables)
+
+
+def write_unit(ofile: str, var_channels: Dict[str, List[int]], sample: int, member: int, traj: np.ndarray) -> None:
+    """One (sample, member) trajectory ``traj [steps+1, C, H, W]`` -> one chunk per variable (chunk batch 1), generate.py:143-152."""
+    for var, ch in var_channels.items():
+        if len(ch) == 1 and not _has_level(ofile, var):
+            write_chunk(ofile, var, (sample, member, 0, 0, 0), traj[None, None, :, ch[0]])
+        else:
+            write_chunk(ofile, var, (sample, member, 0, 0, 0, 0), traj[None, None][:, :, :, ch])
+
+
+_LEVEL_CACHE: Dict[Tuple[str, str], bool] = {}
+
+
+def _has_level(ofile: str, var: str) -> bool:
+    key = (ofile, var)
+    if key not in _LEVEL_CACHE:
+        with open(os.path.join(ofile, var, ".zarray")) as f:
+            _LEVEL_CACHE[key] = len(json.load(f)["shape"]) == 6
+    return _LEVEL_CACHE[key]
+
+
+# ------------------------------------------------------------------------------------------ reader (tests, eval)
+def read_array(root: str, name: str) -> np.ndarray:
+    """Whole array from an uncompressed v2 store (missing chunks = fill_value)."""
+    with open(os.path.join(root, name, ".zarray")) as f:
+        meta = json.load(f)
+    if meta.get("compressor") is not None or meta.get("filters"):
+        raise NotImplementedError("zarrlite reads uncompressed stores only")
+    shape, chunks, dt = tuple(meta["shape"]), tuple(meta["chunks"]), np.dtype(meta["dtype"])
+    fill = meta.get("fill_value")
+    fill = np.nan if fill == "NaN" else (0 if fill is None else fill)
+    out = np.full(shape, fill, dtype=dt)
+    grid = [range((s + c - 1) // c) for s, c in zip(shape, chunks)] if shape else []
+    for idx in np.ndindex(*[len(g) for g in grid]):
+        p = os.path.join(root, name, ".".join(str(i) for i in idx))
+        if not os.path.exists(p):
+            continue
+        blk = np.fromfile(p, dtype=dt).reshape(chunks)
+        sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, shape))
+        out[sl] = blk[tuple(slice(0, s.stop - s.start) for s in sl)]
+    return out
+
+
+def read_attrs(root: str, name: str = "") -> dict:
+    with open(os.path.join(root, name, ".zattrs")) as f:
+        return json.load(f)

@@ -44,13 +44,13 @@ def test_train_then_generate_cli(tmp_path):
     cfg2 = yaml.safe_load(open(rdir2 / ".hydra" / "config.yaml"))
     assert cfg2["loss"]["_target_"].endswith("CRPSLoss") and cfg2["finetune"]["name"] == "multistep"
     # sCM training (forward-mode tangent through the network) distilling from the trigflow run's EMA weights
-    run(["swift_amd.train", "experiment=era5-swinv2-1.4-scm", f"distill={rdir}", "loss.distillation=true",
+    run(["swift_amd.train", "experiment=era5-swinv2-1.4-scm", f"distill={rdir}",
          "loss.tangent_warmup_kimg=1", "trainer.val_target_interval=4", "data.val_local_batch_size=2"] +
         [o for o in small if o not in ("optimizer=adamw", "trainer.val_ticks=null")] + ["trainer.val_ticks=1"], cwd=str(tmp_path),
         env={"HYDRA_RUN_ID": "002"})  # the experiment's own optimiser: MuonWithAuxAdam
     rdir3 = tmp_path / "results" / "era5-swinv2-1.4-scm" / "002"
     cfg3 = yaml.safe_load(open(rdir3 / ".hydra" / "config.yaml"))
-    assert cfg3["loss"]["_target_"].endswith("SCMLoss") and cfg3["loss"]["distillation"] is True
+    assert cfg3["loss"]["_target_"].endswith("SCMLoss") and cfg3["distill"] == str(rdir)  # distillation flag: train.py:318-319
     assert cfg3["optimizer"]["_target_"].endswith("MuonWithAuxAdam")
     # ... with the in-training validation rollout switched on (4 six-hour steps, dpm solver on the EMA weights)
     val = [yaml.safe_load(l) for l in open(rdir3 / "val_stats.jsonl")]
@@ -66,6 +66,23 @@ def test_train_then_generate_cli(tmp_path):
     assert a.shape == (3, 2, 4, 69, 64, 64) and np.isfinite(a).all()
     assert np.abs(a[:, 0] - a[:, 1])[:, 1:].max() > 0  # members differ after the first step, share the initial state
     assert np.array_equal(a[:, 0, 0], a[:, 1, 0])
+    # the reference's DEFAULT invocation (--dump zarr, generate.py:41-43) + on-device ensemble metrics: same numbers in the
+    # per-variable zarr arrays (level axis for the pressure-level variables), metrics file next to the store
+    import json
+    from swift_amd.utils import zarrlite
+    run(["swift_amd.generate", "--input", str(rdir), "--members", "2", "--steps", "3", "--samples", "3", "--batch", "3",
+         "--metrics"], cwd=str(tmp_path))
+    z = rdir / "output" / "latest" / "output-3i-3s-2m-6h.zarr"
+    names = cfg["data"]["dataset"]["variables"]
+    chans = zarrlite.variable_channels(names)
+    assert os.path.exists(z / ".zmetadata") and sum(len(c) for c in chans.values()) == 69
+    for var, ch in chans.items():
+        arr = zarrlite.read_array(str(z), var)
+        ref = a[:, :, :, ch[0]] if arr.ndim == 5 else a[:, :, :, ch]
+        np.testing.assert_array_equal(arr, ref)
+    met = json.load(open(rdir / "output" / "latest" / "evaluation_metrics.json"))
+    assert len(met) == 3 * 3 * 69 and all(np.isfinite(v) for v in met.values())
+    assert f"crps_{names[0]}_6h" in met and f"ssr_{names[-1]}_18h" in met
 
 
 def test_train_cli_5p6deg_one_by_one_patches(tmp_path):
@@ -95,8 +112,9 @@ def test_bench_contract_line(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     e = dict(os.environ, PYTHONPATH=ROOT)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-steps", "0"],
-                       cwd=str(tmp_path), env=e, capture_output=True, text=True, timeout=900)
+    e.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-steps", "0",
+                        "--batch", "16"], cwd=str(tmp_path), env=e, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -109,4 +127,21 @@ def test_bench_contract_line(tmp_path):
     for r in (d["roofline"], d["attention_roofline"]):
         assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r)
         assert 0.05 < r["frac"] < 1.0 and r["achieved"] == pytest.approx(r["frac"] * r["peak"], rel=1e-6)
-    assert d["value"] == pytest.approx(8 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-3)
+    assert d["value"] == pytest.approx(16 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-3)
+    # round-2 objects: what was collected, the process group, the parity (fp32) engine and the bf16 drift
+    assert d["rccl"]["world"] == 1 and d["checksum"]["units_collected"] == 16 and len(d["checksum"]["per_step_all_units_sum"]) == 2
+    assert np.isfinite(d["checksum"]["last_step_rank0_units_sum"])
+    pe, dr = d["parity_engine"], d["bf16_vs_fp32"]
+    assert pe["dtype"] == "f32" and 0.3 < pe["frac_of_fp32_matrix_peak"] < 1.0 and 0.2 < pe["attention_mfma_frac"] < 1.0
+    assert 0 < dr["rel_l2_after_1_steps"] < dr["rel_l2_after_60_steps"] < 1.0
+    # N ranks asked for, one GPU here: the launcher refuses before touching the device; a mismatching process group exits 3
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=str(tmp_path), env=e,
+                        capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert p2.returncode != 0 and "GPU(s)" in p2.stderr and not p2.stdout.strip()
+    p3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=str(tmp_path),
+                        env=dict(e, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert p3.returncode == 3 and "process group" in p3.stderr
+    p4 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "300"], cwd=str(tmp_path), env=e,
+                        capture_output=True, text=True, timeout=300)
+    assert p4.returncode == 2 and "SWIFTK_MAX_UNITS" in p4.stderr

@@ -93,11 +93,12 @@ WORKER = textwrap.dedent("""
     import os, sys, types, numpy as np, torch
     sys.path.insert(0, %(root)r)
     from swift_amd import dist
-    from swift_amd.generate import create_empty_numpy, rollout_and_save, select_indices
+    from swift_amd.generate import create_empty_numpy, create_empty_zarr, rollout_and_save, select_indices
     from swift_amd.data.era5 import SyntheticERA5Dataset
     from swift_amd.rollout import unit_seed
 
     class FakeEngine:   # stands in for RolloutEngine: a deterministic function of (X0, forcings, seed), CPU only
+        interval = 6
         def stage_forcings(self, ics, steps, device):
             return torch.stack([torch.stack([ds.get_forcings(j + i) for j in ics]) for i in range(steps)])
         def run(self, X0, forc, steps, seeds=None, **kw):
@@ -108,12 +109,15 @@ WORKER = textwrap.dedent("""
             return torch.stack(out, 1)
 
     dist.setup_torch(backend="gloo")
-    ds = SyntheticERA5Dataset([f"v{i}" for i in range(3)], ["f0"], img_resolution=(4, 8), length=40, seed=5)
+    ds = SyntheticERA5Dataset(["t2m", "z_500", "z_850"], ["f0"], img_resolution=(4, 8), length=40, seed=5)
     members, steps = 3, 2
     idx = select_indices(len(ds), 5, steps, 6)
-    ofile = sys.argv[1]
-    dist.run_on_rank0(create_empty_numpy, ofile, len(idx), 3, (4, 8), members, steps)
-    args = types.SimpleNamespace(dump="numpy", batch=4)
+    ofile, dump = sys.argv[1], sys.argv[2]
+    if dump == "numpy":
+        dist.run_on_rank0(create_empty_numpy, ofile, len(idx), 3, (4, 8), members, steps)
+    else:
+        dist.run_on_rank0(create_empty_zarr, ofile, ds, idx, members, steps, 6)
+    args = types.SimpleNamespace(dump=dump, batch=4)
     rollout_and_save(FakeEngine(), ds, idx, members, steps, ofile, torch.device("cpu"), args)
     dist.barrier()
     if torch.distributed.is_initialized():
@@ -129,17 +133,34 @@ def test_generate_sharding_world2_gloo_equals_world1(tmp_path):
     script.write_text(WORKER % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     one = str(tmp_path / "one.npy")
-    subprocess.run([sys.executable, str(script), one], check=True, env={**env, "WORLD_SIZE": "1", "RANK": "0"}, timeout=200)
+    subprocess.run([sys.executable, str(script), one, "numpy"], check=True, env={**env, "WORLD_SIZE": "1", "RANK": "0"}, timeout=200)
     a = np.load(one)
     assert a.shape == (5, 3, 3, 3, 4, 8) and np.isfinite(a).all() and np.abs(a).sum() > 0
     for world in (2, 4):
         out = str(tmp_path / f"w{world}.npy")
         port = str(29600 + (os.getpid() + world) % 300)
-        procs = [subprocess.Popen([sys.executable, str(script), out],
+        procs = [subprocess.Popen([sys.executable, str(script), out, "numpy"],
                                   env={**env, "WORLD_SIZE": str(world), "RANK": str(r), "LOCAL_RANK": str(r), "MASTER_PORT": port})
                  for r in range(world)]
         assert [p.wait(timeout=200) for p in procs] == [0] * world
         np.testing.assert_array_equal(a, np.load(out))
+    # the reference's default dump (zarr, utils/io.py:161-235), two ranks: per-variable arrays with the level axis, read back
+    # by the stdlib reader, must hold the same numbers as the npy store
+    from swift_amd.utils import zarrlite
+    zout = str(tmp_path / "w2.zarr")
+    port = str(29600 + (os.getpid() + 7) % 300)
+    procs = [subprocess.Popen([sys.executable, str(script), zout, "zarr"],
+                              env={**env, "WORLD_SIZE": "2", "RANK": str(r), "LOCAL_RANK": str(r), "MASTER_PORT": port})
+             for r in range(2)]
+    assert [p.wait(timeout=200) for p in procs] == [0, 0]
+    t2m, z = zarrlite.read_array(zout, "t2m"), zarrlite.read_array(zout, "z")
+    assert t2m.shape == (5, 3, 3, 4, 8) and z.shape == (5, 3, 3, 2, 4, 8)
+    np.testing.assert_array_equal(t2m, a[:, :, :, 0])
+    np.testing.assert_array_equal(z, a[:, :, :, 1:3])
+    assert zarrlite.read_attrs(zout, "z")["_ARRAY_DIMENSIONS"] == ["time", "number", "prediction_timedelta", "level", "latitude",
+                                                                    "longitude"]
+    assert zarrlite.read_array(zout, "prediction_timedelta").tolist() == [0, 6 * 3600 * 10**9, 12 * 3600 * 10**9]
+    assert zarrlite.read_array(zout, "time").shape == (5,) and zarrlite.read_array(zout, "level").tolist() == [0, 1]
 
 
 DDP_WORKER = textwrap.dedent("""
@@ -245,3 +266,93 @@ def test_lr_schedule_and_param_groups():
     assert opt.param_groups[0]["lr"] == pytest.approx(1e-5 + 0.5 * (1e-3 - 1e-5) * (1 + math.cos(math.pi * 0.5)))
     tr._set_lr(10_000)
     assert opt.param_groups[0]["lr"] == pytest.approx(1e-5)
+
+
+def test_zarrlite_store_layout_and_roundtrip(tmp_path):
+    """The stdlib zarr-v2 writer: reference layout (utils/io.py:161-235), consolidated metadata, chunk files = whole units."""
+    import json
+    from swift_amd.utils import zarrlite
+    names = ["2m_temperature", "geopotential_500", "geopotential_850", "temperature_850", "mean_sea_level_pressure"]
+    assert zarrlite.compress_variables(names) == {"2m_temperature": [], "geopotential": [500, 850], "temperature": [850],
+                                                  "mean_sea_level_pressure": []}
+    assert zarrlite.variable_channels(names) == {"2m_temperature": [0], "geopotential": [1, 2], "temperature": [3],
+                                                 "mean_sea_level_pressure": [4]}
+    root = str(tmp_path / "o.zarr")
+    times = np.array(["2020-01-01T00", "2020-01-03T12"], dtype="datetime64[ns]")
+    ch = zarrlite.create_forecast_store(root, names, times, np.linspace(-90, 90, 4), np.arange(8) * 45.0, members=2, steps=3,
+                                        interval=12)
+    rng = np.random.default_rng(0)
+    traj = rng.standard_normal((2, 2, 4, 5, 4, 8)).astype(np.float32)
+    for s_ in range(2):
+        for m in range(2):
+            if (s_, m) != (1, 1):  # one unit left unwritten: reads back as fill_value 0
+                zarrlite.write_unit(root, ch, s_, m, traj[s_, m])
+    zarrlite.consolidate(root)
+    meta = json.load(open(os.path.join(root, ".zmetadata")))["metadata"]
+    assert meta["geopotential/.zarray"]["chunks"] == [1, 1, 4, 2, 4, 8] and meta["geopotential/.zarray"]["compressor"] is None
+    assert meta["temperature/.zarray"]["shape"] == [2, 2, 4, 1, 4, 8]  # a single pressure level still carries the level axis
+    assert meta["2m_temperature/.zattrs"]["_ARRAY_DIMENSIONS"] == ["time", "number", "prediction_timedelta", "latitude", "longitude"]
+    assert sorted(os.listdir(os.path.join(root, "geopotential"))) == [".zarray", ".zattrs", "0.0.0.0.0.0", "0.1.0.0.0.0", "1.0.0.0.0.0"]
+    g = zarrlite.read_array(root, "geopotential")
+    np.testing.assert_array_equal(g[0], traj[0][:, :, 1:3])
+    np.testing.assert_array_equal(g[1, 0], traj[1, 0][:, 1:3])
+    assert (g[1, 1] == 0).all()
+    np.testing.assert_array_equal(zarrlite.read_array(root, "mean_sea_level_pressure")[0, 1], traj[0, 1][:, 4])
+    assert zarrlite.read_array(root, "time").astype("datetime64[ns]").tolist() == times.tolist()
+    assert zarrlite.read_array(root, "prediction_timedelta").tolist() == [0, 12 * 3600 * 10**9, 24 * 3600 * 10**9, 36 * 3600 * 10**9]
+
+
+def test_finetune_keeps_its_own_optimizer_and_cli_floats():
+    """Hydra keys a defaults entry by group AND package: the experiment's `override /optimizer: muon` must not reach the
+    `/optimizer: adamw` that finetune/multistep.yaml packages at finetune.optimizer (reference finetune = AdamW lr 1e-5)."""
+    from swift_amd.config import compose
+    c = compose(CFG, "train", ["finetune=multistep"])
+    assert c.optimizer._target_.endswith("MuonWithAuxAdam")
+    assert c.finetune.optimizer._target_ == "torch.optim.AdamW" and c.finetune.optimizer.lr == 1e-5
+    assert "adam_lr" not in c.finetune.optimizer
+    c = compose(CFG, "train", ["finetune=multistep", "optimizer@finetune.optimizer=muon"])  # ... unless addressed explicitly
+    assert c.finetune.optimizer._target_.endswith("MuonWithAuxAdam")
+    # YAML 1.2 floats on the command line and in files (PyYAML alone reads `1e-4` as a string)
+    c = compose(CFG, "train", ["optimizer=adamw", "optimizer.lr=1e-4", "trainer.lr_min_factor=3E-4", "resume=007", "seed=12"])
+    assert c.optimizer.lr == 1e-4 and isinstance(c.optimizer.lr, float) and c.trainer.lr_min_factor == 3e-4
+    assert c.resume == "007" and c.seed == 12
+
+
+def test_distill_sets_scm_distillation_flag():
+    """reference train.py:318-319."""
+    from swift_amd.config import compose
+    from swift_amd.train import apply_distill_flag
+    c = apply_distill_flag(compose(CFG, "train", ["distill=/some/teacher/run"]))
+    assert c.loss._target_.endswith("SCMLoss") and c.loss.distillation is True
+    c = apply_distill_flag(compose(CFG, "train", []))
+    assert not c.loss.get("distillation", False)
+    c = apply_distill_flag(compose(CFG, "train", ["experiment=era5-swinv2-1.4-trigflow", "distill=/some/teacher/run"]))
+    assert not c.loss.get("distillation", False)  # TrigFlowLoss has no such switch
+
+
+RUNID_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    from swift_amd import dist
+    from swift_amd.train import shared_run_id
+    rid = shared_run_id()
+    open(sys.argv[1] + "." + os.environ["RANK"], "w").write(rid + " " + os.environ["HYDRA_RUN_ID"])
+    dist.barrier()
+    import torch.distributed as td
+    td.destroy_process_group()
+""")
+
+
+@pytest.mark.timeout(300)
+def test_run_id_is_shared_across_ranks(tmp_path):
+    """Ranks whose own HYDRA_RUN_ID would differ (unset + clocks straddling a second) end up with rank 0's: one run
+    directory, one sampler seed (train.py:154)."""
+    script = tmp_path / "rid_worker.py"
+    script.write_text(RUNID_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", WORLD_SIZE="2", MASTER_PORT=str(29500 + os.getpid() % 90))
+    out = str(tmp_path / "rid")
+    procs = [subprocess.Popen([sys.executable, str(script), out],
+                              env={**env, "RANK": str(r), "LOCAL_RANK": str(r), "HYDRA_RUN_ID": ["20260101_000000", "20260101_000001"][r]})
+             for r in range(2)]
+    assert [p.wait(timeout=200) for p in procs] == [0, 0]
+    assert open(out + ".0").read() == open(out + ".1").read() == "20260101_000000 20260101_000000"
