@@ -346,6 +346,32 @@ typedef struct swiftk_model {
     const swiftk_layer* layers_host; /* HOST array of `depth` entries           */
 } swiftk_model;
 
+/*
+ * The optimisation step of the training loop (trainer.py:219-247) in one pass: nan_to_num of the (all-reduced) gradients,
+ * the torch.optim.Adam / AdamW update (torch/optim/adam.py single-tensor rule) and the EMA rule
+ * p_ema <- p_net.lerp(p_ema, ema_beta).  `chunks` is a DEVICE table, one entry per <= 16384 consecutive elements of one
+ * parameter tensor; gradients and both moments are flat fp32 buffers indexed by flat_off.  `hyper_host` is read on the host.
+ */
+#define SWIFTK_OPT_MAX_GROUPS 8
+typedef struct {
+    float* p;          /* parameter elements of this chunk (fp32)                  */
+    float* ema;        /* the EMA copy's elements, or NULL                         */
+    int64_t flat_off;  /* offset of the chunk in grad / exp_avg / exp_avg_sq        */
+    int32_t n;         /* elements in the chunk                                    */
+    int32_t group;     /* optimizer.param_groups index (lr / weight_decay)         */
+} swiftk_opt_chunk;
+typedef struct {
+    float lr[SWIFTK_OPT_MAX_GROUPS];
+    float weight_decay[SWIFTK_OPT_MAX_GROUPS];
+    float step_size[SWIFTK_OPT_MAX_GROUPS]; /* lr / (1 - beta1^t)                      */
+    float beta1, beta2, eps;
+    float bias2_sqrt;                       /* sqrt(1 - beta2^t)                        */
+    float ema_beta;
+    int32_t decoupled;                      /* 1: AdamW (p *= 1 - lr wd), 0: Adam (g += wd p) */
+} swiftk_opt_hyper;
+int swiftk_adamw_ema_step(const swiftk_opt_chunk* chunks, int n_chunks, float* grad_flat, float* exp_avg_flat,
+                          float* exp_avg_sq_flat, const swiftk_opt_hyper* hyper_host, void* stream);
+
 /* Bytes of scratch swiftk_swinv2_forward needs for batch B (0 on a bad model). */
 int64_t swiftk_workspace_bytes(const swiftk_model* m, int B);
 

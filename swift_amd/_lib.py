@@ -32,6 +32,19 @@ class Layer(C.Structure):
                 ("qkv_w", "wo_w", "w1_w", "w2_w", "scale", "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
 
 
+OPT_MAX_GROUPS = 8
+
+
+class OptChunk(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("ema", C.c_void_p), ("flat_off", C.c_int64), ("n", C.c_int32), ("group", C.c_int32)]
+
+
+class OptHyper(C.Structure):
+    _fields_ = [("lr", C.c_float * OPT_MAX_GROUPS), ("weight_decay", C.c_float * OPT_MAX_GROUPS),
+                ("step_size", C.c_float * OPT_MAX_GROUPS), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("bias2_sqrt", C.c_float), ("ema_beta", C.c_float), ("decoupled", C.c_int32)]
+
+
 class Model(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ("dtype", "H", "W", "p1", "p2", "in_ch", "out_ch", "depth", "dim", "heads", "mlp",
@@ -85,6 +98,7 @@ _SIGS = {
     "swiftk_trigflow_loss": ([_p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _i, _i, _i, _f, _p], _i),
     "swiftk_axpby_per_sample": ([_p, _p, _p, _p, _p, _i, _l, _p], _i),
     "swiftk_channel_axpy": ([_p, _p, _p, _p, _i, _i, _l, _p], _i),
+    "swiftk_adamw_ema_step": ([_p, _i, _p, _p, _p, C.POINTER(OptHyper), _p], _i),
     "swiftk_profile_gemm": ([_i, _l], _i),
     "swiftk_set_tuning": ([_i, _i], _i),
     "swiftk_profile_collect": ([C.POINTER(C.c_double), C.POINTER(C.c_int64)], _i),

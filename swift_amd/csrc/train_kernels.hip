@@ -569,6 +569,43 @@ __global__ __launch_bounds__(256) void ensemble_sums_kernel(const float* __restr
                                                                            red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
+
+// --------------------------------------------------------------------------------- optimiser step (trainer.py:219-247)
+// Gradient sanitising (nan_to_num), Adam / AdamW update and the EMA rule in ONE pass over the parameters: reads g, p, m, v,
+// p_ema and writes p, m, v, p_ema (36 B per parameter) where the reference runs nan_to_num, ~10 _foreach passes of
+// torch.optim.AdamW and a lerp per tensor.  Work arrives as a chunk table (one block per <= 16384-element chunk of one
+// parameter tensor): parameters and EMA copies stay ordinary separately-allocated tensors, gradients and moments are flat.
+__global__ __launch_bounds__(256) void adamw_ema_kernel(const swiftk_opt_chunk* __restrict__ chunks, float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, swiftk_opt_hyper h) {
+    const swiftk_opt_chunk c = chunks[blockIdx.x];
+    float* __restrict__ p = c.p;
+    float* __restrict__ e = c.ema;
+    const float lr = h.lr[c.group], wd = h.weight_decay[c.group], step_size = h.step_size[c.group];
+    const float decay = h.decoupled ? 1.0f - lr * wd : 1.0f;
+    const float l2 = h.decoupled ? 0.0f : wd;
+    const float omb = 1.0f - h.ema_beta;
+    for (int i = threadIdx.x; i < c.n; i += 256) {
+        float gi = g[c.flat_off + i];
+        // torch.nan_to_num(nan=0, posinf=1e5, neginf=-1e5)
+        gi = gi != gi ? 0.0f : (gi == INFINITY ? 1e5f : (gi == -INFINITY ? -1e5f : gi));
+        g[c.flat_off + i] = gi;
+        float pi = p[i] * decay;
+        gi += l2 * pi;                                   // Adam (not W): L2 term joins the gradient
+        float mi = m[c.flat_off + i], vi = v[c.flat_off + i];
+        mi += (gi - mi) * (1.0f - h.beta1);              // exp_avg.lerp_(grad, 1 - beta1)
+        vi = vi * h.beta2 + (1.0f - h.beta2) * gi * gi;
+        const float denom = sqrtf(vi) / h.bias2_sqrt + h.eps;
+        pi -= step_size * (mi / denom);
+        p[i] = pi;
+        m[c.flat_off + i] = mi;
+        v[c.flat_off + i] = vi;
+        if (e) {                                          // p_ema <- p_net.lerp(p_ema, beta): torch's two-sided lerp formula
+            const float ei = e[i];
+            e[i] = h.ema_beta < 0.5f ? pi + h.ema_beta * (ei - pi) : ei - (ei - pi) * omb;
+        }
+    }
+}
+
 }  // namespace
 
 #define DT_SWITCH(dtype, CALL_BF16, CALL_F32) \
@@ -789,6 +826,15 @@ extern "C" int swiftk_ensemble_sums(const float* pred, const float* y, const flo
         hipLaunchKernelGGL(ensemble_sums_kernel<16>, grid, dim3(256), 0, st, pred, y, w_lat, out, N, V, H, W);
     else
         hipLaunchKernelGGL(ensemble_sums_kernel<64>, grid, dim3(256), 0, st, pred, y, w_lat, out, N, V, H, W);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_adamw_ema_step(const swiftk_opt_chunk* chunks, int n_chunks, float* grad_flat, float* exp_avg_flat,
+                                     float* exp_avg_sq_flat, const swiftk_opt_hyper* hyper_host, void* stream) {
+    if (!chunks || !grad_flat || !exp_avg_flat || !exp_avg_sq_flat || !hyper_host || n_chunks <= 0) return SWIFTK_EINVAL;
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream), chunks, grad_flat,
+                       exp_avg_flat, exp_avg_sq_flat, *hyper_host);
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

@@ -194,8 +194,14 @@ class SwinTrainEngine:
         return (out, logvar, ctx) if want_logvar else (out, ctx)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, ctx, dout: torch.Tensor, dlogvar: Optional[torch.Tensor] = None, need_input_grad: Sequence[bool] = ()):
-        """Accumulate parameter gradients into .grad; return input gradients for the sources flagged in need_input_grad."""
+    def backward(self, ctx, dout: torch.Tensor, dlogvar: Optional[torch.Tensor] = None, need_input_grad: Sequence[bool] = (),
+                 grads_final=None):
+        """Accumulate parameter gradients into .grad; return input gradients for the sources flagged in need_input_grad.
+
+        ``grads_final`` (callable taking a list of parameters): this is the LAST backward pass of the iteration, so a
+        parameter's gradient is complete once this pass has added its contribution -- the callable is told layer by
+        layer, and the data-parallel wrapper starts that slice's all-reduce while the remaining layers still compute
+        (what DDP's bucketed all-reduce does for the reference, trainer.py:76-84)."""
         m = self.m
         dev = dout.device
         B, M = ctx["B"], ctx["M"]
@@ -219,6 +225,8 @@ class SwinTrainEngine:
         gh_pad = torch.empty(self.kpo, d, dtype=torch.float32, device=dev)
         self._wgrad(_transpose(dtok_h, M, self.kpo), _transpose(ctx["xT_final"], M, d), self.kpo, d, gh_pad, accumulate=False)
         G(m.head.head[0].weight).add_(gh_pad[:po])
+        if grads_final is not None:
+            grads_final(list(m.head.parameters()))
         dmod = torch.zeros(B, m.depth * 4 * d, dtype=torch.float32, device=dev)
         for i in reversed(range(m.depth)):
             att, ff = m.transformer.layers[i]
@@ -260,6 +268,8 @@ class SwinTrainEngine:
             _gemm(dqkv, W["qkv_t"], dxt)
             self._wgrad(_transpose(dqkv, M, 3 * d), _transpose(A["xT_in"], M, d), 3 * d, d, G(att.to_qkv.weight))
             ops.axpby(1.0, dx, 1.0, dxt, out=dx)
+            if grads_final is not None:  # everything of layer i except its modulation Linears (those follow in _embed_bwd)
+                grads_final([p for n, p in m.transformer.layers[i].named_parameters() if "modulation" not in n])
         # ---- patch embedding: x0 = ape @ Wpe^T + b + pos
         G(m.pos_embed).view(ntok, d)  # ensure buffer exists
         check(L.swiftk_colsum(dx.data_ptr(), d, G(m.patch_embed.emb.bias).data_ptr(), M, d, 0, _s()), "swiftk_colsum")

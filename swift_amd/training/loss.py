@@ -145,7 +145,7 @@ class TrigFlowLoss(_LossBase):
                     dF.mul_(g)
                     if dlv is not None:
                         dlv.mul_(g)
-                eng.backward(ctx, dF, dlv)
+                eng.backward(ctx, dF, dlv, grads_final=getattr(net, "reduce_params", None))
 
         return _Deferred.apply(self._anchor(dev), Runner)
 
@@ -231,7 +231,7 @@ class SCMLoss(_LossBase):
                     dFx.mul_(g)
                     if dlv is not None:
                         dlv.mul_(g)
-                eng.backward(ctx, dFx, dlv)
+                eng.backward(ctx, dFx, dlv, grads_final=getattr(net, "reduce_params", None))
 
         self._last = dict(dF=dF, Fx=Fx)  # kept for tests / diagnostics
         return _Deferred.apply(self._anchor(dev), Runner)
@@ -303,7 +303,9 @@ class CRPSLoss(_LossBase):
                         check(lib().swiftk_channel_axpy(dout.data_ptr(), None, gcond.data_ptr(), (-sd * coef).data_ptr(), B, C, hw,
                                                         torch.cuda.current_stream().cuda_stream), "swiftk_channel_axpy")
                     need = i > 0
-                    dins = eng.backward(ctx, dout, None, need_input_grad=(False, need, False))
+                    last = (e == E - 1 and i == 0)  # the final backward pass of the iteration: gradients complete layer by layer
+                    dins = eng.backward(ctx, dout, None, need_input_grad=(False, need, False),
+                                        grads_final=getattr(net, "reduce_params", None) if last else None)
                     if need:
                         gcond = dins[1] if gcond is None else ops.axpby(1.0, gcond, 1.0, dins[1])
 

@@ -1,10 +1,12 @@
 """Training loop (mirrors reference src/swift/training/trainer.py: same constructor kwargs, LR schedule, gradient
 sanitising, EMA rule, tick bookkeeping and checkpoint format).
 
-Data parallelism: one process per GPU; after ``loss.backward()`` the fp32 gradients -- which live in ONE flat buffer
-that every ``param.grad`` is a view of -- are averaged with a single RCCL all-reduce over xGMI (904 MB at Swift-B,
-~1-2 % of a multistep-CRPS iteration, so overlap with the backward pass is not worth bucket bookkeeping).  The reference
-wraps the net in ``DistributedDataParallel(static_graph=True)`` (trainer.py:76-84); ``GradAllReduce`` keeps its
+Data parallelism: one process per GPU; the fp32 gradients live in ONE flat buffer that every ``param.grad`` is a view of
+and are averaged over RCCL / xGMI in per-layer slices of it: the explicit backward pass announces a layer's parameters as
+soon as their gradients are final (``SwinTrainEngine.backward(grads_final=...)``, last backward pass of the iteration
+only), ``GradAllReduce.reduce_params`` starts that slice's all-reduce asynchronously under the remaining layers, and
+``sync()`` waits and reduces the rest (904 MB at Swift-B in 14 collectives).  The reference wraps the net in
+``DistributedDataParallel(static_graph=True)`` (trainer.py:76-84), whose buckets do the same; ``GradAllReduce`` keeps its
 ``.module`` attribute and call signature so the losses' ``net.module`` accesses (loss.py:213) work unchanged.
 """
 from __future__ import annotations
@@ -30,6 +32,7 @@ class GradAllReduce(torch.nn.Module):
         super().__init__()
         self.module = module
         self._flat = None
+        self._pending, self._ranges = [], []
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
@@ -48,12 +51,57 @@ class GradAllReduce(torch.nn.Module):
 
     def zero_grad_flat(self):
         self.flatten_grads().zero_()
+        self._pending, self._ranges = [], []
+
+    @staticmethod
+    def _world():
+        return tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1
+
+    def _reduce(self, t, async_op=False):
+        # RCCL averages in the collective; gloo (CPU tests) has no AVG: sum, then scale
+        if tdist.get_backend() == "nccl":
+            return tdist.all_reduce(t, op=tdist.ReduceOp.AVG, async_op=async_op), False
+        return tdist.all_reduce(t, op=tdist.ReduceOp.SUM, async_op=async_op), True
+
+    def reduce_params(self, params):
+        """The gradients of ``params`` are final for this iteration: start their all-reduce now (one collective per run of
+        neighbouring parameters in the flat buffer), overlapping the rest of the backward pass.  ``sync()`` waits for
+        these and reduces whatever was never announced."""
+        if self._world() == 1 or self._flat is None or not params:
+            return
+        flat = self._flat
+        spans = sorted(((p.grad.data_ptr() - flat.data_ptr()) // 4, p.numel()) for p in params)
+        runs = []  # maximal runs of NEIGHBOURING announced parameters: what lies between two runs is not final yet
+        for o, n in spans:
+            if runs and runs[-1][1] == o:
+                runs[-1][1] = o + n
+            else:
+                runs.append([o, o + n])
+        for lo, hi in runs:
+            if any(lo < b and a < hi for a, b in self._ranges):  # never reduce an element twice
+                continue
+            handle, scale = self._reduce(flat[lo:hi], async_op=True)
+            self._pending.append((handle, lo, hi, scale))
+            self._ranges.append((lo, hi))
 
     def sync(self):
         flat = self.flatten_grads()
-        if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
-            tdist.all_reduce(flat, op=tdist.ReduceOp.SUM)
-            flat.div_(tdist.get_world_size())
+        world = self._world()
+        if world > 1:
+            pending, self._pending = getattr(self, "_pending", []), []
+            done = sorted(getattr(self, "_ranges", []))
+            self._ranges = []
+            pos = 0
+            for a, b in done + [(flat.numel(), flat.numel())]:  # the complement of what the backward pass announced
+                if a > pos:
+                    _, scale = self._reduce(flat[pos:a])
+                    if scale:
+                        flat[pos:a].div_(world)
+                pos = max(pos, b)
+            for handle, lo, hi, scale in pending:
+                handle.wait()
+                if scale:
+                    flat[lo:hi].div_(world)
         return flat
 
 
@@ -117,6 +165,7 @@ class Trainer:
         self.total_kimg, self.ema_halflife_kimg, self.ema_rampup_ratio = total_kimg, ema_halflife_kimg, ema_rampup_ratio
         self.kimg_per_tick, self.checkpoint_ticks = kimg_per_tick, checkpoint_ticks
         self.global_batch_size = None
+        self._fused = None  # FusedAdamEMA once the flat gradient buffer exists (False: optimiser not covered)
 
     # ------------------------------------------------------------------ one iteration
     def _get_batch(self, it):
@@ -141,20 +190,37 @@ class Trainer:
                 lo = base * self.lr_min_factor
                 g["lr"] = lo + 0.5 * (base - lo) * (1 + math.cos(math.pi * prog))
 
+    def _fused_optim(self, flat):
+        """Adam / AdamW on device parameters: the whole step (sanitise, update, EMA) is one HIP kernel."""
+        if self._fused is None:
+            from . import fused_optim
+            self._fused = False
+            if flat.is_cuda and fused_optim.supported(self.optimizer):
+                net_p = [p for p in self.net.parameters() if p.requires_grad]
+                ema_of = {n: e for n, e in self.ema.named_parameters()}
+                ema_p = [ema_of[n] for n, p in self.net.named_parameters() if p.requires_grad]
+                if len(net_p) == len(list(self.net.parameters())):  # (a frozen parameter would still need its EMA lerp)
+                    self._fused = fused_optim.FusedAdamEMA(self.optimizer, net_p, ema_p, flat)
+        return self._fused
+
     def _backward_step(self, global_nimg: int, loss: torch.Tensor):
         self._set_lr(global_nimg)
         loss.backward()
         flat = self.ddp.sync()
-        torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)  # trainer.py:223-231
-        self.optimizer.step()
         half = self.ema_halflife_kimg * 1000
         if self.ema_rampup_ratio is not None:
             half = min(half, global_nimg * self.ema_rampup_ratio)
         beta = 0.5 ** (self.global_batch_size / max(half, 1e-8))
-        with torch.no_grad():  # p_ema = lerp(p_net -> p_ema, beta)  (trainer.py:245-246)
-            pe, pn = list(self.ema.parameters()), [p.detach() for p in self.net.parameters()]
-            torch._foreach_mul_(pe, beta)
-            torch._foreach_add_(pe, pn, alpha=1.0 - beta)
+        fused = self._fused_optim(flat)
+        if fused:
+            fused.step(beta)  # trainer.py:223-246 in one pass over the parameters
+            return
+        # other optimisers (MuonWithAuxAdam, anything a config names): the reference's sequence on torch ops
+        torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)  # trainer.py:223-231
+        self.optimizer.step()
+        with torch.no_grad():  # p_ema = p_net.lerp(p_ema, beta)  (trainer.py:245-246)
+            for pe, pn in zip(self.ema.parameters(), self.net.parameters()):
+                pe.copy_(pn.detach().lerp(pe, beta))
 
     def train_step(self, x, t, idx, delta, global_nimg: int, steps: int = 1):
         """One optimisation step on a prepared batch; returns the (rank-local) loss value."""

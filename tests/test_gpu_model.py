@@ -251,3 +251,58 @@ def test_swiftb_full_step_vs_reference_golden(dev):
     assert e32 < FP32_TOL
     assert float(y.double().norm()) == pytest.approx(float(g["stats"][3]), rel=1e-4)
     assert e16 < 1.25 * float(g["bf16_autocast_rel"])  # reference's own bf16 path: 1.9e-1 at depth 12
+
+
+def test_swiftb_dpm_2s_vs_reference_golden(dev):
+    """BASELINE configs[2] at full size: dpm_solver_2s, num_steps 20 = 39 chained Swift-B evaluations of one sample, fp32 engine
+    vs the reference's output (tests/golden/swiftb_long.npz).  39 evaluations compound the per-evaluation distance (~1e-5)."""
+    from swift_amd.generating.factory import sampler_factory
+    g = load_golden("swiftb_long")
+    seed = int(g["seed"])
+    net, _ = build(SWIFTB, seed, dev)
+    cond, lat = det_normal((1, 72, 128, 256), seed, "cond"), det_normal((1, 69, 128, 256), seed, "lat")
+    y = sampler_factory("2s", net, num_steps=20, sigma_min=0.02, sigma_max=200.0, auxiliary=0.6)(cond.to(dev), latents=lat.to(dev))
+    e = rel_l2(y[0, ::4, ::8, ::8].cpu(), g["y2s_sub"])
+    print(f"Swift-B dpm_solver_2s (39 evaluations) vs reference: fp32 rel-L2 {e:.3e}")
+    assert e < 3 * FP32_TOL
+    assert float(y.double().norm()) == pytest.approx(float(g["y2s_norm"]), rel=3e-4)
+
+
+def test_swiftb_rollout_60_steps_vs_reference_golden(dev):
+    """BASELINE configs[3], one unit at full length: 60 autoregressive six-hour steps of Swift-B through RolloutEngine.run.
+    fp32 engine vs the reference's trajectory (generate.py:97-131 driven by hand, tools/make_golden.py::fx_swiftb_long) at every
+    lead step -- the north star's "within 1e-4 relative L2 ... on the 60-step rollout" -- and the bf16 engine's drift from
+    it, which is reported with a documented bound (bf16 is the throughput configuration, not the parity one)."""
+    from swift_amd.data.era5 import SyntheticERA5Dataset
+    from swift_amd.rollout import RolloutEngine
+    g = load_golden("swiftb_long")
+    seed, steps = int(g["seed"]), 60
+    net, _ = build(SWIFTB, seed, dev)
+    bank = det_normal((steps + 2, 3, 128, 256), seed, "forc", std=1.5, mean=0.5)
+
+    class DS(SyntheticERA5Dataset):
+        def get_forcings(self, idx):
+            return bank[int(idx)].clone()
+
+    ds = DS([f"v{i}" for i in range(69)], ["f0", "f1", "f2"], img_resolution=(128, 256), length=steps + 8, seed=seed)
+    ds.x_means, ds.x_stds = g["x_mean"], g["x_std"]
+    ds.t_stds = {6: g["t_std6"]}
+    ds.t_means = {6: np.zeros_like(g["t_std6"])}
+    X0 = det_normal((1, 69, 128, 256), seed, "X0")
+    ref = torch.from_numpy(g["traj_sub"])
+    errs = {}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        eng = RolloutEngine(net, ds, interval=6, denoise_dtype=dt)
+        forc = eng.stage_forcings([0], steps, dev)
+        traj = eng.run(X0.to(dev), forc, steps, latents=lambda i: det_normal((1, 69, 128, 256), seed, f"lat{i}").to(dev))
+        sub = traj[0, :, ::4, ::8, ::8].cpu()
+        errs[name] = [rel_l2(sub[i], ref[i]) for i in range(steps + 1)]
+        if name == "fp32":
+            nrm = [float(traj[0, i].double().norm()) for i in (1, 30, 60)]
+            assert nrm == pytest.approx([float(g["traj_norm"][i]) for i in (1, 30, 60)], rel=1e-4)
+    e32, e16 = errs["fp32"], errs["bf16"]
+    print("60-step Swift-B rollout vs reference, rel-L2 of the physical state at lead steps 1 / 10 / 30 / 60: "
+          f"fp32 {e32[1]:.2e} / {e32[10]:.2e} / {e32[30]:.2e} / {e32[60]:.2e}; bf16 {e16[1]:.2e} / {e16[10]:.2e} / {e16[30]:.2e} / {e16[60]:.2e}")
+    assert e32[0] < 1e-6 and max(e32) < FP32_TOL
+    # bf16 drift bound: the physical state is dominated by its mean (|x_mean| ~ 2 sigma), which damps the relative distance
+    assert max(e16) < 5e-2

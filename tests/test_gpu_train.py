@@ -263,12 +263,12 @@ def test_train_engine_gradients_vs_oracle_autograd(dev):
         e = rel_l2(g, gr)
         worst = max(worst, e)
         print(f"{k:55s} cos {cos:.4f} rel-L2 {e:.3e}")
-        assert cos > 0.97, (k, cos, e)
+        assert cos > 0.99, (k, cos, e)  # measured: >= 0.994 for every one of the 40 tensors
     for gi, ref in ((dins[0], xo.grad), (dins[1], co.grad[:, :nv])):
         gg, rr = gi.cpu().flatten().double(), ref.flatten().double()
         cos = float((gg @ rr) / (gg.norm() * rr.norm()))
         print(f"input grad: cos {cos:.4f} rel-L2 {rel_l2(gg, rr):.3e}")
-        assert cos > 0.97
+        assert cos > 0.99
     assert dins[2] is None
 
 
@@ -293,7 +293,7 @@ def _build_pair(dev, seed, logvar=False, depth=2):
     return net.to(dev), OracleNet(ocfg, st, nv, nv + nf), st
 
 
-def _grad_report(net, st, floor=0.97):
+def _grad_report(net, st, floor=0.99):
     worst = 1.0
     for k, p in net.named_parameters():
         g, gr = p.grad.float().cpu().flatten().double(), st[k].grad.flatten().double()
@@ -330,10 +330,11 @@ def test_trigflow_loss_and_grads_vs_oracle(dev):
     ref = oloss.trigflow_loss(onet, x, tau, z, L.w_var.cpu(), L.w_lat.cpu(), 1.0, condition=cond, auxiliary=aux, return_logvar=True)
     ref.backward()
     print(f"trigflow loss {float(loss):.6f} vs oracle {float(ref):.6f}; worst grad cosine {_grad_report(net, st):.4f}")
-    assert float(loss) == pytest.approx(float(ref), rel=2e-2)
+    assert float(loss) == pytest.approx(float(ref), rel=1e-3)  # measured 6e-5 (bf16 operands vs fp32 autograd)
 
 
-def test_crps_multistep_loss_and_grads_vs_oracle(dev):
+@pytest.mark.parametrize("steps", [3, 4])  # 4 = BASELINE configs[4] (finetune/multistep.yaml's last interval)
+def test_crps_multistep_loss_and_grads_vs_oracle(dev, steps):
     from oracle import loss as oloss
     from oracle.rollout import Stats
     from swift_amd.training.loss import CRPSLoss
@@ -342,7 +343,7 @@ def test_crps_multistep_loss_and_grads_vs_oracle(dev):
     net, onet, st = _build_pair(dev, 32)
     ds = _dataset(32)
     L = CRPSLoss(ds, sigma_data=1.0, ensemble_size=2, alpha=0.95).to(dev)
-    B, steps = 2, 3
+    B = 2
     target, cond = det_normal((B, 69, 64, 64), 32, "t"), det_normal((B, 72, 64, 64), 32, "c")
     aux, idx = torch.tensor([0.6, 0.6]), [0, 4]
     lat = [[det_normal((B, 69, 64, 64), 32, f"l{e}{i}") for i in range(steps)] for e in range(2)]
@@ -355,8 +356,8 @@ def test_crps_multistep_loss_and_grads_vs_oracle(dev):
     forc = lambda i: torch.stack([ds.get_forcings(j + i) for j in idx], 0)
     ref = oloss.crps_multistep_loss(onet, stats, target, cond, aux, forc, lat, L.w_var.cpu(), L.w_lat.cpu(), steps=steps, alpha=0.95)
     ref.backward()
-    print(f"CRPS(steps=3) loss {float(loss):.6f} vs oracle {float(ref):.6f}; worst grad cosine {_grad_report(net, st, 0.95):.4f}")
-    assert float(loss) == pytest.approx(float(ref), rel=2e-2)
+    print(f"CRPS(steps={steps}) loss {float(loss):.6f} vs oracle {float(ref):.6f}; worst grad cosine {_grad_report(net, st, 0.999):.4f}")
+    assert float(loss) == pytest.approx(float(ref), rel=2e-3)  # measured 4.4e-4 at steps = 3
 
 
 def test_network_tangent_vs_oracle_jvp(dev):
@@ -405,8 +406,8 @@ def test_scm_loss_and_grads_vs_oracle(dev):
     ref = oloss.scm_loss(onet, x, tau, z, L.w_var.cpu(), L.w_lat.cpu(), step=1200, sigma_data=1.0, tangent_warmup_kimg=3,
                          condition=cond, auxiliary=aux, return_logvar=True)
     ref.backward()
-    print(f"sCM loss {float(loss):.6f} vs oracle {float(ref):.6f}; worst grad cosine {_grad_report(net, st, 0.95):.4f}")
-    assert float(loss) == pytest.approx(float(ref), rel=2e-2)
+    print(f"sCM loss {float(loss):.6f} vs oracle {float(ref):.6f}; worst grad cosine {_grad_report(net, st, 0.999):.4f}")
+    assert float(loss) == pytest.approx(float(ref), rel=1e-3)  # measured 6e-6
     # bf16 tangent pass (the trainer's autocast): same loss within bf16 noise
     L.jvp_dtype = torch.bfloat16
     with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -475,3 +476,16 @@ def test_trainer_steps_ema_and_checkpoint(dev, tmp_path, monkeypatch):
     tr._save_checkpoint(3000)
     state = torch.load(tmp_path / "checkpoints" / "checkpoint-000003.pt", weights_only=True)
     assert set(state) == {"ema", "net", "optimizer", "scaler"} and len(state["ema"]) == len(net.state_dict())
+
+
+def test_trainer_step_fused_kernel_vs_reference_golden(dev):
+    """SURVEY section 8 row a18 with an oracle: swiftk_adamw_ema_step (gradient sanitising + AdamW + EMA in one pass) inside
+    Trainer.train_step against the reference's own Trainer._backward_step on injected gradients with NaN / +-inf entries
+    (tests/golden/trainer_tiny.npz), over warm-up, cosine and final learning rates; then checkpoint round trip of its state."""
+    from test_oracle_golden import _run_trainer_on_fixture
+    tr, worst = _run_trainer_on_fixture(dev)
+    print(f"fused optimiser step vs reference golden: worst rel-L2 {worst:.3e}")
+    assert tr._fused and worst < 3e-6
+    sd = tr.optimizer.state_dict()
+    assert len(sd["state"]) == 6 and float(sd["state"][0]["step"]) == 4.0
+    assert sd["state"][0]["exp_avg"].shape == tr.optimizer.param_groups[0]["params"][0].shape

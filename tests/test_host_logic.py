@@ -178,7 +178,9 @@ DDP_WORKER = textwrap.dedent("""
     lo, hi = rank * 8 // world, (rank + 1) * 8 // world
     ddp.zero_grad_flat()
     ((ddp(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
-    flat = ddp.sync()
+    ddp.reduce_params([net[2].bias, net[0].weight])  # final gradients announced early: two non-neighbouring runs ...
+    ddp.reduce_params([net[2].bias])                 # ... a second announcement of the same run is ignored
+    flat = ddp.sync()                              # ... the rest reduced here
     if rank == 0:
         torch.save(flat.clone(), sys.argv[1])
     dist.barrier()
@@ -356,3 +358,41 @@ def test_run_id_is_shared_across_ranks(tmp_path):
              for r in range(2)]
     assert [p.wait(timeout=200) for p in procs] == [0, 0]
     assert open(out + ".0").read() == open(out + ".1").read() == "20260101_000000 20260101_000000"
+
+
+def test_h5_backed_era5_dataset_vs_reference_golden(tmp_path, monkeypatch):
+    """swift_amd.data.era5.ERA5Dataset / ERA5RollOutDataset over an on-disk tree in the reference's layout against what the
+    REFERENCE's loader returned for the identical tree (tests/golden/era5_tiny.npz): file ordering, NaN fill, residual
+    targets at offsets 1-3, statistics chosen by channel count and by interval, forcings, time stamps, rollout items."""
+    from conftest import load_golden
+    import era5_fixture as fx
+    monkeypatch.setitem(sys.modules, "h5py", fx.install_fake_h5py())
+    from swift_amd.data.era5 import ERA5Dataset, ERA5RollOutDataset
+    from swift_amd.utils.detinit import det_normal
+    g = load_golden("era5_tiny")
+    root = fx.write_tree(str(tmp_path / "era5"))
+    ds = ERA5Dataset(root, list(fx.VARS), list(fx.FORC), intervals=[6, 12, 24], split="train", residual=True)
+    assert len(ds) == int(g["len"]) == fx.N_FILES - 4 and tuple(ds._shape) == tuple(g["shape"])
+    assert ds.n_target_channels == 4 and ds.n_condition_channels == 6 and ds.img_resolution == fx.SHAPE
+    for spec in [(0, 1, 6), (3, 1, 12), (2, 2, 6), (1, 3, 12), (4, 1, 24)]:
+        (x, t), (idx, delta) = ds[spec]
+        tag = "_".join(map(str, spec))
+        np.testing.assert_array_equal(x.numpy(), g[f"x_{tag}"])
+        np.testing.assert_array_equal(t.numpy(), g[f"t_{tag}"])
+        assert idx == spec[0] and float(delta) == float(g[f"d_{tag}"])
+    assert np.isfinite(ds[(3, 1, 6)][0][0].numpy()).all()  # file 3 carries a NaN that the loader fills
+    np.testing.assert_array_equal(ds.get_forcings(5).numpy(), g["forc5"])
+    assert str(ds.get_time(7)) == str(g["time7"])
+    lat, lon = ds.get_lat_lon()
+    np.testing.assert_array_equal(lat, g["lat"])
+    np.testing.assert_array_equal(lon, g["lon"])
+    v = det_normal((2, 4, *fx.SHAPE), 3, "v")
+    np.testing.assert_allclose(ds.unstandardize_t(v.clone(), 12).numpy(), g["unstd_t12"], rtol=1e-6)
+    np.testing.assert_allclose(ds.standardize_x(ds.get_forcings(2)[None]).numpy(), g["std_x_forc"], rtol=1e-6)
+    mx, sx, st = ds.rollout_stats(12, "cpu")  # the flat vectors the fused rollout kernel takes = the same statistics
+    np.testing.assert_allclose((v[0] * st.view(-1, 1, 1)).numpy(), g["unstd_t12"][0], rtol=1e-6)
+    ro = ERA5RollOutDataset(8, root, list(fx.VARS), list(fx.FORC), intervals=[6, 12, 24], split="train", residual=True)
+    x, ts, idx = ro[1]
+    assert len(ro) == int(g["ro_len"]) and idx == 1
+    np.testing.assert_array_equal(x.numpy(), g["ro_x"])
+    np.testing.assert_array_equal(ts.numpy(), g["ro_t"])

@@ -337,6 +337,81 @@ def fx_swiftb_step():
          stats=np.array([float(y.mean()), float(y.std()), float(y.abs().max()), float(y.double().norm())]))
 
 
+@torch.no_grad()
+def fx_swiftb_long():
+    """BASELINE configs[2] and [3] at full size on the reference (fp32 CPU, ~100 Swift-B evaluations, minutes):
+    (a) ``dpm_solver_2s`` with solver/2s.yaml's num_steps 20 = 39 network evaluations of one sample;
+    (b) a 60-step autoregressive rollout of one (member, IC) unit, generate.py:97-131 driven by hand with the reference's
+        scm sampler and ERA5Dataset standardisation, latents keyed per step (det_normal), forcing bank keyed by seed.
+    Outputs are stored sub-sampled ([::4, ::8, ::8]) plus the full-field norm of every step."""
+    from swift.generating.diffusion import DiffusionSampler
+    import time
+    c, seed = SWIFTB, 1234
+    net, state = build_ref_net(c, seed)
+    nv, nf = c["n_vars"], c["n_forc"]
+    S = DiffusionSampler(net)
+    cond = det_normal((1, nv + nf, *c["img"]), seed, "cond")
+    lat = det_normal((1, nv, *c["img"]), seed, "lat")
+    t0 = time.time()
+    y2s = S.dpm_solver_2s(lat, condition=cond, num_steps=20, sigma_min=0.02, sigma_max=200.0, auxiliary=0.6)
+    print(f"reference dpm_solver_2s (39 evaluations): {time.time() - t0:.1f} s")
+    steps, interval = 60, 6
+    bank = det_normal((steps + 2, nf, *c["img"]), seed, "forc", std=1.5, mean=0.5)
+    ds = FakeERA5(c, seed, bank)
+    X = det_normal((1, nv, *c["img"]), seed, "X0")
+    sub, norms = [ds.unstandardize_x(X)[0, ::4, ::8, ::8].clone()], [float(ds.unstandardize_x(X).double().norm())]
+    t0 = time.time()
+    for i in range(steps):
+        Xc = torch.cat([X, ds.standardize_x(ds.get_forcings(i * interval // 6)[None])], 1)
+        Y = S.scm_solver(det_normal((1, nv, *c["img"]), seed, f"lat{i}"), condition=Xc, num_steps=1, sigma_min=0.02, sigma_max=200.0,
+                         auxiliary=interval / 10.0)
+        Xn = ds.unstandardize_x(Xc)[:, :nv] + ds.unstandardize_t(Y, delta=interval)
+        sub.append(Xn[0, ::4, ::8, ::8].clone())
+        norms.append(float(Xn.double().norm()))
+        X = ds.standardize_x(Xn)
+        if i % 10 == 9:
+            print(f"  rollout step {i + 1}/{steps}: {time.time() - t0:.0f} s")
+    save("swiftb_long", seed=seed, fingerprint=state_fingerprint(state), y2s_sub=y2s[0, ::4, ::8, ::8],
+         y2s_norm=float(y2s.double().norm()), traj_sub=torch.stack(sub, 0), traj_norm=np.array(norms),
+         x_mean=ds.x_means, x_std=ds.x_stds, t_std6=ds.t_stds[6])
+
+
+
+def fx_era5_tiny():
+    """The reference's h5-backed ERA5Dataset / ERA5RollOutDataset (data/era5.py:11-256) over a small on-disk tree in its own
+    layout (tests/era5_fixture.py writes it; the ``*.h5`` files are npz underneath and a stand-in h5py exposes the mapping
+    interface the loader uses -- this image has no h5py)."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import era5_fixture as fx
+    from swift.data.era5 import ERA5RollOutDataset
+    sys.modules["h5py"].File = fx._File  # the reference module holds this module object
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        fx.write_tree(root)
+        np.random.seed(0)
+        ds = ERA5Dataset(root, list(fx.VARS), list(fx.FORC), intervals=[6, 12, 24], split="train", residual=True)
+        out["len"], out["shape"] = len(ds), np.array(ds._shape)
+        for spec in [(0, 1, 6), (3, 1, 12), (2, 2, 6), (1, 3, 12), (4, 1, 24)]:
+            (x, t), (idx, delta) = ds[spec]
+            tag = "_".join(map(str, spec))
+            out[f"x_{tag}"], out[f"t_{tag}"], out[f"d_{tag}"] = x, t, float(delta)
+        out["forc5"] = ds.get_forcings(5)
+        out["time7"] = np.array(str(ds.get_time(7)))
+        lat, lon = ds.get_lat_lon()
+        out["lat"], out["lon"] = lat, lon
+        v = det_normal((2, len(fx.VARS), *fx.SHAPE), 3, "v")
+        out["unstd_t12"] = ds.unstandardize_t(v.clone(), 12)
+        out["std_x_forc"] = ds.standardize_x(ds.get_forcings(2)[None])
+        # (residual=False is not exercised: the reference's standardize_t indexes the statistics ARRAY with delta there,
+        #  data/era5.py:161 with :95-99 -- IndexError for fewer than 7 channels, channel 6's statistics otherwise)
+        ro = ERA5RollOutDataset(8, root, list(fx.VARS), list(fx.FORC), intervals=[6, 12, 24], split="train", residual=True)
+        x, ts, idx = ro[1]
+        out["ro_x"], out["ro_t"], out["ro_len"] = x, ts, len(ro)
+    save("era5_tiny", **out)
+
+
+
 def fx_weights_aux():
     import yaml
     with open("/root/reference/src/swift/configs/data/era5-flare-1.4.yaml") as f:
@@ -426,7 +501,61 @@ def fx_metrics_tiny():
     save("metrics_tiny", pred=pred, y=y, lat=lat, keys=np.array(sorted(out)), values=np.array([out[k] for k in sorted(out)]))
 
 
-ALL = dict(metrics_tiny=fx_metrics_tiny, val_tiny=fx_val_tiny, muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
+
+def fx_trainer_tiny():
+    """The reference's optimisation step itself -- ``Trainer._backward_step`` (training/trainer.py:199-247): LR warm-up /
+    cosine schedule, ``nan_to_num`` gradient sanitising, AdamW step, EMA rule -- called unbound on a stand-in ``self`` (the
+    constructor needs ezpz / DDP; the step does not).  Gradients are injected through a loss that is linear in the
+    parameters, NaN / +-inf entries included.  Import-time stubs: xarray, mpi4py, torchinfo, swift.utils.io, ezpz.History."""
+    import torch._dynamo  # noqa: F401  (the optimiser imports it lazily, and its module scan trips over spec-less stubs)
+    for name in ("xarray", "torchinfo"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchinfo"].summary = lambda *a, **k: None
+    sys.modules["xarray"].Dataset = type("Dataset", (), {})  # a return annotation of Trainer.train
+    sys.modules.setdefault("swift.utils.io", types.ModuleType("swift.utils.io"))
+    mp = types.ModuleType("mpi4py")
+    mp.MPI = types.SimpleNamespace(COMM_WORLD=None)
+    sys.modules.setdefault("mpi4py", mp)
+    ez = sys.modules["ezpz"]
+    ez.get_rank, ez.get_world_size = (lambda: 0), (lambda: 1)
+    ez.History = type("History", (), {})
+    from swift.training.trainer import Trainer
+    torch.manual_seed(0)
+    shapes = {"model.pos_embed": (1, 6, 8), "model.layers.0.w1.weight": (16, 8), "model.layers.0.norm.norm.weight": (8,),
+              "model.layers.0.norm.norm.bias": (8,), "model.layers.0.norm.modulation.weight": (16, 8), "model.head.weight": (4, 8)}
+    net = torch.nn.ParameterList([torch.nn.Parameter(det_normal(sh, 12, k, std=0.3)) for k, sh in shapes.items()])  # keeps order
+    ema = torch.nn.ParameterList([torch.nn.Parameter(v.detach().clone() + 0.01, requires_grad=False) for v in net])
+    names = list(shapes)
+    no_decay = [i for i, n in enumerate(names) if "pos_embed" in n or ("norm" in n and "modulation" not in n)]  # train.py:275-286
+    params = list(net.parameters())
+    groups = [{"params": [p for i, p in enumerate(params) if i not in no_decay], "weight_decay": 0.05},
+              {"params": [params[i] for i in no_decay], "weight_decay": 0.0}]
+    opt = torch.optim.AdamW(groups, lr=2e-3, betas=(0.9, 0.95), eps=1e-6)
+    me = types.SimpleNamespace(lr_rampup_kimg=0.004, optimizer=opt, base_lr=[g["lr"] for g in opt.param_groups], lr_min_factor=0.01,
+                               lr_cosine_anneal=True, total_kimg=0.02, scaler=torch.amp.GradScaler("cpu", enabled=False), net=net,
+                               ema=ema, ema_halflife_kimg=0.5, ema_rampup_ratio=0.05, global_batch_size=2)
+    out = {"names": np.array(names), "no_decay": np.array(no_decay)}
+    for k, v in zip(names, params):
+        out[f"p0_{k}"] = v.detach().clone()
+    for k, v in zip(names, ema.parameters()):
+        out[f"e0_{k}"] = v.detach().clone()
+    nimgs = [2, 4, 10, 20]          # warm-up (2 of 4), boundary, mid-cosine, end
+    for st, nimg in enumerate(nimgs):
+        opt.zero_grad(set_to_none=True)
+        G = [det_normal(p.shape, 100 + st, n, std=0.5) for n, p in zip(names, params)]
+        G[1].view(-1)[3] = float("nan")
+        G[1].view(-1)[5] = float("inf")
+        G[5].view(-1)[0] = float("-inf")
+        G[2].view(-1)[1] = float("nan")
+        loss = sum((p * g).sum() for p, g in zip(params, G))
+        Trainer._backward_step(me, nimg, loss)
+        out[f"lr_{st}"] = np.array([g["lr"] for g in opt.param_groups])
+        for n, p, e, g in zip(names, params, ema.parameters(), G):
+            out[f"g{st}_{n}"], out[f"p{st + 1}_{n}"], out[f"e{st + 1}_{n}"] = g, p.detach().clone(), e.detach().clone()
+    save("trainer_tiny", nimgs=np.array(nimgs), **out)
+
+
+ALL = dict(era5_tiny=fx_era5_tiny, swiftb_long=fx_swiftb_long, trainer_tiny=fx_trainer_tiny, metrics_tiny=fx_metrics_tiny, val_tiny=fx_val_tiny, muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
            samplers_tiny=fx_samplers_tiny, rollout_tiny=fx_rollout_tiny, losses_tiny=fx_losses_tiny,
            swiftb_step=fx_swiftb_step, weights_aux=fx_weights_aux)
 
