@@ -44,13 +44,14 @@ extern "C" {
 #define SWIFTK_EPI_NONE 0      /* C = A W^T                                              */
 #define SWIFTK_EPI_BIAS_POS 1  /* C = A W^T + bias[n] + pos[(m % pos_rows)][n]           */
 #define SWIFTK_EPI_SWIGLU 2    /* C[m][j] = silu(acc[m][2j]) * acc[m][2j+1]  (W rows interleaved gate/up) */
-#define SWIFTK_EPI_QKNORM 3    /* to_qkv with head_dim 88: per token and head, q <- q/max(|q|,1e-12)*exp(min(ep0[h],ln100)),
-                                  k <- k/max(|k|,1e-12), v unchanged (swinv2.py:123-127); ep0 = scale[heads]          */
+#define SWIFTK_EPI_QKNORM 3    /* to_qkv: per token and head, q <- q/max(|q|,1e-12)*exp(min(ep0[h],ln100)),
+                                  k <- k/max(|k|,1e-12), v unchanged (swinv2.py:123-127); ep0 = scale[heads]; head_dim
+                                  (80 / 88 / 96; 88 only with fp32 operands) travels in `pos_rows`, 0 = 88            */
 
 /* swiftk_window_attention flags */
 #define SWIFTK_ATTN_PRENORM 1  /* q, k in `qkv` are already normalised / scaled (SWIFTK_EPI_QKNORM); `scale` (optional) bounds
                                   |logit| <= exp(min(scale, ln 100)): where <= 48 softmax needs no row maximum */
-#define SWIFTK_ATTN_TILED 4    /* `qkv` is window-tiled (swiftk_gemm_qkv_tiled): [B][window][head][q|k|v][256][88] bf16, windows
+#define SWIFTK_ATTN_TILED 4    /* `qkv` is window-tiled (swiftk_gemm_qkv_tiled): [B][window][head][q|k|v][256][head_dim] bf16, windows
                                   of the grid rolled by (shift_h, shift_w); needs PRENORM, bf16, head_dim 88; ldq unused */
 #define SWIFTK_ATTN_NO_PIPE 2  /* tuning: keep the one-workgroup-per-item kernel even where the pipelined one applies */
 
@@ -188,14 +189,16 @@ int swiftk_profile_collect(double* total_ms_host, int64_t* launches_host);
 /*
  * to_qkv for the streamed window-attention kernel (swinv2.py:113-121 + window_partition :17-26 + the roll :185-189 in
  * one pass): C = normalise/scale(A W^T) exactly as swiftk_gemm(..., SWIFTK_EPI_QKNORM, scale, ...) computes it, bf16 in
- * and out, N = 3*heads*88, M = B*gh*gw, but stored window-tiled instead of row-major:
- *   qkv_tiled[B][window][head][q|k|v][256][88], window = (ry/16)*(gw/16) + rx/16, index in window = (ry%16)*16 + rx%16,
+ * and out, N = 3*heads*head_dim, M = B*gh*gw, head_dim 80 / 88 / 96 (the 468 M / Swift-B / 664 M variants of
+ * configs/experiment/era5-swinv2-1.4-scm.yaml:21-36), heads even, but stored window-tiled instead of row-major:
+ *   qkv_tiled[B][window][head][q|k|v][256][head_dim], window = (ry/16)*(gw/16) + rx/16, index = (ry%16)*16 + rx%16,
  *   (ry, rx) = ((y - shift_h) mod gh, (x - shift_w) mod gw) for the token at grid position (y, x)
- * so that every (window, head) operand of attention is one contiguous, cache-line-aligned 45,056-byte block.
+ * so that every (window, head) operand of attention is one contiguous, cache-line-aligned 512*head_dim-byte block.
  * Consumed by swiftk_window_attention(..., SWIFTK_ATTN_PRENORM | SWIFTK_ATTN_TILED) with the same shift.
  */
 int swiftk_gemm_qkv_tiled(const void* A, int64_t lda, const void* W, int64_t ldw, void* qkv_tiled, int64_t K,
-                          const float* scale, int B, int gh, int gw, int heads, int shift_h, int shift_w, void* stream);
+                          const float* scale, int B, int gh, int gw, int heads, int head_dim, int shift_h, int shift_w,
+                          void* stream);
 
 /* slabs[s][M, ldc] (fp32) = A[M, K_s] * W[N, K_s]^T for the s-th of `ksplit` equal k-ranges; slab s starts at
  * slabs + s*slab_stride.  Same operand rules as swiftk_gemm; M % 8 == 0, N % 8 == 0. */
@@ -251,10 +254,11 @@ int swiftk_timestep_embed_jvp(const float* t, const float* dt, const float* freq
 int swiftk_silu_jvp(const float* z, const float* dz, float* y, float* dy, int64_t n, void* stream);
 /* In place on qkv / dqkv [M, ld] (head layout [q88|k88|v88]): q <- q/|q| * exp(min(scale,ln100)), k <- k/|k| and their
  * tangents dq, dk (swinv2.py:123-127); v, dv untouched. */
-int swiftk_qknorm_jvp(void* qkv, void* dqkv, int64_t ld, const float* scale, int64_t M, int heads, int dtype, void* stream);
+int swiftk_qknorm_jvp(void* qkv, void* dqkv, int64_t ld, const float* scale, int64_t M, int heads, int head_dim, int dtype,
+                      void* stream);
 /* Explicit-softmax window attention and its tangent on pre-normalised q, k (swinv2.py:129-133 with jvp=True):
  * out = softmax(q k^T) v, dout = d/d(eps) of the same along (dq, dk, dv).  Same window/shift addressing as
- * swiftk_window_attention; head_dim 88. */
+ * swiftk_window_attention; head_dim 80 / 88 / 96. */
 int swiftk_window_attention_jvp(const void* qkv, const void* dqkv, int64_t ldq, void* out, void* dout, int64_t ldo, int B,
                                 int gh, int gw, int heads, int head_dim, int shift_h, int shift_w, int dtype, void* stream);
 /* ModulatedNorm + residual and its tangent (swinv2.py:77-86): x += LN(y)(1+sc)+sh; dx += dLN(y)[dy](1+sc) + LN(y) dsc + dsh,

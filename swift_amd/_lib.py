@@ -74,14 +74,14 @@ _SIGS = {
     "swiftk_unit_checksum": ([_p, _p, _p, _i, _l, _p], _i),
     "swiftk_timestep_embed_jvp": ([_p, _p, _p, _p, _i, _i, _f, _p], _i),
     "swiftk_silu_jvp": ([_p, _p, _p, _p, _l, _p], _i),
-    "swiftk_qknorm_jvp": ([_p, _p, _l, _p, _l, _i, _i, _p], _i),
+    "swiftk_qknorm_jvp": ([_p, _p, _l, _p, _l, _i, _i, _i, _p], _i),
     "swiftk_window_attention_jvp": ([_p, _p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_modnorm_jvp": ([_p, _p, _l, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l, _l, _i, _l, _f, _i, _p], _i),
     "swiftk_swiglu_jvp": ([_p, _p, _l, _p, _p, _l, _l, _i, _i, _p], _i),
     "swiftk_ensemble_sums": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_rmse_sums": ([_p, _p, _l, _p, _p, _i, _i, _i, _i, _p], _i),
     "swiftk_scm_target": ([_p, _p, _p, _p, _p, _f, _f, _p, _p, _i, _l, _p], _i),
-    "swiftk_gemm_qkv_tiled": ([_p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "swiftk_gemm_qkv_tiled": ([_p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_gemm_splitk": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _l, _i, _i, _p], _i),
     "swiftk_reduce_slabs": ([_p, _l, _l, _i, _p, _l, _l, _l, _i, _p], _i),
     "swiftk_transpose": ([_p, _l, _p, _l, _l, _l, _i, _p], _i),

@@ -399,9 +399,10 @@ extern "C" int swiftk_window_attention(const void* qkv, int64_t ldq, void* out, 
     a.nw = (gh / 16) * (gw / 16);
     a.prenorm = prenorm ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (prenorm && dtype == SWIFTK_BF16 && head_dim == 88 && !(flags & SWIFTK_ATTN_NO_PIPE)) {
-        AttnPipeArgs pa{qkv, out, ldq, ldo, B, gh, gw, heads, shift_h, shift_w, g_attn_dbg, scale,
-                        (flags & SWIFTK_ATTN_TILED) ? 1 : 0};
+    if (prenorm && dtype == SWIFTK_BF16 && (head_dim == 80 || head_dim == 88 || head_dim == 96) &&
+        !(flags & SWIFTK_ATTN_NO_PIPE)) {
+        AttnPipeArgs pa{qkv, out, ldq, ldo, B, gh, gw, heads, shift_h, shift_w, head_dim == 88 ? g_attn_dbg : 0, scale,
+                        (flags & SWIFTK_ATTN_TILED) ? 1 : 0, head_dim};
         const bool timed = swiftk_prof_begin(SWIFTK_PROF_ATTENTION, 0, st);
         const int rc = swiftk_launch_attn_pipe(pa, st);
         if (timed) swiftk_prof_end(st);

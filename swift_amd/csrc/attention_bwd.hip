@@ -1,4 +1,4 @@
-// Backward of the shifted-window cosine attention core for gfx950 (bf16, head_dim 88, pre-normalised q/k).
+// Backward of the shifted-window cosine attention core for gfx950 (bf16, head_dim 80 / 88 / 96, pre-normalised q/k).
 //
 // Given qh (scaled, normalised q), kh, v, the forward output O and dO, one workgroup per (sample, window, head)
 // recomputes P = softmax(qh kh^T) (the whole 256 x 256 problem is on chip) and produces
@@ -17,9 +17,7 @@
 namespace {
 
 constexpr int NT = 512;
-constexpr int HD = 88;
-constexpr int NCH = HD / 8;   // 11 chunks of 16 B
-constexpr int KS = 6, DB = 3;
+constexpr int DB = 3;         // 32-row blocks of a transposed head vector (head_dim <= 96)
 constexpr int STR = 208;      // image row stride (96 bf16 + 16 B)
 constexpr int IMG = 256 * STR;
 constexpr float LOG2E = 1.4426950408889634f;
@@ -42,21 +40,25 @@ __device__ __forceinline__ int wtoken(const BwdArgs& a, int w, int j) {
     return gy * a.gw + gx;
 }
 
-// copy one 88-element row (11 x 16 B) into an image row and zero the 16-B tail chunk (d = 88..95)
+// copy one head_dim-element row (HD/8 x 16 B) into an image row and zero the tail chunks up to d = 95
+template <int HD>
 __device__ __forceinline__ void stage_row(char* img, int j, const bf16_t* src) {
+    constexpr int NCH = HD / 8;
     uint4 r[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) r[c] = *reinterpret_cast<const uint4*>(src + 8 * c);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) *reinterpret_cast<uint4*>(img + j * STR + 16 * c) = r[c];
-    *reinterpret_cast<uint4*>(img + j * STR + 16 * NCH) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int c = NCH; c < 12; ++c) *reinterpret_cast<uint4*>(img + j * STR + 16 * c) = make_uint4(0, 0, 0, 0);
 }
 
-// fragments of a row as the MFMA "B" operand with the row index on the lane: chunk 2*ks + hh (chunk 11 = zeros)
+// fragments of a row as the MFMA "B" operand with the row index on the lane: chunk 2*ks + hh (a chunk past the row = zeros)
+template <int HD, int KS>
 __device__ __forceinline__ void row_frags(const bf16_t* row, int hh, uint4 (&f)[KS]) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        if (ks == KS - 1) {
+        if (2 * ks + 1 >= HD / 8) {
             const uint4 t = *reinterpret_cast<const uint4*>(row + 8 * (2 * ks));
             f[ks] = hh ? make_uint4(0, 0, 0, 0) : t;
         } else {
@@ -100,6 +102,7 @@ __device__ __forceinline__ uint4 pack8(const f32x16& s, int s2) {
 }
 
 // store a transposed accumulator set acc[db][reg] = X^T[d][row], row = lane&31 -> dst_row[d] (bf16, 8-B pieces)
+template <int HD>
 __device__ __forceinline__ void store_t(bf16_t* dst_row, const f32x16 (&acc)[DB], int hh) {
 #pragma unroll
     for (int db = 0; db < DB; ++db)
@@ -112,7 +115,9 @@ __device__ __forceinline__ void store_t(bf16_t* dst_row, const f32x16 (&acc)[DB]
         }
 }
 
+template <int HD>
 __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
+    constexpr int KS = (HD + 15) / 16;  // 16-wide k-steps over head_dim: 5 / 6 / 6
     __shared__ __attribute__((aligned(16))) char imgA[IMG];
     __shared__ __attribute__((aligned(16))) char imgB[IMG];
     __shared__ __attribute__((aligned(16))) float st_m[256];
@@ -136,16 +141,16 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
     // ---------------------------------------------------------------- pass A images: K -> imgA, V -> imgB
     if (tid < 256) {
         const bf16_t* src = a.qkvh + (tok0 + wtoken(a, w, tid)) * a.ldq + head * 3 * HD;
-        stage_row(imgA, tid, src + HD);
-        stage_row(imgB, tid, src + 2 * HD);
+        stage_row<HD>(imgA, tid, src + HD);
+        stage_row<HD>(imgB, tid, src + 2 * HD);
     }
     uint4 qf[KS], dof[KS];
-    row_frags(my_qkv, hh, qf);
-    row_frags(my_do, hh, dof);
+    row_frags<HD, KS>(my_qkv, hh, qf);
+    row_frags<HD, KS>(my_do, hh, dof);
     float delta;
     {
         uint4 of[KS];
-        row_frags(my_o, hh, of);
+        row_frags<HD, KS>(my_o, hh, of);
         float s = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) s += dot8(dof[ks], of[ks]);
@@ -208,18 +213,18 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
             for (int db = 0; db < DB; ++db) dq[db] = mfma(tr_frag(imgA, kb * 32 + s2 * 16, db, vbase), ds, dq[db]);
         }
     }
-    store_t(my_dqkv, dq, hh);
+    store_t<HD>(my_dqkv, dq, hh);
     __syncthreads();
 
     // ---------------------------------------------------------------- pass B images: Q -> imgA, dO -> imgB
     if (tid < 256) {
         const int t = wtoken(a, w, tid);
-        stage_row(imgA, tid, a.qkvh + (tok0 + t) * a.ldq + head * 3 * HD);
-        stage_row(imgB, tid, a.d_o + (tok0 + t) * a.ldo + head * HD);
+        stage_row<HD>(imgA, tid, a.qkvh + (tok0 + t) * a.ldq + head * 3 * HD);
+        stage_row<HD>(imgB, tid, a.d_o + (tok0 + t) * a.ldo + head * HD);
     }
     uint4 kf[KS], vf[KS];
-    row_frags(my_qkv + HD, hh, kf);
-    row_frags(my_qkv + 2 * HD, hh, vf);
+    row_frags<HD, KS>(my_qkv + HD, hh, kf);
+    row_frags<HD, KS>(my_qkv + 2 * HD, hh, vf);
     __syncthreads();
 
     f32x16 dk[DB], dv[DB];
@@ -263,8 +268,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
             }
         }
     }
-    store_t(my_dqkv + HD, dk, hh);
-    store_t(my_dqkv + 2 * HD, dv, hh);
+    store_t<HD>(my_dqkv + HD, dk, hh);
+    store_t<HD>(my_dqkv + 2 * HD, dv, hh);
 }
 
 }  // namespace
@@ -273,7 +278,8 @@ extern "C" int swiftk_window_attention_bwd(const void* qkvh, int64_t ldq, const 
                                            void* dqkvh, int B, int gh, int gw, int heads, int head_dim, int shift_h,
                                            int shift_w, int dtype, void* stream) {
     if (!qkvh || !o || !d_o || !dqkvh || B <= 0 || heads <= 0) return SWIFTK_EINVAL;
-    if (dtype != SWIFTK_BF16 || head_dim != 88) return SWIFTK_ESHAPE;  // training runs under bf16 autocast (trainer.py:191)
+    if (dtype != SWIFTK_BF16) return SWIFTK_ESHAPE;  // training runs under bf16 autocast (trainer.py:191)
+    if (head_dim != 80 && head_dim != 88 && head_dim != 96) return SWIFTK_ESHAPE;
     if (gh <= 0 || gw <= 0 || gh % 16 || gw % 16) return SWIFTK_ESHAPE;
     if (shift_h < 0 || shift_w < 0 || shift_h >= gh || shift_w >= gw) return SWIFTK_ESHAPE;
     if (ldq < 3 * heads * head_dim || ldo < heads * head_dim) return SWIFTK_ESHAPE;
@@ -294,7 +300,11 @@ extern "C" int swiftk_window_attention_bwd(const void* qkvh, int64_t ldq, const 
     a.sw = shift_w;
     a.nwx = gw / 16;
     a.nw = (gh / 16) * (gw / 16);
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * a.nw * heads), dim3(NT), 0, static_cast<hipStream_t>(stream), a);
+    const dim3 grid(B * a.nw * heads);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (head_dim == 80) hipLaunchKernelGGL(attn_bwd_kernel<80>, grid, dim3(NT), 0, st, a);
+    else if (head_dim == 96) hipLaunchKernelGGL(attn_bwd_kernel<96>, grid, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL(attn_bwd_kernel<88>, grid, dim3(NT), 0, st, a);
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

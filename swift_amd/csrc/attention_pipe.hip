@@ -1,4 +1,5 @@
-// Persistent, LDS-DMA-streamed shifted-window attention for gfx950 (bf16, head_dim 88, pre-normalised q/k).
+// Persistent, LDS-DMA-streamed shifted-window attention for gfx950 (bf16, head_dim 80 / 88 / 96, pre-normalised q/k;
+// the text below describes the Swift-B geometry, head_dim 88).
 //
 // The to_qkv GEMM epilogue (SWIFTK_EPI_QKNORM) has already L2-normalised q and k and applied the logit scale,
 // so this kernel is pure data movement + MFMA + softmax.  A (sample, window, head) item is 3 x 45 KB in and
@@ -31,19 +32,31 @@ int g_attn_dbg = 0;
 namespace {
 
 constexpr int NT = 512;
-constexpr int HD = 88;
-constexpr int ROW = HD * 2;             // 176 B
-constexpr int TILE = 256 * ROW;         // 45056 B = 44 DMA pieces
 constexpr int CH = 64;                  // keys per ring stage
-constexpr int CHB = CH * ROW;           // 11264 B = 11 pieces
 constexpr int NST = 4;                  // ring stages = chunks per item
-constexpr int OSLAB = 16 * ROW;         // per-wave output staging slab (2816 B)
-constexpr int OFF_K = TILE;             // Q tile | K ring | V ring | zero tail | output slabs
-constexpr int OFF_V = OFF_K + NST * CHB;
-constexpr int OFF_O = OFF_V + NST * CHB + 64;
-constexpr int LDS_TOTAL = OFF_O + 8 * OSLAB;
-constexpr int KS = 6, DB = 3;
+constexpr int DB = 3;                   // 32-row blocks of O^T (head_dim <= 96)
 constexpr float LOG2E = 1.4426950408889634f;
+
+// Geometry by head_dim (80 / 88 / 96: the 468 M, Swift-B and 664 M variants; comments below quote the 88 numbers).
+template <int HD>
+struct Geo {
+    static constexpr int CPR = HD / 8;             // 16-B chunks per row: 10 / 11 / 12
+    static constexpr int ROW = HD * 2;             // 176 B
+    static constexpr int TILE = 256 * ROW;         // 45056 B = 44 DMA pieces
+    static constexpr int NPQ = TILE / 1024;        // pieces of a Q / K / V tile: 40 / 44 / 48
+    static constexpr int CHB = CH * ROW;           // 11264 B = 11 pieces
+    static constexpr int NPC = CHB / 1024;         // pieces of one K (or V) chunk: 10 / 11 / 12
+    static constexpr int OROWS = HD > 88 ? 8 : 16;  // query rows per output round (head_dim 96: 8, or LDS would not fit)
+    static constexpr int ORND = 32 / OROWS;         // rounds per item (a wave owns 32 queries)
+    static constexpr int NOST = ORND * ((OROWS * CPR + 63) / 64);  // output store instructions per wave and item: 6 / 6 / 8
+    static constexpr int OSLAB = OROWS * ROW;       // per-wave output staging slab (2816 B)
+    static constexpr int OFF_K = TILE;             // Q tile | K ring | V ring | zero tail | output slabs
+    static constexpr int OFF_V = OFF_K + NST * CHB;
+    static constexpr int OFF_O = OFF_V + NST * CHB + 64;
+    static constexpr int LDS_TOTAL = OFF_O + 8 * OSLAB;
+    static constexpr int KS = (HD + 15) / 16;      // 16-wide k-steps of S = K Q^T: 5 / 6 / 6
+    static constexpr bool ONES = HD < 32 * DB;     // spare V^T rows carry ones -> the row sum rides on the matrix pipe
+};
 
 __device__ __forceinline__ int win_token(int wy, int wx, int j, int gh, int gw, int sh, int sw) {
     int gy = wy * 16 + (j >> 4) + sh;
@@ -60,8 +73,12 @@ __device__ __forceinline__ void wait_vm() {
 
 // DBG: ablation bits for timing experiments (1 no steady-state K/V DMA, 2 no S/softmax/PV, 4 no steady-state Q DMA,
 // 8 no O stores)
-template <int DBG>
+template <int DBG, int HD>
 __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitems) {
+    using G = Geo<HD>;
+    constexpr int CPR = G::CPR, ROW = G::ROW, TILE = G::TILE, NPQ = G::NPQ, CHB = G::CHB, NPC = G::NPC, OSLAB = G::OSLAB;
+    constexpr int OFF_K = G::OFF_K, OFF_V = G::OFF_V, OFF_O = G::OFF_O, LDS_TOTAL = G::LDS_TOTAL, KS = G::KS;
+    constexpr int OROWS = G::OROWS, ORND = G::ORND, NOST = G::NOST;
     __shared__ __attribute__((aligned(16))) char smem[LDS_TOTAL];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,8 +127,8 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
     int tb_w = 0;  // window of the item the DMA helpers are fetching (tiled storage addresses tiles by window)
     auto piece_off = [&](int wy, int wx, int p) {
         const int c = p * 64 + lane;
-        const int row = (c * 2979) >> 15;  // c / 11 for c < 2816
-        const int cc = c - row * 11;
+        const int row = c / CPR;  // (a constant divisor: multiply-shift)
+        const int cc = c - row * CPR;
         if (a.tiled) return (uint32_t)(p * 1024 + lane * 16);  // window-tiled storage: a tile is one contiguous block
         return (uint32_t)(win_token(wy, wx, row, a.gh, a.gw, a.sh, a.sw) * ldq_b) + 16u * cc;
     };
@@ -119,22 +136,22 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         int q = wv + 8 * s;
-        q = q >= 22 ? q - 22 : q;
-        cslot_part[s] = q >= 11;
-        cslot_j[s] = q - 11 * cslot_part[s];
+        q = q >= 2 * NPC ? q - 2 * NPC : q;
+        cslot_part[s] = q >= NPC;
+        cslot_j[s] = q - NPC * cslot_part[s];
     }
     auto set_window = [&](int w) {
         const int wy = w / nwx, wx = w - wy * nwx;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             int p = wv + 8 * i;
-            p = p >= 44 ? p - 44 : p;
+            p = p >= NPQ ? p - NPQ : p;
             qoff[i] = piece_off(wy, wx, p);
         }
 #pragma unroll
         for (int c = 0; c < NST; ++c)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) coff[c][s] = piece_off(wy, wx, 11 * c + cslot_j[s]);
+            for (int s = 0; s < 3; ++s) coff[c][s] = piece_off(wy, wx, NPC * c + cslot_j[s]);
         cur_w = w;
     };
     auto decode = [&](int item, int& b, int& w, int& h) {
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             int p = wv + 8 * i;
-            p = p >= 44 ? p - 44 : p;
+            p = p >= NPQ ? p - NPQ : p;
             dma_piece(lds0 + p * 1024, base, qoff[i]);
         }
     };
@@ -186,27 +203,27 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
         const int wy = w / nwx, wx = w - wy * nwx;
         bf16_t* obase = static_cast<bf16_t*>(a.out) + (int64_t)b * ntok * a.ldo + h * HD;
 #pragma unroll
-        for (int rnd = 0; rnd < 2; ++rnd) {
-            if ((c32 >> 4) == rnd) {
+        for (int rnd = 0; rnd < ORND; ++rnd) {
+            if (c32 / OROWS == rnd) {
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int d = db * 32 + g * 8 + hh * 4;
                         if (d < HD)
-                            *reinterpret_cast<uint2*>(oslab + (c32 & 15) * ROW + d * 2) =
+                            *reinterpret_cast<uint2*>(oslab + (c32 & (OROWS - 1)) * ROW + d * 2) =
                                 make_uint2(pack_bf16(o[db][4 * g] * rl, o[db][4 * g + 1] * rl),
                                            pack_bf16(o[db][4 * g + 2] * rl, o[db][4 * g + 3] * rl));
                     }
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < (OROWS * CPR + 63) / 64; ++t) {
                 const int c = lane + 64 * t;
-                if (c < 16 * 11) {
-                    const int row = (c * 2979) >> 15, cc = c - row * 11;
+                if (c < OROWS * CPR) {
+                    const int row = c / CPR, cc = c - row * CPR;
                     const uint4 v = *reinterpret_cast<const uint4*>(oslab + row * ROW + cc * 16);
-                    const int tok = win_token(wy, wx, wv * 32 + rnd * 16 + row, a.gh, a.gw, a.sh, a.sw);
+                    const int tok = win_token(wy, wx, wv * 32 + rnd * OROWS + row, a.gh, a.gw, a.sh, a.sw);
                     *reinterpret_cast<uint4*>(obase + (int64_t)tok * a.ldo + cc * 8) = v;
                 }
             }
@@ -233,6 +250,7 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
         const float bound = a.scale ? __expf(fminf(a.scale[h], 4.605170185988092f)) : INFINITY;
         const bool online = !(bound <= 48.f);
         float m_run = -INFINITY;  // running row maximum (online form only)
+        float l_valu = 0.f;       // head_dim 96 only: no spare V^T rows, the row sum is added up on the VALU
         uint4 qf[KS];
 
 #pragma unroll
@@ -247,9 +265,9 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
             } else if (c == 0) {
                 wait_vm<6>();
             } else if (c == 1) {
-                if (have_prev && !(DBG & 8)) wait_vm<12>(); else wait_vm<6>();
+                if (have_prev && !(DBG & 8)) wait_vm<6 + NOST>(); else wait_vm<6>();
             } else {
-                if (have_prev && !(DBG & 8)) wait_vm<18>(); else wait_vm<12>();
+                if (have_prev && !(DBG & 8)) wait_vm<12 + NOST>(); else wait_vm<12>();
             }
             __builtin_amdgcn_s_barrier();
             // every wave's pieces of stage c have landed, and every wave is done with stage c-1 (its fragment reads
@@ -261,7 +279,7 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
                 const char* qrow = smem + (wv * 32 + c32) * ROW;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    if (ks == KS - 1) {
+                    if (ks == KS - 1 && (CPR & 1)) {  // odd chunk count (head_dim 88): the last k-step has one real chunk
                         const uint4 t = *reinterpret_cast<const uint4*>(qrow + (2 * ks) * 16);
                         qf[ks] = hh ? make_uint4(0, 0, 0, 0) : t;
                     } else {
@@ -317,6 +335,7 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
                 for (int db = 0; db < DB; ++db)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                if constexpr (!G::ONES) l_valu *= alpha;
             }
             // P^T = exp(S^T - m) as packed bf16 B operands, then O^T[d][q] += V^T[d][key] P^T[key][q]
 #pragma unroll
@@ -331,6 +350,11 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
                     pf.y = pack_bf16(e[8 * s2 + 2], e[8 * s2 + 3]);
                     pf.z = pack_bf16(e[8 * s2 + 4], e[8 * s2 + 5]);
                     pf.w = pack_bf16(e[8 * s2 + 6], e[8 * s2 + 7]);
+                    if constexpr (!G::ONES) {  // the sum of exactly the bf16-rounded probabilities the numerator uses
+                        const uint32_t pw[4] = {pf.x, pf.y, pf.z, pf.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) l_valu += __uint_as_float(pw[q] << 16) + __uint_as_float(pw[q] & 0xffff0000u);
+                    }
                     const char* vrow = sV + (k2 * 32 + s2 * 16) * ROW + vbase;
 #pragma unroll
                     for (int db = 0; db < DB; ++db) {
@@ -348,7 +372,8 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(AttnPipeArgs a, int nitem
                 }
             }
         }
-        const float l = (DBG & 2) ? 1.f : o[DB - 1][12];  // row 24 (hh = 0) / 28 (hh = 1) of the last block: "ones" rows
+        float l = (DBG & 2) ? 1.f : o[DB - 1][12];  // row 24 (hh = 0) / 28 (hh = 1) of the last block: "ones" rows
+        if constexpr (!G::ONES) l = l_valu + __shfl_xor(l_valu, 32, 64);  // this lane's keys + the other half's
         rl_prev = 1.0f / l;
         pb = b; pw = w; ph = h;
         have_prev = true;
@@ -366,14 +391,22 @@ int swiftk_launch_attn_pipe(const AttnPipeArgs& a, hipStream_t st) {
     // ceil of nitems/grid)
     int grid = 256;
     if (nitems < grid) grid = nitems >= 8 ? (nitems & ~7) : nitems;  // a multiple of 8 keeps the XCD-concurrent order
+    if (a.hd == 80 || a.hd == 96) {
+        if (a.dbg) return SWIFTK_EINVAL;  // the ablation builds exist for head_dim 88 only
+        if (a.hd == 80) hipLaunchKernelGGL((attn_pipe_kernel<0, 80>), dim3(grid), dim3(NT), 0, st, a, nitems);
+        else hipLaunchKernelGGL((attn_pipe_kernel<0, 96>), dim3(grid), dim3(NT), 0, st, a, nitems);
+        SWIFTK_CHECK_LAUNCH();
+        return 0;
+    }
+    if (a.hd != 88) return SWIFTK_ESHAPE;
     switch (a.dbg) {
-        case 0: hipLaunchKernelGGL(attn_pipe_kernel<0>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
-        case 1: hipLaunchKernelGGL(attn_pipe_kernel<1>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
-        case 2: hipLaunchKernelGGL(attn_pipe_kernel<2>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
-        case 5: hipLaunchKernelGGL(attn_pipe_kernel<5>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
-        case 8: hipLaunchKernelGGL(attn_pipe_kernel<8>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
-        case 13: hipLaunchKernelGGL(attn_pipe_kernel<13>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
-        case 14: hipLaunchKernelGGL(attn_pipe_kernel<14>, dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        case 0: hipLaunchKernelGGL((attn_pipe_kernel<0, 88>), dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        case 1: hipLaunchKernelGGL((attn_pipe_kernel<1, 88>), dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        case 2: hipLaunchKernelGGL((attn_pipe_kernel<2, 88>), dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        case 5: hipLaunchKernelGGL((attn_pipe_kernel<5, 88>), dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        case 8: hipLaunchKernelGGL((attn_pipe_kernel<8, 88>), dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        case 13: hipLaunchKernelGGL((attn_pipe_kernel<13, 88>), dim3(grid), dim3(NT), 0, st, a, nitems); break;
+        case 14: hipLaunchKernelGGL((attn_pipe_kernel<14, 88>), dim3(grid), dim3(NT), 0, st, a, nitems); break;
         default: return SWIFTK_EINVAL;
     }
     SWIFTK_CHECK_LAUNCH();

@@ -99,7 +99,8 @@ struct AttnPipeArgs {
     int64_t ldq, ldo;
     int B, gh, gw, heads, sh, sw, dbg;
     const float* scale;  // per-head logit scale parameter (bounds |logit|); null = unknown
-    int tiled;           // qkv is window-tiled: [sample][window][head][q|k|v][256][88] (SWIFTK_ATTN_TILED)
+    int tiled;           // qkv is window-tiled: [sample][window][head][q|k|v][256][hd] (SWIFTK_ATTN_TILED)
+    int hd;              // head_dim: 80, 88 or 96
 };
 int swiftk_launch_attn_pipe(const AttnPipeArgs& a, hipStream_t st);
 

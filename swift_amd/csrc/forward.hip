@@ -128,18 +128,19 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     for (int i = 0; i < m->depth; ++i) {
         const swiftk_layer& ly = m->layers_host[i];
         const bool shifted = do_shift && (i & 1);
-        // head_dim 88: cosine-attention's normalise/scale prologue rides in the to_qkv epilogue (fp32 accumulators)
-        const bool fuse_norm = (hd == 88);
+        // cosine-attention's normalise/scale prologue rides in the to_qkv epilogue (fp32 accumulators): head_dim 88 with
+        // either operand type, 80 / 96 (the 468 M / 664 M variants) with bf16 operands and an even head count
+        const bool fuse_norm = (hd == 88) || (dt == SWIFTK_BF16 && (hd == 80 || hd == 96) && m->heads % 2 == 0);
         if (fuse_norm && dt == SWIFTK_BF16 && g_fwd_tiled) {
             // bf16: q/k/v leave the GEMM window-tiled, so every attention operand is one contiguous 44-KiB block
-            RUN(swiftk_gemm_qkv_tiled(xT, m->kd, ly.qkv_w, m->kd, qkv, kdv, ly.scale, B, gh, gw, m->heads,
+            RUN(swiftk_gemm_qkv_tiled(xT, m->kd, ly.qkv_w, m->kd, qkv, kdv, ly.scale, B, gh, gw, m->heads, hd,
                                       shifted ? m->sh : 0, shifted ? m->sw : 0, stream));
             RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
                                         shifted ? m->sw : 0, dt, SWIFTK_ATTN_PRENORM | SWIFTK_ATTN_TILED, stream));
         } else {
             RUN(swiftk_gemm(xT, m->kd, ly.qkv_w, m->kd, qkv, 3 * d, M, 3 * d, kdv, dt, dt,
-                            fuse_norm ? SWIFTK_EPI_QKNORM : SWIFTK_EPI_NONE, fuse_norm ? ly.scale : nullptr, nullptr, 0,
-                            stream));
+                            fuse_norm ? SWIFTK_EPI_QKNORM : SWIFTK_EPI_NONE, fuse_norm ? ly.scale : nullptr, nullptr,
+                            fuse_norm ? hd : 0, stream));
             RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
                                         shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
         }

@@ -33,7 +33,8 @@ constexpr int LDS_BYTES = 2 * STAGE;      // 152 KiB of the CU's 160 KiB
 constexpr int NT = 512;
 constexpr int A_PIECES = A_BYTES / 1024;  // 32 (4 per wave)
 constexpr int B_PIECES = B_BYTES / 1024;  // 44 (5 or 6 per wave)
-constexpr int MI = 4, NI = 11;
+constexpr int MI = 4, NI = 11;  // NI: W-side MFMA tiles per wave of the 256 x 352 geometry (gemm_kernel); gemm_kernel_p takes it
+                                // as a template parameter: 10 / 11 / 12 -> 320 / 352 / 384 columns per tile
 
 constexpr int EPI_QKNORM_TILED = 4;  // internal: SWIFTK_EPI_QKNORM with the window-tiled store (swiftk_gemm_qkv_tiled)
 
@@ -63,6 +64,7 @@ struct GemmArgs {
     const float* ep1;
     int pos_rows;
     int ntn;
+    int ni;   // W-side MFMA tiles per wave of the persistent kernel's geometry: 10 / 11 / 12 = 320 / 352 / 384 columns per tile
     int dbg;  // tuning experiments only: 1 = no DMA in the loop, 2 = no barrier (both give wrong results)
     int khalf;         // the last k-tile holds data in its first half only (K = 16.5 tiles for d = 1056)
     int ksplit;        // persistent kernel: k-ranges per output tile (1 = plain)
@@ -115,10 +117,12 @@ __device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, float b) {
 // exp(min(scale_h, ln 100)), k <- k/max(|k|,1e-12), v untouched.  A row's 88 values sit in the four 16-lane
 // groups of the wave: 22 accumulator quads -> register sums + two cross-group shuffles.
 // `rn` (optional, training): 1/max(|.|, 1e-12) of every q / k vector, [M][N/88] fp32 (1 for v), for the backward pass.
+template <int NI>
 __device__ __forceinline__ void qknorm_tile(f32x4 (&acc)[MI][NI], int lane, int c0, const float* __restrict__ scale,
                                             float* __restrict__ rn = nullptr, int mrow0 = 0, int M = 0, int nvec = 0) {
+    constexpr int HD = 8 * NI;  // the wave tile's 16*NI columns are two head vectors: 80 / 88 / 96 for NI = 10 / 11 / 12
     const int g4 = lane >> 4;
-    const int vA = c0 / 88, vB = vA + 1;
+    const int vA = c0 / HD, vB = vA + 1;
     const int kA = vA % 3, kB = vB % 3;
     const float tauA = kA == 0 ? expf(fminf(scale[vA / 3], 4.605170185988092f)) : 1.0f;
     const float tauB = kB == 0 ? expf(fminf(scale[vB / 3], 4.605170185988092f)) : 1.0f;
@@ -129,9 +133,11 @@ __device__ __forceinline__ void qknorm_tile(f32x4 (&acc)[MI][NI], int lane, int 
         for (int j = 0; j < NI; ++j) {
             const f32x4 v = acc[i][j];
             const float t = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-            if (j < 5) sa += t;
-            else if (j > 5) sb += t;
-            else { sa += g4 < 2 ? t : 0.f; sb += g4 < 2 ? 0.f : t; }
+            // quad (j, g4) holds columns 16 j + 4 g4 .. + 3: first vector below HD, second from HD on (for HD = 88 the
+            // boundary runs through j = 5 between lane groups 1 and 2)
+            if (16 * j + 12 < HD) sa += t;
+            else if (16 * j >= HD) sb += t;
+            else { sa += 16 * j + 4 * g4 < HD ? t : 0.f; sb += 16 * j + 4 * g4 < HD ? 0.f : t; }
         }
         sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
         sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
@@ -146,7 +152,7 @@ __device__ __forceinline__ void qknorm_tile(f32x4 (&acc)[MI][NI], int lane, int 
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const float f = j < 5 ? fa : (j > 5 ? fb : (g4 < 2 ? fa : fb));
+            const float f = 16 * j + 12 < HD ? fa : (16 * j >= HD ? fb : (16 * j + 4 * g4 < HD ? fa : fb));
             acc[i][j] *= f;
         }
     }
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
 
     // ---- epilogue: lane holds C[m][nb .. nb+3] for m = ..+r16, nb = ..+4*(lane>>4) ----
     if constexpr (EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED)
-        qknorm_tile(acc, lane, n0 + wn * 176, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / 88);
+        qknorm_tile<NI>(acc, lane, n0 + wn * 176, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / 88);
     OutT* C = reinterpret_cast<OutT*>(g.C);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -304,8 +310,15 @@ struct TileIter {
     }
 };
 
-template <typename T, typename OutT, int EPI>
+template <typename T, typename OutT, int EPI, int NI>
 __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm) {
+    // geometry of this instantiation: 8 waves as 4 (M) x 2 (N), each 64 x 16 NI
+    constexpr int WT = 16 * NI;                 // columns of a wave tile (160 / 176 / 192)
+    constexpr int BN = 2 * WT;                  // 320 / 352 / 384
+    constexpr int B_BYTES = BN * ROWB;          // 40 / 44 / 48 KiB
+    constexpr int STAGE = A_BYTES + B_BYTES;    // 72 / 76 / 80 KiB: two stages = 144 / 152 / 160 KiB of the CU's 160
+    constexpr int WP = B_BYTES / 1024;          // W pieces per stage: 40 / 44 / 48 = 5, 5.5, 6 per wave
+    constexpr int HD = 8 * NI;                  // QKNORM: head_dim (a wave tile = two head vectors)
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -366,9 +379,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             dma_piece_fast(sa + (wv * 4 + p) * 1024, abase[p], ((p & 1) ? va_odd : va_even) + koff);
         } else {
             const int i = p - 4;
-            // W has 44 pieces for 8 waves: the sixth one exists for waves 0-3 only (a wave-uniform branch around the asm; the
-            // EXEC-mask form needs an SGPR operand and hipcc hands inline asm a VGPR for it at this SGPR pressure)
-            if (i < 5 || wv < 4) dma_piece_fast(sa + A_BYTES + (wv + 8 * i) * 1024, wbase[i], vb + koff);
+            // W has 40 / 44 / 48 pieces for 8 waves: with 44 the sixth one exists for waves 0-3 only (a wave-uniform branch
+            // around the asm; the EXEC-mask form needs an SGPR operand and hipcc hands inline asm a VGPR for it at this
+            // SGPR pressure)
+            if (wv + 8 * i < WP) dma_piece_fast(sa + A_BYTES + (wv + 8 * i) * 1024, wbase[i], vb + koff);
         }
     };
 
@@ -380,7 +394,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 
     const int r16 = lane & 15;
     const int xoff = (wm * 64 + r16) * ROWB;
-    const int woff = A_BYTES + (wn * 176 + r16) * ROWB;
+    const int woff = A_BYTES + (wn * WT + r16) * ROWB;
     const int ch0 = (((lane >> 4) + 0) ^ (r16 >> 1)) * 16;
     const int ch1 = (((lane >> 4) + 4) ^ (r16 >> 1)) * 16;
 
@@ -507,7 +521,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             it.coords(tile / ksplit, tm, tn);
             const int m0 = tm * BM, n0 = tn * BN;
             if constexpr (EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED)
-                qknorm_tile(acc, lane, n0 + wn * 176, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / 88);
+                qknorm_tile<NI>(acc, lane, n0 + wn * WT, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / HD);
             OutT* C = reinterpret_cast<OutT*>(g.C) + (int64_t)(tile % ksplit) * g.c_split;
             if constexpr (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS) {
                 // bf16 output: transpose each 16-row slab of the wave's tile through LDS so that rows leave as whole
@@ -515,7 +529,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 // stores per wave -- the scattered form is store-issue bound (4.6 us per tile, 14.5 us with SwiGLU).
                 // The stage just consumed (`s`) is free: its refill is issued only after the next barrier, which no
                 // wave passes before every wave has finished this epilogue.  Slabs are wave-private: no barrier.
-                constexpr int COLS = (EPI == SWIFTK_EPI_SWIGLU) ? 88 : 176;  // output columns of the wave tile
+                constexpr int COLS = (EPI == SWIFTK_EPI_SWIGLU) ? WT / 2 : WT;  // output columns of the wave tile
                 constexpr int CPR = COLS / 8;                                  // 16-B chunks per row
                 constexpr int RSTR = COLS * 2 + 16;                            // padded slab row stride (bytes)
                 // the slabs overlay operand bytes of the stage just consumed: every wave must be done READING that stage
@@ -584,11 +598,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                                 {
                                     int rx = tx16 + row - g.t_sw;
                                     rx += rx < 0 ? g.t_gw : 0;
-                                    const int hi = cc >= 11;
+                                    const int hi = cc >= NI;  // NI 16-B chunks per head vector
                                     // tile = ((sample * windows + window) * heads + head) * 3 + part; the last two terms
                                     // are the row's 88-wide slice number 4 * tn + 2 * wn + hi
                                     const int tile_ = (twin0 + (rx >> 4)) * (3 * g.t_heads) + tn * 4 + wn * 2 + hi;
-                                    dst = (int64_t)tile_ * (256 * 88) + ((((try_ & 15) << 4) | (rx & 15)) * 88 + (cc - 11 * hi) * 8);
+                                    dst = (int64_t)tile_ * (256 * HD) + ((((try_ & 15) << 4) | (rx & 15)) * HD + (cc - NI * hi) * 8);
                                 }
                             }
                             if (m < g.M && n < nout) *reinterpret_cast<uint4*>(C + dst) = q;
@@ -602,7 +616,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 const int m = m0 + wm * 64 + i * 16 + r16;
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    const int nb = n0 + wn * 176 + j * 16 + 4 * (lane >> 4);
+                    const int nb = n0 + wn * WT + j * 16 + 4 * (lane >> 4);
                     f32x4 v = acc[i][j];
                     acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (m >= g.M || nb >= g.N) continue;
@@ -638,8 +652,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         // VMEM retires in issue order: the DMA pieces of the next tile's first stage are older than this tile's epilogue
         // stores, so leaving exactly those stores outstanding is enough (no store drain in front of a tile)
         if (interior) {
-            if constexpr (sizeof(OutT) == 2 && EPI == SWIFTK_EPI_SWIGLU) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if constexpr (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            // stores per wave of an interior tile: 4 slabs x ceil(16 rows x (COLS / 8) chunks / 64 lanes)
+            constexpr int NSTORE = 4 * ((16 * ((EPI == SWIFTK_EPI_SWIGLU ? WT / 2 : WT) / 8) + 63) / 64);
+            if constexpr (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -670,11 +685,20 @@ int launch(const GemmArgs& g, hipStream_t st) {
                                                !(g.N & (EPI == SWIFTK_EPI_SWIGLU ? 15 : 7)));  // 16-B row chunks
     if (g_variant == 0 || (g.M & 7) || (g.N & 7) || !wide_ok) {  // ragged edges: per-lane clamped sources
         if (g.ksplit != 1 || g.t_gw) return SWIFTK_ESHAPE;
-        hipLaunchKernelGGL(kern, dim3(ntm * g.ntn), dim3(NT), 0, st, g);
+        if ((EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED) && g.ni != NI) return SWIFTK_ESHAPE;  // 352-wide tiles only
+        GemmArgs g1 = g;
+        g1.ntn = (g.N + BN - 1) / BN;
+        hipLaunchKernelGGL(kern, dim3(ntm * g1.ntn), dim3(NT), 0, st, g1);
     } else {
         const int ntiles = ntm * g.ntn * g.ksplit;
         const int grid = ntiles < g_persist_wgs ? ntiles : g_persist_wgs;
-        hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+        if constexpr (sizeof(T) == 2) {  // bf16 operands: all three tile widths (head_dim 80 / 88 / 96 families)
+            if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 10>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+            else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 12>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+            else hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+        } else {
+            hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+        }
     }
     if (timed) swiftk_prof_end(st);
     SWIFTK_CHECK_LAUNCH();
@@ -774,7 +798,18 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     const int ovec = (epilogue == SWIFTK_EPI_SWIGLU ? 2 : 4) * os;
     if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || (lda * es) % 16 || (ldw * es) % 16) return SWIFTK_EALIGN;
     if (((uintptr_t)C % ovec) || (ldc * os) % ovec) return SWIFTK_EALIGN;
-    if (epilogue == SWIFTK_EPI_QKNORM && (!ep0 || N % 264 != 0)) return SWIFTK_ESHAPE;  // whole heads of 3 x 88
+    // QKNORM: whole heads of 3 x head_dim columns, a wave tile = two head vectors -> tile width 4 x head_dim; head_dim
+    // travels in `pos_rows` (0 = 88); fp32 operands are built for 88 only
+    int ni = 11;
+    if (epilogue == SWIFTK_EPI_QKNORM) {
+        const int64_t hd = pos_rows > 0 ? pos_rows : 88;
+        if (!ep0 || (hd != 80 && hd != 88 && hd != 96) || N % (6 * hd) != 0) return SWIFTK_ESHAPE;
+        if (hd != 88 && dtype != SWIFTK_BF16) return SWIFTK_ESHAPE;
+        ni = (int)(hd / 8);
+    } else if (dtype == SWIFTK_BF16 && N % 352 != 0) {  // tile width that divides N, if one does (dim 1280 / 1536 families)
+        if (N % 384 == 0) ni = 12;
+        else if (N % 320 == 0) ni = 10;
+    }
     if (epilogue == SWIFTK_EPI_BIAS_POS && (!ep0 || ((uintptr_t)ep0 & 15) || (ep1 && (((uintptr_t)ep1 & 15) || pos_rows <= 0))))
         return SWIFTK_EINVAL;
     GemmArgs g;
@@ -790,7 +825,8 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     g.ep0 = ep0;
     g.ep1 = ep1;
     g.pos_rows = (int)pos_rows;
-    g.ntn = (int)((N + BN - 1) / BN);
+    g.ni = ni;
+    g.ntn = (int)((N + 32 * ni - 1) / (32 * ni));
     g.dbg = g_dbg;
     g.ksplit = ksplit;
     g.c_split = c_split;
@@ -814,16 +850,17 @@ extern "C" int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ld
 }
 
 extern "C" int swiftk_gemm_qkv_tiled(const void* A, int64_t lda, const void* W, int64_t ldw, void* qkv_tiled, int64_t K,
-                                     const float* scale, int B, int gh, int gw, int heads, int shift_h, int shift_w,
-                                     void* stream) {
+                                     const float* scale, int B, int gh, int gw, int heads, int head_dim, int shift_h,
+                                     int shift_w, void* stream) {
     if (B <= 0 || heads <= 0 || gh <= 0 || gw <= 0 || gh % 16 || gw % 16) return SWIFTK_ESHAPE;
+    if (head_dim != 80 && head_dim != 88 && head_dim != 96) return SWIFTK_ESHAPE;
     if (shift_h < 0 || shift_w < 0 || shift_h >= gh || shift_w >= gw) return SWIFTK_ESHAPE;
     if ((uintptr_t)qkv_tiled & 15) return SWIFTK_EALIGN;
     if (g_variant == 0) return SWIFTK_ESHAPE;  // the tiled store lives in the persistent kernel's epilogue
     const int tiling[5] = {gh, gw, shift_h, shift_w, heads};
-    const int64_t M = (int64_t)B * gh * gw, N = 3 * (int64_t)heads * 88;
-    return gemm_impl(A, lda, W, ldw, qkv_tiled, N, M, N, K, SWIFTK_BF16, SWIFTK_BF16, SWIFTK_EPI_QKNORM, scale, nullptr, 0, 1,
-                     0, stream, tiling);
+    const int64_t M = (int64_t)B * gh * gw, N = 3 * (int64_t)heads * head_dim;
+    return gemm_impl(A, lda, W, ldw, qkv_tiled, N, M, N, K, SWIFTK_BF16, SWIFTK_BF16, SWIFTK_EPI_QKNORM, scale, nullptr,
+                     head_dim, 1, 0, stream, tiling);
 }
 
 extern "C" int swiftk_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, float* slabs, int64_t ldc,

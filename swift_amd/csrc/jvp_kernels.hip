@@ -49,8 +49,8 @@ __global__ void silu_jvp_kernel(const float* __restrict__ z, const float* __rest
 
 // --------------------------------------------------------------------------------- q/k normalisation tangent
 // v_hat = v / max(|v|, 1e-12) * tau,  d v_hat = tau / n * (dv - v (v . dv) / n^2)   (swinv2.py:123-127; tau = 1 for k)
-// One 16-lane group per (row, head, q|k) vector of 88; in place on the primal and the tangent tensor.
-template <typename T>
+// One 16-lane group per (row, head, q|k) vector of head_dim (80 / 88 / 96); in place on the primal and the tangent tensor.
+template <typename T, int HD>
 __global__ __launch_bounds__(256) void qknorm_jvp_kernel(T* __restrict__ qkv, T* __restrict__ dqkv, int64_t ld,
                                                          const float* __restrict__ scale, int64_t M, int heads) {
     const int l16 = threadIdx.x & 15;
@@ -60,14 +60,14 @@ __global__ __launch_bounds__(256) void qknorm_jvp_kernel(T* __restrict__ qkv, T*
         const int64_t mh = vid >> 1;
         const int h = (int)(mh % heads);
         const int64_t m = mh / heads;
-        T* p = qkv + m * ld + (h * 3 + part) * 88;
-        T* dp = dqkv + m * ld + (h * 3 + part) * 88;
+        T* p = qkv + m * ld + (h * 3 + part) * HD;
+        T* dp = dqkv + m * ld + (h * 3 + part) * HD;
         float v[6], dv[6], ss = 0.f, dot = 0.f;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int e = l16 + 16 * i;
-            v[i] = e < 88 ? ldf(p + e) : 0.f;
-            dv[i] = e < 88 ? ldf(dp + e) : 0.f;
+            v[i] = e < HD ? ldf(p + e) : 0.f;
+            dv[i] = e < HD ? ldf(dp + e) : 0.f;
             ss += v[i] * v[i];
             dot += v[i] * dv[i];
         }
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void qknorm_jvp_kernel(T* __restrict__ qkv, T*
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int e = l16 + 16 * i;
-            if (e < 88) {
+            if (e < HD) {
                 p[e] = elem<T>::from_f(v[i] * a);
                 dp[e] = elem<T>::from_f(a * (dv[i] - v[i] * c));
             }
@@ -200,26 +200,30 @@ __device__ __forceinline__ int jvp_window_token(const AttnJvpArgs& a, int w, int
     return gy * a.gw + gx;
 }
 
-template <typename T>
-__device__ __forceinline__ void load_row88(const T* src, float* dst);
-template <>
-__device__ __forceinline__ void load_row88<float>(const float* src, float* dst) {
+template <typename T, int HD>
+struct RowLoad;
+template <int HD>
+struct RowLoad<float, HD> {
+    __device__ static __forceinline__ void run(const float* src, float* dst) {
 #pragma unroll
-    for (int c = 0; c < 22; ++c) *reinterpret_cast<float4*>(dst + 4 * c) = *reinterpret_cast<const float4*>(src + 4 * c);
-}
-template <>
-__device__ __forceinline__ void load_row88<bf16_t>(const bf16_t* src, float* dst) {
-#pragma unroll
-    for (int c = 0; c < 11; ++c) {
-        const uint4 u = *reinterpret_cast<const uint4*>(src + 8 * c);
-        *reinterpret_cast<float4*>(dst + 8 * c) = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                                                              __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-        *reinterpret_cast<float4*>(dst + 8 * c + 4) = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
-                                                                  __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+        for (int c = 0; c < HD / 4; ++c) *reinterpret_cast<float4*>(dst + 4 * c) = *reinterpret_cast<const float4*>(src + 4 * c);
     }
-}
+};
+template <int HD>
+struct RowLoad<bf16_t, HD> {
+    __device__ static __forceinline__ void run(const bf16_t* src, float* dst) {
+#pragma unroll
+        for (int c = 0; c < HD / 8; ++c) {
+            const uint4 u = *reinterpret_cast<const uint4*>(src + 8 * c);
+            *reinterpret_cast<float4*>(dst + 8 * c) = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                                                  __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+            *reinterpret_cast<float4*>(dst + 8 * c + 4) = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                                                                      __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+        }
+    }
+};
 
-template <typename T>
+template <typename T, int HD>
 __global__ __launch_bounds__(512) void attn_jvp_kernel(AttnJvpArgs a) {
     __shared__ __attribute__((aligned(16))) float img[256 * ISTR];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -237,25 +241,25 @@ __global__ __launch_bounds__(512) void attn_jvp_kernel(AttnJvpArgs a) {
     // fill the image with part `part` (1 = k, 2 = v) of the primal (tan = 0) or tangent (tan = 1) tensor
     auto fill = [&](int part, int tan) {
         if (tid < 256) {
-            const T* src = (tan ? dqkv : qkv) + (tok0 + jvp_window_token(a, w, tid)) * a.ldq + (head * 3 + part) * 88;
+            const T* src = (tan ? dqkv : qkv) + (tok0 + jvp_window_token(a, w, tid)) * a.ldq + (head * 3 + part) * HD;
             float* dst = img + tid * ISTR;
-            load_row88<T>(src, dst);
-            *reinterpret_cast<float4*>(dst + 88) = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(dst + 92) = make_float4(0.f, 0.f, 0.f, 0.f);
+            RowLoad<T, HD>::run(src, dst);
+#pragma unroll
+            for (int z = HD; z < 96; z += 4) *reinterpret_cast<float4*>(dst + z) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
-    // this lane's slice of its query row: d = 24 g + i, i = 0..23 (zero for d >= 88)
+    // this lane's slice of its query row: d = 24 g + i, i = 0..23 (zero for d >= head_dim)
     float qv[24], dqv[24];
     {
         const int tq = jvp_window_token(a, w, qh * 128 + wv * 16 + c16);
-        const T* qs = qkv + (tok0 + tq) * a.ldq + head * 3 * 88;
-        const T* dqs = dqkv + (tok0 + tq) * a.ldq + head * 3 * 88;
+        const T* qs = qkv + (tok0 + tq) * a.ldq + head * 3 * HD;
+        const T* dqs = dqkv + (tok0 + tq) * a.ldq + head * 3 * HD;
 #pragma unroll
         for (int i = 0; i < 24; ++i) {
             const int d = 24 * g + i;
-            qv[i] = d < 88 ? ldf(qs + d) : 0.f;
-            dqv[i] = d < 88 ? ldf(dqs + d) : 0.f;
+            qv[i] = d < HD ? ldf(qs + d) : 0.f;
+            dqv[i] = d < HD ? ldf(dqs + d) : 0.f;
         }
     }
     fill(1, 0);
@@ -354,13 +358,13 @@ __global__ __launch_bounds__(512) void attn_jvp_kernel(AttnJvpArgs a) {
 
     // lane holds O^T[d = 16 db + 4 g + 0..3][q = c16]
     const float rl = 1.0f / l, rr = rs * rl;
-    const int64_t orow = (tok0 + jvp_window_token(a, w, qh * 128 + wv * 16 + c16)) * a.ldo + head * 88;
+    const int64_t orow = (tok0 + jvp_window_token(a, w, qh * 128 + wv * 16 + c16)) * a.ldo + head * HD;
     T* po = static_cast<T*>(a.out) + orow;
     T* pdo = static_cast<T*>(a.dout) + orow;
 #pragma unroll
     for (int db = 0; db < 6; ++db) {
         const int d = 16 * db + 4 * g;
-        if (d < 88) {
+        if (d < HD) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 po[d + r] = elem<T>::from_f(o[db][r] * rl);
@@ -377,6 +381,7 @@ __global__ __launch_bounds__(512) void attn_jvp_kernel(AttnJvpArgs a) {
 // ordered to match the S^T accumulator registers of two 16-key blocks: slot (g, j) <-> key 16 (2p + j/4) + 4 g + j%4.
 constexpr int JK = 208, JV = 192;
 
+template <int HD>
 __global__ __launch_bounds__(512) void attn_jvp_bf16_kernel(AttnJvpArgs a) {
     __shared__ __attribute__((aligned(16))) char img[2 * 256 * JK];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -398,23 +403,23 @@ __global__ __launch_bounds__(512) void attn_jvp_bf16_kernel(AttnJvpArgs a) {
             const int cc0 = c - tan * 256 * 12;
             const int row = cc0 / 12, cc = cc0 - row * 12;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (cc < 11) {
-                const bf16_t* src = (tan ? dqkv : qkv) + (tok0 + jvp_window_token(a, w, row)) * a.ldq + (head * 3 + part) * 88;
+            if (cc < HD / 8) {
+                const bf16_t* src = (tan ? dqkv : qkv) + (tok0 + jvp_window_token(a, w, row)) * a.ldq + (head * 3 + part) * HD;
                 v = *reinterpret_cast<const uint4*>(src + 8 * cc);
             }
             *reinterpret_cast<uint4*>(img + (tan * 256 + row) * stride + cc * 16) = v;
         }
     };
 
-    // q / dq fragments of query row qh*128 + wv*16 + l16: 8 bf16 at d = 32 ks + 8 g (zero beyond d = 88)
+    // q / dq fragments of query row qh*128 + wv*16 + l16: 8 bf16 at d = 32 ks + 8 g (zero beyond head_dim)
     uint4 qf[3], dqf[3];
     {
-        const int64_t r = (tok0 + jvp_window_token(a, w, qh * 128 + wv * 16 + l16)) * a.ldq + head * 3 * 88;
+        const int64_t r = (tok0 + jvp_window_token(a, w, qh * 128 + wv * 16 + l16)) * a.ldq + head * 3 * HD;
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
             const int d = 32 * ks + 8 * g;
-            qf[ks] = d < 88 ? *reinterpret_cast<const uint4*>(qkv + r + d) : make_uint4(0, 0, 0, 0);
-            dqf[ks] = d < 88 ? *reinterpret_cast<const uint4*>(dqkv + r + d) : make_uint4(0, 0, 0, 0);
+            qf[ks] = d < HD ? *reinterpret_cast<const uint4*>(qkv + r + d) : make_uint4(0, 0, 0, 0);
+            dqf[ks] = d < HD ? *reinterpret_cast<const uint4*>(dqkv + r + d) : make_uint4(0, 0, 0, 0);
         }
     }
     fill(1, JK);
@@ -504,13 +509,13 @@ __global__ __launch_bounds__(512) void attn_jvp_bf16_kernel(AttnJvpArgs a) {
     }
 
     const float rl = 1.0f / l, rr = rs * rl;
-    const int64_t orow = (tok0 + jvp_window_token(a, w, qh * 128 + wv * 16 + l16)) * a.ldo + head * 88;
+    const int64_t orow = (tok0 + jvp_window_token(a, w, qh * 128 + wv * 16 + l16)) * a.ldo + head * HD;
     bf16_t* po = static_cast<bf16_t*>(a.out) + orow;
     bf16_t* pdo = static_cast<bf16_t*>(a.dout) + orow;
 #pragma unroll
     for (int db = 0; db < 6; ++db) {
         const int d = 16 * db + 4 * g;
-        if (d < 88) {
+        if (d < HD) {
             *reinterpret_cast<uint2*>(po + d) = make_uint2(pack_bf16(o[db][0] * rl, o[db][1] * rl), pack_bf16(o[db][2] * rl, o[db][3] * rl));
             float dv[4];
 #pragma unroll
@@ -570,19 +575,29 @@ extern "C" int swiftk_silu_jvp(const float* z, const float* dz, float* y, float*
     return 0;
 }
 
-extern "C" int swiftk_qknorm_jvp(void* qkv, void* dqkv, int64_t ld, const float* scale, int64_t M, int heads, int dtype,
-                                 void* stream) {
-    if (!qkv || !dqkv || !scale || M <= 0 || heads <= 0) return SWIFTK_EINVAL;
-    if (ld < 3 * heads * 88) return SWIFTK_ESHAPE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int grid = grid_for(M * heads * 2, 16);
+template <int HD>
+static int launch_qknorm_jvp(void* qkv, void* dqkv, int64_t ld, const float* scale, int64_t M, int heads, int dtype, hipStream_t st) {
+    const int grid = grid_for(M * heads * 2 * 16);
     DT_SWITCH(dtype,
-              hipLaunchKernelGGL(qknorm_jvp_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<bf16_t*>(qkv),
+              hipLaunchKernelGGL((qknorm_jvp_kernel<bf16_t, HD>), dim3(grid), dim3(256), 0, st, static_cast<bf16_t*>(qkv),
                                  static_cast<bf16_t*>(dqkv), ld, scale, M, heads),
-              hipLaunchKernelGGL(qknorm_jvp_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<float*>(qkv),
+              hipLaunchKernelGGL((qknorm_jvp_kernel<float, HD>), dim3(grid), dim3(256), 0, st, static_cast<float*>(qkv),
                                  static_cast<float*>(dqkv), ld, scale, M, heads));
     SWIFTK_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int swiftk_qknorm_jvp(void* qkv, void* dqkv, int64_t ld, const float* scale, int64_t M, int heads, int head_dim,
+                                 int dtype, void* stream) {
+    if (!qkv || !dqkv || !scale || M <= 0 || heads <= 0) return SWIFTK_EINVAL;
+    if (ld < 3 * heads * head_dim) return SWIFTK_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (head_dim) {
+        case 80: return launch_qknorm_jvp<80>(qkv, dqkv, ld, scale, M, heads, dtype, st);
+        case 88: return launch_qknorm_jvp<88>(qkv, dqkv, ld, scale, M, heads, dtype, st);
+        case 96: return launch_qknorm_jvp<96>(qkv, dqkv, ld, scale, M, heads, dtype, st);
+    }
+    return SWIFTK_ESHAPE;
 }
 
 extern "C" int swiftk_swiglu_jvp(const void* h, const void* dh, int64_t ldh, void* out, void* dout, int64_t ldo, int64_t M,
@@ -621,24 +636,31 @@ extern "C" int swiftk_modnorm_jvp(const void* y, const void* dy, int64_t ldy, fl
     return 0;
 }
 
+template <int HD>
+static int launch_attn_jvp(const AttnJvpArgs& a, int grid, int dtype, hipStream_t st) {
+    DT_SWITCH(dtype, hipLaunchKernelGGL(attn_jvp_bf16_kernel<HD>, dim3(grid), dim3(512), 0, st, a),
+              hipLaunchKernelGGL((attn_jvp_kernel<float, HD>), dim3(grid), dim3(512), 0, st, a));
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int swiftk_window_attention_jvp(const void* qkv, const void* dqkv, int64_t ldq, void* out, void* dout, int64_t ldo,
                                            int B, int gh, int gw, int heads, int head_dim, int shift_h, int shift_w, int dtype,
                                            void* stream) {
     if (!qkv || !dqkv || !out || !dout || B <= 0 || heads <= 0) return SWIFTK_EINVAL;
-    if (head_dim != 88) return SWIFTK_ESHAPE;
+    if (head_dim != 80 && head_dim != 88 && head_dim != 96) return SWIFTK_ESHAPE;
     if (gh <= 0 || gw <= 0 || gh % 16 || gw % 16) return SWIFTK_ESHAPE;
     if (shift_h < 0 || shift_w < 0 || shift_h >= gh || shift_w >= gw) return SWIFTK_ESHAPE;
-    if (ldq < 3 * heads * 88 || ldo < heads * 88) return SWIFTK_ESHAPE;
+    if (ldq < 3 * heads * head_dim || ldo < heads * head_dim) return SWIFTK_ESHAPE;
     const int es = dtype == SWIFTK_BF16 ? 2 : 4;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)dqkv & 15) || (ldq * es) % 16) return SWIFTK_EALIGN;
     AttnJvpArgs a{qkv, dqkv, out, dout, ldq, ldo, gh, gw, heads, shift_h, shift_w, gw / 16, (gh / 16) * (gw / 16)};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = B * a.nw * heads * 2;
     if (dtype == SWIFTK_BF16 && ((uintptr_t)out & 7 || (uintptr_t)dout & 7 || (ldo & 3))) return SWIFTK_EALIGN;
-    DT_SWITCH(dtype, hipLaunchKernelGGL(attn_jvp_bf16_kernel, dim3(grid), dim3(512), 0, st, a),
-              hipLaunchKernelGGL(attn_jvp_kernel<float>, dim3(grid), dim3(512), 0, st, a));
-    SWIFTK_CHECK_LAUNCH();
-    return 0;
+    if (head_dim == 80) return launch_attn_jvp<80>(a, grid, dtype, st);
+    if (head_dim == 96) return launch_attn_jvp<96>(a, grid, dtype, st);
+    return launch_attn_jvp<88>(a, grid, dtype, st);
 }
 
 extern "C" int swiftk_scm_target(const float* F, const float* dxt, const float* xt_over_sd, const float* dF, const float* t,

@@ -41,8 +41,9 @@ def _gemm(a, w, out, epi=EPI_NONE, ep0=None, ep1=None, pos_rows=0):
 class SwinJvpEngine:
     def __init__(self, module, dtype: torch.dtype = torch.bfloat16):
         self.m = module
-        if module.dim // module.heads != 88:
-            raise SwiftkError("the tangent kernels are built for head_dim 88 (Swift-B)")
+        self.hd = module.dim // module.heads
+        if self.hd not in (80, 88, 96):
+            raise SwiftkError("the tangent kernels are built for head_dim 80 / 88 / 96")
         self.dt = dtype
         self._stamp = None
 
@@ -52,13 +53,16 @@ class SwinJvpEngine:
         if stamp == self._stamp:
             return
         d, mlp = m.dim, m.mlp_dim
-        self.kd, self.kmlp = ops.k_pad(dt, d), ops.k_pad(dt, mlp)
+        mlp_e = self.mlp_e = mlp + (mlp & 1)  # odd MLP widths (dim 1280 -> 3413): one zero (gate, up) row pair, as in SwinEngine
+        self.kd, self.kmlp = ops.k_pad(dt, d), ops.k_pad(dt, mlp_e)
         self.kpe = ops.k_pad(dt, m.in_channels * m.patch_size[0] * m.patch_size[1])
         cast = lambda w, k: ops.pad_cols(w.detach(), k, dt)
         self.L = []
         mods_w, mods_b = [], []
         for att, ff in m.transformer.layers:
             w1i = ff.w1.weight.detach().view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)  # (gate_j, up_j) interleaved
+            if mlp_e != mlp:
+                w1i = torch.cat([w1i, w1i.new_zeros(2, d)], 0)
             self.L.append(dict(qkv=cast(att.to_qkv.weight, self.kd), wo=cast(att.wo.weight, self.kd), w1=cast(w1i, self.kd),
                                w2=cast(ff.w2.weight, self.kmlp), scale=att.scale.detach().reshape(-1).float().contiguous(),
                                g1=att.norm.norm.weight.detach().float().contiguous(),
@@ -89,7 +93,7 @@ class SwinJvpEngine:
         tc = ops.dtype_code(T)
         dev = srcs[0].device
         B = srcs[0].shape[0]
-        d, heads, mlp = m.dim, m.heads, m.mlp_dim
+        d, heads, mlp = m.dim, m.heads, self.mlp_e
         gh, gw = m.grid_size
         ntok = gh * gw
         M = B * ntok
@@ -147,10 +151,10 @@ class SwinJvpEngine:
             W = self.L[i]
             sh = tuple(m.shift_size) if (do_shift and i % 2) else (0, 0)
             _gemm(XT, W["qkv"], QKV)
-            check(L.swiftk_qknorm_jvp(QKV.data_ptr(), QKV.data_ptr() + M * 3 * d * es, 3 * d, W["scale"].data_ptr(), M, heads, tc,
-                                      _s()), "swiftk_qknorm_jvp")
+            check(L.swiftk_qknorm_jvp(QKV.data_ptr(), QKV.data_ptr() + M * 3 * d * es, 3 * d, W["scale"].data_ptr(), M, heads,
+                                      self.hd, tc, _s()), "swiftk_qknorm_jvp")
             check(L.swiftk_window_attention_jvp(QKV.data_ptr(), QKV.data_ptr() + M * 3 * d * es, 3 * d, ATT.data_ptr(),
-                                                ATT.data_ptr() + M * self.kd * es, self.kd, B, gh, gw, heads, 88, sh[0], sh[1],
+                                                ATT.data_ptr() + M * self.kd * es, self.kd, B, gh, gw, heads, self.hd, sh[0], sh[1],
                                                 tc, _s()), "swiftk_window_attention_jvp")
             _gemm(ATT, W["wo"], Y)
             modnorm(2 * i, W["g1"], W["b1"])

@@ -55,8 +55,9 @@ def pad_cols(w: torch.Tensor, k: int, dtype: torch.dtype) -> torch.Tensor:
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *, n_out: Optional[int] = None,
          out_dtype: Optional[torch.dtype] = None, epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None,
-         pos: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M, N] = epilogue(a[M, K] @ w[N, K]^T); a, w row-major 2-D (row stride may exceed K)."""
+         pos: Optional[torch.Tensor] = None, head_dim: int = 0) -> torch.Tensor:
+    """out[M, N] = epilogue(a[M, K] @ w[N, K]^T); a, w row-major 2-D (row stride may exceed K).
+    ``head_dim``: EPI_QKNORM only (80 / 88 / 96; 0 = 88)."""
     _dev(a, w, out, bias, pos)
     M, K = a.shape
     N = w.shape[0]
@@ -67,37 +68,38 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *
         out = torch.empty(M, n_out or ncol, dtype=odt, device=a.device)
     check(lib().swiftk_gemm(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K,
                             dtype_code(a.dtype), dtype_code(out.dtype), epilogue, _ptr(bias), _ptr(pos),
-                            0 if pos is None else pos.shape[0], _stream()), "swiftk_gemm")
+                            (head_dim if epilogue == EPI_QKNORM else 0) if pos is None else pos.shape[0], _stream()), "swiftk_gemm")
     return out
 
 
 def gemm_qkv_tiled(a: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, B: int, grid: Tuple[int, int], heads: int,
-                   shift: Tuple[int, int] = (0, 0), out: Optional[torch.Tensor] = None, k: Optional[int] = None) -> torch.Tensor:
-    """to_qkv with the QK-norm epilogue, stored window-tiled: out[B, windows, heads, 3, 256, 88] (bf16).
+                   shift: Tuple[int, int] = (0, 0), out: Optional[torch.Tensor] = None, k: Optional[int] = None,
+                   head_dim: int = 88) -> torch.Tensor:
+    """to_qkv with the QK-norm epilogue, stored window-tiled: out[B, windows, heads, 3, 256, head_dim] (bf16).
 
     ``k``: valid K when it ends half-way into the last k-tile of the (padded) operand rows.
     """
     _dev(a, w, scale, out)
     gh, gw = grid
-    assert a.shape[0] == B * gh * gw and w.shape[0] == 3 * heads * 88 and a.dtype == torch.bfloat16
+    assert a.shape[0] == B * gh * gw and w.shape[0] == 3 * heads * head_dim and a.dtype == torch.bfloat16
     if out is None:
-        out = torch.empty(B, (gh // 16) * (gw // 16), heads, 3, 256, 88, dtype=torch.bfloat16, device=a.device)
+        out = torch.empty(B, (gh // 16) * (gw // 16), heads, 3, 256, head_dim, dtype=torch.bfloat16, device=a.device)
     check(lib().swiftk_gemm_qkv_tiled(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(),
-                                      k or a.shape[1], scale.contiguous().data_ptr(), B, gh, gw, heads, shift[0], shift[1],
-                                      _stream()), "swiftk_gemm_qkv_tiled")
+                                      k or a.shape[1], scale.contiguous().data_ptr(), B, gh, gw, heads, head_dim, shift[0],
+                                      shift[1], _stream()), "swiftk_gemm_qkv_tiled")
     return out
 
 
 def window_attention_tiled(qkv_tiled: torch.Tensor, scale: Optional[torch.Tensor], grid: Tuple[int, int], heads: int,
                            shift: Tuple[int, int] = (0, 0), out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Attention over ``gemm_qkv_tiled`` output -> out [B, gh*gw, heads*88] (token order, un-rolled)."""
+    """Attention over ``gemm_qkv_tiled`` output -> out [B, gh*gw, heads*head_dim] (token order, un-rolled)."""
     _dev(qkv_tiled, scale, out)
-    B = qkv_tiled.shape[0]
+    B, hd = qkv_tiled.shape[0], qkv_tiled.shape[-1]
     gh, gw = grid
     if out is None:
-        out = torch.empty(B, gh * gw, heads * 88, dtype=torch.bfloat16, device=qkv_tiled.device)
-    check(lib().swiftk_window_attention(qkv_tiled.data_ptr(), 3 * heads * 88, out.data_ptr(), out.stride(1),
-                                        None if scale is None else scale.contiguous().data_ptr(), B, gh, gw, heads, 88,
+        out = torch.empty(B, gh * gw, heads * hd, dtype=torch.bfloat16, device=qkv_tiled.device)
+    check(lib().swiftk_window_attention(qkv_tiled.data_ptr(), 3 * heads * hd, out.data_ptr(), out.stride(1),
+                                        None if scale is None else scale.contiguous().data_ptr(), B, gh, gw, heads, hd,
                                         shift[0], shift[1], BF16, ATTN_PRENORM | ATTN_TILED, _stream()),
           "swiftk_window_attention")
     return out

@@ -9,7 +9,8 @@ Activations are saved per layer (3.4 GB per sample at Swift-B; the multistep los
 as the reference's ``checkpoint_sequential`` does).  Parameter gradients accumulate into ``param.grad`` (fp32).
 
 bf16 GEMM operands, fp32 accumulation, fp32 residual stream / normalisation statistics / gradients of the residual
-stream -- the same precision split as the inference engine.  Only head_dim 88 (Swift-B) is supported.
+stream -- the same precision split as the inference engine.  head_dim 80 / 88 / 96 (the 468 M, Swift-B and 664 M
+variants of experiment/era5-swinv2-1.4-scm.yaml:21-36).
 """
 from __future__ import annotations
 
@@ -49,8 +50,9 @@ def _transpose(src, rows, cols, ldd=None):
 class SwinTrainEngine:
     def __init__(self, module):
         self.m = module
-        if module.dim // module.heads != 88:
-            raise SwiftkError("the training kernels are built for head_dim 88 (Swift-B)")
+        self.hd = module.dim // module.heads
+        if self.hd not in (80, 88, 96) or module.heads % 2:
+            raise SwiftkError("the training kernels are built for head_dim 80 / 88 / 96 and an even head count")
         self._stamp = None
         self._slabs = None
 
@@ -61,10 +63,13 @@ class SwinTrainEngine:
         if stamp == self._stamp:
             return
         d, mlp = m.dim, m.mlp_dim
-        self.kd, self.kmlp = ops.k_pad(_BF, d), ops.k_pad(_BF, mlp)
+        # int(8/3 dim) need not be a multiple of 4 (dim 1280 -> 3413): zero (gate, up) rows of w1 / zero columns of w2 bring
+        # the MLP width to the GEMMs' granularity (N % 4, split-K rows % 8); silu(0) * 0 = 0 feeds w2's zero columns
+        mlp_e = self.mlp_e = (mlp + 3) // 4 * 4
+        self.kd, self.kmlp = ops.k_pad(_BF, d), ops.k_pad(_BF, mlp_e)
         self.kpe = ops.k_pad(_BF, m.in_channels * m.patch_size[0] * m.patch_size[1])
         self.kqkv = ops.k_pad(_BF, 3 * d)
-        self.kh = ops.k_pad(_BF, 2 * mlp)
+        self.kh = ops.k_pad(_BF, 2 * mlp_e)
         po = m.out_channels * m.patch_size[0] * m.patch_size[1]
         self.kpo = ops.k_pad(_BF, po)
         cast = lambda w, k: ops.pad_cols(w.detach(), k, _BF)
@@ -72,11 +77,15 @@ class SwinTrainEngine:
         self.L = []
         for att, ff in m.transformer.layers:
             w1i = ff.w1.weight.detach().view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)
+            w2p = ff.w2.weight.detach()
+            if mlp_e != mlp:
+                w1i = torch.cat([w1i, w1i.new_zeros(2 * (mlp_e - mlp), d)], 0)
+                w2p = torch.cat([w2p, w2p.new_zeros(d, mlp_e - mlp)], 1)
             self.L.append(dict(
                 qkv=cast(att.to_qkv.weight, self.kd), qkv_t=tr(att.to_qkv.weight, self.kqkv),
                 wo=cast(att.wo.weight, self.kd), wo_t=tr(att.wo.weight, self.kd),
                 w1=cast(w1i, self.kd), w1_t=tr(w1i, self.kh),
-                w2=cast(ff.w2.weight, self.kmlp), w2_t=tr(ff.w2.weight, self.kd),
+                w2=cast(w2p, self.kmlp), w2_t=tr(w2p, self.kd),
                 scale=att.scale.detach().reshape(-1).float().contiguous()))
         self.pe = cast(m.patch_embed.emb.weight, self.kpe)
         self.pe_t = tr(m.patch_embed.emb.weight, self.kd)
@@ -123,7 +132,7 @@ class SwinTrainEngine:
         m = self.m
         dev = srcs[0].device
         B = srcs[0].shape[0]
-        d, heads, mlp = m.dim, m.heads, m.mlp_dim
+        d, heads, mlp = m.dim, m.heads, self.mlp_e
         gh, gw = m.grid_size
         ntok = gh * gw
         M = B * ntok
@@ -160,7 +169,7 @@ class SwinTrainEngine:
             sh = tuple(m.shift_size) if (do_shift and i % 2) else (0, 0)
             qkvh = torch.empty(M, 3 * d, dtype=_BF, device=dev)
             rn = torch.empty(M, 3 * heads, dtype=torch.float32, device=dev)
-            _gemm(xT, W["qkv"], qkvh, EPI_QKNORM, W["scale"], rn)
+            _gemm(xT, W["qkv"], qkvh, EPI_QKNORM, W["scale"], rn, pos_rows=self.hd)  # (QKNORM: head_dim rides in pos_rows)
             a = torch.zeros(M, self.kd, dtype=_BF, device=dev)
             ops.window_attention(qkvh.view(B, ntok, 3 * d), None, (gh, gw), heads, sh, out=a.view(B, ntok, self.kd),
                                  flags=ATTN_PRENORM)
@@ -205,7 +214,7 @@ class SwinTrainEngine:
         m = self.m
         dev = dout.device
         B, M = ctx["B"], ctx["M"]
-        d, heads, mlp = m.dim, m.heads, m.mlp_dim
+        d, heads, mlp, mlp0 = m.dim, m.heads, self.mlp_e, m.mlp_dim
         gh, gw = m.grid_size
         ntok = gh * gw
         L = lib()
@@ -238,7 +247,12 @@ class SwinTrainEngine:
                               dmod[:, (2 * i + 1) * 2 * d:(2 * i + 2) * 2 * d], M, d, ntok)
             dhmid = torch.empty(M, mlp, dtype=_BF, device=dev)
             _gemm(dy2, W["w2_t"], dhmid)
-            self._wgrad(_transpose(dy2, M, d), _transpose(A["hmid"], M, mlp), d, mlp, G(ff.w2.weight))
+            if mlp == mlp0:
+                self._wgrad(_transpose(dy2, M, d), _transpose(A["hmid"], M, mlp), d, mlp, G(ff.w2.weight))
+            else:
+                g2 = torch.empty(d, mlp, dtype=torch.float32, device=dev)
+                self._wgrad(_transpose(dy2, M, d), _transpose(A["hmid"], M, mlp), d, mlp, g2, accumulate=False)
+                G(ff.w2.weight).add_(g2[:, :mlp0])
             dh = torch.zeros(M, self.kh, dtype=_BF, device=dev) if self.kh > 2 * mlp else torch.empty(M, 2 * mlp, dtype=_BF, device=dev)
             check(L.swiftk_swiglu_bwd(A["h"].data_ptr(), A["h"].stride(0), dhmid.data_ptr(), dhmid.stride(0), dh.data_ptr(),
                                       dh.stride(0), M, mlp, BF16, _s()), "swiftk_swiglu_bwd")
@@ -246,7 +260,7 @@ class SwinTrainEngine:
             _gemm(dh, W["w1_t"], dxt)
             g1i = torch.empty(2 * mlp, d, dtype=torch.float32, device=dev)
             self._wgrad(_transpose(dh, M, 2 * mlp), _transpose(A["xT_mid"], M, d), 2 * mlp, d, g1i, accumulate=False)
-            G(ff.w1.weight).add_(g1i.view(mlp, 2, d).permute(1, 0, 2).reshape(2 * mlp, d))  # undo the gate/up interleave
+            G(ff.w1.weight).add_(g1i[:2 * mlp0].view(mlp0, 2, d).permute(1, 0, 2).reshape(2 * mlp0, d))  # undo the interleave
             ops.axpby(1.0, dx, 1.0, dxt, out=dx)                             # residual + w1 path
             # ---- attention branch
             dy1 = torch.zeros(M, self.kd, dtype=_BF, device=dev)
@@ -258,12 +272,12 @@ class SwinTrainEngine:
             dqkvh = torch.empty(M, 3 * d, dtype=_BF, device=dev)
             sh = A["shift"]
             check(L.swiftk_window_attention_bwd(A["qkvh"].data_ptr(), 3 * d, A["att"].data_ptr(), datt.data_ptr(), self.kd,
-                                                dqkvh.data_ptr(), B, gh, gw, heads, 88, sh[0], sh[1], BF16, _s()),
+                                                dqkvh.data_ptr(), B, gh, gw, heads, self.hd, sh[0], sh[1], BF16, _s()),
                   "swiftk_window_attention_bwd")
             dqkv = torch.zeros(M, self.kqkv, dtype=_BF, device=dev)
             dscale = torch.zeros(heads, dtype=torch.float32, device=dev)
             check(L.swiftk_qknorm_bwd(A["qkvh"].data_ptr(), dqkvh.data_ptr(), 3 * d, A["rn"].data_ptr(), dqkv.data_ptr(), self.kqkv,
-                                      W["scale"].data_ptr(), dscale.data_ptr(), M, heads, 88, BF16, _s()), "swiftk_qknorm_bwd")
+                                      W["scale"].data_ptr(), dscale.data_ptr(), M, heads, self.hd, BF16, _s()), "swiftk_qknorm_bwd")
             G(att.scale).add_(dscale.view_as(att.scale))
             _gemm(dqkv, W["qkv_t"], dxt)
             self._wgrad(_transpose(dqkv, M, 3 * d), _transpose(A["xT_in"], M, d), 3 * d, d, G(att.to_qkv.weight))

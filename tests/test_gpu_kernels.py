@@ -233,28 +233,30 @@ def _prenorm_reference(qkv, scale, heads, hd):
     return v.reshape(B, n, -1)
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_gemm_qknorm_epilogue(dev, dt):
+@pytest.mark.parametrize("dt,hd", [(torch.float32, 88), (torch.bfloat16, 88), (torch.bfloat16, 80), (torch.bfloat16, 96)])
+def test_gemm_qknorm_epilogue(dev, dt, hd):
+    """head_dim 80 / 96 (dim 1280 / 1536 with 16 heads in the reference's larger variants): 320- / 384-wide GEMM tiles."""
     from swift_amd import ops
-    M, heads, hd = 1024, 12, 88
-    K = ops.k_pad(dt, 1056)
+    M, heads = 1024, 12
+    K = ops.k_pad(dt, heads * hd)
     a, w = rnd((M, K), 40), rnd((3 * heads * hd, K), 41, 0.03)
     scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 10.0]))
     ad, wd = to_dt(a, dt, dev), to_dt(w, dt, dev)
-    c = ops.gemm(ad, wd, epilogue=ops.EPI_QKNORM, bias=scale.to(dev))
+    c = ops.gemm(ad, wd, epilogue=ops.EPI_QKNORM, bias=scale.to(dev), head_dim=hd)
     raw = (ad.float().cpu().double() @ wd.float().cpu().double().T).float()
     ref = _prenorm_reference(raw.view(1, M, -1), scale, heads, hd)[0]
     assert rel_l2(c.float().cpu(), ref) < (F32_TOL if dt == torch.float32 else 4e-3)
 
 
-@pytest.mark.parametrize("dt,flags", [(torch.bfloat16, 1), (torch.bfloat16, 3), (torch.float32, 1)])
+@pytest.mark.parametrize("dt,flags,hd", [(torch.bfloat16, 1, 88), (torch.bfloat16, 3, 88), (torch.float32, 1, 88),
+                                         (torch.bfloat16, 1, 80), (torch.bfloat16, 1, 96)])
 @pytest.mark.parametrize("shift", [(0, 0), (8, 8)])
 @pytest.mark.parametrize("B", [1, 3, 8])  # 8: 576 items > 256 workgroups, the steady state of the streamed kernel
-def test_window_attention_prenormalised(dev, dt, flags, shift, B):
-    """flags 1 = PRENORM (bf16: persistent LDS-DMA-pipelined kernel), 3 = PRENORM|NO_PIPE (per-item kernel)."""
+def test_window_attention_prenormalised(dev, dt, flags, shift, B, hd):
+    """flags 1 = PRENORM (bf16: persistent LDS-DMA-pipelined kernel, head_dim 80 / 88 / 96), 3 = PRENORM|NO_PIPE (per-item)."""
     from oracle.swinv2 import window_token_index
     from swift_amd import ops
-    grid, heads, hd = (32, 48), 12, 88
+    grid, heads = (32, 48), 12
     n = grid[0] * grid[1]
     qkv = rnd((B, n, 3 * heads * hd), 42 + B)
     scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 10.0]))
@@ -269,29 +271,30 @@ def test_window_attention_prenormalised(dev, dt, flags, shift, B):
     assert rel_l2(out.float().cpu(), ref) < (2e-5 if dt == torch.float32 else 1.2e-2)
 
 
+@pytest.mark.parametrize("hd", [88, 80, 96])
 @pytest.mark.parametrize("shift", [(0, 0), (8, 8), (3, 5)])
 @pytest.mark.parametrize("B", [1, 3, 8])  # 8: several tiles per GEMM workgroup and several items per attention workgroup
-def test_window_tiled_qkv_path(dev, shift, B):
+def test_window_tiled_qkv_path(dev, shift, B, hd):
     """to_qkv stored window-tiled (swiftk_gemm_qkv_tiled) + SWIFTK_ATTN_TILED attention: the tiled tensor is an exact
     permutation of the row-major QK-norm GEMM output (window_partition of the rolled grid, swinv2.py:17-26,185-189),
     attention over it is bit-identical to attention over the row-major tensor, and both match the fp32 formula.
     The scale vector mixes heads whose logit bound is <= 48 (max-free streaming softmax) and > 48 (online form)."""
     from oracle.swinv2 import window_token_index
     from swift_amd import ops
-    grid, heads, hd = (32, 48), 12, 88
-    n = grid[0] * grid[1]
-    K = ops.k_pad(torch.bfloat16, 1056)
+    grid, heads = (32, 48), 12
+    n, d = grid[0] * grid[1], heads * hd
+    K = ops.k_pad(torch.bfloat16, d)
     a, w = rnd((B * n, K), 50 + B), rnd((3 * heads * hd, K), 51, 0.03)
-    a[:, 1056:] = 0
+    a[:, d:] = 0
     scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 48.0])).to(dev)
     ad, wd = to_dt(a, torch.bfloat16, dev), to_dt(w, torch.bfloat16, dev)
-    c = ops.gemm(ad, wd, epilogue=ops.EPI_QKNORM, bias=scale)
-    ct = ops.gemm_qkv_tiled(ad, wd, scale, B, grid, heads, shift)
+    c = ops.gemm(ad, wd, epilogue=ops.EPI_QKNORM, bias=scale, head_dim=hd)
+    ct = ops.gemm_qkv_tiled(ad, wd, scale, B, grid, heads, shift, head_dim=hd)
     idx = window_token_index(grid, (16, 16), shift)  # [windows, 256] token of each window slot
     perm = c.view(B, n, heads, 3, hd)[:, idx.reshape(-1).to(dev)].view(B, idx.shape[0], 256, heads, 3, hd)
     assert torch.equal(ct, perm.permute(0, 1, 3, 4, 2, 5).contiguous())
     # K ending half-way into the last k-tile (1056 of 1088) gives the same numbers
-    assert torch.equal(ct, ops.gemm_qkv_tiled(ad, wd, scale, B, grid, heads, shift, k=1056))
+    assert torch.equal(ct, ops.gemm_qkv_tiled(ad, wd, scale, B, grid, heads, shift, k=d, head_dim=hd))
     out_rm = ops.window_attention(c.view(B, n, -1), scale, grid, heads, shift, flags=ops.ATTN_PRENORM)
     out_t = ops.window_attention_tiled(ct, scale, grid, heads, shift)
     assert torch.equal(out_rm, out_t)

@@ -78,6 +78,12 @@ def test_forward_vs_reference_golden(dev):
                          depth=2)),
     ("head_dim-96", dict(img=(64, 64), n_vars=69, n_forc=3, window=(16, 16), shift=(8, 8), patch=(2, 2), dim=384, heads=4,
                          depth=2)),
+    # ... and at their real widths (16 heads; depth cut to 2): bf16 runs the QK-norm epilogue on 320- / 384-wide GEMM tiles,
+    # the window-tiled q/k/v store and the streamed attention kernel templated on head_dim; dim 1280 has an odd MLP width
+    ("468M-width-dim1280-hd80", dict(img=(64, 64), n_vars=69, n_forc=3, window=(16, 16), shift=(8, 8), patch=(2, 2), dim=1280,
+                                     heads=16, depth=2)),
+    ("664M-width-dim1536-hd96", dict(img=(64, 64), n_vars=69, n_forc=3, window=(16, 16), shift=(8, 8), patch=(2, 2), dim=1536,
+                                     heads=16, depth=2)),
 ])
 def test_forward_other_swift_variants_vs_oracle(dev, name, c):
     net, onet = build(c, 12, dev)

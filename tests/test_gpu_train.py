@@ -272,11 +272,13 @@ def test_train_engine_gradients_vs_oracle_autograd(dev):
     assert dins[2] is None
 
 
-def _build_pair(dev, seed, logvar=False, depth=2):
+def _build_pair(dev, seed, logvar=False, depth=2, dim=None, heads=None):
     from oracle.swinv2 import OracleNet, SwinCfg
     from swift_amd.models.precond import PassPrecond
     from swift_amd.utils.detinit import swinv2_state
     c = dict(SMALLB, depth=depth)
+    if dim is not None:
+        c.update(dim=dim, heads=heads)
     nv, nf = c["n_vars"], c["n_forc"]
     mcfg = dict(_target_="swift.models.swinv2.SwinV2", window_size=[16, 16], shift_size=[8, 8], patch_size=[2, 2],
                 depth=depth, dim=c["dim"], heads=c["heads"], logvar=logvar)
@@ -489,3 +491,43 @@ def test_trainer_step_fused_kernel_vs_reference_golden(dev):
     sd = tr.optimizer.state_dict()
     assert len(sd["state"]) == 6 and float(sd["state"][0]["step"]) == 4.0
     assert sd["state"][0]["exp_avg"].shape == tr.optimizer.param_groups[0]["params"][0].shape
+
+
+@pytest.mark.parametrize("dim,heads", [(1280, 16), (1536, 16)])  # head_dim 80 / 96: experiment/era5-swinv2-1.4-scm.yaml:29-36
+def test_larger_variants_training_step_and_tangent_vs_oracle(dev, dim, heads):
+    """the 468 M / 664 M widths (depth cut to 2) through the same training path as Swift-B -- QK-norm
+    GEMM epilogue on 320- / 384-wide tiles, streamed attention, attention / QK-norm backward and the tangent kernels
+    templated on head_dim; dim 1280 also has the odd MLP width int(8/3 * 1280) = 3413."""
+    from oracle import loss as oloss
+    from swift_amd.jvp_engine import SwinJvpEngine
+    from swift_amd.models.precond import _process_auxiliary
+    from swift_amd.training.loss import TrigFlowLoss
+    from swift_amd.training.trainer import GradAllReduce
+    from swift_amd.utils.detinit import det_normal
+    net, onet, st = _build_pair(dev, 61, logvar=True, dim=dim, heads=heads)
+    ds = _dataset(61)
+    L = TrigFlowLoss(ds, dict(dist="loguniform", sigma_min=0.02, sigma_max=200.0), sigma_data=1.0).to(dev)
+    B = 2
+    x, cond, z = det_normal((B, 69, 64, 64), 61, "x"), det_normal((B, 72, 64, 64), 61, "c"), det_normal((B, 69, 64, 64), 61, "z")
+    tau, aux = torch.tensor([0.3, 4.0]).view(B, 1, 1, 1), torch.tensor([0.6, 0.6])
+    ddp = GradAllReduce(net)
+    ddp.zero_grad_flat()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = L(ddp, x.to(dev), condition=cond.to(dev), auxiliary=aux.to(dev), _tau=tau.to(dev), _z=z.to(dev))
+    loss.backward()
+    ref = oloss.trigflow_loss(onet, x, tau, z, L.w_var.cpu(), L.w_lat.cpu(), 1.0, condition=cond, auxiliary=aux, return_logvar=True)
+    ref.backward()
+    print(f"dim {dim}: trigflow loss {float(loss):.6f} vs oracle {float(ref):.6f}; worst grad cosine {_grad_report(net, st):.4f}")
+    assert float(loss) == pytest.approx(float(ref), rel=1e-3)
+    # the forward-mode tangent of the same network (sCM pre-training), fp32 and bf16 operands
+    vx = det_normal((B, 69, 64, 64), 61, "vx")
+    t, vt = torch.tensor([0.4, 1.3]), torch.tensor([0.35, 0.2])
+    with torch.no_grad():
+        Fref, dref = torch.func.jvp(lambda xx, tt: onet(xx, tt, cond, aux, jvp=True), (x, t), (vx, vt))
+    auxd = _process_auxiliary(aux.to(dev), 1, B, dev)
+    errs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        dF = SwinJvpEngine(net.model, dt).jvp([x.to(dev), cond.to(dev)], vx.to(dev), t.to(dev), vt.to(dev), auxd)
+        errs[dt] = rel_l2(dF.cpu(), dref)
+    print(f"dim {dim}: network tangent vs oracle jvp: fp32 rel-L2 {errs[torch.float32]:.3e}, bf16 {errs[torch.bfloat16]:.3e}")
+    assert errs[torch.float32] < 1e-4 and errs[torch.bfloat16] < 8e-2

@@ -51,7 +51,7 @@ for sname, N, K, Kalg, epi in shapes:
         h, o = libs[n], outs[n]
         if epi == "tiled":
             rc = h.swiftk_gemm_qkv_tiled(a.data_ptr(), K, w.data_ptr(), K, o.data_ptr(), Kalg, scale.data_ptr(), B, 64, 128, 12,
-                                         8, 8, st())
+                                         88, 8, 8, st())
         else:
             rc = h.swiftk_gemm(a.data_ptr(), K, w.data_ptr(), K, o.data_ptr(), ncol, M, N, Kalg, _lib.BF16, _lib.BF16, epi, None,
                                None, 0, st())
