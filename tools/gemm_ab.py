@@ -21,14 +21,15 @@ want = sys.argv[3:]
 paths = {"product": os.path.join(ROOT, "swift_amd", "csrc", "libswiftk.so")}
 for p in sorted(glob.glob(os.path.join(ROOT, "swift_amd", "csrc", "variants", "libswiftk_*.so"))):
     paths[os.path.basename(p)[len("libswiftk_"):-3]] = p
-if want:
-    paths = {k: v for k, v in paths.items() if k in want}
-libs = {}
+if want:  # "name" or "name@V": the lib `name` with swiftk_set_tuning(0, V) (kernel variant) applied before each of its runs
+    paths = {k: paths[k.partition("@")[0]] for k in want}
+libs, variant = {}, {}
 for name, p in paths.items():
     h = C.CDLL(p)
-    for fn in ("swiftk_gemm", "swiftk_gemm_qkv_tiled"):
+    for fn in ("swiftk_gemm", "swiftk_gemm_qkv_tiled", "swiftk_set_tuning"):
         getattr(h, fn).argtypes, getattr(h, fn).restype = _lib._SIGS[fn]
     libs[name] = h
+    variant[name] = int(name.partition("@")[2] or 1)
 names = list(libs)
 dev = torch.device("cuda")
 M = B * 8192
@@ -49,6 +50,7 @@ for sname, N, K, Kalg, epi in shapes:
 
     def run(n):
         h, o = libs[n], outs[n]
+        h.swiftk_set_tuning(0, variant[n])
         if epi == "tiled":
             rc = h.swiftk_gemm_qkv_tiled(a.data_ptr(), K, w.data_ptr(), K, o.data_ptr(), Kalg, scale.data_ptr(), B, 64, 128, 12,
                                          88, 8, 8, st())
