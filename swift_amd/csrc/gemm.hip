@@ -52,12 +52,6 @@ constexpr int EPI_QKNORM_TILED = 4;  // internal: SWIFTK_EPI_QKNORM with the win
 #ifndef SWIFTK_X_PF2
 #define SWIFTK_X_PF2 1
 #endif
-#ifndef SWIFTK_X_SPLITDMA
-#define SWIFTK_X_SPLITDMA 0   // 1: waves 4-7 issue their DMA pieces in the second k-half (their SIMD partners in the first)
-#endif
-#ifndef SWIFTK_X_TOUCH
-#define SWIFTK_X_TOUCH 0   // 0 = off, n >= 2: touch the lines of stage kt + n
-#endif
 
 struct GemmArgs {
     const char* A;
@@ -325,10 +319,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     constexpr int STAGE = A_BYTES + B_BYTES;    // 72 / 76 / 80 KiB: two stages = 144 / 152 / 160 KiB of the CU's 160
     constexpr int WP = B_BYTES / 1024;          // W pieces per stage: 40 / 44 / 48 = 5, 5.5, 6 per wave
     constexpr int HD = 8 * NI;                  // QKNORM: head_dim (a wave tile = two head vectors)
-    // L2 touches (SWIFTK_X_TOUCH): 4-byte LDS-DMA reads of the lines the stage AFTER the next one will need, into a 256-B
-    // sink per wave -- no VGPR destination that a late return could clobber; needs 2 KiB beside the stages (NI <= 11)
-    constexpr bool TOUCH = SWIFTK_X_TOUCH && NI <= 11;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (TOUCH ? 2048 : 0)];
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wv >> 1, wn = wv & 1;
@@ -365,11 +356,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     // ten pieces per k-tile the scalar arithmetic alone used to take as many issue slots as the 88 MFMAs.
     const char* abase[4];
     const char* wbase[6];
-    bool src_inside = false;  // the tile the sources point at lies wholly inside the matrices (touches read whole rows)
     auto set_sources = [&](int t) {
         int tm, tn;
         it.coords(t / ksplit, tm, tn);
-        src_inside = (tm * BM + BM <= g.M) && (tn * BN + BN <= g.N);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             int rb = tm * BM + (wv * 4 + p) * 8;
@@ -395,22 +384,6 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             // SGPR pressure)
             if (wv + 8 * i < WP) dma_piece_fast(sa + A_BYTES + (wv + 8 * i) * 1024, wbase[i], vb + koff);
         }
-    };
-
-    // touch addressing: this wave's A rows are the 32 rows of its four pieces (contiguous), its W rows those of pieces
-    // wv + 8 i (8 rows every 64); one lane per 128-B row segment, lanes beyond the wave's rows repeat lane 0..7's
-    const uint32_t tsink = lds0 + 2 * STAGE + wv * 256;
-    const uint32_t vta = (uint32_t)((lane & 31) * g.lda_b);
-    const int tl = (lane >> 3) < (WP - wv + 7) / 8 ? lane : (lane & 7);
-    const uint32_t vtw = (uint32_t)(((tl >> 3) * 64 + (tl & 7)) * g.ldw_b);
-    auto touch = [&](const char* base, uint32_t voff) {
-        asm volatile(
-            "s_mov_b32 m0, %1\n\t"
-            "s_nop 1\n\t"
-            "global_load_lds_dword %0, %2"
-            :
-            : "v"(voff), "s"(tsink), "s"(base)
-            : "memory");
     };
 
     f32x4 acc[MI][NI];
@@ -479,7 +452,6 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         const uint32_t fill = lds0 + (par ^ 1) * STAGE;
         const bool last_k = (kt + 1 == nk);
         const bool half = g.khalf && (kt + 1 == nk_all);
-        bool touched = false;
         uint32_t koff = (uint32_t)(kt + 1) * ROWB;
         if (last_k) {
             const int ntile = tile + stride;
@@ -516,38 +488,17 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                     wf = wn_;
                 }
             };
-#if SWIFTK_X_SPLITDMA
-            // The two k-halves as a two-trip loop over ONE copy of the MFMA stream (two copies make hipcc spill ~200
-            // accumulator dwords), so that the DMA pieces can ride in the first half for waves 0-3 and in the second for
-            // waves 4-7: SIMD partners (w, w + 4) otherwise stall in VMEM issue at the same moments.
-            {
-                const int dma_it = (SWIFTK_X_SPLITDMA == 1 && wv >= 4 && !half) ? 1 : 0;  // (2 = loop form, no split: A/B control)
-                const int nhalf = half ? 1 : 2;
-#pragma unroll 1
-                for (int it = 0; it < nhalf; ++it) {
-                    const int ch = it ? ch1 : ch0;
-                    if (it) {
-#pragma unroll
-                        for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch);
-                    }
-                    k_half(ch, it == dma_it);
-                }
-            }
-#else
             k_half(ch0, true);
             if (!half) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch1);
                 k_half(ch1, false);
             }
-#endif
         }
         par ^= 1;
         if (!last_k) {
             ++kt;
-            // the next stage's pieces are older than this step's two touches (VMEM retires in issue order)
-            if (TOUCH && touched) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             continue;
         }
         bool interior = false;
@@ -712,297 +663,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing dummy DMA must not outlive the LDS allocation
 }
 
-// ------------------------------------------------------------------------------------------------
-// Four-stage variant (bf16 operands): the same 256 x 32 NI tile and wave layout, but the k-step is 32 elements (64-B
-// rows, ONE 16x16x32 MFMA deep) and the LDS holds a ring of FOUR stages, so the LDS-DMA of stage s + 3 is issued while
-// stage s computes and stays in flight across two barriers (counted vmcnt) -- a workgroup's 36-40 pieces per stage keep
-// the CU's load path busy continuously instead of in bursts that must land before the very next barrier
-// (cdna_hip_programming.md section 5, "Pipelining across barriers": 3-deep spans are worth +30 % over 2-deep at one
-// workgroup per CU).  The hand-over of stage s + 1 (wait + barrier) happens at the TOP of stage s, one stage before its
-// use, so the first fragments of stage s + 1 are read at the end of stage s and the MFMAs restart right behind the
-// barrier.  K = 1056 is 33 whole k-steps: no half tile, no padded MFMAs.
-// LDS image of a stage: rows of 64 B, A rows then W rows; a 1-KiB DMA piece is 16 rows, lane l carries row l >> 2 and
-// the 16-B chunk (l & 3) ^ sw((l >> 4) & 3) of it, sw = {0, 2, 3, 1}: with that permutation every 16-lane group of a
-// ds_read_b128 fragment read (row = lane & 15, chunk = lane >> 4) touches 16 distinct 16-B bank slots.
-template <typename OutT, int EPI, int NI>
-__global__ __launch_bounds__(NT) void gemm_kernel_q(GemmArgs g, int ntm, int gm) {
-    typedef bf16_t T;
-    constexpr int RB = 64;                      // bytes per row per stage (32 bf16)
-    constexpr int WT = 16 * NI;                 // columns of a wave tile
-    constexpr int BN = 2 * WT;                  // 320 / 352 / 384
-    constexpr int A_ST = BM * RB;               // 16 KiB
-    constexpr int STG = A_ST + BN * RB;         // 36 / 38 / 40 KiB
-    constexpr int NSTG = 4;
-    constexpr int WPC = BN / 16;                // W pieces per stage: 20 / 22 / 24 (A: 16, two per wave)
-    constexpr int HD = 8 * NI;
-    __shared__ __attribute__((aligned(16))) char smem[NSTG * STG];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wv >> 1, wn = wv & 1;
-    const TileIter it{ntm, g.ntn, gm};
-    const int ksplit = g.ksplit;
-    const int ntiles = ntm * g.ntn * ksplit;
-    int vid;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int stride = gridDim.x;
-    if (vid >= ntiles) return;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
-    const int nk_all = g.K / 32;
-    auto k_begin = [&](int item) { return (int)((int64_t)(item % ksplit) * nk_all / ksplit); };
-    auto k_end = [&](int item) { return (int)((int64_t)(item % ksplit + 1) * nk_all / ksplit); };
-
-    // ---- DMA side: a cursor (item, k-step) that runs three stages ahead of the compute cursor
-    const int qsw = (lane >> 4) & 3, gq = qsw ^ (qsw >> 1);
-    const int sw = ((gq & 1) << 1) | (gq >> 1);  // {0, 2, 3, 1}[(lane >> 4) & 3]
-    const uint32_t va = (uint32_t)((lane >> 2) * g.lda_b) + 16u * ((lane & 3) ^ sw);
-    const uint32_t vw = (uint32_t)((lane >> 2) * g.ldw_b) + 16u * ((lane & 3) ^ sw);
-    const int nwp = (WPC - wv + 7) / 8;  // W pieces of this wave: 3, or 2 for the last waves when WPC = 20 / 22
-    const char* abase[2];
-    const char* wbase[3];
-    auto set_sources = [&](int t) {
-        int tm, tn;
-        it.coords(t / ksplit, tm, tn);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            int rb = tm * BM + (wv * 2 + p) * 16;
-            rb = rb < g.M ? rb : g.M - 16;
-            abase[p] = g.A + (int64_t)rb * g.lda_b;
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            int rb = tn * BN + (wv + 8 * i) * 16;
-            rb = rb < g.N ? rb : g.N - 16;
-            wbase[i] = g.W + (int64_t)rb * g.ldw_b;
-        }
-    };
-    int d_item = vid, d_k = k_begin(vid), d_slot = 0;  // next stage the DMA will fetch, and the ring slot it goes to
-    set_sources(d_item);
-    auto issue_piece = [&](int p) {  // piece p (0-1 A, 2-4 W) of the DMA cursor's stage
-        const uint32_t sa = lds0 + d_slot * STG, koff = (uint32_t)d_k * RB;
-        if (p < 2) {
-            dma_piece_fast(sa + (wv * 2 + p) * 1024, abase[p], va + koff);
-        } else {
-            const int i = p - 2;
-            if (i < nwp) dma_piece_fast(sa + A_ST + (wv + 8 * i) * 1024, wbase[i], vw + koff);
-        }
-    };
-    auto advance_dma = [&]() {  // past the last item the cursor parks on it: harmless re-loads keep the counts uniform
-        d_slot = (d_slot + 1) & 3;
-        if (++d_k == k_end(d_item)) {
-            const int n = d_item + stride;
-            if (n < ntiles) {
-                d_item = n;
-                set_sources(n);
-            }
-            d_k = k_begin(d_item);
-        }
-    };
-
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // fragment read offset inside a stage: row r16 of a 16-row block, chunk (lane >> 4) ^ sw'((r16 >> 2) & 3)
-    const int r16 = lane & 15;
-    const int q2 = (r16 >> 2) & 3, g2 = q2 ^ (q2 >> 1);
-    const int fro = r16 * RB + 16 * ((lane >> 4) ^ (((g2 & 1) << 1) | (g2 >> 1)));
-    const int xoff = wm * 64 * RB + fro;
-    const int woff = A_ST + wn * WT * RB + fro;
-
-    // ---- prologue: stages 0, 1, 2 in flight; stage 0 handed over; its first fragments in registers
-#pragma unroll
-    for (int st = 0; st < 3; ++st) {
-#pragma unroll
-        for (int p = 0; p < 5; ++p) issue_piece(p);
-        advance_dma();
-    }
-    if (nwp == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int tile = vid, kt = k_begin(vid), nk = k_end(vid), slot = 0;
-    int after_epi = 0;  // stage tops that still have an interior epilogue's stores younger than the DMA they wait for
-    uint4 xf[MI], wf, wf1;
-    {
-        const char* s = smem;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * RB);
-        wf = *reinterpret_cast<const uint4*>(s + woff);
-        wf1 = *reinterpret_cast<const uint4*>(s + woff + 16 * RB);
-    }
-#if SWIFTK_X_PRIO
-    if (wv >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
-    constexpr int COLS = (EPI == SWIFTK_EPI_SWIGLU) ? WT / 2 : WT;  // output columns of the wave tile
-    constexpr int CPR = COLS / 8;                                  // 16-B chunks per output row
-    constexpr int RSTR = COLS * 2 + 16;                            // slab row stride (bytes)
-    constexpr int SROWS = 8;                                       // rows per slab round (8 slabs must fit one stage)
-    constexpr int NST = (64 / SROWS) * ((SROWS * CPR + 63) / 64);  // output stores per wave of an interior tile
-    static_assert(8 * SROWS * RSTR <= STG, "output slabs overlay one stage");
-    for (;;) {
-        // ---- top of stage (tile, kt) in ring slot `slot`: hand over the NEXT stage.  Younger than its pieces, per wave, are
-        // the pieces of the stage after it (and, for two tops after an interior tile's epilogue, that tile's stores).
-        if (after_epi > 0) {
-            if constexpr (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS) {
-                if (nwp == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 + NST) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            --after_epi;
-        } else {
-            if (nwp == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        // every wave's pieces of the next stage have landed; every wave is done reading the stage before this one (its
-        // last fragment reads fed MFMAs it issued before arriving here): that slot takes the stage three ahead
-        const char* s = smem + slot * STG;
-        const char* sn = smem + ((slot + 1) & 3) * STG;
-        const bool last_k = (kt + 1 == nk);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            uint4 wn_ = wf1;
-            if (j + 2 < NI) wf1 = *reinterpret_cast<const uint4*>(s + woff + (j + 2) * 16 * RB);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) mma_chunk<T>(acc[i][j], wf, xf[i]);
-            if (j < 5) issue_piece(j);
-            wf = wn_;
-        }
-        advance_dma();
-        // first fragments of the next stage (handed over at the top of this one): the MFMAs restart behind the barrier
-#pragma unroll
-        for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(sn + xoff + i * 16 * RB);
-        wf = *reinterpret_cast<const uint4*>(sn + woff);
-        wf1 = *reinterpret_cast<const uint4*>(sn + woff + 16 * RB);
-        slot = (slot + 1) & 3;
-        if (!last_k) {
-            ++kt;
-            continue;
-        }
-        // ---- epilogue of `tile`: lane holds C[m][nb .. nb+3] for m = ..+r16, nb = ..+4*(lane>>4) ----
-        {
-            int tm, tn;
-            it.coords(tile / ksplit, tm, tn);
-            const int m0 = tm * BM, n0 = tn * BN;
-            if constexpr (EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED)
-                qknorm_tile<NI>(acc, lane, n0 + wn * WT, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / HD);
-            OutT* C = reinterpret_cast<OutT*>(g.C) + (int64_t)(tile % ksplit) * g.c_split;
-            if constexpr (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS) {
-                // bf16 output through wave-private LDS slabs (8 rows per round) so that rows leave as whole 16-B chunks.
-                // The slabs overlay the stage just computed: every wave must be done reading it first (barrier); its
-                // refill is issued only after the next stage top's barrier, which no wave passes before it has finished
-                // this epilogue.
-                __builtin_amdgcn_s_barrier();
-                if ((m0 + BM <= g.M) && (n0 + BN <= g.N)) after_epi = 2;
-                char* slab = const_cast<char*>(s) + wv * (SROWS * RSTR);
-                int elane = lane;
-                asm volatile("" : "+v"(elane));  // (keeps epilogue address arithmetic out of the k-loop's live ranges)
-                const int g4 = elane >> 4;
-                const int er = elane & 15;
-                const int ncol0 = (EPI == SWIFTK_EPI_SWIGLU ? (n0 >> 1) : n0) + wn * COLS;
-                const int nout = EPI == SWIFTK_EPI_SWIGLU ? (g.N >> 1) : g.N;
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                    for (int rnd = 0; rnd < 16 / SROWS; ++rnd) {
-                        if ((er / SROWS) == rnd) {
-#pragma unroll
-                            for (int j = 0; j < NI; ++j) {
-                                const f32x4 v = acc[i][j];
-                                if constexpr (EPI == SWIFTK_EPI_SWIGLU) {
-                                    const float h0 = v[0] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[0])) * v[1];
-                                    const float h1 = v[2] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[2])) * v[3];
-                                    *reinterpret_cast<uint32_t*>(slab + (er % SROWS) * RSTR + (j * 8 + 2 * g4) * 2) = pack_bf16(h0, h1);
-                                } else {
-                                    *reinterpret_cast<uint2*>(slab + (er % SROWS) * RSTR + (j * 16 + 4 * g4) * 2) =
-                                        make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
-                                }
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                        const int mrow0 = m0 + wm * 64 + i * 16 + rnd * SROWS;
-                        int try_ = 0, tx8 = 0, twin0 = 0;
-                        if constexpr (EPI == EPI_QKNORM_TILED) {
-                            const int ntok = g.t_gh * g.t_gw;
-                            const int tb = mrow0 / ntok;
-                            const int tt = mrow0 - tb * ntok, y = tt / g.t_gw;
-                            tx8 = tt - y * g.t_gw;
-                            try_ = y - g.t_sh;
-                            try_ += try_ < 0 ? g.t_gh : 0;
-                            twin0 = tb * ((g.t_gh >> 4) * (g.t_gw >> 4)) + (try_ >> 4) * (g.t_gw >> 4);
-                        }
-#pragma unroll
-                        for (int t = 0; t < (SROWS * CPR + 63) / 64; ++t) {
-                            const int c = elane + 64 * t;
-                            const int row = c / CPR, cc = c - row * CPR;
-                            if (c < SROWS * CPR) {
-                                const uint4 q = *reinterpret_cast<const uint4*>(slab + row * RSTR + cc * 16);
-                                const int m = mrow0 + row, n = ncol0 + cc * 8;
-                                int64_t dst = (int64_t)m * g.ldc + n;
-                                if constexpr (EPI == EPI_QKNORM_TILED) {
-                                    int rx = tx8 + row - g.t_sw;
-                                    rx += rx < 0 ? g.t_gw : 0;
-                                    const int hi = cc >= NI;
-                                    const int tile_ = (twin0 + (rx >> 4)) * (3 * g.t_heads) + tn * 4 + wn * 2 + hi;
-                                    dst = (int64_t)tile_ * (256 * HD) + ((((try_ & 15) << 4) | (rx & 15)) * HD + (cc - NI * hi) * 8);
-                                }
-                                if (m < g.M && n < nout) *reinterpret_cast<uint4*>(C + dst) = q;
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    }
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            } else {
-                int elane = lane;
-                asm volatile("" : "+v"(elane));
-                const int er = elane & 15;
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int m = m0 + wm * 64 + i * 16 + er;
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        const int nb = n0 + wn * WT + j * 16 + 4 * (elane >> 4);
-                        f32x4 v = acc[i][j];
-                        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (m >= g.M || nb >= g.N) continue;
-                        if constexpr (EPI == SWIFTK_EPI_BIAS_POS) {
-                            const float4 b = *reinterpret_cast<const float4*>(g.ep0 + nb);
-                            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                            if (g.ep1) {
-                                const float4 pp = *reinterpret_cast<const float4*>(g.ep1 + (int64_t)(m % g.pos_rows) * g.N + nb);
-                                v[0] += pp.x; v[1] += pp.y; v[2] += pp.z; v[3] += pp.w;
-                            }
-                        }
-                        if constexpr (EPI == SWIFTK_EPI_SWIGLU) {
-                            const float h0 = v[0] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[0])) * v[1];
-                            const float h1 = v[2] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[2])) * v[3];
-                            store2<OutT>(C + (int64_t)m * g.ldc + (nb >> 1), h0, h1);
-                        } else {
-                            store4<OutT>(C + (int64_t)m * g.ldc + nb, v[0], v[1], v[2], v[3]);
-                        }
-                    }
-                }
-                after_epi = 2;  // (fp32 / BIAS_POS outputs: the two following tops drain everything, vmcnt(0))
-            }
-        }
-        tile += stride;
-        if (tile >= ntiles) break;
-        kt = k_begin(tile);
-        nk = k_end(tile);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing re-loads must not outlive the LDS allocation
-}
-
 // ---- optional live timing of one GEMM flavour (bench.py's roofline leg): HIP events on the launch stream ----
-int g_variant = 1;   // 0: one tile per workgroup; 1: persistent, two 64-deep stages; 2: persistent, four 32-deep stages (bf16)
+int g_variant = 1;   // 0: one tile per workgroup; 1: persistent, grouped tile order, interleaved DMA
 int g_group_m = 8;   // tile rows per group in the persistent order
 int g_persist_wgs = 256;
 int g_dbg = 0;
@@ -1031,14 +693,7 @@ int launch(const GemmArgs& g, hipStream_t st) {
         const int ntiles = ntm * g.ntn * g.ksplit;
         const int grid = ntiles < g_persist_wgs ? ntiles : g_persist_wgs;
         if constexpr (sizeof(T) == 2) {  // bf16 operands: all three tile widths (head_dim 80 / 88 / 96 families)
-            const int kq = g.khalf ? g.K - 32 : g.K;  // the four-stage kernel walks K in whole 32-element steps
-            if (g_variant == 2 && !(g.M & 15) && !(g.N & 15) && !(kq & 31) && kq / 32 >= g.ksplit) {
-                GemmArgs gq = g;
-                gq.K = kq;
-                if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_q<OutT, EPI, 10>), dim3(grid), dim3(NT), 0, st, gq, ntm, g_group_m);
-                else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_q<OutT, EPI, 12>), dim3(grid), dim3(NT), 0, st, gq, ntm, g_group_m);
-                else hipLaunchKernelGGL((gemm_kernel_q<OutT, EPI, 11>), dim3(grid), dim3(NT), 0, st, gq, ntm, g_group_m);
-            } else if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 10>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+            if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 10>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
             else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 12>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
             else hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
         } else {
@@ -1201,7 +856,7 @@ extern "C" int swiftk_gemm_qkv_tiled(const void* A, int64_t lda, const void* W, 
     if (head_dim != 80 && head_dim != 88 && head_dim != 96) return SWIFTK_ESHAPE;
     if (shift_h < 0 || shift_w < 0 || shift_h >= gh || shift_w >= gw) return SWIFTK_ESHAPE;
     if ((uintptr_t)qkv_tiled & 15) return SWIFTK_EALIGN;
-    if (g_variant == 0) return SWIFTK_ESHAPE;  // the tiled store lives in the persistent kernels' epilogues
+    if (g_variant == 0) return SWIFTK_ESHAPE;  // the tiled store lives in the persistent kernel's epilogue
     const int tiling[5] = {gh, gw, shift_h, shift_w, heads};
     const int64_t M = (int64_t)B * gh * gw, N = 3 * (int64_t)heads * head_dim;
     return gemm_impl(A, lda, W, ldw, qkv_tiled, N, M, N, K, SWIFTK_BF16, SWIFTK_BF16, SWIFTK_EPI_QKNORM, scale, nullptr,
