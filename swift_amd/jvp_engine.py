@@ -23,6 +23,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import ops
+from .graphs import GraphCache
 from ._lib import EPI_BIAS_POS, EPI_NONE, SwiftkError, check, lib
 
 
@@ -46,6 +47,8 @@ class SwinJvpEngine:
             raise SwiftkError("the tangent kernels are built for head_dim 80 / 88 / 96")
         self.dt = dtype
         self._stamp = None
+        self._buf = {}            # persistent operand copies (fixed addresses for the captured launch sequence)
+        self.graphs = GraphCache()
 
     def refresh(self):
         m, dt = self.m, self.dt
@@ -56,7 +59,26 @@ class SwinJvpEngine:
         mlp_e = self.mlp_e = mlp + (mlp & 1)  # odd MLP widths (dim 1280 -> 3413): one zero (gate, up) row pair, as in SwinEngine
         self.kd, self.kmlp = ops.k_pad(dt, d), ops.k_pad(dt, mlp_e)
         self.kpe = ops.k_pad(dt, m.in_channels * m.patch_size[0] * m.patch_size[1])
-        cast = lambda w, k: ops.pad_cols(w.detach(), k, dt)
+        dev0 = m.pos_embed.device
+        ctr = [0]
+
+        def keep(name, make, fill):
+            if name not in self._buf:
+                self._buf[name] = make()
+            fill(self._buf[name])
+            return self._buf[name]
+
+        def cast(w, k):
+            ctr[0] += 1
+            w = w.detach()
+            return keep(f"c{ctr[0]}", lambda: torch.empty(w.shape[0], k, dtype=dt, device=dev0),
+                        lambda b: ops.pad_cols(w, k, dt, out=b))
+
+        def keep_f32(t):
+            ctr[0] += 1
+            t = t.detach().float()
+            return keep(f"f{ctr[0]}", lambda: torch.empty_like(t, memory_format=torch.contiguous_format), lambda b: b.copy_(t))
+
         self.L = []
         mods_w, mods_b = [], []
         for att, ff in m.transformer.layers:
@@ -76,9 +98,11 @@ class SwinJvpEngine:
         if hw.shape[0] % 4:  # GEMM N granularity (1x1 patches: 69 -> 72 output columns, the zero ones unused)
             hw = torch.cat([hw, hw.new_zeros(4 - hw.shape[0] % 4, hw.shape[1])], 0)
         self.head = cast(hw, self.kd)
-        self.mod_w, self.mod_b = torch.cat(mods_w, 0).float().contiguous(), torch.cat(mods_b, 0).float().contiguous()
+        self.mod_w, self.mod_b = keep_f32(torch.cat(mods_w, 0)), keep_f32(torch.cat(mods_b, 0))
         half = d // 2
-        self.freqs = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32) / half).to(self.mod_w.device)
+        if "freqs" not in self._buf:
+            self._buf["freqs"] = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32) / half).to(dev0)
+        self.freqs = self._buf["freqs"]
         self._stamp = stamp
 
     @staticmethod
@@ -87,8 +111,19 @@ class SwinJvpEngine:
 
     def jvp(self, srcs: Sequence[torch.Tensor], dsrc0: torch.Tensor, t: torch.Tensor, dt_: torch.Tensor,
             aux: Optional[torch.Tensor]) -> torch.Tensor:
-        """srcs: channel-concatenated network inputs (srcs[0] carries the tangent ``dsrc0``); t, dt_: [B].  Returns dF."""
+        """srcs: channel-concatenated network inputs (srcs[0] carries the tangent ``dsrc0``); t, dt_: [B].  Returns dF
+        (after the first call of a signature: the captured sequence's own tensor, overwritten by the next call)."""
         self.refresh()
+        srcs = [s.contiguous().float() for s in srcs]
+        ins = list(srcs) + [dsrc0.contiguous().float(), t.contiguous().float(), dt_.contiguous().float()] + \
+            ([aux.contiguous().float()] if aux is not None else [])
+        n = len(srcs)
+        key = ("jvp", tuple(tuple(s.shape) for s in srcs), aux is not None)
+        fn = lambda *a: self._jvp(list(a[:n]), a[n], a[n + 1], a[n + 2], a[n + 3] if aux is not None else None)
+        return self.graphs.call(key, fn, ins)
+
+    def _jvp(self, srcs: Sequence[torch.Tensor], dsrc0: torch.Tensor, t: torch.Tensor, dt_: torch.Tensor,
+             aux: Optional[torch.Tensor]) -> torch.Tensor:
         m, T = self.m, self.dt
         tc = ops.dtype_code(T)
         dev = srcs[0].device

@@ -43,11 +43,14 @@ def k_pad(dtype: torch.dtype, k: int) -> int:
     return int(lib().swiftk_gemm_k_pad(dtype_code(dtype), k))
 
 
-def pad_cols(w: torch.Tensor, k: int, dtype: torch.dtype) -> torch.Tensor:
-    """[rows, cols] fp32 -> [rows, k] ``dtype`` with zero padding (GEMM operand layout), on the device."""
+def pad_cols(w: torch.Tensor, k: int, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[rows, cols] fp32 -> [rows, k] ``dtype`` with zero padding (GEMM operand layout), on the device.
+    ``out``: refill an existing operand buffer (same address for captured launch sequences)."""
     _dev(w)
     w = w.contiguous().float()
-    out = torch.empty(w.shape[0], k, dtype=dtype, device=w.device)
+    if out is None:
+        out = torch.empty(w.shape[0], k, dtype=dtype, device=w.device)
+    assert out.shape == (w.shape[0], k) and out.dtype == dtype and out.is_contiguous()
     check(lib().swiftk_cast_pad(w.data_ptr(), w.shape[1], out.data_ptr(), k, w.shape[0], w.shape[1], dtype_code(dtype),
                                 _stream()), "swiftk_cast_pad")
     return out

@@ -21,6 +21,7 @@ import torch
 
 from . import ops
 from ._lib import (ATTN_PRENORM, BF16, EPI_BIAS_POS, EPI_NONE, EPI_QKNORM, F32, SwiftkError, check, lib)
+from .graphs import GraphCache
 
 _BF = torch.bfloat16
 
@@ -55,8 +56,17 @@ class SwinTrainEngine:
             raise SwiftkError("the training kernels are built for head_dim 80 / 88 / 96 and an even head count")
         self._stamp = None
         self._slabs = None
+        self._buf = {}            # persistent operand copies (fixed addresses: captured launch sequences read them)
+        self.graphs = GraphCache()
 
     # ------------------------------------------------------------------ operands
+    def _keep(self, name, make, fill):
+        """Persistent buffer ``name``: allocated by ``make()`` once, refilled in place by ``fill(buf)`` on every refresh."""
+        if name not in self._buf:
+            self._buf[name] = make()
+        fill(self._buf[name])
+        return self._buf[name]
+
     def refresh(self):
         m = self.m
         stamp = tuple((p.data_ptr(), p._version) for p in m.parameters())
@@ -72,8 +82,24 @@ class SwinTrainEngine:
         self.kh = ops.k_pad(_BF, 2 * mlp_e)
         po = m.out_channels * m.patch_size[0] * m.patch_size[1]
         self.kpo = ops.k_pad(_BF, po)
-        cast = lambda w, k: ops.pad_cols(w.detach(), k, _BF)
-        tr = lambda w, k: ops.pad_cols(w.detach().t().contiguous(), k, _BF)  # W^T operand for the data gradient
+        dev0 = m.pos_embed.device
+        ctr = [0]
+
+        def cast(w, k):
+            ctr[0] += 1
+            w = w.detach()
+            return self._keep(f"c{ctr[0]}", lambda: torch.empty(w.shape[0], k, dtype=_BF, device=dev0),
+                              lambda b: ops.pad_cols(w, k, _BF, out=b))
+
+        def tr(w, k):  # W^T operand for the data gradient
+            return cast(w.detach().t().contiguous(), k)
+
+        def keep_f32(t):
+            ctr[0] += 1
+            t = t.detach().float()
+            return self._keep(f"f{ctr[0]}", lambda: torch.empty_like(t, memory_format=torch.contiguous_format),
+                              lambda b: b.copy_(t))
+
         self.L = []
         for att, ff in m.transformer.layers:
             w1i = ff.w1.weight.detach().view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)
@@ -98,9 +124,11 @@ class SwinTrainEngine:
         for att, ff in m.transformer.layers:
             mods_w += [att.norm.modulation.weight.detach(), ff.norm.modulation.weight.detach()]
             mods_b += [att.norm.modulation.bias.detach(), ff.norm.modulation.bias.detach()]
-        self.mod_w, self.mod_b = torch.cat(mods_w, 0).float().contiguous(), torch.cat(mods_b, 0).float().contiguous()
+        self.mod_w, self.mod_b = keep_f32(torch.cat(mods_w, 0)), keep_f32(torch.cat(mods_b, 0))
         half = d // 2
-        self.freqs = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32) / half).to(self.mod_w.device)
+        if "freqs" not in self._buf:
+            self._buf["freqs"] = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32) / half).to(dev0)
+        self.freqs = self._buf["freqs"]
         self._stamp = stamp
 
     # ------------------------------------------------------------------ helpers
@@ -115,6 +143,7 @@ class SwinTrainEngine:
         need = ks * rows * cols
         if self._slabs is None or self._slabs.numel() < need:
             self._slabs = torch.empty(need, dtype=torch.float32, device=dy_t.device)
+            self.graphs.invalidate()  # (captured sequences hold the old buffer's address)
         check(lib().swiftk_gemm_splitk(dy_t.data_ptr(), dy_t.stride(0), x_t.data_ptr(), x_t.stride(0), self._slabs.data_ptr(), cols,
                                        rows * cols, rows, cols, Mtok, BF16, ks, _s()), "swiftk_gemm_splitk")
         check(lib().swiftk_reduce_slabs(self._slabs.data_ptr(), cols, rows * cols, ks, out_grad.data_ptr(), out_grad.stride(0),
@@ -128,7 +157,20 @@ class SwinTrainEngine:
 
     # ------------------------------------------------------------------ forward (saves activations)
     def forward(self, srcs: Sequence[torch.Tensor], scales: Sequence[float], t, aux, want_logvar=False):
+        """Forward pass that keeps the activations (``ctx``) for :meth:`backward`.  After the first call of a given
+        signature the launch sequence is replayed as one HIP graph (``graphs.GraphCache``): ``out`` / ``ctx`` then are
+        the capture's own tensors, overwritten by the next call with the same signature."""
         self.refresh()
+        srcs = [s.contiguous().float() for s in srcs]
+        ins = list(srcs) + [t.contiguous().float()] + ([aux.contiguous().float()] if aux is not None else [])
+        key = ("fwd", tuple(tuple(s.shape) for s in srcs), tuple(float(c) for c in scales), aux is not None, bool(want_logvar))
+        n = len(srcs)
+        fn = lambda *a: self._forward(list(a[:n]), list(scales), a[n], a[n + 1] if aux is not None else None, want_logvar)
+        res = self.graphs.call(key, fn, ins)
+        res[-1]["graph_key"] = key
+        return res
+
+    def _forward(self, srcs: Sequence[torch.Tensor], scales: Sequence[float], t, aux, want_logvar=False):
         m = self.m
         dev = srcs[0].device
         B = srcs[0].shape[0]
@@ -205,6 +247,23 @@ class SwinTrainEngine:
     # ------------------------------------------------------------------ backward
     def backward(self, ctx, dout: torch.Tensor, dlogvar: Optional[torch.Tensor] = None, need_input_grad: Sequence[bool] = (),
                  grads_final=None):
+        """See :meth:`_backward`.  Without a ``grads_final`` hook (single process, or not the last pass of the iteration) the
+        launch sequence is replayed as a HIP graph; with one it runs eagerly so the per-layer all-reduces can be started
+        from Python between the layers."""
+        import torch.distributed as tdist
+        if grads_final is not None and not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1):
+            grads_final = None  # nothing to reduce in one process
+        if grads_final is not None:
+            return self._backward(ctx, dout, dlogvar, need_input_grad, grads_final)
+        for p in self.m.parameters():  # gradient buffers must exist (fixed addresses) before anything is captured
+            self._grad_buf(p)
+        ins = [dout.contiguous().float()] + ([dlogvar.contiguous().float()] if dlogvar is not None else [])
+        key = ("bwd", ctx.get("graph_key"), dlogvar is not None, tuple(bool(b) for b in need_input_grad))
+        fn = lambda *a: self._backward(ctx, a[0], a[1] if dlogvar is not None else None, need_input_grad, None)
+        return self.graphs.call(key, fn, ins)
+
+    def _backward(self, ctx, dout: torch.Tensor, dlogvar: Optional[torch.Tensor] = None, need_input_grad: Sequence[bool] = (),
+                  grads_final=None):
         """Accumulate parameter gradients into .grad; return input gradients for the sources flagged in need_input_grad.
 
         ``grads_final`` (callable taking a list of parameters): this is the LAST backward pass of the iteration, so a
@@ -318,6 +377,7 @@ class SwinTrainEngine:
     def _modnorm_bwd(self, y, g, dy, ln, mod_slice, dmod_slice, M, d, ntok):
         if getattr(self, "_row_stats", None) is None or self._row_stats.numel() < 2 * M:
             self._row_stats = torch.empty(2 * M, dtype=torch.float32, device=y.device)
+            self.graphs.invalidate()  # (captured sequences hold the old buffer's address)
         check(lib().swiftk_modnorm_bwd(y.data_ptr(), y.stride(0), g.data_ptr(), dy.data_ptr(), dy.stride(0),
                                        ln.weight.detach().float().data_ptr(), ln.bias.detach().float().data_ptr(),
                                        mod_slice.data_ptr(), mod_slice.stride(0), self._grad_buf(ln.weight).data_ptr(),

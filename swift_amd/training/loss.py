@@ -306,8 +306,8 @@ class CRPSLoss(_LossBase):
                     last = (e == E - 1 and i == 0)  # the final backward pass of the iteration: gradients complete layer by layer
                     dins = eng.backward(ctx, dout, None, need_input_grad=(False, need, False),
                                         grads_final=getattr(net, "reduce_params", None) if last else None)
-                    if need:
-                        gcond = dins[1] if gcond is None else ops.axpby(1.0, gcond, 1.0, dins[1])
+                    if need:  # (a replayed backward returns ITS OWN output tensor, overwritten by the next replay: copy it)
+                        gcond = dins[1].clone() if gcond is None else ops.axpby(1.0, gcond, 1.0, dins[1])
 
         class Runner:
             value = loss.reshape(())

@@ -531,3 +531,51 @@ def test_larger_variants_training_step_and_tangent_vs_oracle(dev, dim, heads):
         errs[dt] = rel_l2(dF.cpu(), dref)
     print(f"dim {dim}: network tangent vs oracle jvp: fp32 rel-L2 {errs[torch.float32]:.3e}, bf16 {errs[torch.bfloat16]:.3e}")
     assert errs[torch.float32] < 1e-4 and errs[torch.bfloat16] < 8e-2
+
+
+def test_graph_replay_equals_eager(dev):
+    """graphs.GraphCache: the first call of a signature runs eagerly, the second is captured into a HIP graph and replayed,
+    later ones replay -- same loss and gradients each time (fp32 atomics in the LayerNorm / bias column sums are the only
+    run-to-run noise), with fresh inputs picked up by the replays and updated weights by the persistent operand buffers."""
+    from swift_amd.training.loss import TrigFlowLoss
+    from swift_amd.training.trainer import GradAllReduce
+    from swift_amd.utils.detinit import det_normal
+    net, onet, st = _build_pair(dev, 77, logvar=True)
+    ds = _dataset(77)
+    L = TrigFlowLoss(ds, dict(dist="loguniform", sigma_min=0.02, sigma_max=200.0), sigma_data=1.0).to(dev)
+    B = 2
+    ddp = GradAllReduce(net)
+    tau, aux = torch.tensor([0.3, 4.0]).view(B, 1, 1, 1).to(dev), torch.tensor([0.6, 0.6]).to(dev)
+
+    def run(tag):
+        x, cond, z = (det_normal((B, 69, 64, 64), 77, f"x{tag}").to(dev), det_normal((B, 72, 64, 64), 77, f"c{tag}").to(dev),
+                      det_normal((B, 69, 64, 64), 77, f"z{tag}").to(dev))
+        ddp.zero_grad_flat()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = L(ddp, x, condition=cond, auxiliary=aux, _tau=tau, _z=z)
+        loss.backward()
+        return float(loss), ddp.flatten_grads().clone()
+
+    eng = net.model._train_engine if hasattr(net.model, "_train_engine") else None
+    l_a, g_a = run("a")           # eager
+    eng = net.model._train_engine
+    assert not eng.graphs._graphs
+    l_a2, g_a2 = run("a")         # captured, then replayed
+    assert len(eng.graphs._graphs) == 2  # forward + backward
+    l_a3, g_a3 = run("a")         # replayed
+    assert l_a2 == pytest.approx(l_a, rel=1e-6) and l_a3 == pytest.approx(l_a, rel=1e-6)
+    assert rel_l2(g_a2.cpu(), g_a.cpu()) < 1e-5 and rel_l2(g_a3.cpu(), g_a.cpu()) < 1e-5
+    l_b, g_b = run("b")           # other inputs through the same graphs ...
+    assert abs(l_b - l_a) > 1e-4 and rel_l2(g_b.cpu(), g_a.cpu()) > 1e-2
+    import os
+    os.environ["SWIFTK_TRAIN_GRAPHS"] = "0"
+    try:
+        l_be, g_be = run("b")     # ... match the eager path on those inputs
+    finally:
+        del os.environ["SWIFTK_TRAIN_GRAPHS"]
+    assert l_b == pytest.approx(l_be, rel=1e-6) and rel_l2(g_b.cpu(), g_be.cpu()) < 1e-5
+    with torch.no_grad():         # a weight update is seen by the replays (operand copies are refreshed in place)
+        for p in net.parameters():
+            p.mul_(1.01)
+    l_c, g_c = run("b")
+    assert abs(l_c - l_b) > 1e-5 and len(eng.graphs._graphs) == 2

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """BASELINE config 5 on one GPU: Swift-B multistep-CRPS finetune iteration (ensemble 2, `steps` rollout steps, AdamW),
 local batch B.  Prints seconds per iteration and a per-kernel share if run under rocprofv3."""
-import argparse, os, sys, time
+import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from swift_amd.data.era5 import SyntheticERA5Dataset
@@ -52,13 +52,26 @@ for k in range(a.iters):
     loss = tr.train_step(x, t, idx, delta, 1000 * (k + 2), steps=a.steps)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
+PEAK = 2.5e15  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+fused = bool(getattr(tr, "_fused", None))
 if a.loss == "scm":
     # tangent pass = every GEMM on 2M rows (2 fwd) + forward-with-activations (1) + backward (2)
+    fl = 5 * a.batch * 2.7535e12 * a.depth / 12
+    print(json.dumps({"metric": "sCM pre-training iteration (Swift-B, local batch %d, optimizer %s)" % (a.batch, a.opt), "value": dt, "unit": "s/iteration",
+                      "samples_per_s": a.batch / dt, "flop_per_iteration": fl, "what": "~5 forward-equivalents per sample (tangent pass 2, forward 1, backward 2)",
+                      "roofline": {"bound": "mfma", "achieved": fl / dt / 1e12, "peak": PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / dt / PEAK, "traffic": None},
+                      "fused_optimizer_step": fused, "peak_mem_gib": torch.cuda.max_memory_allocated() / 2**30}))
     print(f"sCM pre-training: batch {a.batch}, depth {a.depth}: {dt:.3f} s/iteration, loss {float(loss):.4f}; "
           f"{a.batch / dt:.2f} samples/s; ~5 fwd-equivalents -> {(5 * a.batch * 2.7535e12 * a.depth / 12) / dt / 1e12:.0f} TFLOP/s; "
           f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sys.exit(0)
 evals = 2 * a.steps
+fl = 4 * evals * a.batch * 2.7535e12 * a.depth / 12
+print(json.dumps({"metric": "multistep-CRPS finetune iteration (Swift-B, steps %d, ensemble 2, local batch %d; BASELINE configs[4] per GPU)" % (a.steps, a.batch),
+                  "value": dt, "unit": "s/iteration", "samples_per_s": a.batch / dt, "flop_per_iteration": fl,
+                  "what": f"{evals} rollout forwards + {evals} recomputed forwards + {evals} backwards (2x) = {4 * evals} forward-equivalents per sample",
+                  "roofline": {"bound": "mfma", "achieved": fl / dt / 1e12, "peak": PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / dt / PEAK, "traffic": None},
+                  "fused_optimizer_step": fused, "peak_mem_gib": torch.cuda.max_memory_allocated() / 2**30}))
 print(f"CRPS finetune: batch {a.batch}, steps {a.steps}, depth {a.depth}: {dt:.3f} s/iteration, loss {float(loss):.4f}; "
       f"{a.batch / dt:.2f} samples/s; fwd-equivalents/iter = {evals} fwd + {evals} recompute + {evals} bwd(2x) -> "
       f"{(4 * evals * a.batch * 2.7535e12 * a.depth / 12) / dt / 1e12:.0f} TFLOP/s; peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
