@@ -58,6 +58,7 @@ def setup_torch(backend: Optional[str] = None, timeout_s: int = 1800) -> int:
         be = "nccl" if use_cuda else "gloo"
         if backend in ("gloo", "nccl"):
             be = backend
+        be = os.environ.get("SWIFTK_DIST_BACKEND", be)  # tests: N ranks sharing one GPU run their collectives over gloo
         import datetime
         dist.init_process_group(be, rank=_env_int("RANK"), world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
     return get_rank()
@@ -76,7 +77,7 @@ def maybe_launch_ranks(n_gpus: Optional[int], module: str) -> None:
             raise SystemExit(f"--gpus {n_gpus} but launched with {get_world_size()} rank(s)")
         return
     have = torch.cuda.device_count()  # counting devices does not initialise the GPU runtime
-    if 0 < have < n_gpus:
+    if 0 < have < n_gpus and not os.environ.get("SWIFTK_ALLOW_SHARED_GPU"):
         raise SystemExit(f"--gpus {n_gpus} but this node exposes {have} GPU(s)")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))

@@ -83,6 +83,14 @@ def test_train_then_generate_cli(tmp_path):
     met = json.load(open(rdir / "output" / "latest" / "evaluation_metrics.json"))
     assert len(met) == 3 * 3 * 69 and all(np.isfinite(v) for v in met.values())
     assert f"crps_{names[0]}_6h" in met and f"ssr_{names[-1]}_18h" in met
+    # the same job as two ranks started by `--gpus 2` (sharing this box's one GPU, collectives over gloo): IC-major units
+    # sharded over the ranks, weights broadcast, per-IC ensemble sums all-gathered -> same store, same metrics
+    os.rename(rdir / "output" / "latest" / "evaluation_metrics.json", rdir / "output" / "latest" / "metrics_1rank.json")
+    run(["swift_amd.generate", "--gpus", "2", "--input", str(rdir), "--members", "2", "--steps", "3", "--samples", "3", "--batch",
+         "3", "--metrics", "--dump", "numpy"], cwd=str(tmp_path), env={"SWIFTK_ALLOW_SHARED_GPU": "1", "SWIFTK_DIST_BACKEND": "gloo"})
+    np.testing.assert_array_equal(np.load(f), a)
+    met2 = json.load(open(rdir / "output" / "latest" / "evaluation_metrics.json"))
+    assert met2.keys() == met.keys() and all(met2[k] == pytest.approx(met[k], rel=1e-6) for k in met)
 
 
 def test_train_cli_5p6deg_one_by_one_patches(tmp_path):
@@ -145,3 +153,32 @@ def test_bench_contract_line(tmp_path):
     p4 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "300"], cwd=str(tmp_path), env=e,
                         capture_output=True, text=True, timeout=300)
     assert p4.returncode == 2 and "SWIFTK_MAX_UNITS" in p4.stderr
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """The N-rank path of bench.py end to end on this one-GPU box: `bench.py --gpus 2` starts two fresh rank processes that
+    share GPU 0 (SWIFTK_ALLOW_SHARED_GPU) and run their collectives over gloo (SWIFTK_DIST_BACKEND; RCCL refuses two ranks on
+    one device): weight broadcast, per-step all-gather of the unit checksums, max-over-ranks timing.  Rank 0's units are the
+    1-rank run's units, so their checksums must agree bit for bit; `generate --gpus 2` shards IC-major units the same way."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    e = dict(os.environ, PYTHONPATH=ROOT, SWIFTK_ALLOW_SHARED_GPU="1", SWIFTK_DIST_BACKEND="gloo")
+    e.pop("WORLD_SIZE", None)
+    common = ["--steps", "3", "--warmup", "1", "--batch", "4", "--no-extras"]
+    out = {}
+    for n in (1, 2):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + common, cwd=str(tmp_path), env=e,
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        out[n] = json.loads(lines[0])
+    d1, d2 = out[1], out[2]
+    assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d2["rccl"]["world"] == 2 and d2["rccl"]["backend"] == "gloo"
+    assert d2["checksum"]["units_collected"] == 8 and d1["checksum"]["units_collected"] == 4
+    assert d2["checksum"]["last_step_rank0_units_sum"] == d1["checksum"]["last_step_rank0_units_sum"]
+    assert d2["checksum"]["last_step_first_units"] == d1["checksum"]["last_step_first_units"]
+    assert d2["checksum"]["last_step_all_units_sum"] != d1["checksum"]["last_step_all_units_sum"]
+    assert d2["value"] == pytest.approx(2 * 4 * 3 / (d2["ms_per_step"] * 3 / 1e3), rel=1e-3)
