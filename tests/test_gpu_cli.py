@@ -111,6 +111,17 @@ def test_train_cli_5p6deg_one_by_one_patches(tmp_path):
          "--dump", "numpy"], cwd=str(tmp_path))
     a = np.load(rdir / "output" / "latest" / "output-2i-2s-2m-6h.npy")
     assert a.shape == (2, 2, 3, 69, 32, 64) and np.isfinite(a).all()
+    # the data-parallel training step as two ranks started by `--gpus 2` (one GPU shared, collectives over gloo): per-layer
+    # gradient all-reduces overlapped with the eager final backward pass, shared run id, rank-0 checkpoint
+    run(["swift_amd.train", "--gpus", "2", "experiment=era5-swinv2-5.6-scm", "data=era5-synthetic-5.6", "data.dataset.length=48",
+         "data.data_workers=0", "model.depth=2", "optimizer=adamw", "trainer.total_kimg=0.008", "trainer.kimg_per_tick=0.004",
+         "trainer.checkpoint_ticks=1", "trainer.lr_rampup_kimg=0", "trainer.val_ticks=null", "data.batch_size=2",
+         "loss.tangent_warmup_kimg=1"], cwd=str(tmp_path),
+        env={"HYDRA_RUN_ID": "003", "SWIFTK_ALLOW_SHARED_GPU": "1", "SWIFTK_DIST_BACKEND": "gloo"})
+    rdir2 = tmp_path / "results" / "era5-swinv2-5.6-scm" / "003"
+    lines = [yaml.safe_load(l) for l in open(rdir2 / "stats.jsonl")]
+    assert len(lines) >= 2 and all(np.isfinite(l["train/loss"]) for l in lines)
+    assert sorted(os.listdir(rdir2 / "checkpoints"))
 
 
 def test_bench_contract_line(tmp_path):
