@@ -97,9 +97,24 @@ def launch_ranks(n: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    return wait_ranks(procs)
+
+
+def wait_ranks(procs) -> int:
+    """Worst exit code of the rank processes; when one fails the others (which would wait in a collective until the
+    process-group timeout) are terminated -- by their own PIDs."""
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(code))
+            if code != 0:
+                for q in live:
+                    q.terminate()
     return rc
 
 

@@ -90,9 +90,19 @@ def maybe_launch_ranks(n_gpus: Optional[int], module: str) -> None:
         if run_id is not None:
             env["HYDRA_RUN_ID"] = run_id
         procs.append(subprocess.Popen([sys.executable, "-m", module, *sys.argv[1:]], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    import time
+    rc, live = 0, list(procs)
+    while live:  # a failed rank would leave the others waiting in a collective: stop them (by their own PIDs)
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(code))
+            if code != 0:
+                for q in live:
+                    q.terminate()
     raise SystemExit(rc)
 
 
