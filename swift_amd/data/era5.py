@@ -147,6 +147,10 @@ class ERA5Dataset(_ERA5Base):
     def get_forcings(self, idx: int) -> torch.Tensor:
         return torch.from_numpy(self._load_file(self.files[idx], self.forcings)).float()
 
+    def get_state(self, idx: int) -> torch.Tensor:
+        """Physical fields of time step ``idx`` [n_vars, H, W]: one file read (``self[idx]`` reads two: x and its target)."""
+        return torch.from_numpy(self._load_file(self.files[idx], self.variables)).float()
+
     def get_lat_lon(self):
         """data/era5.py:172-175."""
         return (np.load(os.path.join(self.root, "lat.npy")).astype(np.float32),
@@ -224,6 +228,9 @@ class SyntheticERA5Dataset(_ERA5Base):
 
     def get_forcings(self, idx: int) -> torch.Tensor:
         return self._fields(idx, "forc", len(self.forcings))
+
+    def get_state(self, idx: int) -> torch.Tensor:
+        return self._fields(idx, "state", len(self.variables))
 
     def __len__(self):
         return self.length - (max(self.intervals) // 6)

@@ -129,11 +129,12 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
             ev.synchronize()
         t1 = time.time()
         h = host.numpy()
-        for k, (m, ic) in enumerate(us):    # buffer is step-major [steps+1, B, ...]
-            if dump == "numpy":
+        if dump == "numpy":
+            for k, (m, ic) in enumerate(us):    # buffer is step-major [steps+1, B, ...]
                 store[ic, m] = h[:, k]
-            else:
-                zarrlite.write_unit(ofile, var_channels, ic, m, h[:, k])
+        else:  # one chunk file per unit and variable: independent files, written by a few threads
+            list(loaders.map(lambda kmi: zarrlite.write_unit(ofile, var_channels, kmi[1][1], kmi[1][0], h[:, kmi[0]]),
+                             enumerate(us)))
         if dump == "numpy":
             store.flush()
         t_host[1] += time.time() - t1
@@ -143,14 +144,17 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
         t1 = time.time()
         units = [unit_of(u, members) for u in range(s, min(s + batch, mine.stop))]
         ics = [indices[ic] for _, ic in units]
-        x0 = {int(j): dataset[int(j)][0][0][:nv] for j in set(ics)}
+        state = getattr(dataset, "get_state", None)  # one read per IC; dataset[j] would also read j's training target
+        x0 = {int(j): (dataset.standardize_x(state(int(j))) if state else dataset[int(j)][0][0][:nv]) for j in set(ics)}
         X0 = torch.stack([x0[int(j)] for j in ics], 0)
         forc = engine.stage_forcings(ics, steps, "cpu")
         truth = None
         if want_metrics:  # verifying fields of every lead step, physical units, one copy per IC of the batch
             uniq = sorted(set(ic for _, ic in units))
-            truth = torch.stack([torch.stack([dataset.unstandardize_x(dataset[int(indices[ic]) + (i + 1) * interval // 6][0][0][:nv])
-                                              for i in range(steps)], 0) for ic in uniq], 0)
+            get = state if state else (lambda j: dataset.unstandardize_x(dataset[j][0][0][:nv]))
+            jobs = [int(indices[ic]) + (i + 1) * interval // 6 for ic in uniq for i in range(steps)]
+            fields = list(loaders.map(get, jobs))  # file reads / field synthesis in parallel (numpy and h5 release the GIL)
+            truth = torch.stack(fields, 0).view(len(uniq), steps, *fields[0].shape)
         if on_gpu:
             X0, forc = X0.pin_memory(), forc.pin_memory()
             truth = None if truth is None else truth.pin_memory()
@@ -169,6 +173,7 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
             metric_sums[ic] = ensemble_sums(pred, truth[k].to(pred.device, non_blocking=True), lat).double().cpu()
 
     reader = ThreadPoolExecutor(max_workers=1)
+    loaders = ThreadPoolExecutor(max_workers=8)
     starts = list(range(mine.start, mine.stop, batch))
     nxt = reader.submit(stage, starts[0]) if starts else None
     for bi, s in enumerate(starts):
@@ -205,6 +210,7 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
         pending.result()
     writer.shutdown()
     reader.shutdown()
+    loaders.shutdown()
     dist.log0(f"host side: {t_host[0]:.2f} s staging inputs, {t_host[1]:.2f} s writing outputs")
     if want_metrics:
         return collect_metrics(metric_sums, n_ic, steps, nv, members, dataset, interval, device, os.path.dirname(ofile))

@@ -75,15 +75,26 @@ def create_array(root: str, name: str, shape: Sequence[int], chunks: Sequence[in
     _dump(os.path.join(d, ".zattrs"), {"_ARRAY_DIMENSIONS": list(dims), **(attrs or {})})
 
 
+_META_CACHE: Dict[Tuple[str, str], Tuple[tuple, np.dtype]] = {}
+
+
+def _chunk_meta(root: str, name: str):
+    key = (root, name)
+    if key not in _META_CACHE:
+        with open(os.path.join(root, name, ".zarray")) as f:
+            meta = json.load(f)
+        _META_CACHE[key] = (tuple(meta["chunks"]), np.dtype(meta["dtype"]))
+    return _META_CACHE[key]
+
+
 def write_chunk(root: str, name: str, index: Sequence[int], data: np.ndarray) -> None:
     """Write one WHOLE chunk (``data.shape`` == the array's chunk shape; edge chunks are padded by the caller)."""
-    with open(os.path.join(root, name, ".zarray")) as f:
-        meta = json.load(f)
-    assert tuple(data.shape) == tuple(meta["chunks"]), (data.shape, meta["chunks"])
-    data = np.ascontiguousarray(data, dtype=np.dtype(meta["dtype"]))
+    chunks, dt = _chunk_meta(root, name)
+    assert tuple(data.shape) == chunks, (data.shape, chunks)
+    data = np.ascontiguousarray(data, dtype=dt)
     tmp = os.path.join(root, name, "." + ".".join(str(int(i)) for i in index) + f".{os.getpid()}.tmp")
     with open(tmp, "wb") as f:
-        f.write(data.tobytes())
+        f.write(memoryview(data).cast("B"))
     os.replace(tmp, os.path.join(root, name, ".".join(str(int(i)) for i in index)))
 
 
@@ -144,15 +155,8 @@ def write_unit(ofile: str, var_channels: Dict[str, List[int]], sample: int, memb
             write_chunk(ofile, var, (sample, member, 0, 0, 0, 0), traj[None, None][:, :, :, ch])
 
 
-_LEVEL_CACHE: Dict[Tuple[str, str], bool] = {}
-
-
 def _has_level(ofile: str, var: str) -> bool:
-    key = (ofile, var)
-    if key not in _LEVEL_CACHE:
-        with open(os.path.join(ofile, var, ".zarray")) as f:
-            _LEVEL_CACHE[key] = len(json.load(f)["shape"]) == 6
-    return _LEVEL_CACHE[key]
+    return len(_chunk_meta(ofile, var)[0]) == 6
 
 
 # ------------------------------------------------------------------------------------------ reader (tests, eval)

@@ -382,6 +382,7 @@ def test_h5_backed_era5_dataset_vs_reference_golden(tmp_path, monkeypatch):
         assert idx == spec[0] and float(delta) == float(g[f"d_{tag}"])
     assert np.isfinite(ds[(3, 1, 6)][0][0].numpy()).all()  # file 3 carries a NaN that the loader fills
     np.testing.assert_array_equal(ds.get_forcings(5).numpy(), g["forc5"])
+    np.testing.assert_array_equal(ds.standardize_x(ds.get_state(2)).numpy(), g["x_2_2_6"][:4])  # the one-read form generate uses
     assert str(ds.get_time(7)) == str(g["time7"])
     lat, lon = ds.get_lat_lon()
     np.testing.assert_array_equal(lat, g["lat"])
