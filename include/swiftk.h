@@ -204,6 +204,14 @@ int swiftk_gemm_qkv_tiled(const void* A, int64_t lda, const void* W, int64_t ldw
  * slabs + s*slab_stride.  Same operand rules as swiftk_gemm; M % 8 == 0, N % 8 == 0. */
 int swiftk_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, float* slabs, int64_t ldc, int64_t slab_stride,
                        int64_t M, int64_t N, int64_t K, int dtype, int ksplit, void* stream);
+/* The same weight gradient without the transposed copies (TN form; autograd of the Linears at swinv2.py:96-98,112-113,134):
+ *   slabs[s][N1, ldc] (fp32) = sum over the s-th of `ksplit` ranges of the K token rows of P[m, 0..N1)^T * Q[m, 0..N2)
+ * P = dY [K, ldp], Q = X [K, ldq], bf16, token-major as the forward / backward passes leave them.  K % 64 == 0,
+ * N1 % 8 == 0, N2 % 4 == 0; rows must be readable to the end of the last 64-column (P) / 352-column (Q) block:
+ * ldp >= roundup(N1, 64), ldq >= roundup(N2, 352) -- what lies past N1 / N2 there is never used.  SWIFTK_ESHAPE when a
+ * shape does not fit (callers then use swiftk_transpose + swiftk_gemm_splitk).  Bit-equal to that path. */
+int swiftk_gemm_tn_splitk(const void* P, int64_t ldp, const void* Q, int64_t ldq, float* slabs, int64_t ldc,
+                          int64_t slab_stride, int64_t N1, int64_t N2, int64_t K, int ksplit, void* stream);
 /* out[r][c] (= | +=) sum_s slabs[s*slab_stride + r*ld_slab + c] */
 int swiftk_reduce_slabs(const float* slabs, int64_t ld_slab, int64_t slab_stride, int nslabs, float* out, int64_t ld_out,
                         int64_t rows, int64_t cols, int accumulate, void* stream);

@@ -34,6 +34,7 @@ class GraphCache:
     def invalidate(self) -> None:
         """Drop every captured sequence (a buffer they address was re-allocated); the next call of a key captures anew."""
         self._graphs.clear()
+        self._pool = None  # the private pool dies with its last graph; a stale handle fails capture_begin
 
     def call(self, key: tuple, fn: Callable, inputs: Sequence[torch.Tensor]):
         if not enabled() or torch.cuda.is_current_stream_capturing():

@@ -48,6 +48,15 @@ def _transpose(src, rows, cols, ldd=None):
     return dst
 
 
+def _padded(rows, width, valid):
+    """[rows, width] bf16 GEMM operand whose columns [valid, width) are zero (the k-padding a GEMM may read); the kernel
+    that fills it writes columns [0, valid) only -- zeroing 32 pad columns instead of the whole buffer."""
+    t = torch.empty(rows, width, dtype=_BF, device=torch.device("cuda", torch.cuda.current_device()))
+    if width > valid:
+        t[:, valid:].zero_()
+    return t
+
+
 class SwinTrainEngine:
     def __init__(self, module):
         self.m = module
@@ -135,17 +144,24 @@ class SwinTrainEngine:
     def _small(self, x, w, b, act=0):
         return ops.linear_small(x, w.detach().float().contiguous(), None if b is None else b.detach().float().contiguous(), act)
 
-    def _wgrad(self, dy_t, x_t, rows, cols, out_grad, accumulate=True):
-        """out_grad[rows, cols] (+)= dy_t[rows, M] @ x_t[cols, M]^T via split-K fp32 slabs."""
-        Mtok = dy_t.shape[1]
+    def _wgrad(self, dy, x, rows, cols, out_grad, accumulate=True):
+        """out_grad[rows, cols] (+)= dy[M, :rows]^T @ x[M, :cols] via split-K fp32 slabs; both operands token-major as the
+        passes leave them (``swiftk_gemm_tn_splitk``).  Shapes that kernel does not take (a column count that is not whole
+        352-wide tiles: patch embedding, the dim-1280 / 1536 families) go through transposed copies and the NT kernel."""
+        Mtok = dy.shape[0]
         tiles = ((rows + 255) // 256) * ((cols + 351) // 352)
-        ks = max(1, min(32, 512 // tiles, Mtok // 64))
+        ks = max(1, min(32, 256 // tiles, Mtok // 64))  # one round of work items over the 256 CUs
         need = ks * rows * cols
         if self._slabs is None or self._slabs.numel() < need:
-            self._slabs = torch.empty(need, dtype=torch.float32, device=dy_t.device)
+            self._slabs = torch.empty(need, dtype=torch.float32, device=dy.device)
             self.graphs.invalidate()  # (captured sequences hold the old buffer's address)
-        check(lib().swiftk_gemm_splitk(dy_t.data_ptr(), dy_t.stride(0), x_t.data_ptr(), x_t.stride(0), self._slabs.data_ptr(), cols,
-                                       rows * cols, rows, cols, Mtok, BF16, ks, _s()), "swiftk_gemm_splitk")
+        rc = lib().swiftk_gemm_tn_splitk(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), self._slabs.data_ptr(), cols,
+                                         rows * cols, rows, cols, Mtok, ks, _s())
+        if rc == -2:  # SWIFTK_ESHAPE
+            dy_t, x_t = _transpose(dy, Mtok, rows), _transpose(x, Mtok, cols)
+            rc = lib().swiftk_gemm_splitk(dy_t.data_ptr(), dy_t.stride(0), x_t.data_ptr(), x_t.stride(0), self._slabs.data_ptr(),
+                                          cols, rows * cols, rows, cols, Mtok, BF16, ks, _s())
+        check(rc, "swiftk_gemm_tn_splitk")
         check(lib().swiftk_reduce_slabs(self._slabs.data_ptr(), cols, rows * cols, ks, out_grad.data_ptr(), out_grad.stride(0),
                                         rows, cols, int(accumulate), _s()), "swiftk_reduce_slabs")
 
@@ -212,25 +228,23 @@ class SwinTrainEngine:
             qkvh = torch.empty(M, 3 * d, dtype=_BF, device=dev)
             rn = torch.empty(M, 3 * heads, dtype=torch.float32, device=dev)
             _gemm(xT, W["qkv"], qkvh, EPI_QKNORM, W["scale"], rn, pos_rows=self.hd)  # (QKNORM: head_dim rides in pos_rows)
-            a = torch.zeros(M, self.kd, dtype=_BF, device=dev)
+            a = _padded(M, self.kd, d)
             ops.window_attention(qkvh.view(B, ntok, 3 * d), None, (gh, gw), heads, sh, out=a.view(B, ntok, self.kd),
                                  flags=ATTN_PRENORM)
             y1 = torch.empty(M, d, dtype=_BF, device=dev)
             _gemm(a, W["wo"], y1)
-            xT_mid = torch.zeros(M, self.kd, dtype=_BF, device=dev)
+            xT_mid = _padded(M, self.kd, d)
             msl1 = mod[:, (2 * i) * 2 * d:(2 * i + 1) * 2 * d]
             ops.modnorm_residual(y1, x, att.norm.norm.weight.detach().float(), att.norm.norm.bias.detach().float(), msl1, ntok,
                                  xcopy=xT_mid)
             h = torch.empty(M, 2 * mlp, dtype=_BF, device=dev)
             _gemm(xT_mid, W["w1"], h)
-            hmid = torch.empty(M, self.kmlp, dtype=_BF, device=dev)
-            if self.kmlp > mlp:
-                hmid.zero_()
+            hmid = _padded(M, self.kmlp, mlp)
             check(lib().swiftk_swiglu_fwd(h.data_ptr(), h.stride(0), hmid.data_ptr(), hmid.stride(0), M, mlp, BF16, _s()),
                   "swiftk_swiglu_fwd")
             y2 = torch.empty(M, d, dtype=_BF, device=dev)
             _gemm(hmid, W["w2"], y2)
-            xT_out = torch.zeros(M, self.kd, dtype=_BF, device=dev)
+            xT_out = _padded(M, self.kd, d)
             msl2 = mod[:, (2 * i + 1) * 2 * d:(2 * i + 2) * 2 * d]
             ops.modnorm_residual(y2, x, ff.norm.norm.weight.detach().float(), ff.norm.norm.bias.detach().float(), msl2, ntok,
                                  xcopy=xT_out)
@@ -291,7 +305,7 @@ class SwinTrainEngine:
         _gemm(dtok_h, self.head_t, dx)                                     # dgrad -> d xT_final
         # the split-K kernel wants row counts in multiples of 8: use the zero-padded kpo rows and keep the first po
         gh_pad = torch.empty(self.kpo, d, dtype=torch.float32, device=dev)
-        self._wgrad(_transpose(dtok_h, M, self.kpo), _transpose(ctx["xT_final"], M, d), self.kpo, d, gh_pad, accumulate=False)
+        self._wgrad(dtok_h, ctx["xT_final"], self.kpo, d, gh_pad, accumulate=False)
         G(m.head.head[0].weight).add_(gh_pad[:po])
         if grads_final is not None:
             grads_final(list(m.head.parameters()))
@@ -301,45 +315,45 @@ class SwinTrainEngine:
             W, A = self.L[i], ctx["layers"][i]
             mod = ctx["mod"]
             # ---- feed-forward branch
-            dy2 = torch.zeros(M, self.kd, dtype=_BF, device=dev)
+            dy2 = _padded(M, self.kd, d)
             self._modnorm_bwd(A["y2"], dx, dy2, ff.norm.norm, mod[:, (2 * i + 1) * 2 * d:(2 * i + 2) * 2 * d],
                               dmod[:, (2 * i + 1) * 2 * d:(2 * i + 2) * 2 * d], M, d, ntok)
             dhmid = torch.empty(M, mlp, dtype=_BF, device=dev)
             _gemm(dy2, W["w2_t"], dhmid)
             if mlp == mlp0:
-                self._wgrad(_transpose(dy2, M, d), _transpose(A["hmid"], M, mlp), d, mlp, G(ff.w2.weight))
+                self._wgrad(dy2, A["hmid"], d, mlp, G(ff.w2.weight))
             else:
                 g2 = torch.empty(d, mlp, dtype=torch.float32, device=dev)
-                self._wgrad(_transpose(dy2, M, d), _transpose(A["hmid"], M, mlp), d, mlp, g2, accumulate=False)
+                self._wgrad(dy2, A["hmid"], d, mlp, g2, accumulate=False)
                 G(ff.w2.weight).add_(g2[:, :mlp0])
-            dh = torch.zeros(M, self.kh, dtype=_BF, device=dev) if self.kh > 2 * mlp else torch.empty(M, 2 * mlp, dtype=_BF, device=dev)
+            dh = _padded(M, max(self.kh, 2 * mlp), 2 * mlp)
             check(L.swiftk_swiglu_bwd(A["h"].data_ptr(), A["h"].stride(0), dhmid.data_ptr(), dhmid.stride(0), dh.data_ptr(),
                                       dh.stride(0), M, mlp, BF16, _s()), "swiftk_swiglu_bwd")
             dxt = torch.empty(M, d, dtype=torch.float32, device=dev)
             _gemm(dh, W["w1_t"], dxt)
             g1i = torch.empty(2 * mlp, d, dtype=torch.float32, device=dev)
-            self._wgrad(_transpose(dh, M, 2 * mlp), _transpose(A["xT_mid"], M, d), 2 * mlp, d, g1i, accumulate=False)
+            self._wgrad(dh, A["xT_mid"], 2 * mlp, d, g1i, accumulate=False)
             G(ff.w1.weight).add_(g1i[:2 * mlp0].view(mlp0, 2, d).permute(1, 0, 2).reshape(2 * mlp0, d))  # undo the interleave
             ops.axpby(1.0, dx, 1.0, dxt, out=dx)                             # residual + w1 path
             # ---- attention branch
-            dy1 = torch.zeros(M, self.kd, dtype=_BF, device=dev)
+            dy1 = _padded(M, self.kd, d)
             self._modnorm_bwd(A["y1"], dx, dy1, att.norm.norm, mod[:, (2 * i) * 2 * d:(2 * i + 1) * 2 * d],
                               dmod[:, (2 * i) * 2 * d:(2 * i + 1) * 2 * d], M, d, ntok)
             datt = torch.empty(M, self.kd, dtype=_BF, device=dev)
             _gemm(dy1, W["wo_t"], datt)  # N = d columns written, row stride kd
-            self._wgrad(_transpose(dy1, M, d), _transpose(A["att"], M, d), d, d, G(att.wo.weight))
+            self._wgrad(dy1, A["att"], d, d, G(att.wo.weight))
             dqkvh = torch.empty(M, 3 * d, dtype=_BF, device=dev)
             sh = A["shift"]
             check(L.swiftk_window_attention_bwd(A["qkvh"].data_ptr(), 3 * d, A["att"].data_ptr(), datt.data_ptr(), self.kd,
                                                 dqkvh.data_ptr(), B, gh, gw, heads, self.hd, sh[0], sh[1], BF16, _s()),
                   "swiftk_window_attention_bwd")
-            dqkv = torch.zeros(M, self.kqkv, dtype=_BF, device=dev)
+            dqkv = _padded(M, self.kqkv, 3 * d)
             dscale = torch.zeros(heads, dtype=torch.float32, device=dev)
             check(L.swiftk_qknorm_bwd(A["qkvh"].data_ptr(), dqkvh.data_ptr(), 3 * d, A["rn"].data_ptr(), dqkv.data_ptr(), self.kqkv,
                                       W["scale"].data_ptr(), dscale.data_ptr(), M, heads, self.hd, BF16, _s()), "swiftk_qknorm_bwd")
             G(att.scale).add_(dscale.view_as(att.scale))
             _gemm(dqkv, W["qkv_t"], dxt)
-            self._wgrad(_transpose(dqkv, M, 3 * d), _transpose(A["xT_in"], M, d), 3 * d, d, G(att.to_qkv.weight))
+            self._wgrad(dqkv, A["xT_in"], 3 * d, d, G(att.to_qkv.weight))
             ops.axpby(1.0, dx, 1.0, dxt, out=dx)
             if grads_final is not None:  # everything of layer i except its modulation Linears (those follow in _embed_bwd)
                 grads_final([p for n, p in m.transformer.layers[i].named_parameters() if "modulation" not in n])
@@ -350,7 +364,7 @@ class SwinTrainEngine:
         dxb = ops.pad_cols(dx, self.kd, _BF)
         pf = m.in_channels * p1 * p2
         gpe = torch.empty(d, self.kpe, dtype=torch.float32, device=dev)  # kpe (multiple of 8) columns; the pad ones are 0
-        self._wgrad(_transpose(dxb, M, d), _transpose(ctx["ape"], M, self.kpe), d, self.kpe, gpe, accumulate=False)
+        self._wgrad(dxb, ctx["ape"], d, self.kpe, gpe, accumulate=False)
         G(m.patch_embed.emb.weight).add_(gpe[:, :pf])
         dins: List[Optional[torch.Tensor]] = []
         if any(need_input_grad):

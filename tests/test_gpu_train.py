@@ -59,6 +59,47 @@ def test_transpose_and_splitk_wgrad(dev):
     assert rel_l2(slabs[0].cpu(), ref0) < 1e-5
 
 
+@pytest.mark.parametrize("M,N1,N2,ks,ldp,ldq", [
+    (1024, 1056, 704, 3, 1088, 704),      # partial 256-row tile (1056 = 4 x 256 + 32), garbage in the pad columns of P
+    (4096, 256, 352, 16, 320, 360),       # exactly one tile, many splits, leading dimensions past the tile
+    (2048, 3168, 1056, 1, 3200, 1088),    # the to_qkv gradient's shape, one k-range
+    (640, 72, 1408, 2, 128, 1408),        # fewer rows than one wave tile
+])
+def test_tn_wgrad_equals_transposed_path(dev, M, N1, N2, ks, ldp, ldq):
+    """swiftk_gemm_tn_splitk (operands token-major, transposed in LDS) against fp64 and, bit for bit, against the
+    transposed-copies path it replaces."""
+    from swift_amd import _lib
+    from swift_amd.train_engine import _transpose
+    L = _lib.lib()
+    P = torch.full((M, ldp), float("nan"), dtype=BF, device=dev)   # NaN pad columns must not reach any stored value
+    Q = torch.full((M, ldq), float("nan"), dtype=BF, device=dev)
+    P[:, :N1] = rnd((M, N1), 5).to(dev).to(BF)
+    Q[:, :N2] = rnd((M, N2), 6).to(dev).to(BF)
+    slabs = torch.zeros(ks, N1, N2, dtype=torch.float32, device=dev)
+    rc = L.swiftk_gemm_tn_splitk(P.data_ptr(), ldp, Q.data_ptr(), ldq, slabs.data_ptr(), N2, N1 * N2, N1, N2, M, ks, s())
+    assert rc == 0
+    ref = P[:, :N1].float().cpu().double().t() @ Q[:, :N2].float().cpu().double()
+    assert rel_l2(slabs.sum(0).cpu(), ref) < 1e-5
+    pt, qt = _transpose(P, M, N1), _transpose(Q, M, N2)
+    slabs2 = torch.zeros(ks, N1, N2, dtype=torch.float32, device=dev)
+    if N1 % 8 == 0 and N2 % 8 == 0:
+        assert L.swiftk_gemm_splitk(pt.data_ptr(), M, qt.data_ptr(), M, slabs2.data_ptr(), N2, N1 * N2, N1, N2, M, _lib.BF16, ks, s()) == 0
+        assert torch.equal(slabs, slabs2)
+
+
+def test_tn_wgrad_rejects_what_it_cannot_read(dev):
+    from swift_amd import _lib
+    L = _lib.lib()
+    P = torch.zeros(256, 1056, dtype=BF, device=dev)
+    Q = torch.zeros(256, 1280, dtype=BF, device=dev)
+    out = torch.zeros(1056 * 1280, device=dev)
+    args = lambda ldp, ldq, n1, n2, k: (P.data_ptr(), ldp, Q.data_ptr(), ldq, out.data_ptr(), n2, n1 * n2, n1, n2, k, 1, s())
+    assert L.swiftk_gemm_tn_splitk(*args(1056, 1280, 1056, 1056, 256)) == -2   # P rows end inside a 64-column block
+    assert L.swiftk_gemm_tn_splitk(*args(1056, 1280, 1024, 1280, 256)) == -2   # 1280 columns are not whole 352-wide tiles
+    assert L.swiftk_gemm_tn_splitk(*args(1056, 1280, 1024, 1056, 200)) == -2   # token count not in 64-row k-tiles
+    assert L.swiftk_gemm_tn_splitk(*args(1056, 1280, 1024, 1056, 256)) == 0
+
+
 def test_swiglu_fwd_bwd(dev):
     from swift_amd import _lib
     L = _lib.lib()
@@ -535,8 +576,8 @@ def test_larger_variants_training_step_and_tangent_vs_oracle(dev, dim, heads):
 
 def test_graph_replay_equals_eager(dev):
     """graphs.GraphCache: the first call of a signature runs eagerly, the second is captured into a HIP graph and replayed,
-    later ones replay -- same loss and gradients each time (fp32 atomics in the LayerNorm / bias column sums are the only
-    run-to-run noise), with fresh inputs picked up by the replays and updated weights by the persistent operand buffers."""
+    later ones replay -- same loss and gradients each time (fp32 atomics in the loss mean and the LayerNorm / bias column
+    sums are the only run-to-run noise: ~3e-6 of the loss between two eager runs), with fresh inputs picked up by the replays and updated weights by the persistent operand buffers."""
     from swift_amd.training.loss import TrigFlowLoss
     from swift_amd.training.trainer import GradAllReduce
     from swift_amd.utils.detinit import det_normal
@@ -563,8 +604,8 @@ def test_graph_replay_equals_eager(dev):
     l_a2, g_a2 = run("a")         # captured, then replayed
     assert len(eng.graphs._graphs) == 2  # forward + backward
     l_a3, g_a3 = run("a")         # replayed
-    assert l_a2 == pytest.approx(l_a, rel=1e-6) and l_a3 == pytest.approx(l_a, rel=1e-6)
-    assert rel_l2(g_a2.cpu(), g_a.cpu()) < 1e-5 and rel_l2(g_a3.cpu(), g_a.cpu()) < 1e-5
+    assert l_a2 == pytest.approx(l_a, rel=1e-5) and l_a3 == pytest.approx(l_a, rel=1e-5)
+    assert rel_l2(g_a2.cpu(), g_a.cpu()) < 5e-5 and rel_l2(g_a3.cpu(), g_a.cpu()) < 5e-5
     l_b, g_b = run("b")           # other inputs through the same graphs ...
     assert abs(l_b - l_a) > 1e-4 and rel_l2(g_b.cpu(), g_a.cpu()) > 1e-2
     import os
@@ -573,7 +614,7 @@ def test_graph_replay_equals_eager(dev):
         l_be, g_be = run("b")     # ... match the eager path on those inputs
     finally:
         del os.environ["SWIFTK_TRAIN_GRAPHS"]
-    assert l_b == pytest.approx(l_be, rel=1e-6) and rel_l2(g_b.cpu(), g_be.cpu()) < 1e-5
+    assert l_b == pytest.approx(l_be, rel=1e-5) and rel_l2(g_b.cpu(), g_be.cpu()) < 5e-5
     with torch.no_grad():         # a weight update is seen by the replays (operand copies are refreshed in place)
         for p in net.parameters():
             p.mul_(1.01)
