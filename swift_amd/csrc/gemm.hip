@@ -523,6 +523,66 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             if constexpr (EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED)
                 qknorm_tile<NI>(acc, lane, n0 + wn * WT, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / HD);
             OutT* C = reinterpret_cast<OutT*>(g.C) + (int64_t)(tile % ksplit) * g.c_split;
+            if constexpr (EPI == SWIFTK_EPI_SWIGLU_BOTH) {
+                // training forward: the pre-activation h (the backward pass needs gate and up) AND silu(gate) * up leave in
+                // one epilogue -- two passes through the wave's LDS slab per 16-row group, 1.5x the stores of a plain tile,
+                // instead of a second kernel that re-reads h (3.4 % of a CRPS iteration)
+                constexpr int RS1 = WT * 2 + 16, RS2 = WT + 16;  // padded slab row strides (bytes): WT / WT/2 columns
+                constexpr int CP1 = WT / 8, CP2 = WT / 16;       // 16-B chunks per row
+                __builtin_amdgcn_s_barrier();
+#if SWIFTK_X_VMCNT
+                interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+#endif
+                char* slab = const_cast<char*>(s) + wv * (16 * RS1);
+                int elane = lane;
+                asm volatile("" : "+v"(elane));
+                const int g4 = elane >> 4;
+                const int r16 = elane & 15;
+                bf16_t* C2 = reinterpret_cast<bf16_t*>(const_cast<float*>(g.ep1));
+                const int64_t ldc2 = g.pos_rows;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int mrow0 = m0 + wm * 64 + i * 16;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const f32x4 v = acc[i][j];
+                        *reinterpret_cast<uint2*>(slab + r16 * RS1 + (j * 16 + 4 * g4) * 2) =
+                            make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int t = 0; t < (16 * CP1 + 63) / 64; ++t) {
+                        const int c = elane + 64 * t;
+                        const int row = c / CP1, cc = c - row * CP1;
+                        if (c < 16 * CP1) {
+                            const uint4 q = *reinterpret_cast<const uint4*>(slab + row * RS1 + cc * 16);
+                            const int m = mrow0 + row, n = n0 + wn * WT + cc * 8;
+                            if (m < g.M && n < g.N) *reinterpret_cast<uint4*>(C + (int64_t)m * g.ldc + n) = q;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const f32x4 v = acc[i][j];
+                        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const float h0 = v[0] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[0])) * v[1];
+                        const float h1 = v[2] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[2])) * v[3];
+                        *reinterpret_cast<uint32_t*>(slab + r16 * RS2 + (j * 8 + 2 * g4) * 2) = pack_bf16(h0, h1);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int t = 0; t < (16 * CP2 + 63) / 64; ++t) {
+                        const int c = elane + 64 * t;
+                        const int row = c / CP2, cc = c - row * CP2;
+                        if (c < 16 * CP2) {
+                            const uint4 q = *reinterpret_cast<const uint4*>(slab + row * RS2 + cc * 16);
+                            const int m = mrow0 + row, n = (n0 >> 1) + wn * (WT / 2) + cc * 8;
+                            if (m < g.M && n < (g.N >> 1)) *reinterpret_cast<uint4*>(C2 + (int64_t)m * ldc2 + n) = q;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else
             if constexpr (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS) {
                 // bf16 output: transpose each 16-row slab of the wave's tile through LDS so that rows leave as whole
                 // 16-B chunks (one dwordx4 store covers 5.8 contiguous rows' worth) instead of 44 scattered 4..8-B
@@ -610,6 +670,33 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                     }
                     __builtin_amdgcn_wave_barrier();  // slab read before the next slab overwrites it
                 }
+            } else if constexpr (EPI == SWIFTK_EPI_ACCUM) {
+                // C += A W^T (fp32): the residual-stream gradient picks up a branch's input gradient in the GEMM that
+                // produces it.  Half a 16-row slab's loads are issued before its first store (same array: the compiler
+                // would otherwise order load j+1 behind store j).
+                constexpr int JH = (NI + 1) / 2;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int m = m0 + wm * 64 + i * 16 + r16;
+#pragma unroll
+                    for (int jh = 0; jh < NI; jh += JH) {
+                        float4 old[JH];
+#pragma unroll
+                        for (int j = jh; j < jh + JH && j < NI; ++j) {
+                            const int nb = n0 + wn * WT + j * 16 + 4 * (lane >> 4);
+                            old[j - jh] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (m < g.M && nb < g.N) old[j - jh] = *reinterpret_cast<const float4*>(C + (int64_t)m * g.ldc + nb);
+                        }
+#pragma unroll
+                        for (int j = jh; j < jh + JH && j < NI; ++j) {
+                            const int nb = n0 + wn * WT + j * 16 + 4 * (lane >> 4);
+                            const f32x4 v = acc[i][j];
+                            const float4 o = old[j - jh];
+                            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (m < g.M && nb < g.N) store4<OutT>(C + (int64_t)m * g.ldc + nb, v[0] + o.x, v[1] + o.y, v[2] + o.z, v[3] + o.w);
+                        }
+                    }
+                }
             } else
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -653,7 +740,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         // stores, so leaving exactly those stores outstanding is enough (no store drain in front of a tile)
         if (interior) {
             // stores per wave of an interior tile: 4 slabs x ceil(16 rows x (COLS / 8) chunks / 64 lanes)
-            constexpr int NSTORE = 4 * ((16 * ((EPI == SWIFTK_EPI_SWIGLU ? WT / 2 : WT) / 8) + 63) / 64);
+            constexpr int NSTORE = 4 * ((16 * ((EPI == SWIFTK_EPI_SWIGLU ? WT / 2 : WT) / 8) + 63) / 64) +
+                                   (EPI == SWIFTK_EPI_SWIGLU_BOTH ? 4 * ((16 * (WT / 16) + 63) / 64) : 0);
             if constexpr (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
@@ -682,9 +770,9 @@ int launch(const GemmArgs& g, hipStream_t st) {
     const int ntm = (g.M + BM - 1) / BM;
     const bool timed = swiftk_prof_begin(EPI, g.N, st);
     const bool wide_ok = sizeof(OutT) != 2 || (!((uintptr_t)g.C & 15) && !(g.ldc & 7) &&
-                                               !(g.N & (EPI == SWIFTK_EPI_SWIGLU ? 15 : 7)));  // 16-B row chunks
+                                               !(g.N & (EPI == SWIFTK_EPI_SWIGLU || EPI == SWIFTK_EPI_SWIGLU_BOTH ? 15 : 7)));  // 16-B row chunks
     if (g_variant == 0 || (g.M & 7) || (g.N & 7) || !wide_ok) {  // ragged edges: per-lane clamped sources
-        if (g.ksplit != 1 || g.t_gw) return SWIFTK_ESHAPE;
+        if (g.ksplit != 1 || g.t_gw || EPI == SWIFTK_EPI_ACCUM || EPI == SWIFTK_EPI_SWIGLU_BOTH) return SWIFTK_ESHAPE;
         if ((EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED) && g.ni != NI) return SWIFTK_ESHAPE;  // 352-wide tiles only
         GemmArgs g1 = g;
         g1.ntn = (g.N + BN - 1) / BN;
@@ -711,6 +799,12 @@ int dispatch_epi(int epi, const GemmArgs& g, hipStream_t st) {
         case SWIFTK_EPI_NONE: return launch<T, OutT, SWIFTK_EPI_NONE>(g, st);
         case SWIFTK_EPI_BIAS_POS: return launch<T, OutT, SWIFTK_EPI_BIAS_POS>(g, st);
         case SWIFTK_EPI_SWIGLU: return launch<T, OutT, SWIFTK_EPI_SWIGLU>(g, st);
+        case SWIFTK_EPI_SWIGLU_BOTH:
+            if constexpr (sizeof(OutT) == 2 && sizeof(T) == 2) return launch<T, OutT, SWIFTK_EPI_SWIGLU_BOTH>(g, st);
+            return SWIFTK_EINVAL;
+        case SWIFTK_EPI_ACCUM:
+            if constexpr (sizeof(OutT) == 4) return launch<T, OutT, SWIFTK_EPI_ACCUM>(g, st);
+            return SWIFTK_EINVAL;
         case SWIFTK_EPI_QKNORM:
             if constexpr (sizeof(OutT) == 2)
                 if (g.t_gw) return launch<T, OutT, EPI_QKNORM_TILED>(g, st);
@@ -781,6 +875,9 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
                      int ksplit, int64_t c_split, void* stream, const int* tiling = nullptr) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || ksplit < 1) return SWIFTK_EINVAL;
     if (ksplit > 1 && (out_dtype != SWIFTK_F32 || epilogue != SWIFTK_EPI_NONE || c_split < M * ldc)) return SWIFTK_EINVAL;
+    if (epilogue == SWIFTK_EPI_ACCUM && out_dtype != SWIFTK_F32) return SWIFTK_EINVAL;
+    if (epilogue == SWIFTK_EPI_SWIGLU_BOTH && (out_dtype != SWIFTK_BF16 || !ep1 || ((uintptr_t)ep1 & 15) || pos_rows < N / 2 || pos_rows % 8 || N % 16))
+        return SWIFTK_EINVAL;
     if (dtype != SWIFTK_F32 && dtype != SWIFTK_BF16) return SWIFTK_EINVAL;
     if (out_dtype != SWIFTK_F32 && out_dtype != dtype) return SWIFTK_EINVAL;
     const int es = dtype == SWIFTK_BF16 ? 2 : 4, os = out_dtype == SWIFTK_BF16 ? 2 : 4;

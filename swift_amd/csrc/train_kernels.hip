@@ -366,14 +366,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ s
 __global__ __launch_bounds__(256) void small_dgrad_kernel(const float* __restrict__ dz, int64_t lddz,
                                                           const float* __restrict__ W, int64_t ldw, float* __restrict__ dx,
                                                           int64_t lddx, int B, int N, int K, int n_chunk) {
-    // block (k-slab of 256, n-chunk): partial sums over its n range, atomically added
+    // block (k-slab of 256, n-chunk): partial sums over its n range, atomically added.  W (N x K fp32: 214 MB for the
+    // modulation Linears of Swift-B) is streamed ONCE per group of eight samples -- eight accumulators per thread, the dz
+    // values are wave-uniform loads -- so the kernel runs at the HBM rate of one pass over W.
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int n0 = blockIdx.y * n_chunk, n1 = min(n0 + n_chunk, N);
     if (k >= K) return;
-    for (int b = 0; b < B; ++b) {
-        float s = 0.f;
-        for (int n = n0; n < n1; ++n) s += dz[(int64_t)b * lddz + n] * W[(int64_t)n * ldw + k];
-        atomicAdd(dx + (int64_t)b * lddx + k, s);
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int nb = min(8, B - b0);
+#pragma unroll 4
+        for (int n = n0; n < n1; ++n) {
+            const float w = W[(int64_t)n * ldw + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nb) s[j] += dz[(int64_t)(b0 + j) * lddz + n] * w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < nb) atomicAdd(dx + (int64_t)(b0 + j) * lddx + k, s[j]);
     }
 }
 __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restrict__ dz, int64_t lddz,
@@ -732,7 +743,7 @@ extern "C" int swiftk_linear_small_bwd(const float* dz, int64_t lddz, const floa
     if (!dz || !W || B <= 0 || N <= 0 || K <= 0 || B > 64) return SWIFTK_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dx) {  // caller zero-fills dx (partial sums over n-chunks are added atomically)
-        const int n_chunk = 512;
+        const int n_chunk = 128;
         hipLaunchKernelGGL(small_dgrad_kernel, dim3((K + 255) / 256, (N + n_chunk - 1) / n_chunk), dim3(256), 0, st, dz, lddz, W,
                            ldw, dx, lddx, B, N, K, n_chunk);
         SWIFTK_CHECK_LAUNCH();

@@ -12,7 +12,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ATTN_NO_PIPE, ATTN_PRENORM, ATTN_TILED, BF16, EPI_BIAS_POS, EPI_NONE, EPI_QKNORM, EPI_SWIGLU, F32, SwiftkError,
+from ._lib import (ATTN_NO_PIPE, ATTN_PRENORM, ATTN_TILED, BF16, EPI_ACCUM, EPI_BIAS_POS, EPI_NONE, EPI_QKNORM, EPI_SWIGLU, F32, SwiftkError,
                    check, lib)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}

@@ -20,7 +20,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import ops
-from ._lib import (ATTN_PRENORM, BF16, EPI_BIAS_POS, EPI_NONE, EPI_QKNORM, F32, SwiftkError, check, lib)
+from ._lib import (ATTN_PRENORM, BF16, EPI_ACCUM, EPI_BIAS_POS, EPI_NONE, EPI_QKNORM, EPI_SWIGLU_BOTH, F32, SwiftkError, check, lib)
 from .graphs import GraphCache
 
 _BF = torch.bfloat16
@@ -238,10 +238,13 @@ class SwinTrainEngine:
             ops.modnorm_residual(y1, x, att.norm.norm.weight.detach().float(), att.norm.norm.bias.detach().float(), msl1, ntok,
                                  xcopy=xT_mid)
             h = torch.empty(M, 2 * mlp, dtype=_BF, device=dev)
-            _gemm(xT_mid, W["w1"], h)
             hmid = _padded(M, self.kmlp, mlp)
-            check(lib().swiftk_swiglu_fwd(h.data_ptr(), h.stride(0), hmid.data_ptr(), hmid.stride(0), M, mlp, BF16, _s()),
-                  "swiftk_swiglu_fwd")
+            if mlp % 8 == 0:  # h (kept for the backward pass) and silu(gate) * up out of one GEMM epilogue
+                _gemm(xT_mid, W["w1"], h, EPI_SWIGLU_BOTH, None, hmid, pos_rows=hmid.stride(0))
+            else:
+                _gemm(xT_mid, W["w1"], h)
+                check(lib().swiftk_swiglu_fwd(h.data_ptr(), h.stride(0), hmid.data_ptr(), hmid.stride(0), M, mlp, BF16, _s()),
+                      "swiftk_swiglu_fwd")
             y2 = torch.empty(M, d, dtype=_BF, device=dev)
             _gemm(hmid, W["w2"], y2)
             xT_out = _padded(M, self.kd, d)
@@ -329,12 +332,10 @@ class SwinTrainEngine:
             dh = _padded(M, max(self.kh, 2 * mlp), 2 * mlp)
             check(L.swiftk_swiglu_bwd(A["h"].data_ptr(), A["h"].stride(0), dhmid.data_ptr(), dhmid.stride(0), dh.data_ptr(),
                                       dh.stride(0), M, mlp, BF16, _s()), "swiftk_swiglu_bwd")
-            dxt = torch.empty(M, d, dtype=torch.float32, device=dev)
-            _gemm(dh, W["w1_t"], dxt)
+            _gemm(dh, W["w1_t"], dx, EPI_ACCUM)                              # residual + w1 path: dx += dh @ w1
             g1i = torch.empty(2 * mlp, d, dtype=torch.float32, device=dev)
             self._wgrad(dh, A["xT_mid"], 2 * mlp, d, g1i, accumulate=False)
             G(ff.w1.weight).add_(g1i[:2 * mlp0].view(mlp0, 2, d).permute(1, 0, 2).reshape(2 * mlp0, d))  # undo the interleave
-            ops.axpby(1.0, dx, 1.0, dxt, out=dx)                             # residual + w1 path
             # ---- attention branch
             dy1 = _padded(M, self.kd, d)
             self._modnorm_bwd(A["y1"], dx, dy1, att.norm.norm, mod[:, (2 * i) * 2 * d:(2 * i + 1) * 2 * d],
@@ -352,9 +353,8 @@ class SwinTrainEngine:
             check(L.swiftk_qknorm_bwd(A["qkvh"].data_ptr(), dqkvh.data_ptr(), 3 * d, A["rn"].data_ptr(), dqkv.data_ptr(), self.kqkv,
                                       W["scale"].data_ptr(), dscale.data_ptr(), M, heads, self.hd, BF16, _s()), "swiftk_qknorm_bwd")
             G(att.scale).add_(dscale.view_as(att.scale))
-            _gemm(dqkv, W["qkv_t"], dxt)
+            _gemm(dqkv, W["qkv_t"], dx, EPI_ACCUM)
             self._wgrad(dqkv, A["xT_in"], 3 * d, d, G(att.to_qkv.weight))
-            ops.axpby(1.0, dx, 1.0, dxt, out=dx)
             if grads_final is not None:  # everything of layer i except its modulation Linears (those follow in _embed_bwd)
                 grads_final([p for n, p in m.transformer.layers[i].named_parameters() if "modulation" not in n])
         # ---- patch embedding: x0 = ape @ Wpe^T + b + pos

@@ -79,6 +79,41 @@ def test_gemm_bias_pos(dev, dt):
     assert rel_l2(c.cpu(), ref) < F32_TOL
 
 
+@pytest.mark.parametrize("H", [2816, 2560, 3072])
+def test_gemm_swiglu_both_outputs(dev, H):
+    """EPI_SWIGLU_BOTH (training forward): the pre-activation and silu(gate) * up from one launch, each bit-equal to the
+    launch that produces it alone (plain GEMM / EPI_SWIGLU); ragged last row tile; all three tile widths."""
+    from swift_amd import _lib, ops
+    M, K = 1000, ops.k_pad(torch.bfloat16, 1056)
+    a, w = to_dt(rnd((M, K), 7), torch.bfloat16, dev), to_dt(rnd((2 * H, K), 8, 0.03), torch.bfloat16, dev)
+    h = torch.full((M, 2 * H), float("nan"), dtype=torch.bfloat16, device=dev)
+    hm = torch.full((M, H + 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.lib().swiftk_gemm(a.data_ptr(), K, w.data_ptr(), K, h.data_ptr(), 2 * H, M, 2 * H, K, _lib.BF16, _lib.BF16,
+                                      _lib.EPI_SWIGLU_BOTH, None, hm.data_ptr(), H + 64, torch.cuda.current_stream().cuda_stream), "gemm")
+    assert torch.equal(h.view(torch.int16), ops.gemm(a, w).view(torch.int16))
+    assert torch.equal(hm[:, :H].view(torch.int16), ops.gemm(a, w, epilogue=ops.EPI_SWIGLU).view(torch.int16))
+    assert bool(hm[:, H:].isnan().all())  # nothing written past the H valid columns
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N", [1056, 1280, 1536])
+def test_gemm_accumulate(dev, dt, N):
+    """EPI_ACCUM: C += A W^T in fp32 (the backward pass's `dx += dY W`), all three tile widths, a ragged last row tile."""
+    from swift_amd import ops
+    if dt == torch.float32 and N != 1056:
+        pytest.skip("fp32 operands use the 352-wide tile only")
+    M, K = 1000, ops.k_pad(dt, 704)
+    a, w, c0 = rnd((M, K), 11), rnd((N, K), 12, 0.05), rnd((M, N), 13)
+    ad, wd = to_dt(a, dt, dev), to_dt(w, dt, dev)
+    c = c0.to(dev)
+    assert ops.gemm(ad, wd, out=c, epilogue=ops.EPI_ACCUM) is c
+    ref = c0.double() + ad.float().cpu().double() @ wd.float().cpu().double().T
+    assert rel_l2(c.cpu(), ref) < F32_TOL
+    with pytest.raises(Exception):
+        ops.gemm(ad, wd, out=torch.zeros(M, N, dtype=dt, device=dev) if dt != torch.float32 else None, epilogue=ops.EPI_ACCUM,
+                 out_dtype=torch.bfloat16)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_gemm_swiglu(dev, dt):
     from swift_amd import ops
