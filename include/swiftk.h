@@ -50,6 +50,10 @@ extern "C" {
 #define SWIFTK_EPI_SWIGLU_BOTH 6 /* training forward of the FeedForward (swinv2.py:96-101): C = A W^T (bf16, the pre-activation the
                                   backward pass needs) AND C2[m][j] = silu(C[m][2j]) * C[m][2j+1]; C2 (bf16) = ep1, its row
                                   stride (elements) = pos_rows; bf16 operands only */
+#define SWIFTK_EPI_SWIGLU_BWD 7 /* backward through silu(gate) * up inside the GEMM that produces d(hidden) = dY W2 (autograd of
+                                  swinv2.py:100-101): with H = ep1 (bf16 [M, pos_rows], the saved pre-activation, gate/up
+                                  interleaved) C[m][2j] = acc * up * (s + gate s (1 - s)), C[m][2j+1] = acc * gate * s,
+                                  s = sigmoid(gate); C is bf16 [M, >= 2N]; bf16 operands only */
 #define SWIFTK_EPI_ACCUM 5     /* C += A W^T, fp32 C only: the backward pass adds a branch's input gradient onto the
                                   residual-stream gradient (autograd of x + f(x), swinv2.py:211-212) in the GEMM itself */
 

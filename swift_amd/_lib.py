@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SWIFTK_LIB") or os.path.join(_HERE, "csrc", "libswiftk.so")
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_BIAS_POS, EPI_SWIGLU, EPI_QKNORM, EPI_ACCUM, EPI_SWIGLU_BOTH = 0, 1, 2, 3, 5, 6
+EPI_NONE, EPI_BIAS_POS, EPI_SWIGLU, EPI_QKNORM, EPI_ACCUM, EPI_SWIGLU_BOTH, EPI_SWIGLU_BWD = 0, 1, 2, 3, 5, 6, 7
 ATTN_PRENORM, ATTN_NO_PIPE, ATTN_TILED = 1, 2, 4
 PROF_ATTENTION = 100
 

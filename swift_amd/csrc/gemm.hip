@@ -523,6 +523,47 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             if constexpr (EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED)
                 qknorm_tile<NI>(acc, lane, n0 + wn * WT, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / HD);
             OutT* C = reinterpret_cast<OutT*>(g.C) + (int64_t)(tile % ksplit) * g.c_split;
+            if constexpr (EPI == SWIFTK_EPI_SWIGLU_BWD) {
+                // backward of the FeedForward's gate: the accumulators are d(hidden)[m][j]; with the saved pre-activation
+                // (gate, up) = H[m][2j], H[m][2j+1] the tile leaves as d(pre-activation)[m][2j .. 2j+1] -- a lane's four
+                // columns are 16 contiguous bytes of H and of the output, so no LDS pass; d(hidden) never reaches memory
+                const bf16_t* H = reinterpret_cast<const bf16_t*>(g.ep1);
+                const int64_t ldh = g.pos_rows;
+                int elane = lane;
+                asm volatile("" : "+v"(elane));
+                const int g4 = elane >> 4;
+                constexpr int JH = (NI + 1) / 2;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int m = m0 + wm * 64 + i * 16 + (elane & 15);
+#pragma unroll
+                    for (int jh = 0; jh < NI; jh += JH) {
+                        uint4 hv[JH];
+#pragma unroll
+                        for (int j = jh; j < jh + JH && j < NI; ++j) {
+                            const int nb = n0 + wn * WT + j * 16 + 4 * g4;
+                            hv[j - jh] = make_uint4(0u, 0u, 0u, 0u);
+                            if (m < g.M && nb < g.N) hv[j - jh] = *reinterpret_cast<const uint4*>(H + (int64_t)m * ldh + 2 * nb);
+                        }
+#pragma unroll
+                        for (int j = jh; j < jh + JH && j < NI; ++j) {
+                            const int nb = n0 + wn * WT + j * 16 + 4 * g4;
+                            const f32x4 v = acc[i][j];
+                            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            const uint32_t hw[4] = {hv[j - jh].x, hv[j - jh].y, hv[j - jh].z, hv[j - jh].w};
+                            uint32_t o[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float gt = __uint_as_float(hw[e] << 16), up = __uint_as_float(hw[e] & 0xffff0000u);
+                                const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-gt));
+                                o[e] = pack_bf16(v[e] * up * (sg + gt * sg * (1.0f - sg)), v[e] * gt * sg);
+                            }
+                            if (m < g.M && nb < g.N)
+                                *reinterpret_cast<uint4*>(C + (int64_t)m * g.ldc + 2 * nb) = make_uint4(o[0], o[1], o[2], o[3]);
+                        }
+                    }
+                }
+            } else
             if constexpr (EPI == SWIFTK_EPI_SWIGLU_BOTH) {
                 // training forward: the pre-activation h (the backward pass needs gate and up) AND silu(gate) * up leave in
                 // one epilogue -- two passes through the wave's LDS slab per 16-row group, 1.5x the stores of a plain tile,
@@ -772,7 +813,8 @@ int launch(const GemmArgs& g, hipStream_t st) {
     const bool wide_ok = sizeof(OutT) != 2 || (!((uintptr_t)g.C & 15) && !(g.ldc & 7) &&
                                                !(g.N & (EPI == SWIFTK_EPI_SWIGLU || EPI == SWIFTK_EPI_SWIGLU_BOTH ? 15 : 7)));  // 16-B row chunks
     if (g_variant == 0 || (g.M & 7) || (g.N & 7) || !wide_ok) {  // ragged edges: per-lane clamped sources
-        if (g.ksplit != 1 || g.t_gw || EPI == SWIFTK_EPI_ACCUM || EPI == SWIFTK_EPI_SWIGLU_BOTH) return SWIFTK_ESHAPE;
+        if (g.ksplit != 1 || g.t_gw || EPI == SWIFTK_EPI_ACCUM || EPI == SWIFTK_EPI_SWIGLU_BOTH || EPI == SWIFTK_EPI_SWIGLU_BWD)
+            return SWIFTK_ESHAPE;
         if ((EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED) && g.ni != NI) return SWIFTK_ESHAPE;  // 352-wide tiles only
         GemmArgs g1 = g;
         g1.ntn = (g.N + BN - 1) / BN;
@@ -799,6 +841,9 @@ int dispatch_epi(int epi, const GemmArgs& g, hipStream_t st) {
         case SWIFTK_EPI_NONE: return launch<T, OutT, SWIFTK_EPI_NONE>(g, st);
         case SWIFTK_EPI_BIAS_POS: return launch<T, OutT, SWIFTK_EPI_BIAS_POS>(g, st);
         case SWIFTK_EPI_SWIGLU: return launch<T, OutT, SWIFTK_EPI_SWIGLU>(g, st);
+        case SWIFTK_EPI_SWIGLU_BWD:
+            if constexpr (sizeof(OutT) == 2 && sizeof(T) == 2) return launch<T, OutT, SWIFTK_EPI_SWIGLU_BWD>(g, st);
+            return SWIFTK_EINVAL;
         case SWIFTK_EPI_SWIGLU_BOTH:
             if constexpr (sizeof(OutT) == 2 && sizeof(T) == 2) return launch<T, OutT, SWIFTK_EPI_SWIGLU_BOTH>(g, st);
             return SWIFTK_EINVAL;
@@ -876,6 +921,9 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || ksplit < 1) return SWIFTK_EINVAL;
     if (ksplit > 1 && (out_dtype != SWIFTK_F32 || epilogue != SWIFTK_EPI_NONE || c_split < M * ldc)) return SWIFTK_EINVAL;
     if (epilogue == SWIFTK_EPI_ACCUM && out_dtype != SWIFTK_F32) return SWIFTK_EINVAL;
+    if (epilogue == SWIFTK_EPI_SWIGLU_BWD && (out_dtype != SWIFTK_BF16 || !ep1 || ((uintptr_t)ep1 & 15) || pos_rows < 2 * N || pos_rows % 8 ||
+                                              ldc < 2 * N || ldc % 8 || ((uintptr_t)C & 15)))
+        return SWIFTK_EINVAL;
     if (epilogue == SWIFTK_EPI_SWIGLU_BOTH && (out_dtype != SWIFTK_BF16 || !ep1 || ((uintptr_t)ep1 & 15) || pos_rows < N / 2 || pos_rows % 8 || N % 16))
         return SWIFTK_EINVAL;
     if (dtype != SWIFTK_F32 && dtype != SWIFTK_BF16) return SWIFTK_EINVAL;

@@ -96,6 +96,10 @@ class _ERA5Base(Dataset):
         With SST present and delta != 24 every quantity of that channel is forced to 0 by
         ``zero_field`` (era5.py:135-149); mean 0 / std 1 / residual-std 0 reproduces that.
         """
+        key = (int(delta), str(device))
+        cache = self.__dict__.setdefault("_rollout_stats_cache", {})
+        if key in cache:  # (three small host-to-device copies per call otherwise, each a stream synchronisation)
+            return cache[key]
         nv = len(self.variables)
         mx = torch.as_tensor(np.asarray(self.x_means), dtype=torch.float32).reshape(-1)[:nv].clone()
         sx = torch.as_tensor(np.asarray(self.x_stds), dtype=torch.float32).reshape(-1)[:nv].clone()
@@ -106,7 +110,8 @@ class _ERA5Base(Dataset):
         if delta != 24 and "sea_surface_temperature" in self.variables:
             i = list(self.variables).index("sea_surface_temperature")
             mx[i], sx[i], st[i] = 0.0, 1.0, 0.0
-        return mx.to(device), sx.to(device), st.to(device)
+        cache[key] = (mx.to(device), sx.to(device), st.to(device))
+        return cache[key]
 
 
 class ERA5Dataset(_ERA5Base):

@@ -80,7 +80,7 @@ class SwinEngine:
             mods_b += [att.norm.modulation.bias.detach(), ff.norm.modulation.bias.detach()]
 
         half = d // 2
-        freqs = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32) / half).to(dev)  # swinv2.py:48-50
+        freqs = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32, device=dev) / half)  # swinv2.py:48-50
 
         mo = Model()
         mo.dtype = ops.dtype_code(dt)

@@ -34,6 +34,8 @@ def _process_auxiliary(auxiliary, auxiliary_dim, batch_size, device):
             auxiliary = torch.full((), float(auxiliary), dtype=torch.float32, device=device)
         else:
             auxiliary = torch.tensor(auxiliary, device=device)
+    if auxiliary.device != torch.device(device):  # (the trainer keeps lead times on the host; pinned loader batches copy asynchronously)
+        auxiliary = auxiliary.to(device, non_blocking=True)
     if auxiliary.dim() == 0 or (auxiliary.dim() == 1 and auxiliary.size(0) == 1):
         auxiliary = auxiliary.repeat(batch_size)
     return auxiliary.reshape(-1, auxiliary_dim)

@@ -20,7 +20,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import ops
-from ._lib import (ATTN_PRENORM, BF16, EPI_ACCUM, EPI_BIAS_POS, EPI_NONE, EPI_QKNORM, EPI_SWIGLU_BOTH, F32, SwiftkError, check, lib)
+from ._lib import (ATTN_PRENORM, BF16, EPI_ACCUM, EPI_BIAS_POS, EPI_NONE, EPI_QKNORM, EPI_SWIGLU_BOTH, EPI_SWIGLU_BWD, F32, SwiftkError, check, lib)
 from .graphs import GraphCache
 
 _BF = torch.bfloat16
@@ -321,17 +321,20 @@ class SwinTrainEngine:
             dy2 = _padded(M, self.kd, d)
             self._modnorm_bwd(A["y2"], dx, dy2, ff.norm.norm, mod[:, (2 * i + 1) * 2 * d:(2 * i + 2) * 2 * d],
                               dmod[:, (2 * i + 1) * 2 * d:(2 * i + 2) * 2 * d], M, d, ntok)
-            dhmid = torch.empty(M, mlp, dtype=_BF, device=dev)
-            _gemm(dy2, W["w2_t"], dhmid)
+            dh = _padded(M, max(self.kh, 2 * mlp), 2 * mlp)
+            if mlp % 8 == 0:  # d(hidden) = dy2 @ w2 and the step back through silu(gate) * up in one launch
+                _gemm(dy2, W["w2_t"], dh, EPI_SWIGLU_BWD, None, A["h"], pos_rows=A["h"].stride(0))
+            else:
+                dhmid = torch.empty(M, mlp, dtype=_BF, device=dev)
+                _gemm(dy2, W["w2_t"], dhmid)
+                check(L.swiftk_swiglu_bwd(A["h"].data_ptr(), A["h"].stride(0), dhmid.data_ptr(), dhmid.stride(0), dh.data_ptr(),
+                                          dh.stride(0), M, mlp, BF16, _s()), "swiftk_swiglu_bwd")
             if mlp == mlp0:
                 self._wgrad(dy2, A["hmid"], d, mlp, G(ff.w2.weight))
             else:
                 g2 = torch.empty(d, mlp, dtype=torch.float32, device=dev)
                 self._wgrad(dy2, A["hmid"], d, mlp, g2, accumulate=False)
                 G(ff.w2.weight).add_(g2[:, :mlp0])
-            dh = _padded(M, max(self.kh, 2 * mlp), 2 * mlp)
-            check(L.swiftk_swiglu_bwd(A["h"].data_ptr(), A["h"].stride(0), dhmid.data_ptr(), dhmid.stride(0), dh.data_ptr(),
-                                      dh.stride(0), M, mlp, BF16, _s()), "swiftk_swiglu_bwd")
             _gemm(dh, W["w1_t"], dx, EPI_ACCUM)                              # residual + w1 path: dx += dh @ w1
             g1i = torch.empty(2 * mlp, d, dtype=torch.float32, device=dev)
             self._wgrad(dh, A["xT_mid"], 2 * mlp, d, g1i, accumulate=False)

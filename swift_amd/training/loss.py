@@ -69,7 +69,7 @@ class _Deferred(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        ctx.runner.run_backward(float(g))
+        ctx.runner.run_backward(g.detach().float())  # stays a device scalar: reading it would stall the host behind the GPU
         return None, None
 
 
@@ -141,10 +141,9 @@ class TrigFlowLoss(_LossBase):
 
             @staticmethod
             def run_backward(g):
-                if g != 1.0:
-                    dF.mul_(g)
-                    if dlv is not None:
-                        dlv.mul_(g)
+                dF.mul_(g)
+                if dlv is not None:
+                    dlv.mul_(g)
                 eng.backward(ctx, dF, dlv, grads_final=getattr(net, "reduce_params", None))
 
         return _Deferred.apply(self._anchor(dev), Runner)
@@ -227,10 +226,9 @@ class SCMLoss(_LossBase):
 
             @staticmethod
             def run_backward(g):
-                if g != 1.0:
-                    dFx.mul_(g)
-                    if dlv is not None:
-                        dlv.mul_(g)
+                dFx.mul_(g)
+                if dlv is not None:
+                    dlv.mul_(g)
                 eng.backward(ctx, dFx, dlv, grads_final=getattr(net, "reduce_params", None))
 
         self._last = dict(dF=dF, Fx=Fx)  # kept for tests / diagnostics
@@ -244,8 +242,8 @@ class CRPSLoss(_LossBase):
         super().__init__(dataset, sigma_data)
         self.ensemble_size, self.alpha = ensemble_size, alpha
 
-    def _forcings(self, idx, auxiliary, i, dev):
-        f = torch.stack([self.dataset.get_forcings(int(j) + int(i * float(dt) * 10 // 6)) for j, dt in zip(idx, auxiliary)], 0)
+    def _forcings(self, idx, aux_host, i, dev):
+        f = torch.stack([self.dataset.get_forcings(int(j) + int(i * float(dt) * 10 // 6)) for j, dt in zip(idx, aux_host)], 0)
         return self.dataset.standardize_x(f).to(dev, non_blocking=True).float().contiguous()
 
     def forward(self, net, target, condition, auxiliary, idx, steps: int = 1, chunk_size: int = 2, _latents=None, **kwargs):
@@ -255,14 +253,18 @@ class CRPSLoss(_LossBase):
         B, C, H, W = target.shape
         sd = float(self.sigma_data)
         nv = len(self.dataset.variables)
-        delta = int(float(auxiliary[0]) * 10)  # NOTE: assumes same delta within a batch (loss.py:378)
+        # per-sample lead times and indices as host numbers, read ONCE (the trainer hands them over on the CPU; a device
+        # tensor costs one stall here instead of one per sample and step as in loss.py:378-392)
+        aux_host = [float(v) for v in (auxiliary.tolist() if torch.is_tensor(auxiliary) else auxiliary)]
+        idx = [int(j) for j in (idx.tolist() if torch.is_tensor(idx) else idx)]
+        delta = int(aux_host[0] * 10)  # NOTE: assumes same delta within a batch (loss.py:378)
         mx, sx, stt = self.dataset.rollout_stats(delta, dev)
         coef = (stt / sx).contiguous()         # cond_std += pred * st/sx  ==  standardize(unstd(cond) + unstd_t(pred))
         aux = _process_auxiliary(auxiliary, mod.auxiliary_dim, B, dev)
         t = torch.full((B,), math.pi / 2, device=dev)
         st = torch.cuda.current_stream().cuda_stream
         hw = H * W
-        forc = [self._forcings(idx, auxiliary, i, dev) for i in range(steps)]
+        forc = [self._forcings(idx, aux_host, i, dev) for i in range(steps)]
         target = target.contiguous().float()
         E = self.ensemble_size
         lat = [[(torch.randn_like(target) if _latents is None else _latents[e][i].to(dev)).contiguous() for i in range(steps)]
@@ -298,7 +300,8 @@ class CRPSLoss(_LossBase):
                     out, ctx = eng.forward([lat[e][i], conds[e][i], forc[i]], [1.0, 1.0, 1.0], t, aux)
                     dout = torch.empty_like(out)
                     if i == steps - 1:
-                        ops.axpby(-sd * g, dpreds[e], 0.0, dpreds[e], out=dout)
+                        ops.axpby(-sd, dpreds[e], 0.0, dpreds[e], out=dout)
+                        dout.mul_(g)
                     else:
                         check(lib().swiftk_channel_axpy(dout.data_ptr(), None, gcond.data_ptr(), (-sd * coef).data_ptr(), B, C, hw,
                                                         torch.cuda.current_stream().cuda_stream), "swiftk_channel_axpy")

@@ -170,7 +170,9 @@ class Trainer:
     # ------------------------------------------------------------------ one iteration
     def _get_batch(self, it):
         (x, t), (idx, delta) = next(it)
-        return x.to(self.device, non_blocking=True), t.to(self.device, non_blocking=True), idx, delta.to(self.device)
+        # idx and delta stay on the host: the losses read them as numbers (forcing look-ups, rollout statistics) and move
+        # what the network needs themselves -- a device copy would have to be read back, stalling the host behind the GPU
+        return x.to(self.device, non_blocking=True), t.to(self.device, non_blocking=True), idx, delta
 
     def _forward_step(self, x, t, delta, **kwargs):
         with torch.autocast(self.device.type, enabled=True, dtype=torch.bfloat16):

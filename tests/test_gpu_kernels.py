@@ -95,6 +95,24 @@ def test_gemm_swiglu_both_outputs(dev, H):
     assert bool(hm[:, H:].isnan().all())  # nothing written past the H valid columns
 
 
+@pytest.mark.parametrize("H", [2816, 2560, 3072])
+def test_gemm_swiglu_backward_epilogue(dev, H):
+    """EPI_SWIGLU_BWD: d(pre-activation) from dY @ W2 and the saved (gate, up), against autograd of silu(gate) * up applied
+    to the fp64 product (the fused form skips the bf16 rounding of d(hidden) the two-kernel path has)."""
+    from swift_amd import _lib, ops
+    M, K = 1000, ops.k_pad(torch.bfloat16, 1056)
+    a, w = to_dt(rnd((M, K), 17), torch.bfloat16, dev), to_dt(rnd((H, K), 18, 0.03), torch.bfloat16, dev)
+    h = to_dt(rnd((M, 2 * H), 19), torch.bfloat16, dev)
+    dh = torch.full((M, 2 * H + 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.lib().swiftk_gemm(a.data_ptr(), K, w.data_ptr(), K, dh.data_ptr(), 2 * H + 64, M, H, K, _lib.BF16, _lib.BF16,
+                                      _lib.EPI_SWIGLU_BWD, None, h.data_ptr(), 2 * H, torch.cuda.current_stream().cuda_stream), "gemm")
+    dhid = a.float().cpu().double() @ w.float().cpu().double().T
+    hc = h.float().cpu().double().requires_grad_(True)
+    (torch.nn.functional.silu(hc[:, 0::2]) * hc[:, 1::2]).backward(dhid)
+    assert rel_l2(dh[:, :2 * H].float().cpu(), hc.grad) < 4e-3
+    assert bool(dh[:, 2 * H:].isnan().all())
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N", [1056, 1280, 1536])
 def test_gemm_accumulate(dev, dt, N):

@@ -13,7 +13,7 @@ from swift_amd.utils.detinit import swinv2_state
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8); ap.add_argument("--steps", type=int, default=4)
-ap.add_argument("--iters", type=int, default=3); ap.add_argument("--depth", type=int, default=12)
+ap.add_argument("--iters", type=int, default=6); ap.add_argument("--depth", type=int, default=12)
 ap.add_argument("--loss", default="crps", choices=["crps", "scm"])
 ap.add_argument("--opt", default="adamw", choices=["adamw", "muon"])
 a = ap.parse_args()
@@ -44,15 +44,33 @@ tr.global_batch_size = a.batch
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.randn(a.batch, 72, 128, 256, generator=g, device=dev)
 t = 0.3 * torch.randn(a.batch, 69, 128, 256, generator=g, device=dev)
-delta, idx = torch.full((a.batch,), 0.6, device=dev), list(range(a.batch))
+delta, idx = torch.full((a.batch,), 0.6).pin_memory(), list(range(a.batch))  # host side, as Trainer._get_batch hands them over
 for _ in range(3):  # warm-up: operand prep and allocator, then the HIP-graph capture of every launch sequence, then one replay
     loss = tr.train_step(x, t, idx, delta, 1000, steps=a.steps)
 torch.cuda.synchronize()
+if os.environ.get("SWIFTK_SYNC_DEBUG"):  # list every call that makes the host wait for the GPU inside the timed iterations
+    import collections, traceback, warnings
+    sync_sites = collections.Counter()
+    def _show(message, category, filename, lineno, file=None, line=None):
+        if "synchroniz" in str(message):
+            st = [f for f in traceback.extract_stack() if "swift_amd" in f.filename or "train_bench" in f.filename]
+            sync_sites[" <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in st[-4:][::-1])] += 1
+    warnings.showwarning = _show
+    warnings.simplefilter("always")
+    torch.cuda.set_sync_debug_mode(1)
 t0 = time.perf_counter()
+host_ms = []
 for k in range(a.iters):
+    h0 = time.perf_counter()
     loss = tr.train_step(x, t, idx, delta, 1000 * (k + 2), steps=a.steps)
+    host_ms.append(1e3 * (time.perf_counter() - h0))  # time the host needs to ISSUE an iteration (it may run ahead of the GPU)
+if os.environ.get("SWIFTK_SYNC_DEBUG"):
+    torch.cuda.set_sync_debug_mode(0)
+    for site, n in sync_sites.most_common(40):
+        print(f"sync x{n}: {site}", file=sys.stderr)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
+print("host issue time per iteration (ms):", " ".join(f"{h:.0f}" for h in host_ms), file=sys.stderr)
 PEAK = 2.5e15  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 fused = bool(getattr(tr, "_fused", None))
 if a.loss == "scm":
