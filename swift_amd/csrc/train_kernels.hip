@@ -278,66 +278,75 @@ __global__ __launch_bounds__(256) void modnorm_bwd_cols_kernel(const T* __restri
 // Forward (SWIFTK_EPI_QKNORM): qh = tau_h * q/|q|, kh = k/|k|, v unchanged; rn = 1/max(|.|, 1e-12) saved per vector.
 //   dq = tau rn (dqh - u (u . dqh)), u = qh/tau;   dk = rn (dkh - kh (kh . dkh));   dv = dvh
 //   d scale_h += tau * sum_tokens (u . dqh)   (zero when the clamp at ln 100 is active)
-// One lane per (token, 88-vector); a wave takes 64 consecutive vectors (rows are contiguous in memory).
+// Sixteen lanes per (token, head vector), one 16-B chunk per lane (10 / 11 / 12 of them live for head_dim 80 / 88 / 96), so a
+// wave's four vectors are one contiguous 4 x 2*head_dim-byte run of the row: whole-line requests (a lane per vector, each
+// walking its own 176 B, made 11 requests of 16 scattered bytes per lane and ran at 60 % of this form's rate).  The dot
+// product is a 4-step butterfly inside the 16-lane group; UNR vectors per group are in flight at once.
 template <typename T>
 __global__ __launch_bounds__(256) void qknorm_bwd_kernel(const T* __restrict__ qkvh, const T* __restrict__ dqkvh,
                                                          int64_t ld, const float* __restrict__ rn, T* __restrict__ dqkv,
                                                          int64_t ldo, const float* __restrict__ scale,
                                                          float* __restrict__ dscale, int64_t M, int heads, int hd) {
     constexpr int PER = 16 / (int)sizeof(T);  // elements per 16-B chunk
-    constexpr int MAXC = 96 / PER;            // head_dim <= 96
+    constexpr int UNR = 4;
     __shared__ float sacc[64];
     if (threadIdx.x < 64) sacc[threadIdx.x] = 0.f;
     __syncthreads();
     const int nvec = 3 * heads, nch = hd / PER;
     const int64_t total = M * nvec;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t m = i / nvec;
-        const int v = (int)(i - m * nvec), kind = v % 3, h = v / 3;
-        const T* a = qkvh + m * ld + (int64_t)v * hd;
-        const T* da = dqkvh + m * ld + (int64_t)v * hd;
-        T* o = dqkv + m * ldo + (int64_t)v * hd;
-        uint4 ra[MAXC], rd[MAXC];
+    const int sub = threadIdx.x & 15;                                   // chunk of the vector
+    const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;  // 16-lane group
+    const int64_t ngrp = ((int64_t)gridDim.x * 256) >> 4;
+    const bool live = sub < nch;
+    for (int64_t i0 = grp; i0 < total; i0 += ngrp * UNR) {
+        uint4 ra[UNR], rd[UNR];
+        float r[UNR];
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c)
-            if (c < nch) {
-                rd[c] = *reinterpret_cast<const uint4*>(da + c * PER);
-                if (kind != 2) ra[c] = *reinterpret_cast<const uint4*>(a + c * PER);
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + u * ngrp;
+            ra[u] = rd[u] = make_uint4(0u, 0u, 0u, 0u);
+            r[u] = 0.f;
+            if (i < total && live) {
+                const int64_t m = i / nvec;
+                const int v = (int)(i - m * nvec);
+                const int64_t off = m * ld + (int64_t)v * hd + sub * PER;
+                rd[u] = *reinterpret_cast<const uint4*>(dqkvh + off);
+                if (v % 3 != 2) {
+                    ra[u] = *reinterpret_cast<const uint4*>(qkvh + off);
+                    r[u] = rn[i];
+                }
             }
-        if (kind == 2) {
-#pragma unroll
-            for (int c = 0; c < MAXC; ++c)
-                if (c < nch) *reinterpret_cast<uint4*>(o + c * PER) = rd[c];
-            continue;
         }
-        const float s = scale[h];
-        const float tau = kind == 0 ? expf(fminf(s, 4.605170185988092f)) : 1.0f;
-        const float r = rn[i];
-        float dot = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c)
-            if (c < nch) {
-                const T* pa = reinterpret_cast<const T*>(&ra[c]);
-                const T* pd = reinterpret_cast<const T*>(&rd[c]);
-#pragma unroll
-                for (int e = 0; e < PER; ++e) dot += elem<T>::to_f(pa[e]) * elem<T>::to_f(pd[e]);
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + u * ngrp;
+            if (i >= total) break;  // (group-uniform)
+            const int64_t m = i / nvec;
+            const int v = (int)(i - m * nvec), kind = v % 3, h = v / 3;
+            T* o = dqkv + m * ldo + (int64_t)v * hd + sub * PER;
+            if (kind == 2) {
+                if (live) *reinterpret_cast<uint4*>(o) = rd[u];
+                continue;
             }
-        const float itau = 1.0f / tau;
-        dot *= itau;  // u . d(qh)   (a = tau u)
-        const float f = tau * r;
+            const T* pa = reinterpret_cast<const T*>(&ra[u]);
+            const T* pd = reinterpret_cast<const T*>(&rd[u]);
+            float dot = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c)
-            if (c < nch) {
-                const T* pa = reinterpret_cast<const T*>(&ra[c]);
-                const T* pd = reinterpret_cast<const T*>(&rd[c]);
-                uint4 ov;
-                T* po = reinterpret_cast<T*>(&ov);
+            for (int e = 0; e < PER; ++e) dot += elem<T>::to_f(pa[e]) * elem<T>::to_f(pd[e]);
 #pragma unroll
-                for (int e = 0; e < PER; ++e)
-                    po[e] = elem<T>::from_f(f * (elem<T>::to_f(pd[e]) - elem<T>::to_f(pa[e]) * itau * dot));
-                *reinterpret_cast<uint4*>(o + c * PER) = ov;
-            }
-        if (kind == 0 && s < 4.605170185988092f) atomicAdd(&sacc[h], tau * dot);  // LDS first: 12 hot addresses
+            for (int sft = 1; sft < 16; sft <<= 1) dot += __shfl_xor(dot, sft, 16);
+            const float s = scale[h];
+            const float tau = kind == 0 ? expf(fminf(s, 4.605170185988092f)) : 1.0f;
+            const float itau = 1.0f / tau;
+            dot *= itau;  // u . d(qh)   (a = tau u)
+            const float f = tau * r[u];
+            uint4 ov;
+            T* po = reinterpret_cast<T*>(&ov);
+#pragma unroll
+            for (int e = 0; e < PER; ++e) po[e] = elem<T>::from_f(f * (elem<T>::to_f(pd[e]) - elem<T>::to_f(pa[e]) * itau * dot));
+            if (live) *reinterpret_cast<uint4*>(o) = ov;
+            if (kind == 0 && s < 4.605170185988092f && sub == 0) atomicAdd(&sacc[h], tau * dot);  // LDS first: 12 hot addresses
+        }
     }
     __syncthreads();
     if (threadIdx.x < heads && sacc[threadIdx.x] != 0.f) atomicAdd(dscale + threadIdx.x, sacc[threadIdx.x]);
@@ -716,7 +725,7 @@ extern "C" int swiftk_qknorm_bwd(const void* qkvh, const void* dqkvh, int64_t ld
                                  void* stream) {
     if (!qkvh || !dqkvh || !rn || !dqkv || !scale || !dscale || M <= 0) return SWIFTK_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int grid = grid_for(M * 3 * heads);
+    const int grid = grid_for(M * 3 * heads * 4);  // sixteen lanes per vector, four vectors per group and trip
     DT_SWITCH(dtype,
               hipLaunchKernelGGL(qknorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(qkvh),
                                  static_cast<const bf16_t*>(dqkvh), ld, rn, static_cast<bf16_t*>(dqkv), ldo, scale, dscale, M,
