@@ -12,6 +12,7 @@ csrc/jvp_kernels.hip) instead of ``torch.func.jvp``.
 from __future__ import annotations
 
 import math
+import os
 from functools import partial
 from typing import Callable, Optional, Sequence
 
@@ -271,13 +272,21 @@ class CRPSLoss(_LossBase):
                for e in range(E)]
         conds = [[None] * steps for _ in range(E)]
         preds = torch.empty(E, B, C, H, W, device=dev)
-        # ---- pass 1: the rollouts, nothing saved but each step's input state (inference engine, bf16 operands)
+        # ---- pass 1: the rollouts, nothing saved but each step's input state (inference engine, bf16 operands).  The very
+        # last network call (last member, last step) is the first one pass 2 differentiates: it runs on the training engine
+        # and keeps its activations, which saves one of the 2 x steps recomputed forwards
+        kept = None
+        keep_last = os.environ.get("SWIFTK_CRPS_KEEP_LAST", "1") != "0"
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             for e in range(E):
                 cond = condition[:, :nv].contiguous().float()
                 for i in range(steps):
                     conds[e][i] = cond
-                    out = mod(lat[e][i], t, (cond, forc[i]), aux, x_scale=1.0)  # x_t / sigma_d with x_t = z * sigma_d
+                    if keep_last and e == E - 1 and i == steps - 1:
+                        kept = eng.forward([lat[e][i], cond, forc[i]], [1.0, 1.0, 1.0], t, aux)
+                        out = kept[0]
+                    else:
+                        out = mod(lat[e][i], t, (cond, forc[i]), aux, x_scale=1.0)  # x_t / sigma_d with x_t = z * sigma_d
                     if i < steps - 1:
                         nxt = torch.empty_like(cond)
                         # pred = -sigma_d * out ; cond' = cond + pred * st/sx
@@ -294,10 +303,13 @@ class CRPSLoss(_LossBase):
 
         def run_backward(g):
             # ---- pass 2: per member, walk the steps backwards; recompute one step with activations, then backprop it
-            for e in range(E):
+            for e in reversed(range(E)):
                 gcond = None  # dL/d cond_{i+1}
                 for i in reversed(range(steps)):
-                    out, ctx = eng.forward([lat[e][i], conds[e][i], forc[i]], [1.0, 1.0, 1.0], t, aux)
+                    if keep_last and e == E - 1 and i == steps - 1:
+                        out, ctx = kept  # (a replayed forward's outputs stay valid until the next replay, which follows below)
+                    else:
+                        out, ctx = eng.forward([lat[e][i], conds[e][i], forc[i]], [1.0, 1.0, 1.0], t, aux)
                     dout = torch.empty_like(out)
                     if i == steps - 1:
                         ops.axpby(-sd, dpreds[e], 0.0, dpreds[e], out=dout)
@@ -306,7 +318,7 @@ class CRPSLoss(_LossBase):
                         check(lib().swiftk_channel_axpy(dout.data_ptr(), None, gcond.data_ptr(), (-sd * coef).data_ptr(), B, C, hw,
                                                         torch.cuda.current_stream().cuda_stream), "swiftk_channel_axpy")
                     need = i > 0
-                    last = (e == E - 1 and i == 0)  # the final backward pass of the iteration: gradients complete layer by layer
+                    last = (e == 0 and i == 0)  # the final backward pass of the iteration: gradients complete layer by layer
                     dins = eng.backward(ctx, dout, None, need_input_grad=(False, need, False),
                                         grads_final=getattr(net, "reduce_params", None) if last else None)
                     if need:  # (a replayed backward returns ITS OWN output tensor, overwritten by the next replay: copy it)

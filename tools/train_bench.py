@@ -85,12 +85,13 @@ if a.loss == "scm":
           f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sys.exit(0)
 evals = 2 * a.steps
-fl = 4 * evals * a.batch * 2.7535e12 * a.depth / 12
+fwd_eq = 4 * evals - 1  # the last rollout step keeps its activations: one recomputed forward fewer
+fl = fwd_eq * a.batch * 2.7535e12 * a.depth / 12
 print(json.dumps({"metric": "multistep-CRPS finetune iteration (Swift-B, steps %d, ensemble 2, local batch %d; BASELINE configs[4] per GPU)" % (a.steps, a.batch),
                   "value": dt, "unit": "s/iteration", "samples_per_s": a.batch / dt, "flop_per_iteration": fl,
-                  "what": f"{evals} rollout forwards + {evals} recomputed forwards + {evals} backwards (2x) = {4 * evals} forward-equivalents per sample",
+                  "what": f"{evals} rollout forwards + {evals - 1} recomputed forwards + {evals} backwards (2x) = {fwd_eq} forward-equivalents per sample",
                   "roofline": {"bound": "mfma", "achieved": fl / dt / 1e12, "peak": PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / dt / PEAK, "traffic": None},
                   "fused_optimizer_step": fused, "peak_mem_gib": torch.cuda.max_memory_allocated() / 2**30}))
 print(f"CRPS finetune: batch {a.batch}, steps {a.steps}, depth {a.depth}: {dt:.3f} s/iteration, loss {float(loss):.4f}; "
-      f"{a.batch / dt:.2f} samples/s; fwd-equivalents/iter = {evals} fwd + {evals} recompute + {evals} bwd(2x) -> "
-      f"{(4 * evals * a.batch * 2.7535e12 * a.depth / 12) / dt / 1e12:.0f} TFLOP/s; peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+      f"{a.batch / dt:.2f} samples/s; fwd-equivalents/iter = {evals} fwd + {evals - 1} recompute + {evals} bwd(2x) -> "
+      f"{fl / dt / 1e12:.0f} TFLOP/s; peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
