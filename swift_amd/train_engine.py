@@ -171,15 +171,25 @@ class SwinTrainEngine:
             p.grad = torch.zeros_like(p, dtype=torch.float32)
         return p.grad
 
+    def activation_bytes(self, B: int) -> int:
+        """Bytes of saved activations of one forward pass at batch ``B`` (what a kept rollout step costs in HBM)."""
+        self.refresh()
+        m = self.m
+        M = B * m.grid_size[0] * m.grid_size[1]
+        per_token_layer = 2 * (3 * self.kd + 3 * m.dim + 2 * m.dim + 2 * self.mlp_e + self.kmlp) + 4 * 3 * m.heads
+        return M * m.depth * per_token_layer
+
     # ------------------------------------------------------------------ forward (saves activations)
-    def forward(self, srcs: Sequence[torch.Tensor], scales: Sequence[float], t, aux, want_logvar=False):
+    def forward(self, srcs: Sequence[torch.Tensor], scales: Sequence[float], t, aux, want_logvar=False, slot: int = 0):
         """Forward pass that keeps the activations (``ctx``) for :meth:`backward`.  After the first call of a given
         signature the launch sequence is replayed as one HIP graph (``graphs.GraphCache``): ``out`` / ``ctx`` then are
-        the capture's own tensors, overwritten by the next call with the same signature."""
+        the capture's own tensors, overwritten by the next call with the same signature.  ``slot`` is part of the
+        signature: calls whose activations must stay alive side by side (the kept rollout steps of the multistep CRPS
+        loss) use different slots and so get their own buffers."""
         self.refresh()
         srcs = [s.contiguous().float() for s in srcs]
         ins = list(srcs) + [t.contiguous().float()] + ([aux.contiguous().float()] if aux is not None else [])
-        key = ("fwd", tuple(tuple(s.shape) for s in srcs), tuple(float(c) for c in scales), aux is not None, bool(want_logvar))
+        key = ("fwd", tuple(tuple(s.shape) for s in srcs), tuple(float(c) for c in scales), aux is not None, bool(want_logvar), int(slot))
         n = len(srcs)
         fn = lambda *a: self._forward(list(a[:n]), list(scales), a[n], a[n + 1] if aux is not None else None, want_logvar)
         res = self.graphs.call(key, fn, ins)

@@ -243,6 +243,16 @@ class CRPSLoss(_LossBase):
         super().__init__(dataset, sigma_data)
         self.ensemble_size, self.alpha = ensemble_size, alpha
 
+    @staticmethod
+    def _n_keep(eng, B, calls, dev) -> int:
+        """How many trailing network calls keep their activations: SWIFTK_CRPS_KEEP if set, else as many as fit beside a
+        64 GiB working set in 80 % of the device's memory (6 of the 8 calls of BASELINE configs[4] at local batch 8)."""
+        env = os.environ.get("SWIFTK_CRPS_KEEP")
+        if env is not None:
+            return max(0, min(calls, int(env)))
+        total = torch.cuda.get_device_properties(dev).total_memory
+        return max(0, min(calls, int((0.8 * total - 64 * 2**30) // max(1, eng.activation_bytes(B)))))
+
     def _forcings(self, idx, aux_host, i, dev):
         f = torch.stack([self.dataset.get_forcings(int(j) + int(i * float(dt) * 10 // 6)) for j, dt in zip(idx, aux_host)], 0)
         return self.dataset.standardize_x(f).to(dev, non_blocking=True).float().contiguous()
@@ -272,19 +282,21 @@ class CRPSLoss(_LossBase):
                for e in range(E)]
         conds = [[None] * steps for _ in range(E)]
         preds = torch.empty(E, B, C, H, W, device=dev)
-        # ---- pass 1: the rollouts, nothing saved but each step's input state (inference engine, bf16 operands).  The very
-        # last network call (last member, last step) is the first one pass 2 differentiates: it runs on the training engine
-        # and keeps its activations, which saves one of the 2 x steps recomputed forwards
-        kept = None
-        keep_last = os.environ.get("SWIFTK_CRPS_KEEP_LAST", "1") != "0"
+        # ---- pass 1: the rollouts on the inference engine (bf16 operands), saving each step's input state.  The reference
+        # recomputes every step in the backward pass (checkpoint_sequential, loss.py:395-437) because activations of 2 x steps
+        # network calls do not fit its GPUs; with 288 GB of HBM the LAST `n_keep` calls (in rollout order: the ones pass 2
+        # differentiates first) run on the training engine and keep their activations, one buffer set ("slot") each
+        n_keep = self.last_n_keep = self._n_keep(eng, B, E * steps, dev)
+        kept = {}
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             for e in range(E):
                 cond = condition[:, :nv].contiguous().float()
                 for i in range(steps):
                     conds[e][i] = cond
-                    if keep_last and e == E - 1 and i == steps - 1:
-                        kept = eng.forward([lat[e][i], cond, forc[i]], [1.0, 1.0, 1.0], t, aux)
-                        out = kept[0]
+                    c = e * steps + i
+                    if c >= E * steps - n_keep:
+                        kept[(e, i)] = eng.forward([lat[e][i], cond, forc[i]], [1.0, 1.0, 1.0], t, aux, slot=1 + E * steps - 1 - c)
+                        out = kept[(e, i)][0]
                     else:
                         out = mod(lat[e][i], t, (cond, forc[i]), aux, x_scale=1.0)  # x_t / sigma_d with x_t = z * sigma_d
                     if i < steps - 1:
@@ -306,8 +318,8 @@ class CRPSLoss(_LossBase):
             for e in reversed(range(E)):
                 gcond = None  # dL/d cond_{i+1}
                 for i in reversed(range(steps)):
-                    if keep_last and e == E - 1 and i == steps - 1:
-                        out, ctx = kept  # (a replayed forward's outputs stay valid until the next replay, which follows below)
+                    if (e, i) in kept:
+                        out, ctx = kept.pop((e, i))  # (a slot's buffers stay valid until its next replay: the next iteration)
                     else:
                         out, ctx = eng.forward([lat[e][i], conds[e][i], forc[i]], [1.0, 1.0, 1.0], t, aux)
                     dout = torch.empty_like(out)

@@ -85,13 +85,16 @@ if a.loss == "scm":
           f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sys.exit(0)
 evals = 2 * a.steps
-fwd_eq = 4 * evals - 1  # the last rollout step keeps its activations: one recomputed forward fewer
+n_keep = int(getattr(loss_fn, "last_n_keep", 0))  # rollout steps whose activations stayed in HBM: no recomputed forward for those
+fwd_eq = 4 * evals - n_keep  # EXECUTED work; the reference's schedule (checkpoint_sequential) is 4 * evals
 fl = fwd_eq * a.batch * 2.7535e12 * a.depth / 12
 print(json.dumps({"metric": "multistep-CRPS finetune iteration (Swift-B, steps %d, ensemble 2, local batch %d; BASELINE configs[4] per GPU)" % (a.steps, a.batch),
                   "value": dt, "unit": "s/iteration", "samples_per_s": a.batch / dt, "flop_per_iteration": fl,
-                  "what": f"{evals} rollout forwards + {evals - 1} recomputed forwards + {evals} backwards (2x) = {fwd_eq} forward-equivalents per sample",
+                  "what": f"{evals} rollout forwards + {evals - n_keep} recomputed forwards + {evals} backwards (2x) = {fwd_eq} forward-equivalents executed per sample "
+                          f"({n_keep} of {evals} rollout steps keep their activations; the reference's schedule recomputes all: {4 * evals})",
+                  "kept_rollout_steps": n_keep,
                   "roofline": {"bound": "mfma", "achieved": fl / dt / 1e12, "peak": PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / dt / PEAK, "traffic": None},
                   "fused_optimizer_step": fused, "peak_mem_gib": torch.cuda.max_memory_allocated() / 2**30}))
 print(f"CRPS finetune: batch {a.batch}, steps {a.steps}, depth {a.depth}: {dt:.3f} s/iteration, loss {float(loss):.4f}; "
-      f"{a.batch / dt:.2f} samples/s; fwd-equivalents/iter = {evals} fwd + {evals - 1} recompute + {evals} bwd(2x) -> "
+      f"{a.batch / dt:.2f} samples/s; fwd-equivalents/iter = {evals} fwd + {evals - n_keep} recompute + {evals} bwd(2x) -> "
       f"{fl / dt / 1e12:.0f} TFLOP/s; peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
