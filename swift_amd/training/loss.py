@@ -245,13 +245,15 @@ class CRPSLoss(_LossBase):
 
     @staticmethod
     def _n_keep(eng, B, calls, dev) -> int:
-        """How many trailing network calls keep their activations: SWIFTK_CRPS_KEEP if set, else as many as fit beside a
-        64 GiB working set in 80 % of the device's memory (6 of the 8 calls of BASELINE configs[4] at local batch 8)."""
+        """How many trailing network calls keep their activations: SWIFTK_CRPS_KEEP if set, else what fits into 75 % of the
+        device's memory beside the iteration's own working set (measured: 2.2 activation sets -- rollout states, one
+        step's backward temporaries, gradients, optimiser state): 6 of the 8 calls of BASELINE configs[4] at local batch 8
+        on 288 GB (195 GiB peak), 2 at batch 16, none at batch 32."""
         env = os.environ.get("SWIFTK_CRPS_KEEP")
         if env is not None:
             return max(0, min(calls, int(env)))
         total = torch.cuda.get_device_properties(dev).total_memory
-        return max(0, min(calls, int((0.8 * total - 64 * 2**30) // max(1, eng.activation_bytes(B)))))
+        return max(0, min(calls, int(0.75 * total / max(1, eng.activation_bytes(B)) - 2.2)))
 
     def _forcings(self, idx, aux_host, i, dev):
         f = torch.stack([self.dataset.get_forcings(int(j) + int(i * float(dt) * 10 // 6)) for j, dt in zip(idx, aux_host)], 0)

@@ -376,9 +376,15 @@ def test_trigflow_loss_and_grads_vs_oracle(dev):
     assert float(loss) == pytest.approx(float(ref), rel=1e-3)  # measured 6e-5 (bf16 operands vs fp32 autograd)
 
 
-@pytest.mark.parametrize("steps", [3, 4])  # 4 = BASELINE configs[4] (finetune/multistep.yaml's last interval)
-def test_crps_multistep_loss_and_grads_vs_oracle(dev, steps):
+@pytest.mark.parametrize("steps,keep", [(3, "0"), (3, None), (4, "3"), (4, "0")])  # 4 = BASELINE configs[4] (finetune/multistep.yaml's last interval)
+def test_crps_multistep_loss_and_grads_vs_oracle(dev, steps, keep, monkeypatch):
+    """keep: rollout steps whose activations stay resident for the backward walk ("0": every step recomputed as in the
+    reference's checkpoint_sequential; None: the memory rule, which keeps all 2 x steps calls of this small net; "3": mixed)."""
     from oracle import loss as oloss
+    if keep is None:
+        monkeypatch.delenv("SWIFTK_CRPS_KEEP", raising=False)
+    else:
+        monkeypatch.setenv("SWIFTK_CRPS_KEEP", keep)
     from oracle.rollout import Stats
     from swift_amd.training.loss import CRPSLoss
     from swift_amd.training.trainer import GradAllReduce
@@ -399,8 +405,9 @@ def test_crps_multistep_loss_and_grads_vs_oracle(dev, steps):
     forc = lambda i: torch.stack([ds.get_forcings(j + i) for j in idx], 0)
     ref = oloss.crps_multistep_loss(onet, stats, target, cond, aux, forc, lat, L.w_var.cpu(), L.w_lat.cpu(), steps=steps, alpha=0.95)
     ref.backward()
-    print(f"CRPS(steps={steps}) loss {float(loss):.6f} vs oracle {float(ref):.6f}; worst grad cosine {_grad_report(net, st, 0.999):.4f}")
+    print(f"CRPS(steps={steps}, keep={keep}) loss {float(loss):.6f} vs oracle {float(ref):.6f}; worst grad cosine {_grad_report(net, st, 0.999):.4f}")
     assert float(loss) == pytest.approx(float(ref), rel=2e-3)  # measured 4.4e-4 at steps = 3
+    assert L.last_n_keep == (2 * steps if keep is None else int(keep))
 
 
 def test_network_tangent_vs_oracle_jvp(dev):
