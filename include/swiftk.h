@@ -216,9 +216,10 @@ int swiftk_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, f
 /* The same weight gradient without the transposed copies (TN form; autograd of the Linears at swinv2.py:96-98,112-113,134):
  *   slabs[s][N1, ldc] (fp32) = sum over the s-th of `ksplit` ranges of the K token rows of P[m, 0..N1)^T * Q[m, 0..N2)
  * P = dY [K, ldp], Q = X [K, ldq], bf16, token-major as the forward / backward passes leave them.  K % 64 == 0,
- * N1 % 8 == 0, N2 % 4 == 0; rows must be readable to the end of the last 64-column (P) / 352-column (Q) block:
- * ldp >= roundup(N1, 64), ldq >= roundup(N2, 352) -- what lies past N1 / N2 there is never used.  SWIFTK_ESHAPE when a
- * shape does not fit (callers then use swiftk_transpose + swiftk_gemm_splitk).  Bit-equal to that path. */
+ * N1 % 8 == 0, N2 % 4 == 0; rows must be readable to the end of their last 64-column block: ldp >= roundup(N1, 64),
+ * ldq >= roundup(N2, 64) (what lies past N1 / N2 there is never used); output tiles are 352 columns wide where that divides
+ * N2, else 320 or 384 (the 352-wide form reads whole tiles: N2 % 352 == 0 or ldq >= roundup(N2, 352)).  SWIFTK_ESHAPE when
+ * a shape does not fit (callers then use swiftk_transpose + swiftk_gemm_splitk).  Bit-equal to that path. */
 int swiftk_gemm_tn_splitk(const void* P, int64_t ldp, const void* Q, int64_t ldq, float* slabs, int64_t ldc,
                           int64_t slab_stride, int64_t N1, int64_t N2, int64_t K, int ksplit, void* stream);
 /* out[r][c] (= | +=) sum_s slabs[s*slab_stride + r*ld_slab + c] */

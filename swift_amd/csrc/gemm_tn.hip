@@ -10,20 +10,19 @@
 //     so lane (n = l&15, g = l>>4) receives k = 8g + 4h + {0..3} of column n -- the same (lane, element) -> k map as the row
 //     reads of gemm.hip, hence the same products summed in the same order: results are bit-equal to the NT kernel run on
 //     transposed copies.  The two blocks of a 32-lane half sit 8 rows apart in the same columns: conflict-free (T10).
-// Everything else (256 x 352 tiles, 8 waves 4 x 2, two 76-KiB stages, DMA pieces issued between MFMA groups, persistent
-// grid over (tile, k-split) items, XCD-grouped tile order, fp32 slab store) follows gemm_kernel_p.
+// Everything else (256 x 320 / 352 / 384 tiles, 8 waves 4 x 2, two 72-80-KiB stages, DMA pieces issued between MFMA groups,
+// persistent grid over (tile, k-split) items, XCD-grouped tile order, fp32 slab store) follows gemm_kernel_p.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 256, BN = 352, KT = 64;
+constexpr int BM = 256, KT = 64;
 constexpr int A_RG = BM / 32 * 512;        // bytes of one 8-row group of the P image: 8 subtiles
-constexpr int B_RG = BN / 32 * 512;        // Q image: 11 subtiles
 constexpr int A_BYTES = 8 * A_RG;          // 32 KiB
-constexpr int B_BYTES = 8 * B_RG;          // 44 KiB
-constexpr int STAGE = A_BYTES + B_BYTES;   // 76 KiB
 constexpr int NT = 512;
-constexpr int MI = 4, NI = 11;
+constexpr int MI = 4;
+// NI = W-side MFMA tiles per wave: 10 / 11 / 12 -> 320 / 352 / 384 output columns per tile (as gemm_kernel_p): the Q image
+// has NI subtiles per 8-row group, a stage is 72 / 76 / 80 KiB
 
 struct TnArgs {
     const char* P;
@@ -54,7 +53,11 @@ __device__ __forceinline__ uint4 tr_pair(const char* lo, const char* hi) {
     return __builtin_bit_cast(uint4, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+template <int NI>
 __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) {
+    constexpr int WT = 16 * NI, BN = 2 * WT;
+    constexpr int B_RG = NI * 512, B_BYTES = 8 * B_RG, STAGE = A_BYTES + B_BYTES;
+    constexpr bool ODD = NI & 1;  // 11 subtiles per row group do not pair up: one piece straddles two row groups
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -72,15 +75,15 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
     if (vid >= ntiles) return;
     const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
 
-    // ---- DMA sources.  A 1-KiB piece = two neighbouring subtiles.  Wave w fills row group w of the P image (4 pieces) and,
-    // of the Q image's 11 subtiles per row group, either the pairs (0,1)..(8,9) of row group 2G plus the piece made of
+    // ---- DMA sources.  A 1-KiB piece = two neighbouring subtiles.  Wave w fills row group w of the P image (4 pieces) and of
+    // the Q image: with an even subtile count (NI = 10 / 12) the NI / 2 pairs of row group w; with 11 subtiles per row group either the pairs (0,1)..(8,9) of row group 2G plus the piece made of
     // (2G, 10) and (2G+1, 0) [even w], or the pairs (1,2)..(9,10) of row group 2G+1 [odd w], G = w>>1.  Lane l writes LDS
     // byte 16*l of its piece: subtile l>>5, row (l&31)>>2, position l&3 <- chunk (l&3) ^ ((row>>2)&3).
     const int dhalf = lane >> 5, drow = (lane & 31) >> 2, dslot = lane & 3, dhb = (lane >> 4) & 1;
     const uint32_t va = (uint32_t)(drow * g.ldp_b) + 64u * dhalf + 16u * (dslot ^ (2 * (wv & 1) | dhb));
     const uint32_t vb = (uint32_t)(drow * g.ldq_b) + 64u * dhalf + 16u * (dslot ^ (2 * (wv & 1) | dhb));
     const uint32_t vs = dhalf ? (uint32_t)((8 + drow) * g.ldq_b) - 640u + 16u * (dslot ^ (2 | dhb))
-                              : (uint32_t)(drow * g.ldq_b) + 16u * (dslot ^ dhb);
+                              : (uint32_t)(drow * g.ldq_b) + 16u * (dslot ^ dhb);  // (NI = 11 only)
     const int nk_all = g.K / KT;
     auto k_begin = [&](int item) { return (int)((int64_t)(item % ksplit) * nk_all / ksplit); };
     auto k_end = [&](int item) { return (int)((int64_t)(item % ksplit + 1) * nk_all / ksplit); };
@@ -98,19 +101,29 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
             c = c < g.N1 ? c : n1;  // columns past the matrix feed accumulators that are never stored: any readable address
             abase[p] = g.P + (k0 + 8 * wv) * g.ldp_b + 2 * c;
         }
-        const int G = wv >> 1;
+        if constexpr (ODD) {
+            const int G = wv >> 1;
 #pragma unroll
-        for (int y = 0; y < 5; ++y)
-            qbase[y] = g.Q + (k0 + 16 * G + 8 * (wv & 1)) * g.ldq_b + 2 * (n2 + 32 * (wv & 1) + 64 * y);
-        qbase[5] = g.Q + (k0 + 16 * G) * g.ldq_b + 2 * (n2 + 320);
+            for (int y = 0; y < 5; ++y)
+                qbase[y] = g.Q + (k0 + 16 * G + 8 * (wv & 1)) * g.ldq_b + 2 * (n2 + 32 * (wv & 1) + 64 * y);
+            qbase[5] = g.Q + (k0 + 16 * G) * g.ldq_b + 2 * (n2 + 320);
+        } else {  // NI / 2 aligned pairs of row group wv; columns past the matrix are redirected like P's
+#pragma unroll
+            for (int y = 0; y < NI / 2; ++y) {
+                int c = n2 + 64 * y;
+                c = c < g.N2 ? c : n2;
+                qbase[y] = g.Q + (k0 + 8 * wv) * g.ldq_b + 2 * c;
+            }
+        }
     };
     auto issue_piece = [&](uint32_t sa, uint32_t koff_a, uint32_t koff_q, int p) {
         if (p < 4) {
             dma_piece_fast(sa + wv * A_RG + p * 1024, abase[p], va + koff_a);
-        } else if (p < 9) {
-            dma_piece_fast(sa + A_BYTES + wv * B_RG + 512 * (wv & 1) + (p - 4) * 1024, qbase[p - 4], vb + koff_q);
+        } else if constexpr (ODD) {
+            if (p < 9) dma_piece_fast(sa + A_BYTES + wv * B_RG + 512 * (wv & 1) + (p - 4) * 1024, qbase[p - 4], vb + koff_q);
+            else if (!(wv & 1)) dma_piece_fast(sa + A_BYTES + wv * B_RG + 5120, qbase[5], vs + koff_q);
         } else {
-            if (!(wv & 1)) dma_piece_fast(sa + A_BYTES + wv * B_RG + 5120, qbase[5], vs + koff_q);
+            if (p - 4 < NI / 2) dma_piece_fast(sa + A_BYTES + wv * B_RG + (p - 4) * 1024, qbase[p - 4], vb + koff_q);
         }
     };
 
@@ -132,8 +145,10 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
         for (int h = 0; h < 2; ++h) {
             const int xr = 2 * (fg & 1) | h;
             vA[par][h] = fg * A_RG + 512 * (2 * wm) + 64 * (4 * h + fq) + 16 * ((2 * par + (fp >> 1)) ^ xr) + 8 * (fp & 1);
-            vW[par][h] = A_BYTES + fg * B_RG + 512 * (wn ? 5 + par : 0) + 64 * (4 * h + fq) +
-                         16 * ((2 * (par ^ wn) + (fp >> 1)) ^ xr) + 8 * (fp & 1);
+            // block c0 = wn * WT + 16 j: subtile (c0 >> 5) = wn * (WT / 32) + (j >> 1) [+ (j & 1) when WT / 16 is odd and wn = 1],
+            // chunk bit (c0 >> 4) & 1 = (j & 1) ^ (wn & ODD)
+            vW[par][h] = A_BYTES + fg * B_RG + 512 * (wn ? (WT / 32) + (ODD ? par : 0) : 0) + 64 * (4 * h + fq) +
+                         16 * ((2 * (par ^ (ODD ? wn : 0)) + (fp >> 1)) ^ xr) + 8 * (fp & 1);
         }
 
     int tile = vid, kt = 0;
@@ -168,12 +183,17 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
                     const int o = 512 * (j >> 1) + ks * 4 * B_RG;
                     return tr_pair(s + vW[j & 1][0] + o, s + vW[j & 1][1] + o);
                 };
+                constexpr int AHEAD = NI == 12 ? 1 : 2;  // W fragments in flight (192 accumulators leave room for one)
                 uint4 wf = wfrag(0);
-                uint4 wf1 = wfrag(1);
+                uint4 wf1 = wfrag(AHEAD == 2 ? 1 : 0);
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    const uint4 wn_ = wf1;
-                    if (j + 2 < NI) wf1 = wfrag(j + 2);
+                    uint4 wn_ = wf1;
+                    if constexpr (AHEAD == 2) {
+                        if (j + 2 < NI) wf1 = wfrag(j + 2);
+                    } else {
+                        if (j + 1 < NI) wn_ = wfrag(j + 1);
+                    }
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf),
@@ -204,7 +224,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
                 const int m = tm * BM + wm * 64 + i * 16 + r16;
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    const int nb = tn * BN + wn * 176 + j * 16 + 4 * g4;
+                    const int nb = tn * BN + wn * WT + j * 16 + 4 * g4;
                     const f32x4 v = acc[i][j];
                     acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (m < g.N1 && nb < g.N2)
@@ -225,14 +245,23 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
 
 // slabs[s][N1][N2] (fp32, row stride ldc, slab stride `slab_stride`) = partial products over the s-th of `ksplit` ranges of
 // the K token rows.  P: [K, >= N1] bf16 with row stride ldp, Q: [K, >= N2] with ldq.  Shapes this kernel does not take
-// (SWIFTK_ESHAPE) go through swiftk_transpose + swiftk_gemm_splitk instead.
+// (SWIFTK_ESHAPE: token counts that are not whole 64-row k-tiles, rows too short to read whole 128-B segments) go through
+// swiftk_transpose + swiftk_gemm_splitk instead.
 extern "C" int swiftk_gemm_tn_splitk(const void* P, int64_t ldp, const void* Q, int64_t ldq, float* slabs, int64_t ldc,
                                      int64_t slab_stride, int64_t N1, int64_t N2, int64_t K, int ksplit, void* stream) {
     if (!P || !Q || !slabs || N1 <= 0 || N2 <= 0 || K <= 0 || ksplit < 1) return SWIFTK_EINVAL;
     if (ksplit > 1 && slab_stride < N1 * ldc) return SWIFTK_EINVAL;
     if (K % KT || N1 % 8 || N2 % 4 || K / KT < ksplit) return SWIFTK_ESHAPE;
-    // whole 128-B source segments: P pieces are 64 columns wide at multiples of 64, Q tiles are read in full
-    if (ldp < (N1 + 63) / 64 * 64 || ldq < (N2 + BN - 1) / BN * BN || ldc < N2) return SWIFTK_ESHAPE;
+    // tile width: 352 where it divides N2 (Swift-B), else the even forms (320 / 384), whichever wastes fewer columns.  Whole
+    // 128-B source segments: pieces are 64 columns wide at multiples of 64 -- except the 352-wide form, whose odd subtile
+    // count makes it read its Q tiles in full
+    int ni = 11;
+    if (N2 % 352) {
+        const int64_t w10 = (N2 + 319) / 320 * 320, w12 = (N2 + 383) / 384 * 384;
+        ni = w12 <= w10 ? 12 : 10;
+    }
+    const int bn = 32 * ni;
+    if (ldp < (N1 + 63) / 64 * 64 || ldq < (ni == 11 ? (N2 + bn - 1) / bn * bn : (N2 + 63) / 64 * 64) || ldc < N2) return SWIFTK_ESHAPE;
     if (N1 > (1 << 30) || N2 > (1 << 30) || K > (1 << 30)) return SWIFTK_ESHAPE;
     // the per-lane DMA offset is 32 bits and runs over one split's rows
     const int64_t rows_per_split = (K / KT + ksplit - 1) / ksplit * KT + 16;
@@ -250,11 +279,15 @@ extern "C" int swiftk_gemm_tn_splitk(const void* P, int64_t ldp, const void* Q, 
     g.N1 = (int)N1;
     g.N2 = (int)N2;
     g.K = (int)K;
-    g.ntn = (int)((N2 + BN - 1) / BN);
+    g.ntn = (int)((N2 + bn - 1) / bn);
     g.ksplit = ksplit;
     const int ntm = (int)((N1 + BM - 1) / BM);
     const int items = ntm * g.ntn * ksplit;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(items < 256 ? items : 256), dim3(NT), 0, static_cast<hipStream_t>(stream), g, ntm, 8);
+    const dim3 grid(items < 256 ? items : 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ni == 10) hipLaunchKernelGGL(gemm_tn_kernel<10>, grid, dim3(NT), 0, st, g, ntm, 8);
+    else if (ni == 12) hipLaunchKernelGGL(gemm_tn_kernel<12>, grid, dim3(NT), 0, st, g, ntm, 8);
+    else hipLaunchKernelGGL(gemm_tn_kernel<11>, grid, dim3(NT), 0, st, g, ntm, 8);
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

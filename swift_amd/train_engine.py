@@ -146,10 +146,11 @@ class SwinTrainEngine:
 
     def _wgrad(self, dy, x, rows, cols, out_grad, accumulate=True):
         """out_grad[rows, cols] (+)= dy[M, :rows]^T @ x[M, :cols] via split-K fp32 slabs; both operands token-major as the
-        passes leave them (``swiftk_gemm_tn_splitk``).  Shapes that kernel does not take (a column count that is not whole
-        352-wide tiles: patch embedding, the dim-1280 / 1536 families) go through transposed copies and the NT kernel."""
+        passes leave them (``swiftk_gemm_tn_splitk``); anything that kernel rejects (rows too short to read whole
+        128-B segments) goes through transposed copies and the NT kernel."""
         Mtok = dy.shape[0]
-        tiles = ((rows + 255) // 256) * ((cols + 351) // 352)
+        bn = 352 if cols % 352 == 0 else (384 if (cols + 383) // 384 * 384 <= (cols + 319) // 320 * 320 else 320)  # the kernel's tile width
+        tiles = ((rows + 255) // 256) * ((cols + bn - 1) // bn)
         ks = max(1, min(32, 256 // tiles, Mtok // 64))  # one round of work items over the 256 CUs
         need = ks * rows * cols
         if self._slabs is None or self._slabs.numel() < need:

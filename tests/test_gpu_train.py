@@ -64,6 +64,9 @@ def test_transpose_and_splitk_wgrad(dev):
     (4096, 256, 352, 16, 320, 360),       # exactly one tile, many splits, leading dimensions past the tile
     (2048, 3168, 1056, 1, 3200, 1088),    # the to_qkv gradient's shape, one k-range
     (640, 72, 1408, 2, 128, 1408),        # fewer rows than one wave tile
+    (1024, 1280, 1280, 2, 1280, 1280),    # dim 1280: 320-wide tiles (even subtile count, no straddling piece)
+    (1024, 512, 1536, 1, 512, 1536),      # dim 1536: 384-wide tiles, all 160 KiB of LDS
+    (512, 1536, 3416, 1, 1536, 3456),     # ragged MLP width of the 468 M variant (int(8/3 1280) = 3413 -> 3416): 9 x 384, NaN pad read, never used
 ])
 def test_tn_wgrad_equals_transposed_path(dev, M, N1, N2, ks, ldp, ldq):
     """swiftk_gemm_tn_splitk (operands token-major, transposed in LDS) against fp64 and, bit for bit, against the
@@ -95,7 +98,7 @@ def test_tn_wgrad_rejects_what_it_cannot_read(dev):
     out = torch.zeros(1056 * 1280, device=dev)
     args = lambda ldp, ldq, n1, n2, k: (P.data_ptr(), ldp, Q.data_ptr(), ldq, out.data_ptr(), n2, n1 * n2, n1, n2, k, 1, s())
     assert L.swiftk_gemm_tn_splitk(*args(1056, 1280, 1056, 1056, 256)) == -2   # P rows end inside a 64-column block
-    assert L.swiftk_gemm_tn_splitk(*args(1056, 1280, 1024, 1280, 256)) == -2   # 1280 columns are not whole 352-wide tiles
+    assert L.swiftk_gemm_tn_splitk(*args(1056, 1272, 1024, 1272, 256)) == -2   # Q rows end inside a 64-column block
     assert L.swiftk_gemm_tn_splitk(*args(1056, 1280, 1024, 1056, 200)) == -2   # token count not in 64-row k-tiles
     assert L.swiftk_gemm_tn_splitk(*args(1056, 1280, 1024, 1056, 256)) == 0
 
