@@ -403,7 +403,8 @@ def test_h5_backed_era5_dataset_vs_reference_golden(tmp_path, monkeypatch):
 def test_bench_launcher_contract_without_gpu():
     """`python bench.py --gpus N` launched bare starts N rank processes before anything touches the GPU and propagates their
     failure; on this GPU-less machine: too few devices -> refused (rc 2); forced -> every rank builds the process group,
-    finds no GPU and exits 1 with the "no CPU fallback" message (the hot path never falls back); a process group whose size
+    finds no GPU and exits 1 with the "no CPU fallback" message (the hot path never falls back; the first rank to fail takes its
+    sibling down); a process group whose size
     is not --gpus -> rc 3."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     bench = os.path.join(ROOT, "bench.py")
@@ -413,7 +414,8 @@ def test_bench_launcher_contract_without_gpu():
     assert p.returncode == 2 and "exposes 0 GPU(s)" in p.stderr and not p.stdout.strip()
     p = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
                        env=dict(env, SWIFTK_ALLOW_SHARED_GPU="1"), timeout=200)
-    assert p.returncode == 1 and p.stderr.count("no CPU fallback") == 2 and "{" not in p.stdout  # (gloo logs its ranks to stdout)
+    # (the launcher ends the sibling rank as soon as one fails, so the message appears once or twice; gloo logs its ranks to stdout)
+    assert p.returncode == 1 and 1 <= p.stderr.count("no CPU fallback") <= 2 and "{" not in p.stdout
     p = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="1", RANK="0"), timeout=120)
     assert p.returncode == 3 and "process group has 1 rank(s)" in p.stderr
