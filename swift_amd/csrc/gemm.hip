@@ -532,25 +532,34 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 int elane = lane;
                 asm volatile("" : "+v"(elane));
                 const int g4 = elane >> 4;
-                constexpr int JH = (NI + 1) / 2;
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
+                // groups of four 16-column blocks, the saved pre-activations of group g+1 requested before group g is computed
+                constexpr int JH = 4, GPI = (NI + JH - 1) / JH, NG = MI * GPI;
+                uint4 hb[2][JH];
+                auto load_group = [&](int gidx, uint4 (&b)[JH]) {
+                    const int i = gidx / GPI, jh = (gidx - i * GPI) * JH;
                     const int m = m0 + wm * 64 + i * 16 + (elane & 15);
 #pragma unroll
-                    for (int jh = 0; jh < NI; jh += JH) {
-                        uint4 hv[JH];
+                    for (int jj = 0; jj < JH; ++jj) {
+                        const int nb = n0 + wn * WT + (jh + jj) * 16 + 4 * g4;
+                        b[jj] = make_uint4(0u, 0u, 0u, 0u);
+                        if (jh + jj < NI && m < g.M && nb < g.N) b[jj] = *reinterpret_cast<const uint4*>(H + (int64_t)m * ldh + 2 * nb);
+                    }
+                };
+                load_group(0, hb[0]);
 #pragma unroll
-                        for (int j = jh; j < jh + JH && j < NI; ++j) {
-                            const int nb = n0 + wn * WT + j * 16 + 4 * g4;
-                            hv[j - jh] = make_uint4(0u, 0u, 0u, 0u);
-                            if (m < g.M && nb < g.N) hv[j - jh] = *reinterpret_cast<const uint4*>(H + (int64_t)m * ldh + 2 * nb);
-                        }
+                for (int gidx = 0; gidx < NG; ++gidx) {
+                    if (gidx + 1 < NG) load_group(gidx + 1, hb[(gidx + 1) & 1]);
+                    const int i = gidx / GPI, jh = (gidx - i * GPI) * JH;
+                    const int m = m0 + wm * 64 + i * 16 + (elane & 15);
 #pragma unroll
-                        for (int j = jh; j < jh + JH && j < NI; ++j) {
+                    for (int jj = 0; jj < JH; ++jj) {
+                        if (jh + jj < NI) {
+                            const int j = jh + jj;
                             const int nb = n0 + wn * WT + j * 16 + 4 * g4;
                             const f32x4 v = acc[i][j];
                             acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            const uint32_t hw[4] = {hv[j - jh].x, hv[j - jh].y, hv[j - jh].z, hv[j - jh].w};
+                            const uint4 hq = hb[gidx & 1][jj];
+                            const uint32_t hw[4] = {hq.x, hq.y, hq.z, hq.w};
                             uint32_t o[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -713,26 +722,34 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 }
             } else if constexpr (EPI == SWIFTK_EPI_ACCUM) {
                 // C += A W^T (fp32): the residual-stream gradient picks up a branch's input gradient in the GEMM that
-                // produces it.  Half a 16-row slab's loads are issued before its first store (same array: the compiler
-                // would otherwise order load j+1 behind store j).
-                constexpr int JH = (NI + 1) / 2;
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
+                // produces it.  The tile is walked in groups of four 16-column blocks; the loads of group g+1 are issued
+                // before group g is added and stored (same array: the compiler keeps load g+1 behind the stores of g-1,
+                // so one group of look-ahead is what program order allows) -- one exposed load latency per tile, not twelve.
+                constexpr int JH = 4, GPI = (NI + JH - 1) / JH, NG = MI * GPI;
+                float4 buf[2][JH];
+                auto load_group = [&](int gidx, float4 (&b)[JH]) {
+                    const int i = gidx / GPI, jh = (gidx - i * GPI) * JH;
                     const int m = m0 + wm * 64 + i * 16 + r16;
 #pragma unroll
-                    for (int jh = 0; jh < NI; jh += JH) {
-                        float4 old[JH];
+                    for (int jj = 0; jj < JH; ++jj) {
+                        const int nb = n0 + wn * WT + (jh + jj) * 16 + 4 * (lane >> 4);
+                        b[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (jh + jj < NI && m < g.M && nb < g.N) b[jj] = *reinterpret_cast<const float4*>(C + (int64_t)m * g.ldc + nb);
+                    }
+                };
+                load_group(0, buf[0]);
 #pragma unroll
-                        for (int j = jh; j < jh + JH && j < NI; ++j) {
-                            const int nb = n0 + wn * WT + j * 16 + 4 * (lane >> 4);
-                            old[j - jh] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (m < g.M && nb < g.N) old[j - jh] = *reinterpret_cast<const float4*>(C + (int64_t)m * g.ldc + nb);
-                        }
+                for (int gidx = 0; gidx < NG; ++gidx) {
+                    if (gidx + 1 < NG) load_group(gidx + 1, buf[(gidx + 1) & 1]);
+                    const int i = gidx / GPI, jh = (gidx - i * GPI) * JH;
+                    const int m = m0 + wm * 64 + i * 16 + r16;
 #pragma unroll
-                        for (int j = jh; j < jh + JH && j < NI; ++j) {
+                    for (int jj = 0; jj < JH; ++jj) {
+                        if (jh + jj < NI) {
+                            const int j = jh + jj;
                             const int nb = n0 + wn * WT + j * 16 + 4 * (lane >> 4);
                             const f32x4 v = acc[i][j];
-                            const float4 o = old[j - jh];
+                            const float4 o = buf[gidx & 1][jj];
                             acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                             if (m < g.M && nb < g.N) store4<OutT>(C + (int64_t)m * g.ldc + nb, v[0] + o.x, v[1] + o.y, v[2] + o.z, v[3] + o.w);
                         }

@@ -709,10 +709,8 @@ extern "C" int swiftk_modnorm_jvp(const void* y, const void* dy, int64_t ldy, fl
     if (d > 1536 || M % rows_per_sample || ldxT < d || ldy < d) return SWIFTK_ESHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const unsigned grid = (unsigned)((M + 3) / 4);
-    const int es = dtype == SWIFTK_BF16 ? 2 : 4;
     const bool vec = !(d & 7) && !(ldy & 7) && !(ldxT & 7) && !(ldmod & 3) && !(((uintptr_t)y | (uintptr_t)dy | (uintptr_t)xT | (uintptr_t)dxT) & 15) &&
                      !(((uintptr_t)x | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mod | (uintptr_t)dmod) & 15);
-    (void)es;
 #define SWIFTK_MNJ(KERN)                                                                                                       \
     DT_SWITCH(dtype,                                                                                                           \
               hipLaunchKernelGGL(KERN<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(y),                    \
