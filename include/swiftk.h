@@ -271,9 +271,11 @@ int swiftk_timestep_embed_jvp(const float* t, const float* dt, const float* freq
 /* y = silu(z) (y may be NULL), dy = silu'(z) dz  (LatentEmbedding, swinv2.py:67-74). */
 int swiftk_silu_jvp(const float* z, const float* dz, float* y, float* dy, int64_t n, void* stream);
 /* In place on qkv / dqkv [M, ld] (head layout [q88|k88|v88]): q <- q/|q| * exp(min(scale,ln100)), k <- k/|k| and their
- * tangents dq, dk (swinv2.py:123-127); v, dv untouched. */
-int swiftk_qknorm_jvp(void* qkv, void* dqkv, int64_t ld, const float* scale, int64_t M, int heads, int head_dim, int dtype,
-                      void* stream);
+ * tangents dq, dk (swinv2.py:123-127); v, dv untouched.  `rn` (optional, [M, 3*heads] fp32): 1/max(|.|, 1e-12) per q / k
+ * vector and 1 for v -- what SWIFTK_EPI_QKNORM saves for swiftk_qknorm_bwd, so the tangent pass's primal rows can serve as
+ * the saved activations of the backward pass. */
+int swiftk_qknorm_jvp(void* qkv, void* dqkv, int64_t ld, const float* scale, float* rn, int64_t M, int heads, int head_dim,
+                      int dtype, void* stream);
 /* Explicit-softmax window attention and its tangent on pre-normalised q, k (swinv2.py:129-133 with jvp=True):
  * out = softmax(q k^T) v, dout = d/d(eps) of the same along (dq, dk, dv).  Same window/shift addressing as
  * swiftk_window_attention; head_dim 80 / 88 / 96. */

@@ -74,7 +74,7 @@ _SIGS = {
     "swiftk_unit_checksum": ([_p, _p, _p, _i, _l, _p], _i),
     "swiftk_timestep_embed_jvp": ([_p, _p, _p, _p, _i, _i, _f, _p], _i),
     "swiftk_silu_jvp": ([_p, _p, _p, _p, _l, _p], _i),
-    "swiftk_qknorm_jvp": ([_p, _p, _l, _p, _l, _i, _i, _i, _p], _i),
+    "swiftk_qknorm_jvp": ([_p, _p, _l, _p, _p, _l, _i, _i, _i, _p], _i),
     "swiftk_window_attention_jvp": ([_p, _p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_modnorm_jvp": ([_p, _p, _l, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l, _l, _i, _l, _f, _i, _p], _i),
     "swiftk_swiglu_jvp": ([_p, _p, _l, _p, _p, _l, _l, _i, _i, _p], _i),

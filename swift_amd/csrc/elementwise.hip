@@ -542,4 +542,4 @@ extern "C" int swiftk_unit_checksum(const float* x, double* out, double* scratch
     return 0;
 }
 
-extern "C" int swiftk_version(void) { return 2; }
+extern "C" int swiftk_version(void) { return 3; }

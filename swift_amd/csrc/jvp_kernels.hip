@@ -52,7 +52,8 @@ __global__ void silu_jvp_kernel(const float* __restrict__ z, const float* __rest
 // One 16-lane group per (row, head, q|k) vector of head_dim (80 / 88 / 96); in place on the primal and the tangent tensor.
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void qknorm_jvp_kernel(T* __restrict__ qkv, T* __restrict__ dqkv, int64_t ld,
-                                                         const float* __restrict__ scale, int64_t M, int heads) {
+                                                         const float* __restrict__ scale, float* __restrict__ rn, int64_t M,
+                                                         int heads) {
     const int l16 = threadIdx.x & 15;
     const int64_t nvec = M * heads * 2;
     for (int64_t vid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; vid < nvec; vid += ((int64_t)gridDim.x * 256) >> 4) {
@@ -79,6 +80,10 @@ __global__ __launch_bounds__(256) void qknorm_jvp_kernel(T* __restrict__ qkv, T*
         const float n = fmaxf(sqrtf(ss), 1e-12f);
         const float tau = part == 0 ? expf(fminf(scale[h], LN100)) : 1.0f;
         const float a = tau / n, c = dot / (n * n);
+        if (rn && l16 == 0) {  // what SWIFTK_EPI_QKNORM saves for the backward pass: 1 / max(|.|, 1e-12) per q / k vector, 1 for v
+            rn[m * (3 * heads) + h * 3 + part] = 1.0f / n;
+            if (part == 0) rn[m * (3 * heads) + h * 3 + 2] = 1.0f;
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int e = l16 + 16 * i;
@@ -660,26 +665,27 @@ extern "C" int swiftk_silu_jvp(const float* z, const float* dz, float* y, float*
 }
 
 template <int HD>
-static int launch_qknorm_jvp(void* qkv, void* dqkv, int64_t ld, const float* scale, int64_t M, int heads, int dtype, hipStream_t st) {
+static int launch_qknorm_jvp(void* qkv, void* dqkv, int64_t ld, const float* scale, float* rn, int64_t M, int heads, int dtype,
+                             hipStream_t st) {
     const int grid = grid_for(M * heads * 2 * 16);
     DT_SWITCH(dtype,
               hipLaunchKernelGGL((qknorm_jvp_kernel<bf16_t, HD>), dim3(grid), dim3(256), 0, st, static_cast<bf16_t*>(qkv),
-                                 static_cast<bf16_t*>(dqkv), ld, scale, M, heads),
+                                 static_cast<bf16_t*>(dqkv), ld, scale, rn, M, heads),
               hipLaunchKernelGGL((qknorm_jvp_kernel<float, HD>), dim3(grid), dim3(256), 0, st, static_cast<float*>(qkv),
-                                 static_cast<float*>(dqkv), ld, scale, M, heads));
+                                 static_cast<float*>(dqkv), ld, scale, rn, M, heads));
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int swiftk_qknorm_jvp(void* qkv, void* dqkv, int64_t ld, const float* scale, int64_t M, int heads, int head_dim,
-                                 int dtype, void* stream) {
+extern "C" int swiftk_qknorm_jvp(void* qkv, void* dqkv, int64_t ld, const float* scale, float* rn, int64_t M, int heads,
+                                 int head_dim, int dtype, void* stream) {
     if (!qkv || !dqkv || !scale || M <= 0 || heads <= 0) return SWIFTK_EINVAL;
     if (ld < 3 * heads * head_dim) return SWIFTK_ESHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (head_dim) {
-        case 80: return launch_qknorm_jvp<80>(qkv, dqkv, ld, scale, M, heads, dtype, st);
-        case 88: return launch_qknorm_jvp<88>(qkv, dqkv, ld, scale, M, heads, dtype, st);
-        case 96: return launch_qknorm_jvp<96>(qkv, dqkv, ld, scale, M, heads, dtype, st);
+        case 80: return launch_qknorm_jvp<80>(qkv, dqkv, ld, scale, rn, M, heads, dtype, st);
+        case 88: return launch_qknorm_jvp<88>(qkv, dqkv, ld, scale, rn, M, heads, dtype, st);
+        case 96: return launch_qknorm_jvp<96>(qkv, dqkv, ld, scale, rn, M, heads, dtype, st);
     }
     return SWIFTK_ESHAPE;
 }

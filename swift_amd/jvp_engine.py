@@ -110,20 +110,27 @@ class SwinJvpEngine:
         return p.detach().float().contiguous()
 
     def jvp(self, srcs: Sequence[torch.Tensor], dsrc0: torch.Tensor, t: torch.Tensor, dt_: torch.Tensor,
-            aux: Optional[torch.Tensor]) -> torch.Tensor:
+            aux: Optional[torch.Tensor], save_ctx: bool = False, want_logvar: bool = False):
         """srcs: channel-concatenated network inputs (srcs[0] carries the tangent ``dsrc0``); t, dt_: [B].  Returns dF
-        (after the first call of a signature: the captured sequence's own tensor, overwritten by the next call)."""
+        (after the first call of a signature: the captured sequence's own tensor, overwritten by the next call).
+
+        ``save_ctx``: the primal rows of the pass ARE a forward pass; keep them (per-layer buffers instead of one reused set)
+        and return ``(dF, F, logvar, ctx)`` with ``ctx`` in the form ``SwinTrainEngine.backward`` takes -- the sCM loss
+        then needs no second forward pass through the network (loss.py:212-237 runs ``jvp`` and a grad-enabled forward)."""
         self.refresh()
         srcs = [s.contiguous().float() for s in srcs]
         ins = list(srcs) + [dsrc0.contiguous().float(), t.contiguous().float(), dt_.contiguous().float()] + \
             ([aux.contiguous().float()] if aux is not None else [])
         n = len(srcs)
-        key = ("jvp", tuple(tuple(s.shape) for s in srcs), aux is not None)
-        fn = lambda *a: self._jvp(list(a[:n]), a[n], a[n + 1], a[n + 2], a[n + 3] if aux is not None else None)
-        return self.graphs.call(key, fn, ins)
+        key = ("jvp", tuple(tuple(s.shape) for s in srcs), aux is not None, bool(save_ctx), bool(want_logvar))
+        fn = lambda *a: self._jvp(list(a[:n]), a[n], a[n + 1], a[n + 2], a[n + 3] if aux is not None else None, save_ctx, want_logvar)
+        res = self.graphs.call(key, fn, ins)
+        if save_ctx:
+            res[3]["graph_key"] = key
+        return res
 
     def _jvp(self, srcs: Sequence[torch.Tensor], dsrc0: torch.Tensor, t: torch.Tensor, dt_: torch.Tensor,
-             aux: Optional[torch.Tensor]) -> torch.Tensor:
+             aux: Optional[torch.Tensor], save: bool = False, want_logvar: bool = False):
         m, T = self.m, self.dt
         tc = ops.dtype_code(T)
         dev = srcs[0].device
@@ -151,8 +158,10 @@ class SwinJvpEngine:
 
         l1w, l1b = self._f(m.latent_embed.l1.weight), self._f(m.latent_embed.l1.bias)
         l2w, l2b = self._f(m.latent_embed.l2.weight), self._f(m.latent_embed.l2.bias)
-        h1, dh1 = silu_pair(ops.linear_small(emb, l1w, l1b, 0), ops.linear_small(demb, l1w, None, 0))
-        lat, dlat = silu_pair(ops.linear_small(h1, l2w, l2b, 0), ops.linear_small(dh1, l2w, None, 0))
+        z1 = ops.linear_small(emb, l1w, l1b, 0)
+        h1, dh1 = silu_pair(z1, ops.linear_small(demb, l1w, None, 0))
+        z2 = ops.linear_small(h1, l2w, l2b, 0)
+        lat, dlat = silu_pair(z2, ops.linear_small(dh1, l2w, None, 0))
         mod = ops.linear_small(lat, self.mod_w, self.mod_b, 0)      # [B, depth * 2 * 2d]
         dmod = ops.linear_small(dlat, self.mod_w, None, 0)
         ldmod = mod.stride(0)
@@ -165,40 +174,72 @@ class SwinJvpEngine:
         x, dx = X[:M], X[M:]
         _gemm(ape, self.pe, x, EPI_BIAS_POS, self._f(m.patch_embed.emb.bias), self._f(m.pos_embed).reshape(ntok, d), ntok)
         _gemm(dape, self.pe, dx)
-        XT = torch.zeros(2 * M, self.kd, dtype=T, device=dev)        # GEMM-operand copy (K padding stays zero)
-        check(L.swiftk_cast_pad(X.data_ptr(), d, XT.data_ptr(), self.kd, 2 * M, d, tc, _s()), "swiftk_cast_pad")
-        QKV = torch.empty(2 * M, 3 * d, dtype=T, device=dev)
-        ATT = torch.zeros(2 * M, self.kd, dtype=T, device=dev)
-        Y = torch.empty(2 * M, d, dtype=T, device=dev)
-        H = torch.empty(2 * M, 2 * mlp, dtype=T, device=dev)
-        HM = torch.zeros(2 * M, self.kmlp, dtype=T, device=dev)
-        es = XT.element_size()
+        es = torch.empty(0, dtype=T).element_size()
 
-        def modnorm(i2, gamma, beta):
+        def operand(width, valid):  # [2M, width] GEMM operand, k-padding columns zero
+            b = torch.empty(2 * M, width, dtype=T, device=dev)
+            if width > valid:
+                b[:, valid:].zero_()
+            return b
+
+        XT_in = operand(self.kd, d)
+        check(L.swiftk_cast_pad(X.data_ptr(), d, XT_in.data_ptr(), self.kd, 2 * M, d, tc, _s()), "swiftk_cast_pad")
+        # one buffer set reused by every layer -- or, when the primal rows are kept for a backward pass, one set per layer
+        shared = None if save else dict(QKV=torch.empty(2 * M, 3 * d, dtype=T, device=dev), ATT=operand(self.kd, d),
+                                        Y=torch.empty(2 * M, d, dtype=T, device=dev),
+                                        H=torch.empty(2 * M, 2 * mlp, dtype=T, device=dev), HM=operand(self.kmlp, mlp))
+
+        def modnorm(i2, gamma, beta, Y, XT):
             off = i2 * 2 * d * 4
             check(L.swiftk_modnorm_jvp(Y.data_ptr(), Y.data_ptr() + M * d * es, d, x.data_ptr(), dx.data_ptr(), XT.data_ptr(),
                                        XT.data_ptr() + M * self.kd * es, self.kd, gamma.data_ptr(), beta.data_ptr(),
                                        mod.data_ptr() + off, dmod.data_ptr() + off, ldmod, M, d, ntok, 1e-6, tc, _s()),
                   "swiftk_modnorm_jvp")
 
+        layers = []
         do_shift = any(m.shift_size)
         for i in range(len(self.L)):
             W = self.L[i]
             sh = tuple(m.shift_size) if (do_shift and i % 2) else (0, 0)
-            _gemm(XT, W["qkv"], QKV)
-            check(L.swiftk_qknorm_jvp(QKV.data_ptr(), QKV.data_ptr() + M * 3 * d * es, 3 * d, W["scale"].data_ptr(), M, heads,
-                                      self.hd, tc, _s()), "swiftk_qknorm_jvp")
+            QKV = shared["QKV"] if shared else torch.empty(2 * M, 3 * d, dtype=T, device=dev)
+            _gemm(XT_in, W["qkv"], QKV)
+            rn = torch.empty(M, 3 * heads, dtype=torch.float32, device=dev) if save else None
+            check(L.swiftk_qknorm_jvp(QKV.data_ptr(), QKV.data_ptr() + M * 3 * d * es, 3 * d, W["scale"].data_ptr(),
+                                      None if rn is None else rn.data_ptr(), M, heads, self.hd, tc, _s()), "swiftk_qknorm_jvp")
+            ATT = shared["ATT"] if shared else operand(self.kd, d)
             check(L.swiftk_window_attention_jvp(QKV.data_ptr(), QKV.data_ptr() + M * 3 * d * es, 3 * d, ATT.data_ptr(),
                                                 ATT.data_ptr() + M * self.kd * es, self.kd, B, gh, gw, heads, self.hd, sh[0], sh[1],
                                                 tc, _s()), "swiftk_window_attention_jvp")
-            _gemm(ATT, W["wo"], Y)
-            modnorm(2 * i, W["g1"], W["b1"])
-            _gemm(XT, W["w1"], H)
+            Y1 = shared["Y"] if shared else torch.empty(2 * M, d, dtype=T, device=dev)
+            _gemm(ATT, W["wo"], Y1)
+            XT_mid = XT_in if shared else operand(self.kd, d)
+            modnorm(2 * i, W["g1"], W["b1"], Y1, XT_mid)
+            H = shared["H"] if shared else torch.empty(2 * M, 2 * mlp, dtype=T, device=dev)
+            _gemm(XT_mid, W["w1"], H)
+            HM = shared["HM"] if shared else operand(self.kmlp, mlp)
             check(L.swiftk_swiglu_jvp(H.data_ptr(), H.data_ptr() + M * 2 * mlp * es, 2 * mlp, HM.data_ptr(),
                                       HM.data_ptr() + M * self.kmlp * es, self.kmlp, M, mlp, tc, _s()), "swiftk_swiglu_jvp")
-            _gemm(HM, W["w2"], Y)
-            modnorm(2 * i + 1, W["g2"], W["b2"])
+            Y2 = shared["Y"] if shared else torch.empty(2 * M, d, dtype=T, device=dev)
+            _gemm(HM, W["w2"], Y2)
+            XT_out = XT_mid if shared else operand(self.kd, d)
+            modnorm(2 * i + 1, W["g2"], W["b2"], Y2, XT_out)
+            if save:
+                layers.append(dict(xT_in=XT_in[:M], qkvh=QKV[:M], rn=rn, att=ATT[:M], y1=Y1[:M], xT_mid=XT_mid[:M], h=H[:M],
+                                   hmid=HM[:M], y2=Y2[:M], shift=sh))
+            XT_in = XT_out
         po4 = self.head.shape[0]
-        tok = torch.empty(M, po4, dtype=torch.float32, device=dev)
-        _gemm(XT[M:], self.head, tok)
-        return ops.unpatchify_affine(tok.view(B, ntok, po4), (B, m.out_channels, *m.image_size), m.patch_size)
+        shape = (B, m.out_channels, *m.image_size)
+        if not save:
+            tok = torch.empty(M, po4, dtype=torch.float32, device=dev)
+            _gemm(XT_in[M:], self.head, tok)
+            return ops.unpatchify_affine(tok.view(B, ntok, po4), shape, m.patch_size)
+        tok = torch.empty(2 * M, po4, dtype=torch.float32, device=dev)
+        _gemm(XT_in, self.head, tok)
+        F = ops.unpatchify_affine(tok[:M].view(B, ntok, po4), shape, m.patch_size)
+        dF = ops.unpatchify_affine(tok[M:].view(B, ntok, po4), shape, m.patch_size)
+        logvar = None
+        if want_logvar:
+            logvar = ops.linear_small(lat, self._f(m.logvar_embed.weight), self._f(m.logvar_embed.bias), 0).reshape(B)
+        ctx = dict(B=B, M=M, srcs_ch=[s_.shape[1] for s_ in srcs], scales=[1.0] * len(srcs), layers=layers, aux=aux_s, emb=emb,
+                   z1=z1, h1=h1, z2=z2, lat=lat, mod=mod, ape=ape, xT_final=XT_in[:M])
+        return dF, F, logvar, ctx

@@ -203,11 +203,23 @@ class SCMLoss(_LossBase):
         vx = torch.empty_like(x)
         check(lib().swiftk_axpby_per_sample(vx.data_ptr(), (cs / sd).contiguous().data_ptr(), dxt.data_ptr(), None, None, B, per,
                                             st), "swiftk_axpby_per_sample")
-        with torch.no_grad():
-            dF = self._jvp_engine(mod).jvp(srcs, vx, t, cs, aux)
         want_lv = mod.model.logvar_embed is not None
-        res = eng.forward(srcs, [1.0] * len(srcs), t, aux, want_logvar=want_lv)
-        Fx, lv, ctx = res if want_lv else (res[0], None, res[1])
+        jeng = self._jvp_engine(mod)
+        eng.refresh()
+        jeng.refresh()
+        # The reference runs the network twice here: torch.func.jvp for the tangent, then a grad-enabled forward
+        # (loss.py:212-237).  The tangent pass's primal rows are that forward: with bf16 activations (the trainer's
+        # autocast) they are kept per layer and handed to the backward pass -- one forward-equivalent of five saved.
+        one_pass = (jeng.dt == torch.bfloat16 and jeng.mlp_e == eng.mlp_e and os.environ.get("SWIFTK_SCM_ONE_PASS", "1") != "0")
+        self.last_one_pass = one_pass
+        with torch.no_grad():
+            if one_pass:
+                dF, Fx, lv, ctx = jeng.jvp(srcs, vx, t, cs, aux, save_ctx=True, want_logvar=want_lv)
+            else:
+                dF = jeng.jvp(srcs, vx, t, cs, aux)
+        if not one_pass:
+            res = eng.forward(srcs, [1.0] * len(srcs), t, aux, want_logvar=want_lv)
+            Fx, lv, ctx = res if want_lv else (res[0], None, res[1])
         r = min(1.0, step / (self.tangent_warmup_kimg * 1000)) if self.tangent_warmup_kimg > 0 else 1.0
         target = torch.empty_like(Fx)
         ss = torch.empty(B, device=dev)

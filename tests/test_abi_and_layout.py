@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(h, n), f"{n} declared in include/swiftk.h but not exported by libswiftk.so"
     assert set(names) == set(_lib.EXPORTS), set(names) ^ set(_lib.EXPORTS)
-    assert _lib.lib().swiftk_version() == 2
+    assert _lib.lib().swiftk_version() == 3
     assert _lib.lib().swiftk_gemm_k_pad(_lib.BF16, 1056) == 1088 and _lib.lib().swiftk_gemm_k_pad(_lib.F32, 1056) == 1056
 
 

@@ -466,6 +466,11 @@ def test_scm_loss_and_grads_vs_oracle(dev):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         lb = L(ddp, x.to(dev), 1200, condition=cond.to(dev), auxiliary=aux.to(dev), _tau=tau.to(dev), _z=z.to(dev))
     assert float(lb) == pytest.approx(float(ref), rel=5e-2)
+    # ... and that pass is ALSO the forward pass of the backward (one network pass instead of the reference's two): its
+    # primal rows, kept per layer, give the same parameter gradients
+    ddp.zero_grad_flat()
+    lb.backward()
+    print(f"sCM one-pass (bf16 tangent rows = saved activations): loss {float(lb):.6f}; worst grad cosine {_grad_report(net, st, 0.999):.4f}")
 
 
 def test_muon_with_aux_adam_vs_reference_golden(dev):

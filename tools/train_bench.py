@@ -74,14 +74,19 @@ print("host issue time per iteration (ms):", " ".join(f"{h:.0f}" for h in host_m
 PEAK = 2.5e15  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 fused = bool(getattr(tr, "_fused", None))
 if a.loss == "scm":
-    # tangent pass = every GEMM on 2M rows (2 fwd) + forward-with-activations (1) + backward (2)
-    fl = 5 * a.batch * 2.7535e12 * a.depth / 12
+    # tangent pass = every GEMM on 2M rows (2 fwd) + backward (2); the reference's schedule adds a grad-enabled forward (1), which
+    # the one-pass form does not execute (the tangent pass's primal rows are the saved activations)
+    one_pass = bool(getattr(loss_fn, "last_one_pass", False))
+    fwd_eq = 4 if one_pass else 5
+    fl = fwd_eq * a.batch * 2.7535e12 * a.depth / 12
     print(json.dumps({"metric": "sCM pre-training iteration (Swift-B, local batch %d, optimizer %s)" % (a.batch, a.opt), "value": dt, "unit": "s/iteration",
-                      "samples_per_s": a.batch / dt, "flop_per_iteration": fl, "what": "~5 forward-equivalents per sample (tangent pass 2, forward 1, backward 2)",
+                      "samples_per_s": a.batch / dt, "flop_per_iteration": fl,
+                      "what": f"~{fwd_eq} forward-equivalents executed per sample (tangent pass 2, backward 2" + ("" if one_pass else ", forward 1") +
+                              "; the reference's schedule: 5)", "one_pass": one_pass,
                       "roofline": {"bound": "mfma", "achieved": fl / dt / 1e12, "peak": PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / dt / PEAK, "traffic": None},
                       "fused_optimizer_step": fused, "peak_mem_gib": torch.cuda.max_memory_allocated() / 2**30}))
     print(f"sCM pre-training: batch {a.batch}, depth {a.depth}: {dt:.3f} s/iteration, loss {float(loss):.4f}; "
-          f"{a.batch / dt:.2f} samples/s; ~5 fwd-equivalents -> {(5 * a.batch * 2.7535e12 * a.depth / 12) / dt / 1e12:.0f} TFLOP/s; "
+          f"{a.batch / dt:.2f} samples/s; ~{fwd_eq} fwd-equivalents -> {fl / dt / 1e12:.0f} TFLOP/s; "
           f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sys.exit(0)
 evals = 2 * a.steps
