@@ -210,7 +210,11 @@ class SCMLoss(_LossBase):
         # The reference runs the network twice here: torch.func.jvp for the tangent, then a grad-enabled forward
         # (loss.py:212-237).  The tangent pass's primal rows are that forward: with bf16 activations (the trainer's
         # autocast) they are kept per layer and handed to the backward pass -- one forward-equivalent of five saved.
-        one_pass = (jeng.dt == torch.bfloat16 and jeng.mlp_e == eng.mlp_e and os.environ.get("SWIFTK_SCM_ONE_PASS", "1") != "0")
+        # (the kept buffers hold tangent rows too: 2 x the activations of a forward, 110 GiB peak at local batch 8 -- taken
+        # when 4.4 activation sets fit into 75 % of the device, i.e. up to local batch 15 on 288 GB)
+        fits = 4.4 * eng.activation_bytes(B) <= 0.75 * torch.cuda.get_device_properties(dev).total_memory
+        one_pass = (jeng.dt == torch.bfloat16 and jeng.mlp_e == eng.mlp_e and
+                    os.environ.get("SWIFTK_SCM_ONE_PASS", "1" if fits else "0") != "0")
         self.last_one_pass = one_pass
         with torch.no_grad():
             if one_pass:

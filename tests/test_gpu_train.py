@@ -5,6 +5,7 @@ gradients are compared with fp32 autograd at bf16-level tolerances: per kernel o
 (1-2e-2 relative L2, layout bugs give O(1)), and end to end by cosine similarity and relative L2 per parameter.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -534,6 +535,48 @@ def test_trainer_steps_ema_and_checkpoint(dev, tmp_path, monkeypatch):
     tr._save_checkpoint(3000)
     state = torch.load(tmp_path / "checkpoints" / "checkpoint-000003.pt", weights_only=True)
     assert set(state) == {"ema", "net", "optimizer", "scaler"} and len(state["ema"]) == len(net.state_dict())
+
+
+@pytest.mark.parametrize("kind", ["crps", "scm"])
+def test_training_loop_with_graph_replay_tracks_the_eager_loop(dev, tmp_path, monkeypatch, kind):
+    """Six optimiser steps with the launch sequences replayed as HIP graphs (steps 3+ are pure replays, with weight updates,
+    resident rollout activations / the one-pass sCM buffers in between) against the same six steps issued eagerly: the
+    loss trajectories agree to the noise of the fp32 atomics amplified by Adam (a stale buffer or a mis-replayed sequence
+    shows up as a diverging or non-finite loss by step 3)."""
+    from swift_amd.training.loss import CRPSLoss, SCMLoss
+    from swift_amd.training.trainer import Trainer
+    from swift_amd.train import adamw_param_groups
+    from swift_amd.utils.detinit import det_normal
+    monkeypatch.chdir(tmp_path)
+
+    def run(graph_mode):
+        monkeypatch.setenv("SWIFTK_TRAIN_GRAPHS", graph_mode)
+        net, _, _ = _build_pair(dev, 35, logvar=(kind == "scm"))
+        net.train().requires_grad_(True)
+        ds = _dataset(35)
+        opt = torch.optim.AdamW(adamw_param_groups(net, 1e-5), lr=1e-4, betas=(0.9, 0.95), eps=1e-6)
+        loss_fn = (CRPSLoss(ds, 1.0, 2, 1.0) if kind == "crps" else
+                   SCMLoss(ds, dict(dist="loguniform", sigma_min=0.02, sigma_max=200.0), 1.0, tangent_warmup_kimg=1)).to(dev)
+        tr = Trainer(net, opt, loss_fn, total_kimg=1, ema_halflife_kimg=1, ema_rampup_ratio=0.05, lr_rampup_kimg=0,
+                     lr_min_factor=1.0, kimg_per_tick=1, checkpoint_ticks=None, device=dev)
+        tr.global_batch_size = 2
+        x = det_normal((2, 72, 64, 64), 35, "c").to(dev)
+        t = (0.5 * det_normal((2, 69, 64, 64), 35, "t")).to(dev)
+        delta, idx = torch.tensor([0.6, 0.6]), [0, 3]
+        out = []
+        for k in range(6):
+            torch.manual_seed(100 + k)  # same noise draws in both runs
+            out.append(float(tr.train_step(x, t, idx, delta, global_nimg=2 * (k + 1), steps=2)))
+        return out
+
+    eager, replay = run("0"), run("1")
+    if os.environ.get("SWIFTK_TEST_NOISE_FLOOR"):  # how far do two EAGER runs drift apart (fp32 atomics through Adam)?
+        print(kind, "eager2", [f"{v:.5f}" for v in run("0")])
+    print(kind, "eager ", [f"{v:.5f}" for v in eager])
+    print(kind, "replay", [f"{v:.5f}" for v in replay])
+    assert all(math.isfinite(v) for v in eager + replay)
+    for a, b in zip(eager, replay):
+        assert b == pytest.approx(a, rel=2e-2, abs=2e-2)
 
 
 def test_trainer_step_fused_kernel_vs_reference_golden(dev):

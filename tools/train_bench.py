@@ -45,8 +45,20 @@ g = torch.Generator(device=dev).manual_seed(0)
 x = torch.randn(a.batch, 72, 128, 256, generator=g, device=dev)
 t = 0.3 * torch.randn(a.batch, 69, 128, 256, generator=g, device=dev)
 delta, idx = torch.full((a.batch,), 0.6).pin_memory(), list(range(a.batch))  # host side, as Trainer._get_batch hands them over
+losses = []
+def nan_report(tag):  # SWIFTK_NAN_DEBUG=1: where does a non-finite value first appear?
+    if not os.environ.get("SWIFTK_NAN_DEBUG"):
+        return
+    torch.cuda.synchronize()
+    bad_p = [n for n, p in net.named_parameters() if not torch.isfinite(p).all()]
+    bad_g = [n for n, p in net.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+    print(f"[nan-debug] {tag}: loss {float(loss):.4f}; non-finite params {len(bad_p)} {bad_p[:3]}; non-finite grads {len(bad_g)} {bad_g[:3]}", file=sys.stderr)
+
+
 for _ in range(3):  # warm-up: operand prep and allocator, then the HIP-graph capture of every launch sequence, then one replay
     loss = tr.train_step(x, t, idx, delta, 1000, steps=a.steps)
+    losses.append(loss)
+    nan_report(f"warm-up {_}")
 torch.cuda.synchronize()
 if os.environ.get("SWIFTK_SYNC_DEBUG"):  # list every call that makes the host wait for the GPU inside the timed iterations
     import collections, traceback, warnings
@@ -64,6 +76,7 @@ for k in range(a.iters):
     h0 = time.perf_counter()
     loss = tr.train_step(x, t, idx, delta, 1000 * (k + 2), steps=a.steps)
     host_ms.append(1e3 * (time.perf_counter() - h0))  # time the host needs to ISSUE an iteration (it may run ahead of the GPU)
+    losses.append(loss)
 if os.environ.get("SWIFTK_SYNC_DEBUG"):
     torch.cuda.set_sync_debug_mode(0)
     for site, n in sync_sites.most_common(40):
@@ -71,6 +84,7 @@ if os.environ.get("SWIFTK_SYNC_DEBUG"):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
 print("host issue time per iteration (ms):", " ".join(f"{h:.0f}" for h in host_ms), file=sys.stderr)
+print("loss per iteration (warm-up included):", " ".join(f"{float(l):.4f}" for l in losses), file=sys.stderr)
 PEAK = 2.5e15  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 fused = bool(getattr(tr, "_fused", None))
 if a.loss == "scm":
