@@ -374,10 +374,34 @@ def main():
         if world == 1 and not a.no_extras and a.cpu_steps > 0:
             line["cpu_baseline"] = cpu_baseline(state, a.cpu_steps)
             line["vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+        if world == 1 and not a.no_extras and a.solver == "scm" and nsteps == 1:
+            line["training"] = training_leg()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def training_leg():
+    """The training step that produces the forecast path's weights, measured by
+    tools/train_bench.py in child processes (fresh allocator; they plan their resident activations around what this
+    process still holds): one multistep-CRPS finetune iteration (BASELINE configs[4] per GPU) and one sCM pre-training
+    iteration, Swift-B, local batch 8.  A reported extra, not the metric; a failure is recorded, not raised."""
+    import subprocess
+
+    import torch
+
+    torch.cuda.empty_cache()
+    out = {}
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "train_bench.py")
+    for name, args in (("crps_finetune_steps4", ["--loss", "crps", "--iters", "3"]), ("scm_pretrain", ["--loss", "scm", "--iters", "3"])):
+        try:
+            p = subprocess.run([sys.executable, tool] + args, capture_output=True, text=True, timeout=600)
+            rec = json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{")))
+            out[name] = {k: rec[k] for k in ("metric", "value", "unit", "samples_per_s", "what", "roofline", "peak_mem_gib") if k in rec}
+        except Exception as e:  # noqa: BLE001 -- the forecast metric above must still be printed
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
 
 
 def parity_engine_leg(net, ds, dev, lib, X0, forc, units, nb: int = 8, steps: int = 4):

@@ -83,6 +83,14 @@ def _engine(net) -> SwinTrainEngine:
     return eng
 
 
+def _memory_budget(dev) -> float:
+    """Bytes this process may plan with: 75 % of the device, less what OTHER processes hold on it right now (a second rank
+    sharing the GPU in a test, the parent of a benchmark child)."""
+    free, total = torch.cuda.mem_get_info(dev)
+    others = max(0, total - free - torch.cuda.memory_reserved(dev))
+    return 0.75 * total - others
+
+
 class _LossBase(torch.nn.Module):
     def __init__(self, dataset, sigma_data: float):
         super().__init__()
@@ -212,7 +220,7 @@ class SCMLoss(_LossBase):
         # autocast) they are kept per layer and handed to the backward pass -- one forward-equivalent of five saved.
         # (the kept buffers hold tangent rows too: 2 x the activations of a forward, 110 GiB peak at local batch 8 -- taken
         # when 4.4 activation sets fit into 75 % of the device, i.e. up to local batch 15 on 288 GB)
-        fits = 4.4 * eng.activation_bytes(B) <= 0.75 * torch.cuda.get_device_properties(dev).total_memory
+        fits = 4.4 * eng.activation_bytes(B) <= _memory_budget(dev)
         one_pass = (jeng.dt == torch.bfloat16 and jeng.mlp_e == eng.mlp_e and
                     os.environ.get("SWIFTK_SCM_ONE_PASS", "1" if fits else "0") != "0")
         self.last_one_pass = one_pass
@@ -268,8 +276,7 @@ class CRPSLoss(_LossBase):
         env = os.environ.get("SWIFTK_CRPS_KEEP")
         if env is not None:
             return max(0, min(calls, int(env)))
-        total = torch.cuda.get_device_properties(dev).total_memory
-        return max(0, min(calls, int(0.75 * total / max(1, eng.activation_bytes(B)) - 2.2)))
+        return max(0, min(calls, int(_memory_budget(dev) / max(1, eng.activation_bytes(B)) - 2.2)))
 
     def _forcings(self, idx, aux_host, i, dev):
         f = torch.stack([self.dataset.get_forcings(int(j) + int(i * float(dt) * 10 // 6)) for j, dt in zip(idx, aux_host)], 0)

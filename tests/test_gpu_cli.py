@@ -153,6 +153,11 @@ def test_bench_contract_line(tmp_path):
     pe, dr = d["parity_engine"], d["bf16_vs_fp32"]
     assert pe["dtype"] == "f32" and 0.3 < pe["frac_of_fp32_matrix_peak"] < 1.0 and 0.2 < pe["attention_mfma_frac"] < 1.0
     assert 0 < dr["rel_l2_after_1_steps"] < dr["rel_l2_after_60_steps"] < 1.0
+    # the training step behind the path's weights, measured in child processes (reported extra)
+    for leg, lo, hi in (("crps_finetune_steps4", 0.4, 2.0), ("scm_pretrain", 0.05, 0.5)):
+        t = d["training"][leg]
+        assert "error" not in t, t
+        assert t["unit"] == "s/iteration" and lo < t["value"] < hi and 0.1 < t["roofline"]["frac"] < 0.6
     # N ranks asked for, one GPU here: the launcher refuses before touching the device; a mismatching process group exits 3
     p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=str(tmp_path), env=e,
                         capture_output=True, text=True, timeout=300)
