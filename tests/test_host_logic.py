@@ -421,3 +421,29 @@ def test_bench_launcher_contract_without_gpu():
     assert p.returncode == 3 and "process group has 1 rank(s)" in p.stderr
     p = subprocess.run([sys.executable, bench, "--batch", "0"], capture_output=True, text=True, env=env, timeout=120)
     assert p.returncode == 2 and "SWIFTK_MAX_UNITS" in p.stderr
+
+
+def test_index_streams_vs_reference_golden():
+    """``InfiniteSampler`` / ``DeltaBatchSampler`` emit the reference's index stream (data/samplers.py:9-85; fixture made by
+    the reference's own samplers, tools/make_golden.py::fx_index_streams) -- several laps, rank strides, offsets, no-shuffle."""
+    import itertools
+
+    from swift_amd.data.samplers import DeltaBatchSampler, InfiniteSampler
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "index_streams.npz"))
+    for c, (n, rank, world, shuffle, seed, window, offset, count) in enumerate(g["cases"]):
+        s = InfiniteSampler(range(int(n)), rank=int(rank), num_replicas=int(world), shuffle=bool(shuffle), seed=int(seed),
+                            window_size=float(window))
+        if offset > 1:
+            s.set_offset(int(offset))
+        items = list(itertools.islice(iter(s), int(count)))
+        if offset > 1:
+            assert all(isinstance(i, tuple) and i[1] == int(offset) for i in items)
+            items = [i[0] for i in items]
+        assert np.array_equal(np.array(items, dtype=np.int64), g[f"stream_{c}"]), f"case {c}"
+    s = InfiniteSampler(range(50), rank=1, num_replicas=2, shuffle=True, seed=3)
+    s.set_offset(3)
+    got = np.array(list(itertools.islice(iter(DeltaBatchSampler(s, 4, [6, 12, 24], seed=3)), 12)), dtype=np.int64)
+    assert np.array_equal(got, g["delta_batches"])
+    # the lap form leans on numpy drawing the same bounded integers one at a time and in bulk
+    a, b = np.random.default_rng(9), np.random.default_rng(9)
+    assert np.array_equal(np.array([a.integers(19) for _ in range(500)]), b.integers(19, size=500))

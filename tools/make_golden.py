@@ -555,7 +555,32 @@ def fx_trainer_tiny():
     save("trainer_tiny", nimgs=np.array(nimgs), **out)
 
 
-ALL = dict(era5_tiny=fx_era5_tiny, swiftb_long=fx_swiftb_long, trainer_tiny=fx_trainer_tiny, metrics_tiny=fx_metrics_tiny, val_tiny=fx_val_tiny, muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
+def fx_index_streams():
+    """Index streams of the reference's data samplers (data/samplers.py:9-85): ``InfiniteSampler`` over several (dataset size,
+    rank, world, seed, window, offset) settings -- more than two laps each, so the carried-over swaps and the rank phase
+    across laps are covered -- and ``DeltaBatchSampler`` batches on top of it."""
+    from swift.data.samplers import DeltaBatchSampler, InfiniteSampler
+    import itertools
+    cases = [  # n, rank, world, shuffle, seed, window, offset, count
+        (37, 0, 1, True, 0, 0.5, 1, 120), (37, 1, 3, True, 5, 0.5, 1, 60), (37, 2, 3, True, 5, 0.5, 4, 60),
+        (64, 3, 8, True, 11, 0.25, 2, 40), (10, 0, 2, False, 0, 0.5, 3, 30), (5, 0, 1, True, 1, 0.2, 1, 25),
+        (101, 7, 8, True, 2024, 1.0, 5, 50)]
+    out = {"cases": np.array(cases, dtype=np.float64)}
+    for c, (n, rank, world, shuffle, seed, window, offset, count) in enumerate(cases):
+        s = InfiniteSampler(range(n), rank=rank, num_replicas=world, shuffle=shuffle, seed=seed, window_size=window)
+        if offset > 1:
+            s.set_offset(offset)
+        items = list(itertools.islice(iter(s), count))
+        out[f"stream_{c}"] = np.array([i[0] if isinstance(i, tuple) else i for i in items], dtype=np.int64)
+        assert all((isinstance(i, tuple) and i[1] == offset) == (offset > 1) for i in items)
+    s = InfiniteSampler(range(50), rank=1, num_replicas=2, shuffle=True, seed=3)
+    s.set_offset(3)
+    b = DeltaBatchSampler(s, 4, [6, 12, 24], seed=3)
+    out["delta_batches"] = np.array(list(itertools.islice(iter(b), 12)), dtype=np.int64)  # [12, 4, (index, offset, delta)]
+    save("index_streams", **out)
+
+
+ALL = dict(index_streams=fx_index_streams, era5_tiny=fx_era5_tiny, swiftb_long=fx_swiftb_long, trainer_tiny=fx_trainer_tiny, metrics_tiny=fx_metrics_tiny, val_tiny=fx_val_tiny, muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
            samplers_tiny=fx_samplers_tiny, rollout_tiny=fx_rollout_tiny, losses_tiny=fx_losses_tiny,
            swiftb_step=fx_swiftb_step, weights_aux=fx_weights_aux)
 
