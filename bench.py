@@ -118,7 +118,7 @@ def wait_ranks(procs) -> int:
     return rc
 
 
-def build_net(dev, rank, world):
+def build_net(dev, rank, grouped):
     import torch
     import torch.distributed as dist
 
@@ -133,7 +133,7 @@ def build_net(dev, rank, world):
                              heads=12, seed=1234)
         net.load_state_dict(state)
     net = net.to(dev).eval()
-    if world > 1:  # weights travel once over RCCL/xGMI (north_star: broadcast for weights)
+    if grouped:  # weights travel once over RCCL/xGMI (north_star: broadcast for weights)
         for p in net.parameters():
             dist.broadcast(p.data, src=0)
     return net, state
@@ -191,8 +191,18 @@ def main():
     from swift_amd.data.era5 import SyntheticERA5Dataset
     from swift_amd.rollout import RolloutEngine, unit_seed
 
-    rank = sdist.setup_torch()
-    world = dist.get_world_size() if dist.is_initialized() else 1
+    # A process group is created for ONE rank too: the N = 1 run pushes the same collectives (weight broadcast, per-step
+    # checksum all-gather, barriers, the max-over-ranks of the timing) through a one-rank RCCL communicator instead of
+    # skipping them.  SWIFTK_SINGLE_RANK_GROUP=0 turns that off; an RCCL that cannot initialise is recorded, not fatal, at N = 1.
+    rccl_error = None
+    try:
+        rank = sdist.setup_torch(single_rank_group=os.environ.get("SWIFTK_SINGLE_RANK_GROUP", "1") != "0")
+    except Exception as e:  # noqa: BLE001
+        if sdist.get_world_size() > 1:
+            raise
+        rank, rccl_error = 0, f"{type(e).__name__}: {e}"[:300]
+    grouped = sdist.collectives_active()
+    world = dist.get_world_size() if grouped else 1
     if world != a.gpus:
         print(f"bench.py: --gpus {a.gpus} but the process group has {world} rank(s) (WORLD_SIZE={os.environ.get('WORLD_SIZE')})",
               file=sys.stderr)
@@ -206,19 +216,21 @@ def main():
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     B, K, W = a.batch, a.steps, a.warmup
 
-    net, state = build_net(dev, rank, world)
+    net, state = build_net(dev, rank, grouped)
     ds = SyntheticERA5Dataset([f"v{i}" for i in range(NV)], [f"f{i}" for i in range(NF)], img_resolution=IMG, length=64,
                               seed=1234)
     nsteps = a.num_steps or {"scm": 1, "2s": 20, "dpm": 8}[a.solver]
     evals = {"scm": nsteps, "2s": 2 * nsteps - 1, "dpm": nsteps}[a.solver]  # network evaluations per sample-step
     eng = RolloutEngine(net, ds, interval=6, solver=a.solver, denoise_dtype=dtype, num_steps=nsteps)
-    rccl = {"world": world, "backend": dist.get_backend() if world > 1 else None,
-            "version": (".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None) if world > 1 else None,
-            "collectives": "weight broadcast, per-step all-gather of per-unit fp64 checksums, barriers" if world > 1 else None}
+    rccl = {"world": world, "backend": dist.get_backend() if grouped else None,
+            "version": (".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None) if grouped else None,
+            "collectives": "weight broadcast, per-step all-gather of per-unit fp64 checksums, barriers, all-reduce(MAX) of the timing" if grouped else None}
+    if rccl_error:
+        rccl["error"] = rccl_error
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -226,7 +238,7 @@ def main():
         line = rollout_mode(a, eng, dev, rank, world, B, dtype, rccl, sync)
         if rank == 0:
             print(json.dumps(line), flush=True)
-        if world > 1:
+        if grouped:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -247,7 +259,7 @@ def main():
     def collect():
         """Output collection of one step: per-unit checksums of the physical state, gathered from every rank."""
         ops.unit_checksum(phys, out=ck)
-        if world > 1:
+        if grouped:
             dist.all_gather_into_tensor(ck_all, ck)
         else:
             ck_all.copy_(ck)
@@ -300,7 +312,7 @@ def main():
         lib.swiftk_profile_gemm(-1, 0)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -377,7 +389,7 @@ def main():
         if world == 1 and not a.no_extras and a.solver == "scm" and nsteps == 1:
             line["training"] = training_leg()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -517,7 +529,7 @@ def rollout_mode(a, eng, dev, rank, world, B, dtype, rccl, sync):
         X, F = staged[0] if bi == 0 else batch_inputs(units)
         final = eng.run(X, F, steps, seeds=[unit_seed(m, ic) for ic, m in units], keep_trajectory=False)
         ck_sum += ops.unit_checksum(final).sum()
-    if world > 1:
+    if sdist.collectives_active():
         gathered = torch.zeros(world, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(gathered, ck_sum)
     else:
@@ -525,7 +537,7 @@ def rollout_mode(a, eng, dev, rank, world, B, dtype, rccl, sync):
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sdist.collectives_active():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     total = n_units * steps

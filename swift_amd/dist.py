@@ -41,26 +41,46 @@ def get_torch_device(as_torch_device: bool = True):
     return d if as_torch_device else d.type
 
 
-def setup_torch(backend: Optional[str] = None, timeout_s: int = 1800) -> int:
+def collectives_active() -> bool:
+    """True when a process group exists: the collectives of the data path (weight broadcast, output all-gather, gradient
+    all-reduce, barriers) then run through it -- also in a group of ONE rank (``setup_torch(single_rank_group=True)``),
+    which is how the RCCL calls of the N-rank job are exercised on a single GPU."""
+    return dist.is_available() and dist.is_initialized()
+
+
+def setup_torch(backend: Optional[str] = None, timeout_s: int = 1800, single_rank_group: Optional[bool] = None) -> int:
     """``ezpz.setup_torch`` equivalent: init the default process group when launched with >1 rank.
 
     ``backend`` accepts the reference's config values ("ddp", system/ampere.yaml:3): on a GPU it
     means RCCL (``nccl`` in torch), on CPU ``gloo``.
+
+    ``single_rank_group`` (default: env ``SWIFTK_SINGLE_RANK_GROUP``): also create the group when the job has one rank, so the
+    same collectives run (through a one-rank RCCL communicator) instead of being skipped; rendezvous is an in-process
+    ``HashStore`` unless the launcher provided MASTER_ADDR / MASTER_PORT.
     """
     world = get_world_size()
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         torch.cuda.set_device(get_local_rank() % torch.cuda.device_count())
-    if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+    if single_rank_group is None:
+        single_rank_group = os.environ.get("SWIFTK_SINGLE_RANK_GROUP", "0") not in ("", "0")
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         be = "nccl" if use_cuda else "gloo"
         if backend in ("gloo", "nccl"):
             be = backend
         be = os.environ.get("SWIFTK_DIST_BACKEND", be)  # tests: N ranks sharing one GPU run their collectives over gloo
         import datetime
-        dist.init_process_group(be, rank=_env_int("RANK"), world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+        kw = dict(rank=_env_int("RANK", "PMI_RANK", "OMPI_COMM_WORLD_RANK"), world_size=world,
+                  timeout=datetime.timedelta(seconds=timeout_s))
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            kw["store"] = dist.HashStore()
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+        if be == "nccl":
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())  # eager communicator: init errors surface here
+        dist.init_process_group(be, **kw)
     return get_rank()
 
 

@@ -224,7 +224,7 @@ def collect_metrics(metric_sums, n_ic, steps, nv, members, dataset, interval, de
     local = torch.zeros(n_ic, steps, nv, 4, dtype=torch.float64)
     for ic, v in metric_sums.items():
         local[ic] = v
-    if tdist.is_available() and tdist.is_initialized() and dist.get_world_size() > 1:
+    if dist.collectives_active():
         on_gpu = torch.device(device).type == "cuda"
         buf = local.to(device) if on_gpu else local
         parts = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
@@ -292,7 +292,7 @@ def main(args):
                                          patch_size=m.patch_size, depth=m.depth, dim=m.dim, heads=m.heads,
                                          auxiliary_dim=m.auxiliary_dim, logvar=m.logvar_embed is not None, seed=cfg.seed))
     net = net.to(device).eval()
-    if dist.get_world_size() > 1:  # one-time weight broadcast over RCCL / xGMI
+    if dist.collectives_active():  # one-time weight broadcast over RCCL / xGMI
         for p in net.parameters():
             tdist.broadcast(p.data, src=0)
 

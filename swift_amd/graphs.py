@@ -5,9 +5,16 @@ A training iteration issues ~1000 kernels whose order, shapes and buffers never 
 Swift-B: 0.19 s of kernels per iteration).  ``GraphCache.call(key, fn, inputs)`` runs ``fn`` eagerly the first time a
 key is seen (that run is the warm-up: its side effects -- gradient accumulation -- are real), captures it into a HIP
 graph the second time, and from then on copies the inputs into the capture's static tensors and replays.  Everything
-``fn`` allocates while being captured lives in the cache's private memory pool, so the tensors it returned (activations)
+``fn`` allocates while being captured lives in a private memory pool, so the tensors it returned (activations)
 stay valid until the next replay of the same key overwrites them: callers consume them before calling the key again,
 which is the order the losses use (forward -> backward, one rollout step at a time).
+
+Pools: a capture may place its tensors -- its live OUTPUTS included -- in blocks that an earlier capture of the same
+pool used for temporaries, which is only safe when the graphs replay in capture order.  The losses do not guarantee that
+(kept rollout slots are numbered from the end, so a longer rollout captures new slots late and replays them early), so
+every key owns its pool -- except keys the caller declares ``transient``: their outputs are consumed before any other
+sequence of this cache runs (backward passes: input gradients are copied or accumulated at once), so they share one pool
+and with it their temporaries (several GB per backward pass at Swift-B).
 
 Requirements on ``fn``: no host synchronisation, no Python-side dependence on tensor VALUES, every scalar kernel argument
 constant for the key, and every buffer it reads besides ``inputs`` at a fixed address (the engines keep their operand
@@ -29,14 +36,16 @@ class GraphCache:
     def __init__(self):
         self._seen: Dict[tuple, int] = {}
         self._graphs: Dict[tuple, tuple] = {}
-        self._pool = None
+        self._transient_pool = None
+        self.generation: Dict[tuple, int] = {}  # captures of a key so far: consumers of a key's output tensors (a backward
+        #                                         sequence captured over a forward's activations) key themselves on it
 
     def invalidate(self) -> None:
         """Drop every captured sequence (a buffer they address was re-allocated); the next call of a key captures anew."""
         self._graphs.clear()
-        self._pool = None  # the private pool dies with its last graph; a stale handle fails capture_begin
+        self._transient_pool = None  # a pool dies with its last graph; a stale handle fails capture_begin
 
-    def call(self, key: tuple, fn: Callable, inputs: Sequence[torch.Tensor]):
+    def call(self, key: tuple, fn: Callable, inputs: Sequence[torch.Tensor], transient: bool = False):
         if not enabled() or torch.cuda.is_current_stream_capturing():
             return fn(*inputs)
         ent = self._graphs.get(key)
@@ -48,11 +57,16 @@ class GraphCache:
             static_in = [x.clone() for x in inputs]
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            if self._pool is None:
-                self._pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(graph, pool=self._pool):
+            if transient:
+                if self._transient_pool is None:
+                    self._transient_pool = torch.cuda.graph_pool_handle()
+                pool = self._transient_pool
+            else:
+                pool = torch.cuda.graph_pool_handle()  # outputs outlive other keys' replays: a pool of its own
+            with torch.cuda.graph(graph, pool=pool):
                 out = fn(*static_in)
             ent = self._graphs[key] = (graph, static_in, out)
+            self.generation[key] = self.generation.get(key, 0) + 1
         graph, static_in, out = ent
         for s, x in zip(static_in, inputs):
             if s.data_ptr() != x.data_ptr():

@@ -55,6 +55,11 @@ class SwinJvpEngine:
         stamp = tuple((p.data_ptr(), p._version) for p in m.parameters())
         if stamp == self._stamp:
             return
+        ptrs = tuple(p.data_ptr() for p in m.parameters())  # captured sequences read some parameters in place
+        if ptrs != getattr(self, "_ptrs", None):
+            if getattr(self, "_ptrs", None) is not None:
+                self.graphs.invalidate()
+            self._ptrs = ptrs
         d, mlp = m.dim, m.mlp_dim
         mlp_e = self.mlp_e = mlp + (mlp & 1)  # odd MLP widths (dim 1280 -> 3413): one zero (gate, up) row pair, as in SwinEngine
         self.kd, self.kmlp = ops.k_pad(dt, d), ops.k_pad(dt, mlp_e)
@@ -126,7 +131,7 @@ class SwinJvpEngine:
         fn = lambda *a: self._jvp(list(a[:n]), a[n], a[n + 1], a[n + 2], a[n + 3] if aux is not None else None, save_ctx, want_logvar)
         res = self.graphs.call(key, fn, ins)
         if save_ctx:
-            res[3]["graph_key"] = key
+            res[3]["graph_key"] = (key, max(1, self.graphs.generation.get(key, 0)))  # eager runs before the first capture count as generation 1
         return res
 
     def _jvp(self, srcs: Sequence[torch.Tensor], dsrc0: torch.Tensor, t: torch.Tensor, dt_: torch.Tensor,

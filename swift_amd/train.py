@@ -165,7 +165,7 @@ def main(overrides=None):
                       img_channels=dataset.n_target_channels, condition_channels=dataset.n_condition_channels,
                       _recursive_=False, _convert_="object")
     net.train().requires_grad_(True).to(device)
-    if dist.get_world_size() > 1:  # identical initial weights on every rank (DDP's initial broadcast)
+    if dist.collectives_active():  # identical initial weights on every rank (DDP's initial broadcast)
         for p in net.parameters():
             tdist.broadcast(p.data, src=0)
 

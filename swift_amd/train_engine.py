@@ -81,6 +81,7 @@ class SwinTrainEngine:
         stamp = tuple((p.data_ptr(), p._version) for p in m.parameters())
         if stamp == self._stamp:
             return
+        self._check_addresses()
         d, mlp = m.dim, m.mlp_dim
         # int(8/3 dim) need not be a multiple of 4 (dim 1280 -> 3413): zero (gate, up) rows of w1 / zero columns of w2 bring
         # the MLP width to the GEMMs' granularity (N % 4, split-K rows % 8); silu(0) * 0 = 0 feeds w2's zero columns
@@ -166,6 +167,16 @@ class SwinTrainEngine:
         check(lib().swiftk_reduce_slabs(self._slabs.data_ptr(), cols, rows * cols, ks, out_grad.data_ptr(), out_grad.stride(0),
                                         rows, cols, int(accumulate), _s()), "swiftk_reduce_slabs")
 
+    def _check_addresses(self):
+        """Captured sequences bake in the addresses of the parameters and of their gradient buffers.  When any of them
+        moved (``zero_grad(set_to_none=True)``, ``GradAllReduce.flatten_grads()`` re-pointing ``.grad`` into its flat
+        buffer, ``net.to(...)``, a re-assigned parameter) every capture is stale: drop them, the next calls capture anew."""
+        ptrs = tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr()) for p in self.m.parameters())
+        if ptrs != getattr(self, "_ptrs", None):
+            if getattr(self, "_ptrs", None) is not None:
+                self.graphs.invalidate()
+            self._ptrs = ptrs
+
     @staticmethod
     def _grad_buf(p):
         if p.grad is None:
@@ -194,7 +205,7 @@ class SwinTrainEngine:
         n = len(srcs)
         fn = lambda *a: self._forward(list(a[:n]), list(scales), a[n], a[n + 1] if aux is not None else None, want_logvar)
         res = self.graphs.call(key, fn, ins)
-        res[-1]["graph_key"] = key
+        res[-1]["graph_key"] = (key, max(1, self.graphs.generation.get(key, 0)))  # eager runs before the first capture count as generation 1
         return res
 
     def _forward(self, srcs: Sequence[torch.Tensor], scales: Sequence[float], t, aux, want_logvar=False):
@@ -278,17 +289,18 @@ class SwinTrainEngine:
         """See :meth:`_backward`.  Without a ``grads_final`` hook (single process, or not the last pass of the iteration) the
         launch sequence is replayed as a HIP graph; with one it runs eagerly so the per-layer all-reduces can be started
         from Python between the layers."""
-        import torch.distributed as tdist
-        if grads_final is not None and not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1):
-            grads_final = None  # nothing to reduce in one process
+        from .dist import collectives_active
+        if grads_final is not None and not collectives_active():
+            grads_final = None  # no process group: nothing to reduce
         if grads_final is not None:
             return self._backward(ctx, dout, dlogvar, need_input_grad, grads_final)
         for p in self.m.parameters():  # gradient buffers must exist (fixed addresses) before anything is captured
             self._grad_buf(p)
+        self._check_addresses()
         ins = [dout.contiguous().float()] + ([dlogvar.contiguous().float()] if dlogvar is not None else [])
         key = ("bwd", ctx.get("graph_key"), dlogvar is not None, tuple(bool(b) for b in need_input_grad))
         fn = lambda *a: self._backward(ctx, a[0], a[1] if dlogvar is not None else None, need_input_grad, None)
-        return self.graphs.call(key, fn, ins)
+        return self.graphs.call(key, fn, ins, transient=True)  # input gradients are consumed at once by the losses
 
     def _backward(self, ctx, dout: torch.Tensor, dlogvar: Optional[torch.Tensor] = None, need_input_grad: Sequence[bool] = (),
                   grads_final=None):

@@ -91,11 +91,32 @@ def _memory_budget(dev) -> float:
     return 0.75 * total - others
 
 
+def _plan_once(cache: dict, key, decide: Callable[[], int], what: str, dev) -> int:
+    """A memory-planning decision (how many rollout steps keep their activations, one- or two-pass sCM) is taken ONCE per
+    batch signature, at first sight, and reused: the instantaneous free-memory figure it starts from moves between
+    iterations (RCCL buffers, the HIP context), and a decision that flips creates new capture keys mid-run.  Every rank
+    must walk the same path (the per-layer all-reduces pair up across ranks), so with a process group the ranks agree on
+    the minimum."""
+    if key not in cache:
+        v = int(decide())
+        from ..dist import collectives_active
+        if collectives_active():
+            import torch.distributed as tdist
+            tv = torch.tensor([v], dtype=torch.int64, device=dev if tdist.get_backend() == "nccl" else "cpu")
+            tdist.all_reduce(tv, op=tdist.ReduceOp.MIN)
+            v = int(tv.item())
+        cache[key] = v
+        import logging
+        logging.getLogger("swift_amd").info("%s for %s: %d", what, key, v)
+    return cache[key]
+
+
 class _LossBase(torch.nn.Module):
     def __init__(self, dataset, sigma_data: float):
         super().__init__()
         self.dataset = dataset
         self.sigma_data = sigma_data
+        self._plans = {}
         self.register_buffer("w_lat", _calculate_latitude_weights(dataset._shape[1]))
         self.register_buffer("w_var", _calculate_variable_weights(dataset.variables))
 
@@ -220,9 +241,10 @@ class SCMLoss(_LossBase):
         # autocast) they are kept per layer and handed to the backward pass -- one forward-equivalent of five saved.
         # (the kept buffers hold tangent rows too: 2 x the activations of a forward, 110 GiB peak at local batch 8 -- taken
         # when 4.4 activation sets fit into 75 % of the device, i.e. up to local batch 15 on 288 GB)
-        fits = 4.4 * eng.activation_bytes(B) <= _memory_budget(dev)
-        one_pass = (jeng.dt == torch.bfloat16 and jeng.mlp_e == eng.mlp_e and
-                    os.environ.get("SWIFTK_SCM_ONE_PASS", "1" if fits else "0") != "0")
+        env = os.environ.get("SWIFTK_SCM_ONE_PASS")
+        fits = _plan_once(self._plans, ("scm_one_pass", B, env), lambda: int(env != "0") if env is not None else
+                          int(4.4 * eng.activation_bytes(B) <= _memory_budget(dev)), "one-pass sCM", dev)
+        one_pass = bool(jeng.dt == torch.bfloat16 and jeng.mlp_e == eng.mlp_e and fits)
         self.last_one_pass = one_pass
         with torch.no_grad():
             if one_pass:
@@ -311,7 +333,8 @@ class CRPSLoss(_LossBase):
         # recomputes every step in the backward pass (checkpoint_sequential, loss.py:395-437) because activations of 2 x steps
         # network calls do not fit its GPUs; with 288 GB of HBM the LAST `n_keep` calls (in rollout order: the ones pass 2
         # differentiates first) run on the training engine and keep their activations, one buffer set ("slot") each
-        n_keep = self.last_n_keep = self._n_keep(eng, B, E * steps, dev)
+        n_keep = self.last_n_keep = _plan_once(self._plans, ("crps_keep", B, E * steps, os.environ.get("SWIFTK_CRPS_KEEP")),
+                                               lambda: self._n_keep(eng, B, E * steps, dev), "resident rollout steps", dev)
         kept = {}
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             for e in range(E):

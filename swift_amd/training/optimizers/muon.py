@@ -140,7 +140,7 @@ class MuonWithAuxAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        multi = dist.is_available() and dist.is_initialized()  # (a one-rank group broadcasts to itself: same code path)
         world, rank = (dist.get_world_size(), dist.get_rank()) if multi else (1, 0)
         for group in self.param_groups:
             if group["use_muon"]:

@@ -57,6 +57,11 @@ class GradAllReduce(torch.nn.Module):
     def _world():
         return tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1
 
+    @staticmethod
+    def _active():
+        """A process group exists (of any size: a one-rank RCCL group runs the same collectives, averaging over one rank)."""
+        return tdist.is_available() and tdist.is_initialized()
+
     def _reduce(self, t, async_op=False):
         # RCCL averages in the collective; gloo (CPU tests) has no AVG: sum, then scale
         if tdist.get_backend() == "nccl":
@@ -67,7 +72,7 @@ class GradAllReduce(torch.nn.Module):
         """The gradients of ``params`` are final for this iteration: start their all-reduce now (one collective per run of
         neighbouring parameters in the flat buffer), overlapping the rest of the backward pass.  ``sync()`` waits for
         these and reduces whatever was never announced."""
-        if self._world() == 1 or self._flat is None or not params:
+        if not self._active() or self._flat is None or not params:
             return
         flat = self._flat
         spans = sorted(((p.grad.data_ptr() - flat.data_ptr()) // 4, p.numel()) for p in params)
@@ -78,8 +83,12 @@ class GradAllReduce(torch.nn.Module):
             else:
                 runs.append([o, o + n])
         for lo, hi in runs:
-            if any(lo < b and a < hi for a, b in self._ranges):  # never reduce an element twice
-                continue
+            if any(lo < b and a < hi for a, b in self._ranges):
+                # the slice was averaged earlier in this iteration and a later backward pass has added rank-local gradients
+                # on top of it: only the LAST backward pass of an iteration may announce parameters (gradient accumulation
+                # and multi-term losses pass grads_final=None on all passes but the last; zero_grad_flat() starts an iteration)
+                raise RuntimeError("GradAllReduce.reduce_params: parameters announced twice in one iteration "
+                                   "(a backward pass ran after their gradients had been all-reduced)")
             handle, scale = self._reduce(flat[lo:hi], async_op=True)
             self._pending.append((handle, lo, hi, scale))
             self._ranges.append((lo, hi))
@@ -87,7 +96,7 @@ class GradAllReduce(torch.nn.Module):
     def sync(self):
         flat = self.flatten_grads()
         world = self._world()
-        if world > 1:
+        if self._active():
             pending, self._pending = getattr(self, "_pending", []), []
             done = sorted(getattr(self, "_ranges", []))
             self._ranges = []
@@ -166,6 +175,8 @@ class Trainer:
         self.kimg_per_tick, self.checkpoint_ticks = kimg_per_tick, checkpoint_ticks
         self.global_batch_size = None
         self._fused = None  # FusedAdamEMA once the flat gradient buffer exists (False: optimiser not covered)
+        from .profiling import StepProfiler, _NoProfiler
+        self.prof = StepProfiler() if profile else _NoProfiler()  # trainer.py:155-177
 
     # ------------------------------------------------------------------ one iteration
     def _get_batch(self, it):
@@ -207,8 +218,14 @@ class Trainer:
 
     def _backward_step(self, global_nimg: int, loss: torch.Tensor):
         self._set_lr(global_nimg)
-        loss.backward()
-        flat = self.ddp.sync()
+        with self.prof.phase("backward"):
+            loss.backward()
+        with self.prof.phase("allreduce"):
+            flat = self.ddp.sync()
+        with self.prof.phase("optimizer"):
+            self._optimizer_step(global_nimg, flat)
+
+    def _optimizer_step(self, global_nimg: int, flat: torch.Tensor):
         half = self.ema_halflife_kimg * 1000
         if self.ema_rampup_ratio is not None:
             half = min(half, global_nimg * self.ema_rampup_ratio)
@@ -234,8 +251,10 @@ class Trainer:
             kw["step"] = global_nimg
         elif isinstance(self.loss_fn, CRPSLoss):
             kw.update(steps=steps, idx=idx)
-        loss = self._forward_step(x, t, delta, **kw)
+        with self.prof.phase("forward"):
+            loss = self._forward_step(x, t, delta, **kw)
         self._backward_step(global_nimg, loss)
+        self.prof.step()  # trainer.py:389-396
         return loss.detach()
 
     # ------------------------------------------------------------------ validation (trainer.py:249-307)
@@ -291,7 +310,8 @@ class Trainer:
                         it = iter(train_loader)
             else:
                 steps = 1
-            x, t, idx, delta = self._get_batch(it)
+            with self.prof.phase("data"):
+                x, t, idx, delta = self._get_batch(it)
             if self.global_batch_size is None:
                 self.global_batch_size = x.shape[0] * world
             loss = self.train_step(x, t, idx, delta, global_nimg, steps)

@@ -474,6 +474,47 @@ def test_scm_loss_and_grads_vs_oracle(dev):
     print(f"sCM one-pass (bf16 tangent rows = saved activations): loss {float(lb):.6f}; worst grad cosine {_grad_report(net, st, 0.999):.4f}")
 
 
+def test_scm_distillation_loss_and_grads_vs_oracle(dev):
+    """SCMLoss(distillation=True): dx_t/dt from a frozen v-prediction teacher (training/loss.py:204-208; the oracle's
+    ``teacher=`` branch is pinned to the reference by tests/golden/scm_distill_tiny.npz).  The teacher runs on the fp32
+    inference engine here (no autocast) so that the comparison is at the fp32-tangent level; under the trainer's bf16
+    autocast it runs on the bf16 engine like the reference's teacher under its autocast."""
+    from oracle import loss as oloss
+    from swift_amd.training.loss import SCMLoss
+    from swift_amd.training.trainer import GradAllReduce
+    from swift_amd.utils.detinit import det_normal
+    net, onet, st = _build_pair(dev, 43, logvar=True)
+    teacher, oteacher, _ = _build_pair(dev, 53, logvar=False)
+    teacher.eval().requires_grad_(False)
+    ds = _dataset(43)
+    L = SCMLoss(ds, dict(dist="loguniform", sigma_min=0.02, sigma_max=200.0), sigma_data=1.0, tangent_warmup_kimg=3,
+                distillation=True, jvp_dtype="f32").to(dev)
+    B = 2
+    x, cond, z = det_normal((B, 69, 64, 64), 43, "x"), det_normal((B, 72, 64, 64), 43, "c"), det_normal((B, 69, 64, 64), 43, "z")
+    tau, aux = torch.tensor([0.3, 4.0]).view(B, 1, 1, 1), torch.tensor([0.6, 0.6])
+    ddp = GradAllReduce(net)
+    ddp.zero_grad_flat()
+    loss = L(ddp, x.to(dev), 1200, condition=cond.to(dev), auxiliary=aux.to(dev), net_pretrained=teacher, _tau=tau.to(dev),
+             _z=z.to(dev))
+    loss.backward()
+    kw = dict(step=1200, sigma_data=1.0, tangent_warmup_kimg=3, condition=cond, auxiliary=aux, return_logvar=True)
+    ref = oloss.scm_loss(onet, x, tau, z, L.w_var.cpu(), L.w_lat.cpu(), teacher=oteacher, **kw)
+    ref.backward()
+    with torch.no_grad():
+        plain = oloss.scm_loss(onet, x, tau, z, L.w_var.cpu(), L.w_lat.cpu(), **kw)
+    print(f"sCM distillation loss {float(loss):.6f} vs oracle {float(ref):.6f} (without teacher {float(plain):.6f}); "
+          f"worst grad cosine {_grad_report(net, st, 0.999):.4f}")
+    assert float(loss) == pytest.approx(float(ref), rel=1e-3)
+    assert abs(float(plain) - float(ref)) > 10 * abs(float(loss) - float(ref))  # the teacher is what is being tested
+    assert all(p.grad is None for p in teacher.parameters())
+    # the trainer's configuration: bf16 autocast around the loss (teacher on the bf16 engine, bf16 tangent pass)
+    L.jvp_dtype = torch.bfloat16
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lb = L(ddp, x.to(dev), 1200, condition=cond.to(dev), auxiliary=aux.to(dev), net_pretrained=teacher, _tau=tau.to(dev),
+               _z=z.to(dev))
+    assert float(lb) == pytest.approx(float(ref), rel=5e-2)
+
+
 def test_muon_with_aux_adam_vs_reference_golden(dev):
     """swift_amd MuonWithAuxAdam (Newton-Schulz products on swiftk_gemm) against two steps of the reference's
     SingleDeviceMuonWithAuxAdam (tests/golden/muon_tiny.npz).  The orthogonalisation runs in bf16 in both; a different
@@ -508,30 +549,109 @@ def test_muon_with_aux_adam_vs_reference_golden(dev):
     assert e < 3e-2 and float(sv.max()) < 1.7 and float((sv > 0.5).double().mean()) > 0.8  # most of the spectrum pushed to ~1
 
 
-def test_trainer_steps_ema_and_checkpoint(dev, tmp_path, monkeypatch):
+def test_trainer_trajectory_vs_oracle_net_and_oracle_trainer(dev, tmp_path, monkeypatch):
+    """Three optimisation steps of ``Trainer.train_step`` (multistep-CRPS loss, bf16 autocast, fused AdamW + EMA kernel,
+    LR warm-up then cosine) against the CPU oracle, step by step:
+      (a) loss and every parameter gradient vs fp32 autograd of ``oracle.loss.crps_multistep_loss`` on the oracle net
+          holding the trainer's CURRENT weights (trainer.py:189-197);
+      (b) new weights, EMA weights and learning rates vs ``oracle.trainer.OracleTrainerState.step`` (pinned to the reference's
+          ``Trainer._backward_step``, trainer.py:199-247) fed the trainer's own gradients;
+      (c) a free-running oracle trajectory (its own gradients, its own optimiser state): losses stay together and the net
+          displacement of every large tensor points the same way.
+    Then six more steps with ``profile=True`` bookkeeping (trainer.py:155-177) and the checkpoint format."""
+    import json
+    from oracle import loss as oloss
+    from oracle.rollout import Stats
+    from oracle.trainer import OracleTrainerState
     from swift_amd.training.loss import CRPSLoss
     from swift_amd.training.trainer import Trainer
     from swift_amd.train import adamw_param_groups
     from swift_amd.utils.detinit import det_normal
     monkeypatch.chdir(tmp_path)
-    net, _, _ = _build_pair(dev, 33)
+    net, onet, st = _build_pair(dev, 33)
     net.train().requires_grad_(True)
     ds = _dataset(33)
     opt = torch.optim.AdamW(adamw_param_groups(net, 1e-5), lr=2e-4, betas=(0.9, 0.95), eps=1e-6)
     assert len(opt.param_groups[1]["params"]) == 1 + 2 * 2 * 2  # pos_embed + LayerNorm affine of 2 layers x 2 norms
-    tr = Trainer(net, opt, CRPSLoss(ds, 1.0, 2, 1.0).to(dev), total_kimg=1, ema_halflife_kimg=1, ema_rampup_ratio=0.05,
-                 lr_rampup_kimg=0, lr_min_factor=1.0, kimg_per_tick=1, checkpoint_ticks=None, device=dev)
-    tr.global_batch_size = 2
-    x = det_normal((2, 72, 64, 64), 33, "c").to(dev)
-    t = (0.5 * det_normal((2, 69, 64, 64), 33, "t")).to(dev)
-    delta, idx = torch.tensor([0.6, 0.6], device=dev), [0, 3]
-    p0 = net.model.head.head[0].weight.detach().clone()
-    e0 = tr.ema.model.head.head[0].weight.detach().clone()
-    torch.manual_seed(0)
-    losses = [float(tr.train_step(x, t, idx, delta, global_nimg=2 * (k + 1), steps=1)) for k in range(6)]
-    print("CRPS finetune losses:", [f"{v:.4f}" for v in losses])
-    assert all(math.isfinite(v) for v in losses) and min(losses[3:]) < losses[0]
-    assert not torch.equal(p0, net.model.head.head[0].weight) and not torch.equal(e0, tr.ema.model.head.head[0].weight)
+    B, E, nsteps = 2, 2, 9
+    lats = [[[det_normal((B, 69, 64, 64), 33, f"l{k}{e}")] for e in range(E)] for k in range(nsteps)]
+
+    class FixedNoiseCRPS(CRPSLoss):  # the k-th call draws the k-th prepared latents (the oracle gets the same ones)
+        calls = 0
+
+        def forward(self, *a, **kw):
+            kw["_latents"] = lats[self.calls]
+            self.calls += 1
+            return super().forward(*a, **kw)
+
+    sched = dict(lr_rampup_kimg=0.004, lr_min_factor=0.1, lr_cosine_anneal=True, total_kimg=0.03)
+    tr = Trainer(net, opt, FixedNoiseCRPS(ds, 1.0, E, 0.95).to(dev), ema_halflife_kimg=1, ema_rampup_ratio=0.05, kimg_per_tick=1,
+                 checkpoint_ticks=None, device=dev, profile=True, **sched)
+    tr.global_batch_size = B
+    x = det_normal((B, 72, 64, 64), 33, "c").to(dev)
+    t = (0.5 * det_normal((B, 69, 64, 64), 33, "t")).to(dev)
+    delta, idx = torch.tensor([0.6, 0.6]), [0, 3]
+    names = [n for n, _ in net.named_parameters()]
+    group_of = [1 if ("pos_embed" in n or ("norm" in n and "modulation" not in n)) else 0 for n in names]
+    mk_state = lambda: OracleTrainerState([p.detach().cpu() for p in net.parameters()], [p.detach().cpu() for p in tr.ema.parameters()],
+                                          group_of, base_lr=[2e-4, 2e-4], weight_decay=[1e-5, 0.0], betas=(0.9, 0.95), eps=1e-6)
+    fed, free = mk_state(), mk_state()          # (b): fed the trainer's gradients; (c): free-running
+    p_start = [p.detach().cpu().clone() for p in net.parameters()]
+    stats = Stats(ds.x_means, ds.x_stds, {6: ds.t_stds[6]}, n_vars=69, n_forc=3)
+    forc = lambda i: torch.stack([ds.get_forcings(j + i) for j in idx], 0)
+    w_var, w_lat = tr.loss_fn.w_var.cpu(), tr.loss_fn.w_lat.cpu()
+    tkw = dict(global_batch_size=B, ema_halflife_kimg=1, ema_rampup_ratio=0.05, **sched)
+
+    def oracle_loss_and_grads(weights, k):
+        with torch.no_grad():
+            for n, w in zip(names, weights):
+                st[n].copy_(w)
+        for v in st.values():
+            v.grad = None
+        val = oloss.crps_multistep_loss(onet, stats, t.cpu(), x.cpu(), delta, forc, lats[k], w_var, w_lat, steps=1, alpha=0.95)
+        val.backward()
+        return float(val), [st[n].grad.clone() for n in names]
+
+    snap = {}
+    inner = tr._optimizer_step
+    tr._optimizer_step = lambda nimg, flat: (snap.__setitem__("g", [p.grad.detach().cpu().clone() for p in net.parameters()]),
+                                             inner(nimg, flat))[1]
+    losses, free_losses = [], []
+    for k in range(3):
+        nimg = B * (k + 1)
+        w_now = [p.detach().cpu().clone() for p in net.parameters()]
+        loss = float(tr.train_step(x, t, idx, delta, global_nimg=nimg, steps=1))
+        # (a) the trainer's loss and gradients at w_now vs the oracle's
+        ref, og = oracle_loss_and_grads(w_now, k)
+        assert loss == pytest.approx(ref, rel=2e-3), k
+        for n, g, r in zip(names, snap["g"], og):
+            cos = float((g.flatten().double() @ r.flatten().double()) / (g.norm().double() * r.norm().double()).clamp_min(1e-30))
+            assert cos > 0.999, (k, n, cos)
+        # (b) the optimisation step itself, on the trainer's gradients
+        lr = fed.step(snap["g"], nimg, **tkw)
+        assert [gr["lr"] for gr in opt.param_groups] == pytest.approx(lr, rel=1e-6)
+        for n, p, e, rp, re in zip(names, net.parameters(), tr.ema.parameters(), fed.p, fed.e):
+            assert rel_l2(p.detach().cpu(), rp) < 1e-5 and rel_l2(e.detach().cpu(), re) < 1e-5, (k, n)
+        # (c) free-running oracle
+        fl, fg = oracle_loss_and_grads(free.p, k)
+        free.step(fg, nimg, **tkw)
+        losses.append(loss)
+        free_losses.append(fl)
+    print("CRPS finetune losses:", [f"{v:.5f}" for v in losses], "free-running oracle:", [f"{v:.5f}" for v in free_losses])
+    assert losses == pytest.approx(free_losses, rel=5e-3)
+    for n, p, p0, q in zip(names, net.parameters(), p_start, free.p):
+        if p.numel() >= 1 << 16:  # displacement after three Adam steps (bf16 noise flips the sign of near-zero gradients)
+            d1, d2 = (p.detach().cpu() - p0).flatten().double(), (q - p0).flatten().double()
+            assert float(d1 @ d2 / (d1.norm() * d2.norm())) > 0.9, n
+    assert lr[0] < 2e-4 and opt.param_groups[0]["lr"] < 2e-4  # past the warm-up, on the cosine
+    # ---- profile=True: wait 2 / warm-up 2 / active 5 iterations, then the record (trainer.py:155-177, 389-396)
+    assert not tr.prof.done
+    for k in range(3, nsteps):
+        assert math.isfinite(float(tr.train_step(x, t, idx, delta, global_nimg=B * (k + 1), steps=1)))
+    assert tr.prof.done and set(tr.prof.summary) == {"forward", "backward", "allreduce", "optimizer"}
+    rec = json.load(open(tmp_path / "rank0_prof.json"))
+    assert len(rec["traceEvents"]) == 5 * 4 and all(e["dur"] > 0 for e in rec["traceEvents"])
+    assert rec["otherData"]["mean_ms_per_phase"]["backward"] > rec["otherData"]["mean_ms_per_phase"]["optimizer"]
     tr._save_checkpoint(3000)
     state = torch.load(tmp_path / "checkpoints" / "checkpoint-000003.pt", weights_only=True)
     assert set(state) == {"ema", "net", "optimizer", "scaler"} and len(state["ema"]) == len(net.state_dict())
@@ -678,3 +798,48 @@ def test_graph_replay_equals_eager(dev):
             p.mul_(1.01)
     l_c, g_c = run("b")
     assert abs(l_c - l_b) > 1e-5 and len(eng.graphs._graphs) == 2
+
+
+def test_graph_pools_survive_growing_rollouts_and_moved_gradients(dev, monkeypatch):
+    """Two ways a captured launch sequence can go stale without an error:
+    (1) the multistep schedule grows `steps` (1 -> 2 -> 4), so new resident slots are captured AFTER the old forward /
+        backward sequences but replay BEFORE them: with one shared capture pool the old sequences' temporaries land in the
+        new slots' saved activations -- every key that keeps outputs owns its pool now;
+    (2) gradient buffers move (`zero_grad(set_to_none=True)`): the captured backward would add into freed memory -- the
+        engine stamps parameter / gradient addresses and recaptures.
+    Reference in both cases: the same calls with SWIFTK_TRAIN_GRAPHS=0."""
+    from swift_amd.training.loss import CRPSLoss
+    from swift_amd.utils.detinit import det_normal
+    monkeypatch.delenv("SWIFTK_CRPS_KEEP", raising=False)
+    B = 2
+    ds = _dataset(41)
+    target, cond = det_normal((B, 69, 64, 64), 41, "t").to(dev), det_normal((B, 72, 64, 64), 41, "c").to(dev)
+    aux, idx = torch.tensor([0.6, 0.6]), [0, 4]
+    lat = [[det_normal((B, 69, 64, 64), 41, f"l{e}{i}") for i in range(4)] for e in range(2)]
+
+    def trajectory(graphs_on, set_to_none):
+        monkeypatch.setenv("SWIFTK_TRAIN_GRAPHS", "1" if graphs_on else "0")
+        net, _, _ = _build_pair(dev, 41)
+        L = CRPSLoss(ds, sigma_data=1.0, ensemble_size=2, alpha=0.95).to(dev)
+        out = []
+        for steps in (1, 1, 1, 2, 2, 2, 4, 4, 4, 2, 1):     # every signature: eager, captured, replayed; then back down
+            if set_to_none:
+                net.zero_grad(set_to_none=True)
+            else:
+                for p in net.parameters():
+                    if p.grad is not None:
+                        p.grad.zero_()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = L(net, target, condition=cond, auxiliary=aux, idx=idx, steps=steps, _latents=[l[:steps] for l in lat])
+            loss.backward()
+            out.append((float(loss), torch.cat([p.grad.flatten() for p in net.parameters()]).cpu()))
+        if graphs_on:
+            assert net.model._train_engine.graphs._graphs, "nothing was captured"
+        return out
+
+    ref = trajectory(False, False)
+    for set_to_none in (False, True):
+        got = trajectory(True, set_to_none)
+        for k, ((l0, g0), (l1, g1)) in enumerate(zip(ref, got)):
+            assert l1 == pytest.approx(l0, rel=1e-5), (set_to_none, k)
+            assert rel_l2(g1, g0) < 1e-4, (set_to_none, k, rel_l2(g1, g0))

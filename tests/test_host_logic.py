@@ -168,8 +168,9 @@ DDP_WORKER = textwrap.dedent("""
     sys.path.insert(0, %(root)r)
     from swift_amd import dist
     from swift_amd.training.trainer import GradAllReduce
-    dist.setup_torch(backend="gloo")
+    dist.setup_torch(backend="gloo")                   # (SWIFTK_SINGLE_RANK_GROUP=1: a group of one rank runs the same calls)
     rank, world = dist.get_rank(), dist.get_world_size()
+    assert dist.collectives_active() == (world > 1 or os.environ.get("SWIFTK_SINGLE_RANK_GROUP") == "1")
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
     ddp = GradAllReduce(net)
@@ -179,7 +180,12 @@ DDP_WORKER = textwrap.dedent("""
     ddp.zero_grad_flat()
     ((ddp(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
     ddp.reduce_params([net[2].bias, net[0].weight])  # final gradients announced early: two non-neighbouring runs ...
-    ddp.reduce_params([net[2].bias])                 # ... a second announcement of the same run is ignored
+    if dist.collectives_active():                  # ... a second announcement means a backward pass ran on averaged slices
+        try:
+            ddp.reduce_params([net[2].bias])
+            raise SystemExit("second announcement of a reduced slice was accepted")
+        except RuntimeError:
+            pass
     flat = ddp.sync()                              # ... the rest reduced here
     if rank == 0:
         torch.save(flat.clone(), sys.argv[1])
@@ -204,6 +210,11 @@ def test_gradient_allreduce_world2_equals_single_process(tmp_path):
     assert [p.wait(timeout=200) for p in procs] == [0, 0]
     a, b = torch.load(one), torch.load(two)
     assert a.abs().sum() > 0 and torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    # a process group of ONE rank pushes the same announcements / collectives through the backend: identical gradients
+    solo = str(tmp_path / "g1_group.pt")
+    subprocess.run([sys.executable, str(script), solo], check=True, timeout=200,
+                   env={**env, "WORLD_SIZE": "1", "RANK": "0", "SWIFTK_SINGLE_RANK_GROUP": "1"})
+    assert torch.equal(torch.load(solo), a)
 
 
 MUON_WORKER = textwrap.dedent("""

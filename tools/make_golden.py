@@ -580,7 +580,44 @@ def fx_index_streams():
     save("index_streams", **out)
 
 
-ALL = dict(index_streams=fx_index_streams, era5_tiny=fx_era5_tiny, swiftb_long=fx_swiftb_long, trainer_tiny=fx_trainer_tiny, metrics_tiny=fx_metrics_tiny, val_tiny=fx_val_tiny, muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
+def fx_scm_distill_tiny():
+    """SCMLoss with ``distillation=True`` and a v-prediction teacher (training/loss.py:204-208): dx_t/dt comes from
+    ``sigma_d * net_pretrained(x_t / sigma_d, t, condition, auxiliary)`` instead of ``cos t z - sin t x``.  Student weights:
+    seed 6 (as losses_tiny), teacher weights: seed 16, same tiny architecture (no logvar head on the teacher)."""
+    c, seed = TINY, 6
+    net, state = build_ref_net(c, seed, logvar=True)
+    teacher, tstate = build_ref_net(c, seed + 10, logvar=False)
+    net.train().requires_grad_(True)
+    B, nv, nf = 2, c["n_vars"], c["n_forc"]
+    ds = FakeERA5(c, seed, det_normal((B + 8, nf, *c["img"]), seed, "forc"))
+    ds.variables = ["2m_temperature", "10m_u_component_of_wind", "geopotential_500", "temperature_850"]
+    target = det_normal((B, nv, *c["img"]), seed, "target")
+    cond = det_normal((B, nv + nf, *c["img"]), seed, "cond")
+    aux = torch.tensor([0.6, 0.6])
+    gsel = ["model.head.head.0.weight", "model.transformer.layers.1.0.to_qkv.weight", "model.pos_embed",
+            "model.transformer.layers.0.1.norm.modulation.weight", "model.transformer.layers.2.0.scale",
+            "model.logvar_embed.weight"]
+    torch.manual_seed(24)
+    L = SCMLoss(ds, dict(dist="loguniform", sigma_min=0.02, sigma_max=200.0), sigma_data=1.0, tangent_warmup_kimg=3,
+                distillation=True)
+    val = L(FakeDDP(net), target, step=1200, condition=cond, auxiliary=aux, net_pretrained=teacher)
+    val.backward()
+    named = dict(net.named_parameters())
+    g = np.array([float(named[k].grad.norm()) for k in gsel])
+    assert all(p.grad is None for p in teacher.parameters())
+    torch.manual_seed(24)
+    u, z = torch.rand([B, 1, 1, 1]), torch.randn_like(target)
+    # the same draw without a teacher, for scale: distillation must change the loss
+    net.zero_grad(set_to_none=True)
+    torch.manual_seed(24)
+    plain = SCMLoss(ds, dict(dist="loguniform", sigma_min=0.02, sigma_max=200.0), sigma_data=1.0, tangent_warmup_kimg=3)(
+        FakeDDP(net), target, step=1200, condition=cond, auxiliary=aux)
+    save("scm_distill_tiny", seed=seed, teacher_seed=seed + 10, fingerprint=state_fingerprint(state),
+         teacher_fingerprint=state_fingerprint(tstate), target=target, cond=cond, aux=aux, u=u, z=z, loss=float(val),
+         loss_without_teacher=float(plain), grad_keys=np.array(gsel), grad_norms=g, w_lat=L.w_lat, w_var=L.w_var)
+
+
+ALL = dict(scm_distill_tiny=fx_scm_distill_tiny, index_streams=fx_index_streams, era5_tiny=fx_era5_tiny, swiftb_long=fx_swiftb_long, trainer_tiny=fx_trainer_tiny, metrics_tiny=fx_metrics_tiny, val_tiny=fx_val_tiny, muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
            samplers_tiny=fx_samplers_tiny, rollout_tiny=fx_rollout_tiny, losses_tiny=fx_losses_tiny,
            swiftb_step=fx_swiftb_step, weights_aux=fx_weights_aux)
 
