@@ -90,6 +90,18 @@ __device__ __forceinline__ void dma_piece_fast(uint32_t lds_dst, const char* bas
         : "memory");
 }
 
+// L2 look-ahead: a 4-byte-per-lane LDS-DMA whose only purpose is to pull each lane's 128-B line into the XCD's L2 (the
+// 256 bytes it writes go to a scratch area of LDS)
+__device__ __forceinline__ void dma_touch(uint32_t lds_dst, const char* base, uint32_t voff) {
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dword %0, %2"
+        :
+        : "v"(voff), "s"(lds_dst), "s"(base)
+        : "memory");
+}
+
 // eight consecutive channels per lane: 16 B of bf16 / 32 B of fp32 per access
 template <typename T>
 __device__ __forceinline__ void load8(const T* p, float (&v)[8]);

@@ -3,7 +3,7 @@
 // time-embedding MLP, the rollout state update and operand casts.
 #include "common.h"
 
-int g_modnorm_nt = 1;  // tuning key 6: stream the fp32 residual with non-temporal loads / stores
+int g_modnorm_nt = 3;  // tuning key 6: bit 0 = stream the fp32 residual with non-temporal loads / stores, bit 1 = chunked kernel
 
 namespace {
 
@@ -79,6 +79,134 @@ __global__ __launch_bounds__(256) void modnorm_kernel(const T* __restrict__ y, i
                 if (xc) store8<T>(xc + row * ldc + 8 * c, xr[i]);
             }
         }
+    }
+}
+
+
+// Chunked form (tuning key 6 bit 1, the default): a workgroup owns MN_ROWS consecutive token rows, wave w of it the rows
+// w, w + 4, ...  The per-sample modulation and the LayerNorm affine are folded ONCE per wave and sample into
+//   P = gamma (1 + scale),  Q = beta (1 + scale) + shift        (x += LN(y) P + Q)
+// and stay in registers across the wave's rows -- the row-per-wave form re-reads 17 KB of parameters through L1 / L2 for
+// every 12.7 KB row it moves -- and the loads of the wave's next row are issued before the current row is reduced, so
+// every wave keeps two rows (12.7 KB) in flight.
+#ifndef SWIFTK_MN_ROWS
+#define SWIFTK_MN_ROWS 16
+#endif
+constexpr int MN_ROWS = SWIFTK_MN_ROWS;
+#ifndef SWIFTK_MN_OCC
+#define SWIFTK_MN_OCC 2
+#endif
+
+// raw 8-channel slot of y as loaded (bf16: 16 B, fp32: 32 B); unpacked only when the row is reduced, so a row waiting in
+// flight costs half the registers
+template <typename T> struct raw8;
+template <> struct raw8<bf16_t> { uint4 q; };
+template <> struct raw8<float> { float4 a, b; };
+__device__ __forceinline__ void load_raw(const bf16_t* p, raw8<bf16_t>& r) { r.q = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void load_raw(const float* p, raw8<float>& r) {
+    r.a = *reinterpret_cast<const float4*>(p);
+    r.b = *reinterpret_cast<const float4*>(p + 4);
+}
+__device__ __forceinline__ void unpack_raw(const raw8<bf16_t>& r, float (&v)[8]) {
+    const uint32_t u[4] = {r.q.x, r.q.y, r.q.z, r.q.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __uint_as_float(u[e] << 16);
+        v[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void unpack_raw(const raw8<float>& r, float (&v)[8]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+
+template <typename T, int SLOTS>
+__global__ __launch_bounds__(256, SWIFTK_MN_OCC) void modnorm_chunk_kernel(const T* __restrict__ y, int64_t ldy, float* __restrict__ x,
+                                                            T* __restrict__ xc, int64_t ldc, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ mod,
+                                                            int64_t ldmod, int64_t M, int d, int64_t rps, float eps, int nt_x) {
+    const bool NT_X = nt_x & 1;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int nc = d >> 3;
+    const int64_t row0 = (int64_t)blockIdx.x * MN_ROWS + wv;
+    const int64_t row_end = min((int64_t)(blockIdx.x + 1) * MN_ROWS, M);
+    // P and Q of the chunk's (first) sample live in LDS, shared by the four waves: 8.4 KB per workgroup instead of 48
+    // registers per lane, which is what lets three waves per SIMD keep two rows each in flight
+    __shared__ __attribute__((aligned(16))) float sP[2048], sQ[2048];
+    const int64_t blk_sample = ((int64_t)blockIdx.x * MN_ROWS) / rps;
+    {
+        const float* mrow = mod + blk_sample * ldmod;
+        for (int c = threadIdx.x; c < nc; c += 256) {
+            float g[8], bt[8], sc[8], sh[8], p[8], q[8];
+            load8<float>(gamma + 8 * c, g);
+            load8<float>(beta + 8 * c, bt);
+            load8<float>(mrow + 8 * c, sc);
+            load8<float>(mrow + d + 8 * c, sh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                p[e] = g[e] * (1.0f + sc[e]);
+                q[e] = bt[e] * (1.0f + sc[e]) + sh[e];
+            }
+            store8<float>(sP + 8 * c, p);
+            store8<float>(sQ + 8 * c, q);
+        }
+    }
+    __syncthreads();
+    if (row0 >= row_end) return;
+    raw8<T> ya[SLOTS], yb[SLOTS];
+    float xa[SLOTS][8], xb[SLOTS][8];
+    auto load_row = [&](int64_t row, raw8<T> (&yr)[SLOTS], float (&xr)[SLOTS][8]) {
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                load_raw(y + row * ldy + 8 * c, yr[i]);
+                if (NT_X) load8_nt(x + row * d + 8 * c, xr[i]); else load8<float>(x + row * d + 8 * c, xr[i]);
+            }
+        }
+    };
+    auto finish_row = [&](int64_t row, raw8<T> (&yr)[SLOTS], float (&xr)[SLOTS][8]) {
+        float v[SLOTS][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i)
+            if (lane + 64 * i < nc) {
+                unpack_raw(yr[i], v[i]);
+                sum += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+            }
+        const float mean = wave_sum(sum) / (float)d;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i)
+            if (lane + 64 * i < nc) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[i][e] -= mean;
+                    sq += v[i][e] * v[i][e];
+                }
+            }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)d + eps);
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                float P[8], Q[8];  // (the launcher takes this kernel only when no chunk straddles two samples)
+                load8<float>(sP + 8 * c, P);
+                load8<float>(sQ + 8 * c, Q);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xr[i][e] += (v[i][e] * rstd) * P[e] + Q[e];
+                if (NT_X) store8_nt(x + row * d + 8 * c, xr[i]); else store8<float>(x + row * d + 8 * c, xr[i]);
+                if (xc) store8<T>(xc + row * ldc + 8 * c, xr[i]);
+            }
+        }
+    };
+    load_row(row0, ya, xa);
+    for (int64_t row = row0; row < row_end; row += 8) {  // two rows per trip: the buffers swap roles without register moves
+        if (row + 4 < row_end) load_row(row + 4, yb, xb);
+        finish_row(row, ya, xa);
+        if (row + 4 >= row_end) break;
+        if (row + 8 < row_end) load_row(row + 8, ya, xa);
+        finish_row(row + 4, yb, xb);
     }
 }
 
@@ -397,13 +525,18 @@ extern "C" int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, voi
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = grid_for(M, 4, 1 << 20);  // one row per wave (a capped, looping grid measured 6 % slower)
     const bool small = d <= 3 * 512;  // three 8-channel slots per lane cover d <= 1536 with fewer registers
+    const int cgrid = (int)((M + MN_ROWS - 1) / MN_ROWS);
 #define SWIFTK_MODNORM(TT, SL)                                                                                             \
-    hipLaunchKernelGGL((modnorm_kernel<TT, SL>), dim3(grid), dim3(256), 0, st, static_cast<const TT*>(y), ldy, x,            \
-                       static_cast<TT*>(xcopy), ldc, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps, g_modnorm_nt)
+    if ((g_modnorm_nt & 2) && rows_per_sample % MN_ROWS == 0)                                                              \
+        hipLaunchKernelGGL((modnorm_chunk_kernel<TT, SL>), dim3(cgrid), dim3(256), 0, st, static_cast<const TT*>(y), ldy, x, \
+                           static_cast<TT*>(xcopy), ldc, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps, g_modnorm_nt); \
+    else                                                                                                                   \
+        hipLaunchKernelGGL((modnorm_kernel<TT, SL>), dim3(grid), dim3(256), 0, st, static_cast<const TT*>(y), ldy, x,        \
+                           static_cast<TT*>(xcopy), ldc, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps, g_modnorm_nt & 1)
     if (dtype == SWIFTK_BF16) {
-        if (small) SWIFTK_MODNORM(bf16_t, 3); else SWIFTK_MODNORM(bf16_t, 4);
+        if (small) { SWIFTK_MODNORM(bf16_t, 3); } else { SWIFTK_MODNORM(bf16_t, 4); }
     } else if (dtype == SWIFTK_F32) {
-        if (small) SWIFTK_MODNORM(float, 3); else SWIFTK_MODNORM(float, 4);
+        if (small) { SWIFTK_MODNORM(float, 3); } else { SWIFTK_MODNORM(float, 4); }
     } else {
         return SWIFTK_EINVAL;
     }

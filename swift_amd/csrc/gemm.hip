@@ -52,6 +52,18 @@ constexpr int EPI_QKNORM_TILED = 4;  // internal: SWIFTK_EPI_QKNORM with the win
 #ifndef SWIFTK_X_PF2
 #define SWIFTK_X_PF2 1
 #endif
+// cache policy of the bf16 output tiles' 16-B stores: 0 = default, 1 = nt, 2 = sc1 (write-through, line not kept in the
+// XCD's L2), 3 = sc0 sc1.  The outputs are written once and never re-read by the kernel; a round of 32 tiles per XCD writes
+// 5.8 MB through a 4 MB L2 that should be holding the W panel the XCD re-reads every round.
+#ifndef SWIFTK_X_STORE
+#define SWIFTK_X_STORE 0
+#endif
+// L2 look-ahead of the persistent kernel (k-tiles): in the second half of every k-tile (where no DMA piece is issued) each
+// wave requests one 4-byte LDS-DMA per lane from the 128-B lines its workgroup will stage SWIFTK_X_TOUCH + 1 k-tiles later;
+// the k-tile's closing wait leaves those two requests in flight (counted vmcnt), so their miss latency is never waited for.
+#ifndef SWIFTK_X_TOUCH
+#define SWIFTK_X_TOUCH 0
+#endif
 
 struct GemmArgs {
     const char* A;
@@ -67,6 +79,8 @@ struct GemmArgs {
     int ni;   // W-side MFMA tiles per wave of the persistent kernel's geometry: 10 / 11 / 12 = 320 / 352 / 384 columns per tile
     int dbg;  // tuning experiments only: 1 = no DMA in the loop, 2 = no barrier (both give wrong results)
     int khalf;         // the last k-tile holds data in its first half only (K = 16.5 tiles for d = 1056)
+    int touch;         // persistent kernel: L2 look-ahead requests on (aligned shapes only: M % 256 == 0, N % tile width == 0)
+    int stagger;       // persistent kernel: start-up delay step in 10-ns ticks (workgroup phase p waits p x stagger); 0 = off
     int ksplit;        // persistent kernel: k-ranges per output tile (1 = plain)
     int64_t c_split;   // elements between the fp32 slabs of consecutive splits
     // QKNORM only: window-tiled output [sample][window][head][q|k|v][256][88] (t_gw = 0: plain row-major C)
@@ -100,6 +114,24 @@ template <>
 __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16(a, b), pack_bf16(c, d));
 }
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+// one 16-B output store with the build's cache policy; inline asm keeps the count of VMEM operations the kernel's
+// counted s_waitcnt relies on (the string ends with s_nop 1: the data registers must outlive the issue)
+__device__ __forceinline__ void store16_out(void* p, const uint4& q) {
+#if SWIFTK_X_STORE == 0
+    *reinterpret_cast<uint4*>(p) = q;
+#else
+    const u32x4 v = {q.x, q.y, q.z, q.w};
+#if SWIFTK_X_STORE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif SWIFTK_X_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
+#endif
+}
+
 template <typename OutT>
 __device__ __forceinline__ void store2(OutT* p, float a, float b);
 template <>
@@ -319,7 +351,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     constexpr int STAGE = A_BYTES + B_BYTES;    // 72 / 76 / 80 KiB: two stages = 144 / 152 / 160 KiB of the CU's 160
     constexpr int WP = B_BYTES / 1024;          // W pieces per stage: 40 / 44 / 48 = 5, 5.5, 6 per wave
     constexpr int HD = 8 * NI;                  // QKNORM: head_dim (a wave tile = two head vectors)
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    constexpr bool TOUCH = SWIFTK_X_TOUCH > 0 && NI <= 11 && sizeof(T) == 2;  // (384-wide tiles use all 160 KiB of LDS)
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (TOUCH ? 256 : 0)];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wv >> 1, wn = wv & 1;
@@ -347,6 +380,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     const uint32_t va_even = (uint32_t)(prow * g.lda_b) + 16u * (pchunk ^ ((prow >> 1) & 7));
     const uint32_t va_odd = (uint32_t)(prow * g.lda_b) + 16u * (pchunk ^ ((4 + (prow >> 1)) & 7));
     const uint32_t vb = (uint32_t)(prow * g.ldw_b) + 16u * (pchunk ^ ((4 * (wv & 1) + (prow >> 1)) & 7));
+    // L2 look-ahead: the tile's 256 + BN operand rows as one list, 76 rows per wave: request 1 = rows 64 wv .. + 63 of the list
+    // (waves 0-3: A rows, waves 4-7: W rows 0..255), request 2 = W rows 256 + 12 wv .. + 11 (lanes 12.. repeat the last one)
+    // (row numbers relative to the tile; clamped against the matrix edge where the request is built)
+    const int tr1 = (wv & 3) * 64 + lane;
+    const int tr2 = min(256 + wv * ((BN - 256 + 7) / 8) + min(lane, (BN - 256 + 7) / 8 - 1), BN - 1);
+    int t_m0 = 0, t_n0 = 0;  // origin of the tile the DMA currently feeds (set_sources)
     const int nk_all = g.K / (ROWB / (int)sizeof(T));
     auto k_begin = [&](int item) { return (int)((int64_t)(item % ksplit) * nk_all / ksplit); };
     auto k_end = [&](int item) { return (int)((int64_t)(item % ksplit + 1) * nk_all / ksplit); };
@@ -359,6 +398,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     auto set_sources = [&](int t) {
         int tm, tn;
         it.coords(t / ksplit, tm, tn);
+        t_m0 = tm * BM;
+        t_n0 = tn * BN;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             int rb = tm * BM + (wv * 4 + p) * 8;
@@ -415,6 +456,18 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         tlog = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.ep1)) + (blockIdx.x >> 5) * 8 * 64;
     bool first_k = true;
 #endif
+    // Start-up stagger.  All 256 workgroups walk equally long tiles from the same instant, so every epilogue -- 180 KB of
+    // stores per workgroup -- falls into the same few microseconds: the chip alternates between an HBM-write burst with
+    // idle matrix pipes (6-8 us per tile at 96 units, 6 TB/s) and a k-loop with an idle write path.  Delaying the
+    // workgroups by eighths of a tile time (phase = tile row + tile column inside the XCD's 8 x 4 window: the four
+    // workgroups sharing an A panel stay within half a tile of each other, the eight sharing a W panel cover all phases)
+    // spreads the epilogues over the whole tile period for the rest of the launch.
+    if (g.stagger > 0) {
+        const int ph = ((vid % gm) + (vid / gm)) & 7;
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        const uint64_t wait = (uint64_t)ph * (uint64_t)g.stagger;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
 #if SWIFTK_X_PRIO
     // the second-dispatched half of the workgroup loses every issue arbitration against its SIMD partner; one static
     // priority for that half, no per-segment flips (MI355X_MICROARCH.md, two waves per SIMD, item 4)
@@ -453,6 +506,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         const bool last_k = (kt + 1 == nk);
         const bool half = g.khalf && (kt + 1 == nk_all);
         uint32_t koff = (uint32_t)(kt + 1) * ROWB;
+#if SWIFTK_GEMM_INSTR
+        if (g.dbg & 8) koff = 0;  // timing experiment: every stage re-reads k-tile 0 (L2-resident after a tile's first trip)
+#endif
         if (last_k) {
             const int ntile = tile + stride;
             if (ntile < ntiles) set_sources(ntile);
@@ -468,7 +524,14 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             uint4 xf[MI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch0);
-            auto k_half = [&](const int ch, const bool with_dma) {
+            // look-ahead target: k-tile kt + 1 + SWIFTK_X_TOUCH of the tile the DMA feeds (its last one at most); in a tile's last
+            // k-tile the DMA already feeds the next tile (set_sources above): the second k-tile of that one
+            uint32_t toff = 0;
+            if constexpr (TOUCH) {
+                const int tk = last_k ? (int)(koff / ROWB) + 1 : min(kt + 1 + SWIFTK_X_TOUCH, nk_all - 1);
+                toff = (uint32_t)min(tk, nk_all - 1) * ROWB;
+            }
+            auto k_half = [&](const int ch, const bool with_dma, const bool with_touch) {
                 uint4 wf = *reinterpret_cast<const uint4*>(s + woff + ch);
 #if SWIFTK_X_PF2
                 uint4 wf1 = *reinterpret_cast<const uint4*>(s + woff + 16 * ROWB + ch);  // W fragments run two steps ahead
@@ -484,21 +547,36 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 #endif
 #pragma unroll
                     for (int i = 0; i < MI; ++i) mma_chunk<T>(acc[i][j], wf, xf[i]);
+#if SWIFTK_GEMM_INSTR
+                    if (with_dma && j < 10 && !(g.dbg & 1)) issue_piece(fill, koff, j);
+#else
                     if (with_dma && j < 10) issue_piece(fill, koff, j);
+#endif
+                    if constexpr (TOUCH) {
+                        if (with_touch && j == 2) {
+                            if (wv < 4) dma_touch(lds0 + 2 * STAGE, g.A + (int64_t)t_m0 * g.lda_b, (uint32_t)(min(tr1, g.M - 1 - t_m0) * (int)g.lda_b) + toff);
+                            else dma_touch(lds0 + 2 * STAGE, g.W + (int64_t)t_n0 * g.ldw_b, (uint32_t)(min(tr1, g.N - 1 - t_n0) * (int)g.ldw_b) + toff);
+                        }
+                        if (with_touch && j == 6)
+                            dma_touch(lds0 + 2 * STAGE, g.W + (int64_t)t_n0 * g.ldw_b, (uint32_t)(min(tr2, g.N - 1 - t_n0) * (int)g.ldw_b) + toff);
+                    }
                     wf = wn_;
                 }
             };
-            k_half(ch0, true);
+            k_half(ch0, true, false);
             if (!half) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch1);
-                k_half(ch1, false);
+                k_half(ch1, false, TOUCH);
             }
         }
         par ^= 1;
         if (!last_k) {
             ++kt;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (a k-tile that is not its tile's last is never the half one: both k-halves ran, so with the look-ahead on its two
+            // requests are this wave's youngest VMEM operations and stay in flight)
+            if constexpr (TOUCH) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             continue;
         }
         bool interior = false;
@@ -715,7 +793,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                                     dst = (int64_t)tile_ * (256 * HD) + ((((try_ & 15) << 4) | (rx & 15)) * HD + (cc - NI * hi) * 8);
                                 }
                             }
-                            if (m < g.M && n < nout) *reinterpret_cast<uint4*>(C + dst) = q;
+                            if (m < g.M && n < nout) store16_out(C + dst, q);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();  // slab read before the next slab overwrites it
@@ -814,6 +892,7 @@ int g_variant = 1;   // 0: one tile per workgroup; 1: persistent, grouped tile o
 int g_group_m = 8;   // tile rows per group in the persistent order
 int g_persist_wgs = 256;
 int g_dbg = 0;
+int g_stagger_permille = 0;  // tuning key 7: start-up phase step as a fraction (in 1/1000) of an eighth of the estimated tile time
 
 struct Prof {
     int epilogue = -1, N = 0;
@@ -901,6 +980,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 4: g_attn_dbg = value; return 0;
         case 5: g_fwd_tiled = value; return 0;
         case 6: g_modnorm_nt = value; return 0;
+        case 7: g_stagger_permille = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -993,6 +1073,15 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     g.ksplit = ksplit;
     g.c_split = c_split;
     g.khalf = khalf;
+    g.touch = 0;  // (unused: the look-ahead is a build-time switch, its requests clamp against the matrix edges)
+    // estimated time of one output tile at ~1.35 PFLOP/s chip-wide (5.3 TFLOP/s per CU), in 10-ns ticks; the stagger only
+    // makes sense when a workgroup walks several tiles
+    g.stagger = 0;
+    if (g_stagger_permille > 0 && dtype == SWIFTK_BF16 && ksplit == 1) {
+        const double tile_s = 2.0 * 256.0 * (32.0 * ni) * (double)K / 5.3e12;
+        const int64_t tiles = ((M + 255) / 256) * g.ntn;
+        if (tiles >= 4 * 256) g.stagger = (int)(tile_s * 1e8 / 8.0 * g_stagger_permille / 1000.0);
+    }
     g.t_gh = g.t_gw = g.t_sh = g.t_sw = g.t_heads = 0;
     if (tiling) {
         g.t_gh = tiling[0]; g.t_gw = tiling[1]; g.t_sh = tiling[2]; g.t_sw = tiling[3]; g.t_heads = tiling[4];

@@ -184,9 +184,10 @@ def test_window_attention_sharp_rows(dev, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_modnorm_residual(dev, dt):
+@pytest.mark.parametrize("rps", [200, 208])  # 208 = 13 x 16: the chunked kernel (16-row chunks inside one sample); 200: row per wave
+def test_modnorm_residual(dev, dt, rps):
     from swift_amd import ops
-    B, rps, d = 3, 200, 1056
+    B, d = 3, 1056
     M = B * rps
     y, x = rnd((M, d), 12, 2.0) + 0.5, rnd((M, d), 13)
     gamma, beta, mod = 1 + 0.1 * rnd((d,), 14), 0.1 * rnd((d,), 15), 0.3 * rnd((B, 5 * 2 * d), 16)
