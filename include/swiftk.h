@@ -177,14 +177,17 @@ int swiftk_axpby(float* out, float a, const float* x, float b, const float* y, i
  * N != 0) is bracketed by a HIP event pair recorded on its launch stream; swiftk_profile_collect
  * synchronises on them, returns the summed kernel time and the launch count, and re-arms.
  * swiftk_profile_gemm(-1, 0) switches the hooks off.  At most 4096 launches per collection.
- * epilogue = SWIFTK_PROF_ATTENTION times the swiftk_window_attention launches instead (N ignored).
+ * epilogue = SWIFTK_PROF_ATTENTION times the swiftk_window_attention / swiftk_qkv_attention_fused launches instead
+ * (N ignored).
  */
 #define SWIFTK_PROF_ATTENTION 100
 int swiftk_profile_gemm(int epilogue, int64_t N);
 /* Tuning knobs (A/B measurements only): key 0 = GEMM variant (0 one tile per workgroup, 1 persistent pipeline),
  * key 1 = tile rows per group of the persistent tile order, key 2 = persistent grid size, keys 3 / 4 = ablation
  * bits of the GEMM / attention kernels (timing experiments; results are wrong while set), key 5 = window-tiled q/k/v in
- * swiftk_swinv2_forward (1), key 6 = non-temporal residual-stream accesses in swiftk_modnorm_residual (1). */
+ * swiftk_swinv2_forward (1), key 6 = swiftk_modnorm_residual: bit 0 non-temporal residual-stream accesses, bit 1 chunked
+ * kernel (3), key 7 = start-up stagger of the persistent GEMM's workgroups in 1/1000 of an eighth of a tile time (0),
+ * key 8 = to_qkv + window attention as one kernel in swiftk_swinv2_forward (1; key 4 bits 8.. = that kernel's ablations). */
 int swiftk_set_tuning(int key, int value);
 int swiftk_profile_collect(double* total_ms_host, int64_t* launches_host);
 
@@ -322,6 +325,19 @@ int swiftk_channel_axpy(float* out, const float* x, const float* y, const float*
 /* fp32 -> dtype copy with row padding: dst[r][c] = src[r][c] for c < cols, 0 for cols <= c < ldd. */
 int swiftk_cast_pad(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype,
                     void* stream);
+
+/*
+ * to_qkv + cosine norm + shifted-window attention of one layer in one kernel (bf16, head_dim 88): the q / k / v slab of a
+ * (sample, window, head) is produced, normalised and consumed on the CU; only the attention output reaches memory.
+ * Replaces src/swift/models/swinv2.py:119-136 (to_qkv, split, normalise, scale, attention) and :185-208 (roll,
+ * window_partition, window_reverse) -- i.e. swiftk_gemm_qkv_tiled + swiftk_window_attention.
+ *   x    [B*gh*gw, ldx] bf16 token-major (K valid columns; K = 16.5 k-tiles style padding as in swiftk_gemm)
+ *   w    [3*heads*88, ldw] bf16 (to_qkv.weight as stored: per-head [q|k|v] rows)
+ *   out  [B*gh*gw, ldo] bf16, head h in columns [88 h, 88 h + 88), token order (un-rolled)
+ */
+int swiftk_qkv_attention_fused(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* scale, void* out,
+                               int64_t ldo, int64_t K, int B, int gh, int gw, int heads, int head_dim, int shift_h,
+                               int shift_w, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Whole-network forward (the operator boundary itself).

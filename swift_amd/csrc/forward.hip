@@ -4,6 +4,7 @@
 #include "common.h"
 
 int g_fwd_tiled = 1;  // tuning key 5 (A/B only): 0 keeps q/k/v row-major between to_qkv and attention
+int g_fwd_fused = 1;  // tuning key 8 (A/B only): 0 = to_qkv and window attention as two kernels (q/k/v window-tiled through HBM)
 
 namespace {
 
@@ -131,7 +132,12 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
         // cosine-attention's normalise/scale prologue rides in the to_qkv epilogue (fp32 accumulators): head_dim 88 with
         // either operand type, 80 / 96 (the 468 M / 664 M variants) with bf16 operands and an even head count
         const bool fuse_norm = (hd == 88) || (dt == SWIFTK_BF16 && (hd == 80 || hd == 96) && m->heads % 2 == 0);
-        if (fuse_norm && dt == SWIFTK_BF16 && g_fwd_tiled) {
+        // head_dim 88 with bf16 operands: to_qkv, the cosine norm and the window attention run as ONE kernel (q/k/v stay on
+        // the CU); its stage plan wants an odd number of 64-deep k-tiles (1056 -> 17)
+        if (fuse_norm && dt == SWIFTK_BF16 && hd == 88 && g_fwd_fused && ((m->kd / 64) & 1)) {
+            RUN(swiftk_qkv_attention_fused(xT, m->kd, ly.qkv_w, m->kd, ly.scale, att, m->kd, kdv, B, gh, gw, m->heads, hd,
+                                           shifted ? m->sh : 0, shifted ? m->sw : 0, stream));
+        } else if (fuse_norm && dt == SWIFTK_BF16 && g_fwd_tiled) {
             // bf16: q/k/v leave the GEMM window-tiled, so every attention operand is one contiguous 44-KiB block
             RUN(swiftk_gemm_qkv_tiled(xT, m->kd, ly.qkv_w, m->kd, qkv, kdv, ly.scale, B, gh, gw, m->heads, hd,
                                       shifted ? m->sh : 0, shifted ? m->sw : 0, stream));

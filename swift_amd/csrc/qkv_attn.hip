@@ -1,0 +1,480 @@
+// to_qkv + cosine-norm + shifted-window attention in ONE kernel for gfx950 (bf16, head_dim 88, 16x16 windows).
+//
+// Replaces reference src/swift/models/swinv2.py:119-136 + 185-208 for one layer: F.linear(to_qkv), the per-head
+// [q|k|v] split, q/k L2-normalisation and logit scale, roll + window_partition, softmax(q k^T) v, window_reverse + roll.
+// The separate kernels (swiftk_gemm_qkv_tiled + swiftk_window_attention) move q, k, v through HBM once each way:
+// 8192 x 3168 bf16 written and read back per sample and layer (104 MB, 10 GB per layer at 96 units).  Here a work item is
+// one (sample, window, head): its 256 x 264 slab of q|k|v is produced by an MFMA GEMM over the window's 256 token rows
+// (gathered in window order by the LDS-DMA source addresses, roll included) and the head's 264 weight rows, normalised on
+// the fp32 accumulators, parked as bf16 in the LDS the k-loop has just released, and consumed by the attention core on
+// the spot.  Only the 256 x 88 output tile leaves the CU.
+//
+// Geometry: 8 waves as 4 (M) x 2 (N); a wave owns 64 token rows x 144 columns = 4 x 9 MFMA 16x16 tiles = 144 accumulator
+// VGPRs, v_mfma_f32_16x16x32_bf16 with the roles of gemm.hip (A := weight rows, B := token rows -> a lane holds 4
+// consecutive columns of one row).  The slab's columns are ORDERED for that split by the weight rows' DMA source
+// addresses: column half 0 = [q (88) | v 0..39 | 16 pad], half 1 = [k (88) | v 40..87 | 8 pad] -- so a wave holds complete
+// q rows or complete k rows of its 64 tokens and the cosine norms need no cross-wave exchange (v has no norm).  Pad columns
+// are fed by a clamped weight row and never stored (6 % more MFMAs than the 264 real columns; 13 LDS fragment reads per 36
+// MFMAs, against 19 per 34 for a wave that spans all columns).  k-loop: 64-deep k-tiles, two LDS
+// stages filled by global_load_lds_dwordx4 (1 KiB pieces of 8 rows x 128 B, source-side XOR swizzle), one barrier per
+// k-tile -- the structure of gemm_kernel_p.  Attention core: the S^T = K Q^T / accumulator-as-operand / V^T-by-
+// ds_read_tr16 scheme of attention_pipe.hip (v_mfma_f32_32x32x16_bf16, a wave owns 32 queries, softmax streamed over four
+// 64-key chunks, no row maximum where exp(min(scale, ln 100)) <= 48, row sum on the spare V^T rows).
+//
+// LDS (159,744 B):  [0, 45056) K tile | [45056, 90112) V tile | [90112, 135168) Q tile | tail to 159,744
+//   k-loop stage 1 (odd k-tiles)  = bytes [0, 69632)          (over the K / V tiles, dead during the k-loop)
+//   k-loop stage 0 (even k-tiles) = bytes [90112, 159744)     (over the Q tile and the tail)
+// K = 1056 is 16.5 k-tiles: the last one (index 16, stage 0) carries data in its first half only.  After it: barrier, the
+// normalised q / k / v slabs are written over both stages, barrier, every wave pulls its Q fragments into registers,
+// barrier, and the NEXT item's first k-tile is requested into stage 0 (the Q tile is dead by then) so that it lands
+// under the attention core; the output tile leaves through wave-private slabs in the K tile once all waves are done with
+// K and V.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 512;
+constexpr int HD = 88;
+constexpr int ROWB = 128;                   // bytes of a k-tile row (64 bf16)
+constexpr int BM = 256;                     // tokens of a window
+constexpr int BNP = 288;                    // 264 slab columns + 24 pad: two halves of 144
+constexpr int NI = 9, MI = 4;
+constexpr int WT = 16 * NI;                 // 144 columns per wave
+constexpr int A_BYTES = BM * ROWB;          // 32 KiB
+constexpr int W_BYTES = BNP * ROWB;         // 36 KiB
+constexpr int STAGE = A_BYTES + W_BYTES;    // 69632
+constexpr int ROW = HD * 2;                 // 176 B: a q / k / v row
+constexpr int TILE = 256 * ROW;             // 45056
+constexpr int OFF_K = 0, OFF_V = TILE, OFF_Q = 2 * TILE;
+constexpr int OFF_S1 = 0, OFF_S0 = 2 * TILE;
+constexpr int LDS_TOTAL = OFF_S0 + STAGE;   // 159744
+constexpr int CH = 64, NST = 4, CHB = CH * ROW, DB = 3, KS = 6, CPR = HD / 8;
+constexpr int OROWS = 16, ORND = 2, OSLAB = OROWS * ROW;  // output staging: 16 rows per round, two rounds per item
+constexpr int NOST = ORND * ((OROWS * CPR + 63) / 64);    // 6 output store instructions per wave and item
+constexpr int WP = W_BYTES / 1024;          // 36 weight pieces per stage
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct FusedArgs {
+    const char* x;      // [B * gh * gw, ldx] bf16 token-major operand copy of the residual stream
+    const char* w;      // [3 * heads * 88, ldw] bf16, per-head [q|k|v] row interleave (to_qkv.weight as stored)
+    bf16_t* out;        // [B * gh * gw, ldo] bf16, head h in columns [88 h, 88 h + 88)
+    const float* scale;  // [heads] logit scale parameter
+    int64_t ldx_b, ldw_b, ldo;
+    int B, gh, gw, heads, sh, sw;
+    int nk, khalf;      // k-tiles, and whether the last one is half full
+    int dbg;            // timing experiments: 1 = skip the attention core
+};
+
+__device__ __forceinline__ int win_token(int wy, int wx, int j, int gh, int gw, int sh, int sw) {
+    int gy = wy * 16 + (j >> 4) + sh;
+    int gx = wx * 16 + (j & 15) + sw;
+    gy = gy >= gh ? gy - gh : gy;
+    gx = gx >= gw ? gx - gw : gx;
+    return gy * gw + gx;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS_TOTAL];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwx = a.gw / 16, nw = (a.gh / 16) * nwx;
+    const int64_t ntok = (int64_t)a.gh * a.gw;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+
+    // item order of attention_pipe.hip: (sample, window, head), heads fastest; the workgroups of one XCD take consecutive
+    // items at the same time (same window: its 256 token rows are fetched into that XCD's L2 once for up to 12 heads)
+    int first, last, istep;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, nx = gridDim.x >> 3;
+        first = (int)((int64_t)xcd * nitems / 8) + (blockIdx.x >> 3);
+        last = (int)((int64_t)(xcd + 1) * nitems / 8);
+        istep = nx;
+    } else {
+        first = (int)((int64_t)blockIdx.x * nitems / gridDim.x);
+        last = (int)((int64_t)(blockIdx.x + 1) * nitems / gridDim.x);
+        istep = 1;
+    }
+    if (first >= last) return;
+    for (int o = tid * 16; o < LDS_TOTAL; o += NT * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    auto decode = [&](int item, int& b, int& w, int& h) {
+        h = item % a.heads;
+        const int r = item / a.heads;
+        w = r % nw;
+        b = r / nw;
+    };
+    auto pin = [&](const char* base) {  // a provably wave-uniform pointer (SGPR pair) for the asm operand
+        const uint64_t u = (uint64_t)base;
+        return (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(u >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)u));
+    };
+
+    // ---- LDS-DMA sources.  A piece is 8 rows x 128 B, lane l -> row l >> 3, physical 16-B chunk l & 7, which holds the
+    // row's logical chunk (l & 7) ^ ((row >> 1) & 7) (the fragment reads apply the same XOR: conflict-free ds_read_b128).
+    // Token operand: this wave's pieces 4 wv .. 4 wv + 3 = window rows 32 wv .. 32 wv + 31 (its own query rows, as it
+    // happens); the per-lane offset carries the gather (window partition of the grid rolled by (-sh, -sw)).
+    // Weight operand: pieces wv + 8 i of the 288-row LDS image, i = 0..4 (the fifth exists for waves 0-3); image row r
+    // takes the head's weight row  r (q) | 176 + r - 88 (v 0..39) | pad | 88 + r - 144 (k) | 216 + r - 232 (v 40..87) | pad.
+    const int prow = lane >> 3, pchunk = lane & 7;
+    uint32_t va[4], vb[5];
+    int cur_w = -1;
+    auto set_window = [&](int w) {
+        const int wy = w / nwx, wx = w - wy * nwx;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int j = (wv * 4 + p) * 8 + prow;
+            va[p] = (uint32_t)(win_token(wy, wx, j, a.gh, a.gw, a.sh, a.sw) * (int)a.ldx_b) +
+                    16u * (pchunk ^ ((4 * (p & 1) + (prow >> 1)) & 7));
+        }
+        cur_w = w;
+    };
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int r = (wv + 8 * i) * 8 + prow;
+        const int row = r < HD ? r : (r < 128 ? 2 * HD + (r - HD) : (r < WT ? 3 * HD - 1 : (r < WT + HD ? HD + (r - WT) :
+                        (r < WT + 136 ? 2 * HD + 40 + (r - WT - HD) : 3 * HD - 1))));
+        vb[i] = (uint32_t)(row * (int)a.ldw_b) + 16u * (pchunk ^ ((4 * (wv & 1) + (prow >> 1)) & 7));
+    }
+    const char* xbase = nullptr;
+    const char* wbase = nullptr;
+    auto set_item = [&](int b, int w, int h) {
+        if (w != cur_w) set_window(w);
+        xbase = pin(a.x + (int64_t)b * ntok * a.ldx_b);
+        wbase = pin(a.w + (int64_t)h * (3 * HD) * a.ldw_b);
+    };
+    // piece p of a stage (0-3 token rows, 4-8 weight rows) for k-tile byte offset koff
+    auto issue_piece = [&](uint32_t stage, uint32_t koff, int p) {
+        if (p < 4) {
+            dma_piece_fast(stage + (wv * 4 + p) * 1024, xbase, va[p] + koff);
+        } else {
+            const int i = p - 4;
+            if (wv + 8 * i < WP) dma_piece_fast(stage + A_BYTES + (wv + 8 * i) * 1024, wbase, vb[i] + koff);
+        }
+    };
+
+    // ---- fragment read offsets of the k-loop
+    const int wm = wv >> 1, wn = wv & 1;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const int xoff = (wm * 64 + r16) * ROWB;
+    const int woff = A_BYTES + (wn * WT + r16) * ROWB;
+    const int ch0 = ((g4 + 0) ^ (r16 >> 1)) * 16;
+    const int ch1 = ((g4 + 4) ^ (r16 >> 1)) * 16;
+
+    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+
+    int b, w, h;
+    decode(first, b, w, h);
+    set_item(b, w, h);
+#pragma unroll
+    for (int p = 0; p < 9; ++p) issue_piece(lds0 + OFF_S0, 0u, p);
+    bool have_prev = false;
+
+    for (int item = first; item < last; item += istep) {
+        int nb = b, nwn = w, nh = h;
+        const bool has_next = item + istep < last;
+        if (has_next) decode(item + istep, nb, nwn, nh);
+
+        // =========================================================== k-loop: acc[i][j] = X_window W_head^T (fp32)
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the first k-tile was requested before the previous item's output stores (VMEM retires in issue order)
+        if (have_prev) wait_vm<NOST>(); else wait_vm<0>();
+        for (int kt = 0; kt < a.nk; ++kt) {
+            __builtin_amdgcn_s_barrier();  // stage of kt landed for every wave; every wave is done with the other stage
+            const int so = (kt & 1) ? OFF_S1 : OFF_S0;
+            const char* s = smem + so;
+            const uint32_t fill = lds0 + ((kt & 1) ? OFF_S0 : OFF_S1);
+            const bool more = kt + 1 < a.nk;
+            // (the last k-tile re-requests k-tile 0 into the other stage: one straight-line copy of the first k-half instead
+            // of two -- a second copy makes hipcc split and spill the accumulator tuples; the bytes land before the epilogue
+            // overwrites that stage and are never read)
+            const uint32_t koff = more ? (uint32_t)(kt + 1) * ROWB : 0u;
+            const bool half = a.khalf && !more;
+            uint4 xf[MI];
+            auto k_half = [&](const int ch, const bool with_dma) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch);
+                uint4 wf = *reinterpret_cast<const uint4*>(s + woff + ch);
+                uint4 wf1 = *reinterpret_cast<const uint4*>(s + woff + 16 * ROWB + ch);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const uint4 wn_ = wf1;
+                    if (j + 2 < NI) wf1 = *reinterpret_cast<const uint4*>(s + woff + (j + 2) * 16 * ROWB + ch);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf),
+                                                                            __builtin_bit_cast(bf16x8, xf[i]), acc[i][j], 0, 0, 0);
+                    if (with_dma && j < 9) issue_piece(fill, koff, j);
+                    wf = wn_;
+                }
+            };
+            k_half(ch0, true);
+            if (!half) k_half(ch1, false);
+            wait_vm<0>();
+        }
+
+        // =========================================================== epilogue: cosine norm on the accumulators -> LDS
+        __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage: both stages may be overwritten
+        // Everything lane-derived below is rebuilt from an opaque copy of the lane id: left visible, hipcc hoists the
+        // epilogue's, the attention core's and the output stage's address registers above the k-loop and spills inside it.
+        int el = lane;
+        asm volatile("" : "+v"(el));
+        const int r16 = el & 15, g4 = el >> 4;
+        const int c32 = el & 31, hh = el >> 5;
+        const int vbase = (4 * hh + ((el & 15) >> 2)) * ROW + (16 * ((el >> 4) & 1) + 4 * (el & 3)) * 2;
+        char* oslab = smem + OFF_K + wv * OSLAB;
+        {
+            // wave (wm, wn): rows 64 wm .. + 63; local columns 0..87 = q (wn 0) or k (wn 1), 88.. = v 0..39 / v 40..87, then pad
+            const float tau = wn ? 1.0f : __expf(fminf(a.scale[h], 4.605170185988092f));
+            const int nv = wn ? 48 : 40, v0 = wn ? 40 : 0;
+            char* qk_tile = smem + (wn ? OFF_K : OFF_Q);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {  // columns 0..95: the head vector ends at 88, inside block 5 (lanes g4 < 2)
+                    const f32x4 v = acc[i][j];
+                    const float t = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    ss += (j < 5 || g4 < 2) ? t : 0.f;
+                }
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+                const float f = tau / fmaxf(sqrtf(ss), 1e-12f);
+                const int row = wm * 64 + i * 16 + r16;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int lc = 16 * j + 4 * g4;  // this lane's 4 columns of the wave's 144 (never straddle: 88 % 4 == 0)
+                    const f32x4 v = acc[i][j];
+                    if (lc < HD) {
+                        *reinterpret_cast<uint2*>(qk_tile + row * ROW + lc * 2) =
+                            make_uint2(pack_bf16(v[0] * f, v[1] * f), pack_bf16(v[2] * f, v[3] * f));
+                    } else if (lc < HD + nv) {
+                        *reinterpret_cast<uint2*>(smem + OFF_V + row * ROW + (lc - HD + v0) * 2) =
+                            make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();  // Q, K and V tiles complete
+
+        // =========================================================== attention core
+        const float bound = __expf(fminf(a.scale[h], 4.605170185988092f));
+        const bool online = !(bound <= 48.f);
+        uint4 qf[KS];
+        {
+            const char* qrow = smem + OFF_Q + (wv * 32 + c32) * ROW;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks == KS - 1) {  // head_dim 88 = 5.5 k-steps of 16: the last one has one real chunk
+                    const uint4 t = *reinterpret_cast<const uint4*>(qrow + (2 * ks) * 16);
+                    qf[ks] = hh ? make_uint4(0, 0, 0, 0) : t;
+                } else {
+                    qf[ks] = *reinterpret_cast<const uint4*>(qrow + (2 * ks + hh) * 16);
+                }
+            }
+            // the compiler's own lgkmcnt wait precedes the first use; all waves must hold their fragments before the Q
+            // tile is overwritten by the next item's first k-tile
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (has_next) {
+            set_item(nb, nwn, nh);
+#pragma unroll
+            for (int p = 0; p < 9; ++p) issue_piece(lds0 + OFF_S0, 0u, p);
+        }
+        f32x16 o[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+        // The four 64-key chunks one after the other (S^T, softmax, PV).  A software-pipelined form -- S^T of chunk t + 1 and PV
+        // of chunk t - 1 issued beside the softmax of chunk t, with and without sched_group_barrier hints -- was measured
+        // 2-3 % slower for the whole kernel (256 VGPRs and spills against 198); what overlaps the softmax's VALU work with
+        // MFMAs is the SIMD's other wave, once the two are out of step (the stagger below).
+        auto st_chunk = [&](int c, f32x16 (&sc)[2]) {
+            const char* sK = smem + OFF_K + c * CHB;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[k2][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const uint4 kf = *reinterpret_cast<const uint4*>(sK + (k2 * 32 + c32) * ROW + ks * 32 + hh * 16);
+                    sc[k2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                                     __builtin_bit_cast(bf16x8, qf[ks]), sc[k2], 0, 0, 0);
+                }
+            }
+        };
+        auto pv_chunk = [&](int c, const uint4 (&pf)[4]) {
+            const char* sV = smem + OFF_V + c * CHB;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const char* vrow = sV + (k2 * 32 + s2 * 16) * ROW + vbase;
+#pragma unroll
+                    for (int db = 0; db < DB; ++db) {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(vrow + db * 64));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(vrow + db * 64 + 8 * ROW));
+                        uint4 vf = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        if (db == DB - 1 && c32 >= HD - 32 * (DB - 1)) vf = ones;  // rows 88..95 of V^T: the row sum
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                                        __builtin_bit_cast(bf16x8, pf[2 * k2 + s2]), o[db], 0, 0, 0);
+                    }
+                }
+        };
+        float m_run = -INFINITY;
+        float alpha_next = 1.f;  // online form: factor the softmax of step t found for O before PV of chunk t
+        auto soft_chunk = [&](const f32x16 (&sc)[2], uint4 (&pf)[4], auto online_tag) {
+            float mb = 0.f;
+            if constexpr (decltype(online_tag)::value) {
+                float mx = m_run;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[k2][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                alpha_next = __builtin_amdgcn_exp2f((m_run - mx) * LOG2E);
+                m_run = mx;
+                mb = mx * LOG2E;
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                float e[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(sc[k2][r] * LOG2E - mb);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    pf[2 * k2 + s2].x = pack_bf16(e[8 * s2 + 0], e[8 * s2 + 1]);
+                    pf[2 * k2 + s2].y = pack_bf16(e[8 * s2 + 2], e[8 * s2 + 3]);
+                    pf[2 * k2 + s2].z = pack_bf16(e[8 * s2 + 4], e[8 * s2 + 5]);
+                    pf[2 * k2 + s2].w = pack_bf16(e[8 * s2 + 6], e[8 * s2 + 7]);
+                }
+            }
+        };
+        auto rescale_o = [&](auto online_tag) {
+            if constexpr (decltype(online_tag)::value) {
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha_next;
+            }
+        };
+        auto core = [&](auto online_tag) {
+            f32x16 sc[2];
+            uint4 pf[4];
+#pragma unroll
+            for (int c = 0; c < NST; ++c) {
+                st_chunk(c, sc);
+                soft_chunk(sc, pf, online_tag);
+                rescale_o(online_tag);
+                pv_chunk(c, pf);
+            }
+        };
+        if (!(a.dbg & 1)) {
+            // both waves of a SIMD arrive here from the same barrier and would run their matrix and VALU phases in step:
+            // the second-dispatched half starts a fraction of a chunk later (dbg bits 4..: units of 64 cycles; timing experiments)
+            if (wv >= 4 && (a.dbg >> 2)) __builtin_amdgcn_s_sleep(1);
+            if (wv >= 4 && (a.dbg >> 2) >= 2) __builtin_amdgcn_s_sleep(2);
+            if (wv >= 4 && (a.dbg >> 2) >= 4) __builtin_amdgcn_s_sleep(4);
+            if (wv >= 4 && (a.dbg >> 2) >= 8) __builtin_amdgcn_s_sleep(8);
+            if (online) core(std::true_type{}); else core(std::false_type{});
+        }
+        const float l = (a.dbg & 1) ? 1.f : o[DB - 1][12];
+        const float rl = 1.0f / l;
+
+        // =========================================================== output tile -> HBM through wave-private slabs
+        __builtin_amdgcn_s_barrier();  // every wave is done with K and V: the K tile becomes the output staging area
+        {
+            const int wy = w / nwx, wx = w - wy * nwx;
+            bf16_t* obase = a.out + (int64_t)b * ntok * a.ldo + h * HD;
+#pragma unroll
+            for (int rnd = 0; rnd < ORND; ++rnd) {
+                if (c32 / OROWS == rnd) {
+#pragma unroll
+                    for (int db = 0; db < DB; ++db)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int d = db * 32 + g * 8 + hh * 4;
+                            if (d < HD)
+                                *reinterpret_cast<uint2*>(oslab + (c32 & (OROWS - 1)) * ROW + d * 2) =
+                                    make_uint2(pack_bf16(o[db][4 * g] * rl, o[db][4 * g + 1] * rl),
+                                               pack_bf16(o[db][4 * g + 2] * rl, o[db][4 * g + 3] * rl));
+                        }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < (OROWS * CPR + 63) / 64; ++t) {
+                    const int c = el + 64 * t;
+                    if (c < OROWS * CPR) {
+                        const int row = c / CPR, cc = c - row * CPR;
+                        const uint4 v = *reinterpret_cast<const uint4*>(oslab + row * ROW + cc * 16);
+                        const int tok = win_token(wy, wx, wv * 32 + rnd * OROWS + row, a.gh, a.gw, a.sh, a.sw);
+                        *reinterpret_cast<uint4*>(obase + (int64_t)tok * a.ldo + cc * 8) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        have_prev = true;
+        b = nb; w = nwn; h = nh;
+    }
+    wait_vm<0>();
+}
+
+}  // namespace
+
+extern "C" int swiftk_qkv_attention_fused(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* scale, void* out,
+                                          int64_t ldo, int64_t K, int B, int gh, int gw, int heads, int head_dim, int shift_h,
+                                          int shift_w, void* stream) {
+    if (!x || !w || !scale || !out || B <= 0 || heads <= 0) return SWIFTK_EINVAL;
+    if (head_dim != 88) return SWIFTK_ESHAPE;
+    if (gh <= 0 || gw <= 0 || gh % 16 || gw % 16) return SWIFTK_ESHAPE;
+    if (shift_h < 0 || shift_w < 0 || shift_h >= gh || shift_w >= gw) return SWIFTK_ESHAPE;
+    // K: whole 64-element k-tiles, or ending half-way into the last one with both operands' rows extending (zero / finite
+    // padded) to its end -- the contract of swiftk_gemm
+    int khalf = 0;
+    if (K % 64 == 32 && ldx >= K + 32 && ldw >= K + 32) {
+        khalf = 1;
+        K += 32;
+    }
+    if (K <= 0 || K % 64 || ldx < K || ldw < K || ldo < (int64_t)heads * head_dim) return SWIFTK_ESHAPE;
+    if ((K / 64) % 2 == 0) return SWIFTK_ESHAPE;  // (the stage plan ends the k-loop in stage 0: an odd number of k-tiles)
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15) || (ldx * 2) % 16 || (ldw * 2) % 16 || (ldo * 2) % 16)
+        return SWIFTK_EALIGN;
+    if ((int64_t)gh * gw * ldx * 2 >= (1ll << 32) || (int64_t)3 * head_dim * ldw * 2 >= (1ll << 32)) return SWIFTK_ESHAPE;
+    FusedArgs a;
+    a.x = static_cast<const char*>(x);
+    a.w = static_cast<const char*>(w);
+    a.out = static_cast<bf16_t*>(out);
+    a.scale = scale;
+    a.ldx_b = ldx * 2;
+    a.ldw_b = ldw * 2;
+    a.ldo = ldo;
+    a.B = B; a.gh = gh; a.gw = gw; a.heads = heads; a.sh = shift_h; a.sw = shift_w;
+    a.nk = (int)(K / 64);
+    a.khalf = khalf;
+    a.dbg = g_attn_dbg >> 8;  // tuning key 4, bits 8..: timing experiments of this kernel
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nitems = B * (gh / 16) * (gw / 16) * heads;
+    int grid = 256;
+    if (nitems < grid) grid = nitems >= 8 ? (nitems & ~7) : nitems;
+    const bool timed = swiftk_prof_begin(SWIFTK_PROF_ATTENTION, 0, st);
+    hipLaunchKernelGGL(qkv_attn_kernel, dim3(grid), dim3(NT), 0, st, a, nitems);
+    if (timed) swiftk_prof_end(st);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}

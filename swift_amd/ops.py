@@ -108,6 +108,22 @@ def window_attention_tiled(qkv_tiled: torch.Tensor, scale: Optional[torch.Tensor
     return out
 
 
+def qkv_attention_fused(a: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, B: int, grid: Tuple[int, int], heads: int,
+                        shift: Tuple[int, int] = (0, 0), out: Optional[torch.Tensor] = None, k: Optional[int] = None,
+                        head_dim: int = 88) -> torch.Tensor:
+    """to_qkv + cosine norm + shifted-window attention in one kernel: a [B*gh*gw, >=K] bf16, w [3*heads*hd, >=K] bf16 ->
+    out [B, gh*gw, heads*hd] bf16 (token order).  ``k``: valid K (may end half-way into the last k-tile of the padded rows)."""
+    _dev(a, w, scale, out)
+    gh, gw = grid
+    assert a.shape[0] == B * gh * gw and w.shape[0] == 3 * heads * head_dim and a.dtype == w.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty(B, gh * gw, heads * head_dim, dtype=torch.bfloat16, device=a.device)
+    check(lib().swiftk_qkv_attention_fused(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), scale.contiguous().data_ptr(),
+                                           out.data_ptr(), out.stride(-2), k or a.shape[1], B, gh, gw, heads, head_dim, shift[0],
+                                           shift[1], _stream()), "swiftk_qkv_attention_fused")
+    return out
+
+
 def window_attention(qkv: torch.Tensor, scale: Optional[torch.Tensor], grid: Tuple[int, int], heads: int,
                      shift: Tuple[int, int] = (0, 0), out: Optional[torch.Tensor] = None, flags: int = 0) -> torch.Tensor:
     """qkv [B, gh*gw, >=3*heads*hd] -> out [B, gh*gw, heads*hd] (token order, un-rolled).

@@ -360,6 +360,43 @@ def test_window_tiled_qkv_path(dev, shift, B, hd):
     assert rel_l2(out_t.float().cpu(), ref) < 1.2e-2
 
 
+@pytest.mark.parametrize("shift", [(0, 0), (8, 8), (3, 5)])
+@pytest.mark.parametrize("B", [1, 3, 8])  # 8: several items per workgroup (the cross-item prefetch and the output hand-over)
+def test_fused_qkv_attention(dev, shift, B):
+    """swiftk_qkv_attention_fused (to_qkv + cosine norm + shifted-window attention in one kernel, q/k/v never in HBM)
+    against (a) the two-kernel path it replaces -- same bf16 operands, same fp32 accumulation, so the outputs agree to the
+    rounding of the normalised q/k/v to bf16 and of the probabilities -- and (b) the fp32 formula on the QK-norm GEMM's
+    output (swinv2.py:119-136).  Heads with logit bound <= 48 (max-free softmax) and > 48 (online form) are mixed."""
+    from oracle.swinv2 import window_token_index
+    from swift_amd import ops
+    hd, grid, heads = 88, (32, 48), 12
+    n, d = grid[0] * grid[1], heads * hd
+    K = ops.k_pad(torch.bfloat16, d)
+    a, w = rnd((B * n, K), 60 + B), rnd((3 * heads * hd, K), 61, 0.03)
+    a[:, d:] = 0
+    w[:, d:] = 0
+    scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 48.0])).to(dev)
+    ad, wd = to_dt(a, torch.bfloat16, dev), to_dt(w, torch.bfloat16, dev)
+    ct = ops.gemm_qkv_tiled(ad, wd, scale, B, grid, heads, shift, k=d)
+    two = ops.window_attention_tiled(ct, scale, grid, heads, shift)
+    out = torch.full((B, n, ops.k_pad(torch.bfloat16, d)), 7.0, dtype=torch.bfloat16, device=dev)  # padded rows, as in the engine
+    ops.qkv_attention_fused(ad, wd, scale, B, grid, heads, shift, out=out, k=d)
+    assert torch.isfinite(out.float()).all() and (out[..., d:].float() == 7.0).all()  # pad columns untouched
+    fused = out[..., :d]
+    assert rel_l2(fused.float().cpu(), two.float().cpu()) < 6e-3
+    # second call into the same buffer: bit-identical (no dependence on what the LDS / the output held before)
+    out2 = torch.zeros_like(out)
+    ops.qkv_attention_fused(ad, wd, scale, B, grid, heads, shift, out=out2, k=d)
+    assert torch.equal(out2[..., :d], fused)
+    c = ops.gemm(ad[:, :d], wd[:, :d], epilogue=ops.EPI_QKNORM, bias=scale, head_dim=hd)
+    idx = window_token_index(grid, (16, 16), shift)
+    src = c.float().cpu().view(B, n, -1)[:, idx.reshape(-1)].reshape(B * idx.shape[0], 256, heads, 3, hd).permute(0, 2, 1, 3, 4)
+    ow = (src[..., 0, :] @ src[..., 1, :].transpose(-2, -1)).softmax(-1) @ src[..., 2, :]
+    ref = torch.empty(B, n, heads * hd)
+    ref[:, idx.reshape(-1)] = ow.permute(0, 2, 1, 3).reshape(B, n, -1)
+    assert rel_l2(fused.float().cpu(), ref) < 1.2e-2
+
+
 def test_ensemble_metrics_vs_reference_golden(dev):
     """swiftk_ensemble_sums -> RMSE / CRPS / spread-skill against the reference's eval/metrics.py functions (golden)."""
     from swift_amd.eval.metrics import all_metrics, lat_weighted_crps
