@@ -22,7 +22,8 @@ exits non-zero when the process group's world size is not --gpus.
 Extra objects in the same JSON line:
   roofline        dominant kernel (w1 GEMM + fused SwiGLU, 42.7 % of all FLOPs): algorithmic FLOPs per launch / mean launch
                   time from HIP events recorded on the launch stream during the timed region
-  attention_roofline  the window-attention kernel against the HBM roofline (two more steps, outside the timed region)
+  attention_roofline  the fused to_qkv + window-attention kernel against the MFMA roofline over its fused FLOPs (two more
+                  steps, outside the timed region)
   rccl, checksum  the process group that ran and what it collected
   parity_engine   (N == 1) the exact-fp32 engine -- the configuration that meets the 1e-4 tolerance -- on the same
                   workload: sample-steps/s, fraction of the fp32 matrix peak, its attention kernel's MFMA fraction
@@ -103,7 +104,7 @@ def launch_ranks(n: int) -> int:
 def wait_ranks(procs) -> int:
     """Worst exit code of the rank processes; when one fails the others (which would wait in a collective until the
     process-group timeout) are terminated -- by their own PIDs."""
-    rc, live = 0, list(procs)
+    rc, live, stopped = 0, list(procs), set()
     while live:
         time.sleep(0.2)
         for p in list(live):
@@ -111,9 +112,12 @@ def wait_ranks(procs) -> int:
             if code is None:
                 continue
             live.remove(p)
+            if p.pid in stopped:  # (a sibling this launcher ended itself: its signal is not a result)
+                continue
             rc = max(rc, abs(code))
             if code != 0:
                 for q in live:
+                    stopped.add(q.pid)
                     q.terminate()
     return rc
 
@@ -369,17 +373,34 @@ def main():
                          "flop_per_launch": flop_launch},
         }
         if att_n.value > 0:
-            # per sample-layer the kernel reads qkv (8192 x 3168 bf16) and writes 8192 x 1056 bf16
-            # = 69.2 MB, for 8.858 GFLOP of QK^T + PV: HBM-bound in bf16 (ridge 312 flop/B > 128 flop/B)
+            # The north star's named kernel.  Swift-B / bf16 runs to_qkv + cosine norm + shifted-window attention as ONE kernel
+            # (swiftk_qkv_attention_fused: q, k, v never reach HBM), so it is judged against the MFMA roofline over the fused
+            # FLOPs: 2 x 8192 x 3168 x 1056 (to_qkv) + 8.858e9 (QK^T + PV) per sample and layer.  Algorithmic bytes: the token
+            # operand read once, the attention output written once, the weight once.  SWIFTK_TUNE=8:0 restores the two-kernel
+            # path, whose attention kernel is HBM-bound (69.2 MB per sample-layer, 128 flop/B < ridge 312).
             att_s = att_ms.value / att_n.value * 1e-3
-            att_bytes, att_flop = B * 8192 * 4 * 1056 * 2.0, B * 8.858e9
-            line["attention_roofline"] = {
-                "kernel": "attn_pipe_kernel (shifted-window attention, bf16, window-tiled q/k/v)", "bound": "hbm",
-                "achieved": att_bytes / att_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": att_bytes / att_s / 8e12,
-                "traffic": traffic.get("attention"), "launches": int(att_n.value), "avg_launch_ms": att_s * 1e3, "bytes_per_launch": att_bytes,
-                "mfma_tflops": att_flop / att_s / 1e12, "mfma_frac": att_flop / att_s / PEAK_BF16,
-                "note": "arithmetic intensity 128 flop/B < ridge 312: the HBM roofline caps MFMA utilisation at 41 % in bf16; the "
-                        "MFMA-bound regime is the fp32 engine's kernel (parity_engine.attention_mfma_frac)"}
+            fused = os.environ.get("SWIFTK_TUNE", "").find("8:0") < 0
+            if fused:
+                flop = B * (2.0 * 8192 * 3168 * 1056 + 8.858e9)
+                bytes_ = B * 8192 * 2 * 1056 * 2.0 + 3168 * 1056 * 2.0
+                line["attention_roofline"] = {
+                    "kernel": "qkv_attn_kernel (to_qkv GEMM + cosine norm + shifted-window attention, one kernel per layer, bf16)",
+                    "bound": "mfma", "achieved": flop / att_s / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                    "frac": flop / att_s / PEAK_BF16, "traffic": traffic.get("qkv_attn_fused"), "launches": int(att_n.value),
+                    "avg_launch_ms": att_s * 1e3, "flop_per_launch": flop, "algorithmic_bytes_per_launch": bytes_,
+                    "attention_core_flop_per_launch": B * 8.858e9,
+                    "note": "MFMA utilisation over the fused FLOPs (window attention's QK^T / PV run on the tile the to_qkv k-loop just "
+                            "produced, q/k/v stay in LDS); replaces swiftk_gemm_qkv_tiled + swiftk_window_attention, which moved "
+                            "10 GB of q/k/v per layer through HBM at 96 units"}
+            else:
+                att_bytes, att_flop = B * 8192 * 4 * 1056 * 2.0, B * 8.858e9
+                line["attention_roofline"] = {
+                    "kernel": "attn_pipe_kernel (shifted-window attention, bf16, window-tiled q/k/v)", "bound": "hbm",
+                    "achieved": att_bytes / att_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": att_bytes / att_s / 8e12,
+                    "traffic": traffic.get("attention"), "launches": int(att_n.value), "avg_launch_ms": att_s * 1e3, "bytes_per_launch": att_bytes,
+                    "mfma_tflops": att_flop / att_s / 1e12, "mfma_frac": att_flop / att_s / PEAK_BF16,
+                    "note": "arithmetic intensity 128 flop/B < ridge 312: the HBM roofline caps MFMA utilisation at 41 % in bf16; the "
+                            "MFMA-bound regime is the fp32 engine's kernel (parity_engine.attention_mfma_frac)"}
         if world == 1 and not a.no_extras and a.solver == "scm" and nsteps == 1:
             line["parity_engine"] = parity_engine_leg(eng.net, ds, dev, lib, X0, forc, units)
             line["bf16_vs_fp32"] = drift_leg(eng.net, ds, dev, X0, forc, units)

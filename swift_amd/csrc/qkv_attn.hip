@@ -21,9 +21,9 @@
 // ds_read_tr16 scheme of attention_pipe.hip (v_mfma_f32_32x32x16_bf16, a wave owns 32 queries, softmax streamed over four
 // 64-key chunks, no row maximum where exp(min(scale, ln 100)) <= 48, row sum on the spare V^T rows).
 //
-// LDS (159,744 B):  [0, 45056) K tile | [45056, 90112) V tile | [90112, 135168) Q tile | tail to 159,744
+// LDS (163,840 B):  [0, 45056) K tile | [45056, 94208) V tile (192-B rows) | [94208, 139264) Q tile | tail to 163,840
 //   k-loop stage 1 (odd k-tiles)  = bytes [0, 69632)          (over the K / V tiles, dead during the k-loop)
-//   k-loop stage 0 (even k-tiles) = bytes [90112, 159744)     (over the Q tile and the tail)
+//   k-loop stage 0 (even k-tiles) = bytes [94208, 163840)     (over the Q tile and the tail)
 // K = 1056 is 16.5 k-tiles: the last one (index 16, stage 0) carries data in its first half only.  After it: barrier, the
 // normalised q / k / v slabs are written over both stages, barrier, every wave pulls its Q fragments into registers,
 // barrier, and the NEXT item's first k-tile is requested into stage 0 (the Q tile is dead by then) so that it lands
@@ -47,9 +47,12 @@ constexpr int W_BYTES = BNP * ROWB;         // 36 KiB
 constexpr int STAGE = A_BYTES + W_BYTES;    // 69632
 constexpr int ROW = HD * 2;                 // 176 B: a q / k / v row
 constexpr int TILE = 256 * ROW;             // 45056
-constexpr int OFF_K = 0, OFF_V = TILE, OFF_Q = 2 * TILE;
-constexpr int OFF_S1 = 0, OFF_S0 = 2 * TILE;
-constexpr int LDS_TOTAL = OFF_S0 + STAGE;   // 159744
+constexpr int VROW = 192;                   // V rows are padded to 192 B: the transposed reads (ds_read_b64_tr_b16: 4 rows x 64 B
+                                            // per 32-lane group) are 2-way bank conflicts on 176-B rows and conflict-free on 192
+constexpr int VTILE = 256 * VROW;           // 49152
+constexpr int OFF_K = 0, OFF_V = TILE, OFF_Q = TILE + VTILE;
+constexpr int OFF_S1 = 0, OFF_S0 = TILE + VTILE;
+constexpr int LDS_TOTAL = OFF_S0 + STAGE;   // 163840: all 160 KiB of the CU
 constexpr int CH = 64, NST = 4, CHB = CH * ROW, DB = 3, KS = 6, CPR = HD / 8;
 constexpr int OROWS = 16, ORND = 2, OSLAB = OROWS * ROW;  // output staging: 16 rows per round, two rounds per item
 constexpr int NOST = ORND * ((OROWS * CPR + 63) / 64);    // 6 output store instructions per wave and item
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
         asm volatile("" : "+v"(el));
         const int r16 = el & 15, g4 = el >> 4;
         const int c32 = el & 31, hh = el >> 5;
-        const int vbase = (4 * hh + ((el & 15) >> 2)) * ROW + (16 * ((el >> 4) & 1) + 4 * (el & 3)) * 2;
+        const int vbase = (4 * hh + ((el & 15) >> 2)) * VROW + (16 * ((el >> 4) & 1) + 4 * (el & 3)) * 2;
         char* oslab = smem + OFF_K + wv * OSLAB;
         {
             // wave (wm, wn): rows 64 wm .. + 63; local columns 0..87 = q (wn 0) or k (wn 1), 88.. = v 0..39 / v 40..87, then pad
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
                         *reinterpret_cast<uint2*>(qk_tile + row * ROW + lc * 2) =
                             make_uint2(pack_bf16(v[0] * f, v[1] * f), pack_bf16(v[2] * f, v[3] * f));
                     } else if (lc < HD + nv) {
-                        *reinterpret_cast<uint2*>(smem + OFF_V + row * ROW + (lc - HD + v0) * 2) =
+                        *reinterpret_cast<uint2*>(smem + OFF_V + row * VROW + (lc - HD + v0) * 2) =
                             make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
                     }
                 }
@@ -317,18 +320,18 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
             }
         };
         auto pv_chunk = [&](int c, const uint4 (&pf)[4]) {
-            const char* sV = smem + OFF_V + c * CHB;
+            const char* sV = smem + OFF_V + c * (CH * VROW);
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const char* vrow = sV + (k2 * 32 + s2 * 16) * ROW + vbase;
+                    const char* vrow = sV + (k2 * 32 + s2 * 16) * VROW + vbase;
 #pragma unroll
                     for (int db = 0; db < DB; ++db) {
                         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (__attribute__((address_space(3))) s16x4*)(vrow + db * 64));
                         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(vrow + db * 64 + 8 * ROW));
+                            (__attribute__((address_space(3))) s16x4*)(vrow + db * 64 + 8 * VROW));
                         uint4 vf = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                         if (db == DB - 1 && c32 >= HD - 32 * (DB - 1)) vf = ones;  // rows 88..95 of V^T: the row sum
                         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),

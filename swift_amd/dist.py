@@ -80,8 +80,37 @@ def setup_torch(backend: Optional[str] = None, timeout_s: int = 1800, single_ran
             os.environ.setdefault("MASTER_PORT", "29500")
         if be == "nccl":
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())  # eager communicator: init errors surface here
-        dist.init_process_group(be, **kw)
+        with _stdout_to_stderr():  # RCCL prints a version banner on C stdout when its first communicator comes up
+            dist.init_process_group(be, **kw)
+            if be == "nccl":
+                dist.barrier()
+                torch.cuda.synchronize()
     return get_rank()
+
+
+class _stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block, and C stdio is flushed before it is restored: whatever a native
+    library printf()s meanwhile (RCCL's start-up banner sits in C stdout's buffer until exit otherwise) ends up on stderr,
+    so that a launcher which prints ONE machine-readable line on stdout (bench.py) really prints one."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        import sys
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
 
 
 def maybe_launch_ranks(n_gpus: Optional[int], module: str) -> None:
@@ -111,7 +140,7 @@ def maybe_launch_ranks(n_gpus: Optional[int], module: str) -> None:
             env["HYDRA_RUN_ID"] = run_id
         procs.append(subprocess.Popen([sys.executable, "-m", module, *sys.argv[1:]], env=env))
     import time
-    rc, live = 0, list(procs)
+    rc, live, stopped = 0, list(procs), set()
     while live:  # a failed rank would leave the others waiting in a collective: stop them (by their own PIDs)
         time.sleep(0.2)
         for p in list(live):
@@ -119,9 +148,12 @@ def maybe_launch_ranks(n_gpus: Optional[int], module: str) -> None:
             if code is None:
                 continue
             live.remove(p)
+            if p.pid in stopped:  # (a sibling this launcher ended itself: its signal is not a result)
+                continue
             rc = max(rc, abs(code))
             if code != 0:
                 for q in live:
+                    stopped.add(q.pid)
                     q.terminate()
     raise SystemExit(rc)
 

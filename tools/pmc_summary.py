@@ -8,7 +8,7 @@ for path in sys.argv[1:]:
         k = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:60]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in sorted(acc.items(), key=lambda kv: -sum(len(v) for v in kv[1].values())):
-    if not any(s in k for s in ("gemm", "attn", "modnorm")): continue
+    if not any(s in k for s in ("gemm", "attn", "modnorm", "qkv")): continue
     print(k)
     for c, v in cs.items():
         print(f"    {c:28s} n={len(v):4d} mean={sum(v)/len(v):16.1f}")
