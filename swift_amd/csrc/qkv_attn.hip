@@ -91,8 +91,8 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
     const int64_t ntok = (int64_t)a.gh * a.gw;
     const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
 
-    // item order of attention_pipe.hip: (sample, window, head), heads fastest; the workgroups of one XCD take consecutive
-    // items at the same time (same window: its 256 token rows are fetched into that XCD's L2 once for up to 12 heads)
+    // the workgroups of one XCD take consecutive items at the same time, each XCD walking its own contiguous eighth of the
+    // item list in rounds (item numbering: `decode` below)
     int first, last, istep;
     if ((gridDim.x & 7) == 0) {
         const int xcd = blockIdx.x & 7, nx = gridDim.x >> 3;
@@ -108,6 +108,12 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
     for (int o = tid * 16; o < LDS_TOTAL; o += NT * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
+    // Items are numbered (sample, window, head), heads fastest: the 32 workgroups of an XCD work on the twelve heads of two
+    // to three windows at a time, so a window's token rows are fetched into that XCD's L2 once and the twelve 176-B head
+    // slices of an output row are completed in L2 by neighbouring CUs.  The twelve weight slabs (6.9 MB) do not fit the
+    // 4 MB L2 beside them and stream from the Infinity Cache instead (PMC: 20 GB of fabric reads per launch at 96 units).
+    // The opposite order -- groups of four heads outermost, so that four slabs stay L2-resident and the token rows are
+    // fetched three times -- was measured 2 % slower (profiles/r03e_qkv_attn_fused_ab8.txt).
     auto decode = [&](int item, int& b, int& w, int& h) {
         h = item % a.heads;
         const int r = item / a.heads;
