@@ -90,6 +90,18 @@ __device__ __forceinline__ void dma_piece_fast(uint32_t lds_dst, const char* bas
         : "memory");
 }
 
+// Same with the non-temporal cache policy: for operands that are dead in L2 once the workgroups sharing them have passed
+// (the activation panel of a GEMM tile row), so that the lines of the re-read operand (the weight panel) survive them
+__device__ __forceinline__ void dma_piece_fast_nt(uint32_t lds_dst, const char* base, uint32_t voff) {
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 1\n\t"
+        "global_load_lds_dwordx4 %0, %2 nt"
+        :
+        : "v"(voff), "s"(lds_dst), "s"(base)
+        : "memory");
+}
+
 // L2 look-ahead: a 4-byte-per-lane LDS-DMA whose only purpose is to pull each lane's 128-B line into the XCD's L2 (the
 // 256 bytes it writes go to a scratch area of LDS)
 __device__ __forceinline__ void dma_touch(uint32_t lds_dst, const char* base, uint32_t voff) {

@@ -61,6 +61,10 @@ constexpr int EPI_QKNORM_TILED = 4;  // internal: SWIFTK_EPI_QKNORM with the win
 // L2 look-ahead of the persistent kernel (k-tiles): in the second half of every k-tile (where no DMA piece is issued) each
 // wave requests one 4-byte LDS-DMA per lane from the 128-B lines its workgroup will stage SWIFTK_X_TOUCH + 1 k-tiles later;
 // the k-tile's closing wait leaves those two requests in flight (counted vmcnt), so their miss latency is never waited for.
+// non-temporal LDS-DMA for the activation operand (A/B experiment)
+#ifndef SWIFTK_X_ANT
+#define SWIFTK_X_ANT 0
+#endif
 #ifndef SWIFTK_X_TOUCH
 #define SWIFTK_X_TOUCH 0
 #endif
@@ -417,7 +421,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     // `koff` = byte offset of the k-tile inside a row, carried in the per-lane offset
     auto issue_piece = [&](uint32_t sa, uint32_t koff, int p) {
         if (p < 4) {
+#if SWIFTK_X_ANT
+            dma_piece_fast_nt(sa + (wv * 4 + p) * 1024, abase[p], ((p & 1) ? va_odd : va_even) + koff);
+#else
             dma_piece_fast(sa + (wv * 4 + p) * 1024, abase[p], ((p & 1) ? va_odd : va_even) + koff);
+#endif
         } else {
             const int i = p - 4;
             // W has 40 / 44 / 48 pieces for 8 waves: with 44 the sixth one exists for waves 0-3 only (a wave-uniform branch

@@ -646,6 +646,7 @@ def test_trainer_trajectory_vs_oracle_net_and_oracle_trainer(dev, tmp_path, monk
     assert lr[0] < 2e-4 and opt.param_groups[0]["lr"] < 2e-4  # past the warm-up, on the cosine
     # ---- profile=True: wait 2 / warm-up 2 / active 5 iterations, then the record (trainer.py:155-177, 389-396)
     assert not tr.prof.done
+    tr._optimizer_step = inner  # (the gradient snapshots above copied to the host inside the "optimizer" phase)
     for k in range(3, nsteps):
         assert math.isfinite(float(tr.train_step(x, t, idx, delta, global_nimg=B * (k + 1), steps=1)))
     assert tr.prof.done and set(tr.prof.summary) == {"forward", "backward", "allreduce", "optimizer"}
@@ -834,7 +835,11 @@ def test_graph_pools_survive_growing_rollouts_and_moved_gradients(dev, monkeypat
             loss.backward()
             out.append((float(loss), torch.cat([p.grad.flatten() for p in net.parameters()]).cpu()))
         if graphs_on:
-            assert net.model._train_engine.graphs._graphs, "nothing was captured"
+            cache = net.model._train_engine.graphs
+            if set_to_none:  # gradient buffers move every iteration: every capture is dropped again, none may survive stale
+                assert max(cache.generation.values()) > 1, "moved gradient buffers did not invalidate the captures"
+            else:
+                assert cache._graphs, "nothing was captured"
         return out
 
     ref = trajectory(False, False)

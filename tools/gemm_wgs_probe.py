@@ -16,7 +16,7 @@ for name, N, K, Kalg, epi in shapes:
         a, w = a[:, :Kalg], w[:, :Kalg]
     out = torch.empty(M, N // 2 if epi == ops.EPI_SWIGLU else N, dtype=torch.bfloat16, device=dev)
     base = None
-    for wgs in (256, 128, 64, 32, 256):
+    for wgs in ([int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (256, 128, 64, 32, 256)):
         L.swiftk_set_tuning(2, wgs)
         ts = []
         for _ in range(3):
