@@ -617,7 +617,30 @@ def fx_scm_distill_tiny():
          loss_without_teacher=float(plain), grad_keys=np.array(gsel), grad_norms=g, w_lat=L.w_lat, w_var=L.w_var)
 
 
-ALL = dict(scm_distill_tiny=fx_scm_distill_tiny, index_streams=fx_index_streams, era5_tiny=fx_era5_tiny, swiftb_long=fx_swiftb_long, trainer_tiny=fx_trainer_tiny, metrics_tiny=fx_metrics_tiny, val_tiny=fx_val_tiny, muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
+def fx_swiftb_2s_bf16():
+    """How far the reference's OWN bf16 path is from its fp32 path on BASELINE configs[2] at full size: ``dpm_solver_2s``
+    (39 Swift-B evaluations) with ``denoise_dtype=torch.bfloat16`` (CPU autocast) against the fp32 output stored in
+    swiftb_long.npz, on the stored sub-sample -- the yardstick for the bf16 engine's bound in tests/test_gpu_model.py."""
+    from swift.generating.diffusion import DiffusionSampler
+    import time
+    c, seed = SWIFTB, 1234
+    net, state = build_ref_net(c, seed)
+    nv, nf = c["n_vars"], c["n_forc"]
+    S = DiffusionSampler(net)
+    cond = det_normal((1, nv + nf, *c["img"]), seed, "cond")
+    lat = det_normal((1, nv, *c["img"]), seed, "lat")
+    t0 = time.time()
+    y16 = S.dpm_solver_2s(lat, condition=cond, num_steps=20, sigma_min=0.02, sigma_max=200.0, auxiliary=0.6,
+                          denoise_dtype=torch.bfloat16)
+    print(f"reference dpm_solver_2s under bf16 autocast: {time.time() - t0:.1f} s")
+    ref = torch.from_numpy(np.load(os.path.join(OUT, "swiftb_long.npz"))["y2s_sub"])
+    sub = y16[0, ::4, ::8, ::8].float()
+    rel = float((sub.double() - ref.double()).norm() / ref.double().norm())
+    print(f"bf16-autocast vs fp32 (sub-sample): rel-L2 {rel:.3e}")
+    save("swiftb_2s_bf16", seed=seed, fingerprint=state_fingerprint(state), bf16_autocast_rel_sub=rel)
+
+
+ALL = dict(swiftb_2s_bf16=fx_swiftb_2s_bf16, scm_distill_tiny=fx_scm_distill_tiny, index_streams=fx_index_streams, era5_tiny=fx_era5_tiny, swiftb_long=fx_swiftb_long, trainer_tiny=fx_trainer_tiny, metrics_tiny=fx_metrics_tiny, val_tiny=fx_val_tiny, muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
            samplers_tiny=fx_samplers_tiny, rollout_tiny=fx_rollout_tiny, losses_tiny=fx_losses_tiny,
            swiftb_step=fx_swiftb_step, weights_aux=fx_weights_aux)
 
