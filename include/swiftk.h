@@ -253,6 +253,11 @@ int swiftk_qknorm_bwd(const void* qkvh, const void* dqkvh, int64_t ld, const flo
 /* Backward of the attention core (bf16, head_dim 88, PRENORM layout): dqkvh = d(q-hat | k-hat | v). */
 int swiftk_window_attention_bwd(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo, void* dqkvh, int B,
                                 int gh, int gw, int heads, int head_dim, int shift_h, int shift_w, int dtype, void* stream);
+/* Same, with the per-head logit scale parameter [heads] (or NULL): where exp(min(scale, ln 100)) <= 48 bounds |logit| (q-hat and
+ * k-hat arrive normalised), the softmax is rebuilt without a row-maximum sweep, as in the forward kernel. */
+int swiftk_window_attention_bwd_scaled(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo, void* dqkvh,
+                                       const float* scale, int B, int gh, int gw, int heads, int head_dim, int shift_h,
+                                       int shift_w, int dtype, void* stream);
 
 /* out[c] += sum_r src[r][c]  (period == 0), or out[(r % period)][c] += src[r][c]  (bias / pos_embed gradients) */
 int swiftk_colsum(const float* src, int64_t lds, float* out, int64_t rows, int cols, int64_t period, void* stream);

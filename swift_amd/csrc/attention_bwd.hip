@@ -272,11 +272,332 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
     store_t<HD>(my_dqkv + 2 * HD, dv, hh);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent form for head_dim 88 (round 3).  The kernel above spends 45 us per item for 10.5 us of MFMA time: one
+// workgroup per item, images staged through registers by 256 of its 512 threads, every load latency exposed four times
+// per item (K/V images, fragment rows, Q/dO images, fragment rows) with one workgroup per CU.  Here a fixed grid walks the
+// item list (XCD-concurrent order of attention_pipe.hip) and every image travels by LDS-DMA into one of THREE 45-KB
+// buffers (row-major 176-B rows, lane-linear pieces), rotated so that two of an item's four image loads hide under
+// compute: Q(n) lands under pass A, K(n+1) under pass B.  Pass A no longer keeps S^T of the whole window in registers
+// (128 VGPRs): a first sweep over the key blocks finds the row maximum (skipped when the logit bound exp(min(scale, ln 100))
+// <= 48 lets offset 0 stand in), a second sweep rebuilds S^T block by block and accumulates
+//     l += e,   dq^T += kh^T [e o (dP^T - delta)],     e = exp(S^T - m),
+// with the 1/l factor -- a per-lane scalar, a lane owns one query column -- applied to dq once at the end.
+constexpr int ROW88 = 176, TILE88 = 256 * ROW88;
+constexpr int OSLAB88 = 16 * ROW88;   // wave-private output staging: 16 rows per round
+constexpr int BWD_LDS = 3 * TILE88 + 64 + 3 * 1024 + 8 * OSLAB88;   // 160,832 B
+
+__device__ __forceinline__ uint4 tr_frag88(const char* img, int base_row, int db, int vbase) {
+    const char* p = img + base_row * ROW88 + vbase + db * 64;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 8 * ROW88));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(uint4, v);
+}
+
+struct BwdPArgs {
+    BwdArgs a;
+    const float* scale;  // per-head logit scale parameter (bounds |logit|); null = unknown (always take the maximum)
+    int nitems;
+    int dbg;  // timing experiments (tuning key 4, bits 16..): 1 no pass-A sweeps, 2 no pass-B loop, 4 no output stores, 8 no max sweep
+};
+
+__global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
+    constexpr int HD = 88, KS = 6, CPR = 11, NPQ = TILE88 / 1024;  // 44 pieces per image
+    const BwdArgs& a = pa.a;
+    __shared__ __attribute__((aligned(16))) char smem[BWD_LDS];
+    float* st_m = reinterpret_cast<float*>(smem + 3 * TILE88 + 64);
+    float* st_il = st_m + 256;
+    float* st_dl = st_m + 512;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c32 = lane & 31, hh = lane >> 5, i16 = lane & 15;
+    const int vbase = (4 * hh + (i16 >> 2)) * ROW88 + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
+    char* oslab = smem + 3 * TILE88 + 64 + 3 * 1024 + wv * OSLAB88;
+    const int64_t ntok = (int64_t)a.gh * a.gw;
+    // A transposed accumulator set X^T[d][row] (row = this lane's c32 of the wave's 32 window rows) leaves through the
+    // wave's LDS slab, 16 rows per round: written as the 8-B pieces the MFMA layout yields, read back as 16-B chunks of
+    // consecutive row bytes, so one dwordx4 store covers ~5.8 whole 176-B row segments.  The row-per-lane form (22 8-byte
+    // stores per lane, 64 different rows per instruction) put 4,224 partial-line writes per wave and item on the CU's
+    // memory path -- more than the kernel's arithmetic costs.
+    auto store_rows = [&](const f32x16 (&acc)[DB], int w_, int64_t tok0_, int col0) {
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if ((c32 >> 4) == rnd) {
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int d = db * 32 + g * 8 + hh * 4;
+                        if (d < 88)
+                            *reinterpret_cast<uint2*>(oslab + (c32 & 15) * ROW88 + d * 2) =
+                                make_uint2(pack_bf16(acc[db][4 * g], acc[db][4 * g + 1]), pack_bf16(acc[db][4 * g + 2], acc[db][4 * g + 3]));
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int c = lane + 64 * t;
+                if (c < 16 * 11) {
+                    const int row = c / 11, cc = c - row * 11;
+                    const uint4 v = *reinterpret_cast<const uint4*>(oslab + row * ROW88 + cc * 16);
+                    const int tok = wtoken(a, w_, wv * 32 + rnd * 16 + row);
+                    *reinterpret_cast<uint4*>(a.dqkvh + (tok0_ + tok) * a.ldq + col0 + cc * 8) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    const int64_t ldq_b = a.ldq * 2, ldo_b = a.ldo * 2;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+
+    int first, last, istep;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, nx = gridDim.x >> 3;
+        first = (int)((int64_t)xcd * pa.nitems / 8) + (blockIdx.x >> 3);
+        last = (int)((int64_t)(xcd + 1) * pa.nitems / 8);
+        istep = nx;
+    } else {
+        first = (int)((int64_t)blockIdx.x * pa.nitems / gridDim.x);
+        last = (int)((int64_t)(blockIdx.x + 1) * pa.nitems / gridDim.x);
+        istep = 1;
+    }
+    if (first >= last) return;
+    for (int o = tid * 16; o < BWD_LDS; o += NT * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    auto decode = [&](int item, int& b, int& w, int& h) {
+        h = item % a.heads;
+        const int r = item / a.heads;
+        w = r % a.nw;
+        b = r / a.nw;
+    };
+    auto pin = [&](const char* base) {
+        const uint64_t u = (uint64_t)base;
+        return (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(u >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)u));
+    };
+    // An image = 44 pieces of 1 KiB; this wave issues pieces wv + 8 i, i = 0..5 (slots 44..47 repeat pieces 0..3: uniform
+    // counts).  Chunk c = 64 p + lane of the image is 16-B chunk c % 11 of window row c / 11; the per-lane source offsets are
+    // recomputed for every request (a few dozen VALU instructions per image) rather than held in twelve registers.
+    auto dma_img = [&](int buf, const char* base, int w_, int64_t ld_b) {
+        const char* bs = pin(base);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            int p = wv + 8 * i;
+            p = p >= NPQ ? p - NPQ : p;
+            const int c = p * 64 + lane;
+            const int row = c / CPR, cc = c - row * CPR;
+            dma_piece(lds0 + buf * TILE88 + p * 1024, bs, (uint32_t)(wtoken(a, w_, row) * (int)ld_b) + 16u * cc);
+        }
+    };
+    auto qkv_base = [&](int b, int h, int part) {
+        return reinterpret_cast<const char*>(a.qkvh) + (int64_t)b * ntok * ldq_b + (int64_t)(h * 3 + part) * ROW88;
+    };
+    auto do_base = [&](int b, int h) { return reinterpret_cast<const char*>(a.d_o) + (int64_t)b * ntok * ldo_b + (int64_t)h * ROW88; };
+
+    int b, w, h;
+    decode(first, b, w, h);
+    int bK = 0, bV = 1, bF = 2;
+    dma_img(bK, qkv_base(b, h, 1), w, ldq_b);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dma_img(bV, qkv_base(b, h, 2), w, ldq_b);
+    __builtin_amdgcn_s_barrier();  // the first K image is complete (later ones are published by the end-of-item barrier)
+
+    for (int item = first; item < last; item += istep) {
+        int nb = b, nwn = w, nh = h;
+        const bool has_next = item + istep < last;
+        if (has_next) decode(item + istep, nb, nwn, nh);
+        const float bound = pa.scale ? __expf(fminf(pa.scale[h], 4.605170185988092f)) : INFINITY;
+        const bool online = !(bound <= 48.f) && !(pa.dbg & 8);
+        const int64_t tok0 = (int64_t)b * ntok;
+
+        // ------------------------------------------------------------------------------ pass A: K in bK, V in bV
+        // (every wave is past the previous item: the third buffer is free; K(n) is complete, V(n) still landing)
+        dma_img(bF, qkv_base(b, h, 0), w, ldq_b);  // Q image for pass B lands under pass A
+        // this lane's query row of q-hat and dO as MFMA B-operand fragments, and delta = dO . O of that row.  (Loading them
+        // one item ahead, in front of the previous item's dk / dv stores, with a counted wait here was measured slower:
+        // 571 against 481 us per launch -- 48 more live registers across the item boundary, spills inside the loops.)
+        uint4 qf[KS], dof[KS];
+        float delta;
+        {
+            const int64_t t0 = tok0 + wtoken(a, w, wv * 32 + c32);
+            row_frags<HD, KS>(a.qkvh + t0 * a.ldq + h * 3 * HD, hh, qf);
+            row_frags<HD, KS>(a.d_o + t0 * a.ldo + h * HD, hh, dof);
+            uint4 of[KS];
+            row_frags<HD, KS>(a.o + t0 * a.ldo + h * HD, hh, of);
+            float sd = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) sd += dot8(dof[ks], of[ks]);
+            delta = sd + __shfl_xor(sd, 32, 64);
+        }
+        const char* imK = smem + bK * TILE88;
+        const char* imV = smem + bV * TILE88;
+        float mx = 0.f;
+        if (online) {
+            mx = -INFINITY;
+#pragma unroll 1
+            for (int kb = 0; kb < 8; ++kb) {
+                f32x16 sc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    sc = mfma(*reinterpret_cast<const uint4*>(imK + (kb * 32 + c32) * ROW88 + ks * 32 + hh * 16), qf[ks], sc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of V have landed (under the maximum sweep) ...
+        __builtin_amdgcn_s_barrier();                     // ... every wave's have
+        const float mb = mx * LOG2E;
+        float l = 0.f;
+        f32x16 dq[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+#pragma unroll 1
+        for (int kb = (pa.dbg & 1) ? 8 : 0; kb < 8; ++kb) {
+            f32x16 sc, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                sc = mfma(*reinterpret_cast<const uint4*>(imK + (kb * 32 + c32) * ROW88 + ks * 32 + hh * 16), qf[ks], sc);
+                dp = mfma(*reinterpret_cast<const uint4*>(imV + (kb * 32 + c32) * ROW88 + ks * 32 + hh * 16), dof[ks], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(sc[r] * LOG2E - mb);
+                l += e;
+                sc[r] = e * (dp[r] - delta);  // l x dS^T: the 1/l factor is applied to dq at the end
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint4 ds = pack8(sc, s2);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) dq[db] = mfma(tr_frag88(imK, kb * 32 + s2 * 16, db, vbase), ds, dq[db]);
+            }
+        }
+        l += __shfl_xor(l, 32, 64);
+        const float il = 1.0f / l;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[db][r] *= il;
+        if (hh == 0) {
+            st_m[wv * 32 + c32] = mx;
+            st_il[wv * 32 + c32] = il;
+            st_dl[wv * 32 + c32] = delta;
+        }
+
+        // ------------------------------------------------------------------------------ pass B: Q in bF, dO -> bK
+        // this lane's key row of K and V as MFMA B-operand fragments: straight from the images, which are still intact
+        uint4 kf[KS], vf[KS];
+        {
+            const char* krow = imK + (wv * 32 + c32) * ROW88;
+            const char* vrow = imV + (wv * 32 + c32) * ROW88;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks == KS - 1) {  // 5.5 k-steps: the last one has one real 16-B chunk
+                    const uint4 tk = *reinterpret_cast<const uint4*>(krow + (2 * ks) * 16);
+                    const uint4 tv = *reinterpret_cast<const uint4*>(vrow + (2 * ks) * 16);
+                    kf[ks] = hh ? make_uint4(0, 0, 0, 0) : tk;
+                    vf[ks] = hh ? make_uint4(0, 0, 0, 0) : tv;
+                } else {
+                    kf[ks] = *reinterpret_cast<const uint4*>(krow + (2 * ks + hh) * 16);
+                    vf[ks] = *reinterpret_cast<const uint4*>(vrow + (2 * ks + hh) * 16);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // every wave is done with the K and V images; the row statistics are written
+        dma_img(bK, do_base(b, h), w, ldo_b);
+        if (!(pa.dbg & 4)) store_rows(dq, w, tok0, h * 3 * HD);  // (the dO image lands under the dq stores)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // Q (requested a pass ago) and dO images complete
+        if (has_next) {                // the next item's K image lands under pass B
+            dma_img(bV, qkv_base(nb, nh, 1), nwn, ldq_b);
+        }
+        const char* imQ = smem + bF * TILE88;
+        const char* imO = smem + bK * TILE88;
+        f32x16 dk[DB], dv[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dk[db][r] = dv[db][r] = 0.f;
+#pragma unroll 1
+        for (int qb = (pa.dbg & 2) ? 8 : 0; qb < 8; ++qb) {
+            f32x16 sq, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sq[r] = dp[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                sq = mfma(*reinterpret_cast<const uint4*>(imQ + (qb * 32 + c32) * ROW88 + ks * 32 + hh * 16), kf[ks], sq);
+                dp = mfma(*reinterpret_cast<const uint4*>(imO + (qb * 32 + c32) * ROW88 + ks * 32 + hh * 16), vf[ks], dp);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {  // P and dS overwrite S and dP in place (this phase runs at the register limit)
+                const int q0 = qb * 32 + 8 * g + 4 * hh;
+                const float4 m4 = *reinterpret_cast<const float4*>(st_m + q0);
+                const float4 i4 = *reinterpret_cast<const float4*>(st_il + q0);
+                const float4 d4 = *reinterpret_cast<const float4*>(st_dl + q0);
+                const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = __builtin_amdgcn_exp2f((sq[4 * g + e] - mm[e]) * LOG2E) * ii[e];
+                    sq[4 * g + e] = p;
+                    dp[4 * g + e] = p * (dp[4 * g + e] - dd[e]);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint4 pf = pack8(sq, s2), df = pack8(dp, s2);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    dv[db] = mfma(tr_frag88(imO, qb * 32 + s2 * 16, db, vbase), pf, dv[db]);
+                    dk[db] = mfma(tr_frag88(imQ, qb * 32 + s2 * 16, db, vbase), df, dk[db]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next K image (it had the whole pass) ...
+        __builtin_amdgcn_s_barrier();  // ... every wave's; and every wave is done with the Q and dO images
+        if (has_next) dma_img(bF, qkv_base(nb, nh, 2), nwn, ldq_b);  // next V over the dead Q image: lands under the stores below
+        if (!(pa.dbg & 4)) {                                 // and under the next item's maximum sweep
+            store_rows(dk, w, tok0, h * 3 * HD + HD);
+            store_rows(dv, w, tok0, h * 3 * HD + 2 * HD);
+        }
+        // next item: K sits where this item's V was, V where Q was; this item's K / dO buffer is the free one
+        const int t = bK;
+        bK = bV;
+        bV = bF;
+        bF = t;
+        b = nb; w = nwn; h = nh;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
+
+int g_attn_bwd_pipe = 1;                   // tuning key 9 (A/B): 0 = one workgroup per item (the round-1 kernel)
+static bool ntok_bytes_ok(const BwdArgs& a) {    // per-lane 32-bit source offsets inside one sample
+    return (int64_t)a.gh * a.gw * a.ldq * 2 < (1ll << 32) && (int64_t)a.gh * a.gw * a.ldo * 2 < (1ll << 32);
+}
 
 extern "C" int swiftk_window_attention_bwd(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo,
                                            void* dqkvh, int B, int gh, int gw, int heads, int head_dim, int shift_h,
                                            int shift_w, int dtype, void* stream) {
+    return swiftk_window_attention_bwd_scaled(qkvh, ldq, o, d_o, ldo, dqkvh, nullptr, B, gh, gw, heads, head_dim, shift_h, shift_w,
+                                              dtype, stream);
+}
+
+extern "C" int swiftk_window_attention_bwd_scaled(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo,
+                                                  void* dqkvh, const float* scale, int B, int gh, int gw, int heads, int head_dim,
+                                                  int shift_h, int shift_w, int dtype, void* stream) {
     if (!qkvh || !o || !d_o || !dqkvh || B <= 0 || heads <= 0) return SWIFTK_EINVAL;
     if (dtype != SWIFTK_BF16) return SWIFTK_ESHAPE;  // training runs under bf16 autocast (trainer.py:191)
     if (head_dim != 80 && head_dim != 88 && head_dim != 96) return SWIFTK_ESHAPE;
@@ -302,6 +623,18 @@ extern "C" int swiftk_window_attention_bwd(const void* qkvh, int64_t ldq, const 
     a.nw = (gh / 16) * (gw / 16);
     const dim3 grid(B * a.nw * heads);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (head_dim == 88 && g_attn_bwd_pipe && ntok_bytes_ok(a)) {
+        BwdPArgs pa;
+        pa.a = a;
+        pa.scale = scale;
+        pa.nitems = B * a.nw * heads;
+        pa.dbg = g_attn_dbg >> 16;
+        int pgrid = 256;
+        if (pa.nitems < pgrid) pgrid = pa.nitems >= 8 ? (pa.nitems & ~7) : pa.nitems;
+        hipLaunchKernelGGL(attn_bwd_pipe_kernel, dim3(pgrid), dim3(NT), 0, st, pa);
+        SWIFTK_CHECK_LAUNCH();
+        return 0;
+    }
     if (head_dim == 80) hipLaunchKernelGGL(attn_bwd_kernel<80>, grid, dim3(NT), 0, st, a);
     else if (head_dim == 96) hipLaunchKernelGGL(attn_bwd_kernel<96>, grid, dim3(NT), 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_kernel<88>, grid, dim3(NT), 0, st, a);

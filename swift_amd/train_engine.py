@@ -371,9 +371,9 @@ class SwinTrainEngine:
             self._wgrad(dy1, A["att"], d, d, G(att.wo.weight))
             dqkvh = torch.empty(M, 3 * d, dtype=_BF, device=dev)
             sh = A["shift"]
-            check(L.swiftk_window_attention_bwd(A["qkvh"].data_ptr(), 3 * d, A["att"].data_ptr(), datt.data_ptr(), self.kd,
-                                                dqkvh.data_ptr(), B, gh, gw, heads, self.hd, sh[0], sh[1], BF16, _s()),
-                  "swiftk_window_attention_bwd")
+            check(L.swiftk_window_attention_bwd_scaled(A["qkvh"].data_ptr(), 3 * d, A["att"].data_ptr(), datt.data_ptr(), self.kd,
+                                                       dqkvh.data_ptr(), W["scale"].data_ptr(), B, gh, gw, heads, self.hd, sh[0],
+                                                       sh[1], BF16, _s()), "swiftk_window_attention_bwd")
             dqkv = _padded(M, self.kqkv, 3 * d)
             dscale = torch.zeros(heads, dtype=torch.float32, device=dev)
             check(L.swiftk_qknorm_bwd(A["qkvh"].data_ptr(), dqkvh.data_ptr(), 3 * d, A["rn"].data_ptr(), dqkv.data_ptr(), self.kqkv,

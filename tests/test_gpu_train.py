@@ -193,12 +193,13 @@ def test_qknorm_epilogue_rn_and_bwd(dev):
     assert float(dscale[3]) == 0.0 and float(dscale[8]) == 0.0  # heads clamped at ln(100): no gradient (swinv2.py:125)
 
 
+@pytest.mark.parametrize("B", [2, 16])  # 16: 768 items on 256 persistent workgroups (buffer rotation, cross-item prefetch)
 @pytest.mark.parametrize("shift", [(0, 0), (8, 8)])
-def test_window_attention_bwd(dev, shift):
+def test_window_attention_bwd(dev, shift, B):
     from oracle.swinv2 import window_token_index
     from swift_amd import _lib, ops
     L = _lib.lib()
-    B, grid, heads, hd = 2, (32, 32), 12, 88
+    grid, heads, hd = (32, 32), 12, 88
     n = grid[0] * grid[1]
     scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 60.0, 1.0, 10.0, 50.0, 20.0, 15.0, 5.0, 20.0, 10.0]))
     pre = _prenorm(rnd((B, n, 3 * heads * hd), 13), scale, heads, hd).to(dev).to(BF)
@@ -220,6 +221,24 @@ def test_window_attention_bwd(dev, shift):
         e = rel_l2(g[..., part, :], gr[..., part, :])
         print(f"attention bwd d{name}: rel-L2 {e:.3e}")
         assert e < 2.5e-2, name
+    # the persistent kernel (default for head_dim 88) against the one-workgroup-per-item kernel it replaces: same products,
+    # same bf16 roundings of P and dS up to the postponed 1/l factor
+    d_old = torch.empty_like(pre)
+    L.swiftk_set_tuning(9, 0)
+    try:
+        assert L.swiftk_window_attention_bwd(pre.data_ptr(), 3168, o.data_ptr(), do.data_ptr(), 1056, d_old.data_ptr(), B, grid[0],
+                                             grid[1], heads, hd, shift[0], shift[1], _lib.BF16, s()) == 0
+    finally:
+        L.swiftk_set_tuning(9, 1)
+    assert rel_l2(dpre.float().cpu(), d_old.float().cpu()) < 1e-2
+    # with the logit scales at hand, heads whose bound is <= 48 skip the row-maximum sweep (offset 0): same gradients
+    d_s = torch.empty_like(pre)
+    assert L.swiftk_window_attention_bwd_scaled(pre.data_ptr(), 3168, o.data_ptr(), do.data_ptr(), 1056, d_s.data_ptr(),
+                                                scale.to(dev).data_ptr(), B, grid[0], grid[1], heads, hd, shift[0], shift[1],
+                                                _lib.BF16, s()) == 0
+    assert rel_l2(d_s.float().cpu(), dpre.float().cpu()) < 1e-2
+    for part, name in enumerate("qkv"):
+        assert rel_l2(d_s.float().cpu().view(B, n, heads, 3, hd)[..., part, :], gr[..., part, :]) < 2.5e-2, name
 
 
 def test_loss_kernels(dev):
