@@ -245,6 +245,8 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
         char* oslab = smem + OFF_K + wv * OSLAB;
         {
             // wave (wm, wn): rows 64 wm .. + 63; local columns 0..87 = q (wn 0) or k (wn 1), 88.. = v 0..39 / v 40..87, then pad
+            // (folding log2(e) into tau would save the core 128 v_mul per lane and item, but q-hat would then round differently
+            // from the two-kernel path's: the two agree to 1e-4 as it is, 7e-3 with the fold -- kept as a regression check)
             const float tau = wn ? 1.0f : __expf(fminf(a.scale[h], 4.605170185988092f));
             const int nv = wn ? 48 : 40, v0 = wn ? 40 : 0;
             char* qk_tile = smem + (wn ? OFF_K : OFF_Q);
@@ -325,6 +327,8 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
                 }
             }
         };
+        // (requesting a chunk's 24 transposed V^T reads in front of its softmax, so that the PV MFMAs issue back to back instead
+        // of each behind an `lgkmcnt(0)` on reads issued just before it, was measured 2 % SLOWER for the kernel: 231 VGPRs)
         auto pv_chunk = [&](int c, const uint4 (&pf)[4]) {
             const char* sV = smem + OFF_V + c * (CH * VROW);
 #pragma unroll

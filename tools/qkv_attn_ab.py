@@ -31,7 +31,7 @@ def stag(n):
     def f():
         L.swiftk_set_tuning(4, (n << 2) << 8); fused(); L.swiftk_set_tuning(4, 0)
     return f
-fns = {"two kernels": two, "fused, waves 4-7 +64 cyc": stag(1), "fused, waves 4-7 +192 cyc": stag(2), "fused, waves 4-7 +448 cyc": stag(4), "fused, waves 4-7 +960 cyc": stag(8), "  (to_qkv GEMM alone)": gemm_only, "fused": fused, "  (fused, attention core skipped)": fused_noattn}
+fns = {"two kernels": two, "fused, waves 4-7 +192 cyc": stag(2), "  (to_qkv GEMM alone)": gemm_only, "fused": fused, "  (fused, attention core skipped)": fused_noattn}
 res = {k: [] for k in fns}
 for rnd in range(R):
     for k in (list(fns) if rnd % 2 == 0 else list(fns)[::-1]):
