@@ -408,6 +408,13 @@ def main():
             line["cpu_baseline"] = cpu_baseline(state, a.cpu_steps)
             line["vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
         if world == 1 and not a.no_extras and a.solver == "scm" and nsteps == 1:
+            # the children plan their resident activations around what other processes hold: hand the forecast path's
+            # buffers (workspace for 96 units, states, engines) back first
+            import gc
+            del X, X0, forc, phys, z, eng
+            for e in list(getattr(net.model, "_engines", {}).values()):
+                e._ws = None
+            gc.collect()
             line["training"] = training_leg()
         print(json.dumps(line), flush=True)
     if grouped:

@@ -9,21 +9,24 @@
 // the fp32 accumulators, parked as bf16 in the LDS the k-loop has just released, and consumed by the attention core on
 // the spot.  Only the 256 x 88 output tile leaves the CU.
 //
-// Geometry: 8 waves as 4 (M) x 2 (N); a wave owns 64 token rows x 144 columns = 4 x 9 MFMA 16x16 tiles = 144 accumulator
-// VGPRs, v_mfma_f32_16x16x32_bf16 with the roles of gemm.hip (A := weight rows, B := token rows -> a lane holds 4
-// consecutive columns of one row).  The slab's columns are ORDERED for that split by the weight rows' DMA source
-// addresses: column half 0 = [q (88) | v 0..39 | 16 pad], half 1 = [k (88) | v 40..87 | 8 pad] -- so a wave holds complete
-// q rows or complete k rows of its 64 tokens and the cosine norms need no cross-wave exchange (v has no norm).  Pad columns
-// are fed by a clamped weight row and never stored (6 % more MFMAs than the 264 real columns; 13 LDS fragment reads per 36
-// MFMAs, against 19 per 34 for a wave that spans all columns).  k-loop: 64-deep k-tiles, two LDS
+// Geometry: 8 waves as 4 (M) x 2 (N); a wave owns 64 token rows x 128 or 144 columns = 4 x 8 / 4 x 9 MFMA 16x16 tiles (128 /
+// 144 accumulator VGPRs), v_mfma_f32_16x16x32_bf16 with the roles of gemm.hip (A := weight rows, B := token rows -> a lane
+// holds 4 consecutive columns of one row).  The slab's columns are ORDERED for that split by the weight rows' DMA source
+// addresses: column half 0 = [q (88) | v 0..39], half 1 = [k (88) | v 40..87 | 8 pad] -- so a wave holds complete q rows or
+// complete k rows of its 64 tokens and the cosine norms need no cross-wave exchange (v has no norm); the 8 pad columns are
+// fed by a clamped weight row and never stored.  Waves wv and wv + 4 (partners on a SIMD) take the two halves of the same
+// rows, so every SIMD carries 8 + 9 column blocks; the k-loop and the norm / store epilogue are instantiated once per
+// block count and selected per wave OUTSIDE the loops (a per-wave trip count inside the MFMA stream is a branch there, and
+// hipcc answers branches with split accumulator tuples).  13 LDS fragment reads per 36 MFMAs against 19 per 34 for a wave
+// that spans all columns.  k-loop: 64-deep k-tiles, two LDS
 // stages filled by global_load_lds_dwordx4 (1 KiB pieces of 8 rows x 128 B, source-side XOR swizzle), one barrier per
 // k-tile -- the structure of gemm_kernel_p.  Attention core: the S^T = K Q^T / accumulator-as-operand / V^T-by-
 // ds_read_tr16 scheme of attention_pipe.hip (v_mfma_f32_32x32x16_bf16, a wave owns 32 queries, softmax streamed over four
 // 64-key chunks, no row maximum where exp(min(scale, ln 100)) <= 48, row sum on the spare V^T rows).
 //
-// LDS (163,840 B):  [0, 45056) K tile | [45056, 94208) V tile (192-B rows) | [94208, 139264) Q tile | tail to 163,840
-//   k-loop stage 1 (odd k-tiles)  = bytes [0, 69632)          (over the K / V tiles, dead during the k-loop)
-//   k-loop stage 0 (even k-tiles) = bytes [94208, 163840)     (over the Q tile and the tail)
+// LDS (161,792 B):  [0, 45056) K tile | [45056, 94208) V tile (192-B rows) | [94208, 139264) Q tile | tail to 161,792
+//   k-loop stage 1 (odd k-tiles)  = bytes [0, 67584)          (over the K / V tiles, dead during the k-loop)
+//   k-loop stage 0 (even k-tiles) = bytes [94208, 161792)     (over the Q tile and the tail)
 // K = 1056 is 16.5 k-tiles: the last one (index 16, stage 0) carries data in its first half only.  After it: barrier, the
 // normalised q / k / v slabs are written over both stages, barrier, every wave pulls its Q fragments into registers,
 // barrier, and the NEXT item's first k-tile is requested into stage 0 (the Q tile is dead by then) so that it lands
@@ -39,12 +42,12 @@ constexpr int NT = 512;
 constexpr int HD = 88;
 constexpr int ROWB = 128;                   // bytes of a k-tile row (64 bf16)
 constexpr int BM = 256;                     // tokens of a window
-constexpr int BNP = 288;                    // 264 slab columns + 24 pad: two halves of 144
-constexpr int NI = 9, MI = 4;
-constexpr int WT = 16 * NI;                 // 144 columns per wave
+constexpr int BNP = 272;                    // 264 slab columns + 8 pad: column half 0 = 128, half 1 = 144
+constexpr int NI0 = 8, NI1 = 9, MI = 4;     // MFMA 16-column blocks per wave of column half 0 / 1
+constexpr int WT0 = 16 * NI0;               // 128 columns of half 0
 constexpr int A_BYTES = BM * ROWB;          // 32 KiB
-constexpr int W_BYTES = BNP * ROWB;         // 36 KiB
-constexpr int STAGE = A_BYTES + W_BYTES;    // 69632
+constexpr int W_BYTES = BNP * ROWB;         // 34 KiB
+constexpr int STAGE = A_BYTES + W_BYTES;    // 67584
 constexpr int ROW = HD * 2;                 // 176 B: a q / k / v row
 constexpr int TILE = 256 * ROW;             // 45056
 constexpr int VROW = 192;                   // V rows are padded to 192 B: the transposed reads (ds_read_b64_tr_b16: 4 rows x 64 B
@@ -52,11 +55,11 @@ constexpr int VROW = 192;                   // V rows are padded to 192 B: the t
 constexpr int VTILE = 256 * VROW;           // 49152
 constexpr int OFF_K = 0, OFF_V = TILE, OFF_Q = TILE + VTILE;
 constexpr int OFF_S1 = 0, OFF_S0 = TILE + VTILE;
-constexpr int LDS_TOTAL = OFF_S0 + STAGE;   // 163840: all 160 KiB of the CU
+constexpr int LDS_TOTAL = OFF_S0 + STAGE;   // 161792
 constexpr int CH = 64, NST = 4, CHB = CH * ROW, DB = 3, KS = 6, CPR = HD / 8;
 constexpr int OROWS = 16, ORND = 2, OSLAB = OROWS * ROW;  // output staging: 16 rows per round, two rounds per item
 constexpr int NOST = ORND * ((OROWS * CPR + 63) / 64);    // 6 output store instructions per wave and item
-constexpr int WP = W_BYTES / 1024;          // 36 weight pieces per stage
+constexpr int WP = W_BYTES / 1024;          // 34 weight pieces per stage
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct FusedArgs {
@@ -130,8 +133,8 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
     // row's logical chunk (l & 7) ^ ((row >> 1) & 7) (the fragment reads apply the same XOR: conflict-free ds_read_b128).
     // Token operand: this wave's pieces 4 wv .. 4 wv + 3 = window rows 32 wv .. 32 wv + 31 (its own query rows, as it
     // happens); the per-lane offset carries the gather (window partition of the grid rolled by (-sh, -sw)).
-    // Weight operand: pieces wv + 8 i of the 288-row LDS image, i = 0..4 (the fifth exists for waves 0-3); image row r
-    // takes the head's weight row  r (q) | 176 + r - 88 (v 0..39) | pad | 88 + r - 144 (k) | 216 + r - 232 (v 40..87) | pad.
+    // Weight operand: pieces wv + 8 i of the 272-row LDS image, i = 0..4 (the fifth exists for waves 0 and 1); image row r
+    // takes the head's weight row  r (q) | 176 + r - 88 (v 0..39) | 88 + r - 128 (k) | r (v 40..87 = rows 216..263) | pad.
     const int prow = lane >> 3, pchunk = lane & 7;
     uint32_t va[4], vb[5];
     int cur_w = -1;
@@ -148,8 +151,7 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int r = (wv + 8 * i) * 8 + prow;
-        const int row = r < HD ? r : (r < 128 ? 2 * HD + (r - HD) : (r < WT ? 3 * HD - 1 : (r < WT + HD ? HD + (r - WT) :
-                        (r < WT + 136 ? 2 * HD + 40 + (r - WT - HD) : 3 * HD - 1))));
+        const int row = r < HD ? r : (r < WT0 ? 2 * HD + (r - HD) : (r < WT0 + HD ? HD + (r - WT0) : min(r, 3 * HD - 1)));
         vb[i] = (uint32_t)(row * (int)a.ldw_b) + 16u * (pchunk ^ ((4 * (wv & 1) + (prow >> 1)) & 7));
     }
     const char* xbase = nullptr;
@@ -170,10 +172,10 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
     };
 
     // ---- fragment read offsets of the k-loop
-    const int wm = wv >> 1, wn = wv & 1;
+    const int wm = wv & 3, wn = wv >> 2;
     const int r16 = lane & 15, g4 = lane >> 4;
     const int xoff = (wm * 64 + r16) * ROWB;
-    const int woff = A_BYTES + (wn * WT + r16) * ROWB;
+    const int woff = A_BYTES + (wn * WT0 + r16) * ROWB;
     const int ch0 = ((g4 + 0) ^ (r16 >> 1)) * 16;
     const int ch1 = ((g4 + 4) ^ (r16 >> 1)) * 16;
 
@@ -192,6 +194,8 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
         if (has_next) decode(item + istep, nb, nwn, nh);
 
         // =========================================================== k-loop: acc[i][j] = X_window W_head^T (fp32)
+        auto gemm_part = [&](auto ni_tag) {
+        constexpr int NI = decltype(ni_tag)::value;
         f32x4 acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -224,7 +228,8 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
                     for (int i = 0; i < MI; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf),
                                                                             __builtin_bit_cast(bf16x8, xf[i]), acc[i][j], 0, 0, 0);
-                    if (with_dma && j < 9) issue_piece(fill, koff, j);
+                    if (with_dma) issue_piece(fill, koff, j);
+                    if (with_dma && NI < 9 && j == NI - 1) issue_piece(fill, koff, 8);  // (nine pieces, eight column blocks)
                     wf = wn_;
                 }
             };
@@ -240,9 +245,6 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
         int el = lane;
         asm volatile("" : "+v"(el));
         const int r16 = el & 15, g4 = el >> 4;
-        const int c32 = el & 31, hh = el >> 5;
-        const int vbase = (4 * hh + ((el & 15) >> 2)) * VROW + (16 * ((el >> 4) & 1) + 4 * (el & 3)) * 2;
-        char* oslab = smem + OFF_K + wv * OSLAB;
         {
             // wave (wm, wn): rows 64 wm .. + 63; local columns 0..87 = q (wn 0) or k (wn 1), 88.. = v 0..39 / v 40..87, then pad
             // (folding log2(e) into tau would save the core 128 v_mul per lane and item, but q-hat would then round differently
@@ -277,6 +279,13 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
                 }
             }
         }
+        };
+        if (wn == 0) gemm_part(std::integral_constant<int, NI0>{}); else gemm_part(std::integral_constant<int, NI1>{});
+        int el = lane;
+        asm volatile("" : "+v"(el));
+        const int c32 = el & 31, hh = el >> 5;
+        const int vbase = (4 * hh + ((el & 15) >> 2)) * VROW + (16 * ((el >> 4) & 1) + 4 * (el & 3)) * 2;
+        char* oslab = smem + OFF_K + wv * OSLAB;
         __builtin_amdgcn_s_barrier();  // Q, K and V tiles complete
 
         // =========================================================== attention core
