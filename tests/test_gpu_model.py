@@ -99,6 +99,27 @@ def test_forward_other_swift_variants_vs_oracle(dev, name, c):
     assert e32 < FP32_TOL and e16 < BF16_TOL
 
 
+def test_forward_batch16_vs_oracle(dev):
+    """From 16 samples on the 2 x depth modulation Linears run as ONE fp32 MFMA GEMM instead of the small-batch VALU kernel
+    (csrc/forward.hip); 16 is also several items per workgroup for the fused to_qkv + attention kernel.  Per-sample t and
+    auxiliary values differ, so a row mix-up in the modulation matrix would show."""
+    net, onet = build(SMALLB, 21, dev)
+    B = 16
+    x, cond = det_normal((B, 69, 64, 64), 21, "x"), det_normal((B, 72, 64, 64), 21, "cond")
+    t = torch.linspace(0.1, 1.5, B)
+    aux = torch.tensor([0.6, 1.2, 2.4, 0.6] * 4)
+    with torch.no_grad():
+        y = net(x.to(dev), t.to(dev), cond.to(dev), aux.to(dev))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            yb = net(x.to(dev), t.to(dev), cond.to(dev), aux.to(dev))
+        yo = onet(x, t, cond, aux)
+    e32, e16 = rel_l2(y.cpu(), yo), rel_l2(yb.cpu(), yo)
+    print(f"batch 16: fp32 rel-L2 {e32:.3e}, bf16 rel-L2 {e16:.3e}")
+    assert e32 < FP32_TOL and e16 < BF16_TOL
+    for b in (0, 7, 15):  # per sample, not only in aggregate
+        assert rel_l2(y[b].cpu(), yo[b]) < FP32_TOL
+
+
 def test_forward_logvar_and_split_sources(dev):
     net, onet = build(SMALLB, 8, dev, logvar=True)
     x, cond = det_normal((2, 69, 64, 64), 8, "x"), det_normal((2, 72, 64, 64), 8, "cond")
