@@ -187,7 +187,8 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * bits of the GEMM / attention kernels (timing experiments; results are wrong while set), key 5 = window-tiled q/k/v in
  * swiftk_swinv2_forward (1), key 6 = swiftk_modnorm_residual: bit 0 non-temporal residual-stream accesses, bit 1 chunked
  * kernel (3), key 7 = start-up stagger of the persistent GEMM's workgroups in 1/1000 of an eighth of a tile time (0),
- * key 8 = to_qkv + window attention as one kernel in swiftk_swinv2_forward (1; key 4 bits 8.. = that kernel's ablations). */
+ * key 8 = to_qkv + window attention as one kernel in swiftk_swinv2_forward (1; key 4 bits 8..15 = that kernel's ablations,
+ * bits 16.. = those of the persistent attention backward), key 9 = persistent attention backward for head_dim 88 (1). */
 int swiftk_set_tuning(int key, int value);
 int swiftk_profile_collect(double* total_ms_host, int64_t* launches_host);
 

@@ -397,6 +397,29 @@ def test_fused_qkv_attention(dev, shift, B):
     assert rel_l2(fused.float().cpu(), ref) < 1.2e-2
 
 
+def test_fused_qkv_attention_rejects_what_it_cannot_run(dev):
+    """The fused kernel is built for head_dim 88, 16x16 windows and an odd number of 64-deep k-tiles; anything else is
+    refused with an error code (the forward then takes the two-kernel path) -- never a silent wrong answer."""
+    from swift_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    a = torch.zeros(2 * 512, 1152, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(3168, 1152, dtype=torch.bfloat16, device=dev)
+    sc = torch.zeros(12, device=dev)
+    out = torch.zeros(2 * 512, 1088, dtype=torch.bfloat16, device=dev)
+    call = lambda K, hd, gh, gw, sh=0, sw=0, ldo=1088: L.swiftk_qkv_attention_fused(
+        a.data_ptr(), 1152, w.data_ptr(), 1152, sc.data_ptr(), out.data_ptr(), ldo, K, 2, gh, gw, 12, hd, sh, sw, st)
+    assert call(1056, 88, 16, 32) == 0                      # 16.5 k-tiles -> 17 (odd): runs
+    assert call(1056, 80, 16, 32) == -2                     # head_dim
+    assert call(1152, 88, 16, 32) == -2                     # 18 k-tiles (even)
+    assert call(1056, 88, 24, 32) == -2                     # grid not a multiple of the window
+    assert call(1056, 88, 16, 32, sh=16) == -2              # shift outside the grid
+    assert call(1056, 88, 16, 32, ldo=1000) == -2           # output rows too short for 12 x 88 columns
+    assert L.swiftk_qkv_attention_fused(None, 1152, w.data_ptr(), 1152, sc.data_ptr(), out.data_ptr(), 1088, 1056, 2, 16, 32, 12,
+                                        88, 0, 0, st) == -1
+    torch.cuda.synchronize()
+
+
 def test_ensemble_metrics_vs_reference_golden(dev):
     """swiftk_ensemble_sums -> RMSE / CRPS / spread-skill against the reference's eval/metrics.py functions (golden)."""
     from swift_amd.eval.metrics import all_metrics, lat_weighted_crps
