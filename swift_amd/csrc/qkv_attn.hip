@@ -209,10 +209,10 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
             const char* s = smem + so;
             const uint32_t fill = lds0 + ((kt & 1) ? OFF_S0 : OFF_S1);
             const bool more = kt + 1 < a.nk;
-            // (the last k-tile re-requests k-tile 0 into the other stage: one straight-line copy of the first k-half instead
-            // of two -- a second copy makes hipcc split and spill the accumulator tuples; the bytes land before the epilogue
-            // overwrites that stage and are never read)
-            const uint32_t koff = more ? (uint32_t)(kt + 1) * ROWB : 0u;
+            // (one straight-line copy of the first k-half serves every k-tile -- a second, DMA-free copy for the last k-tile made
+            // hipcc split and spill the accumulator tuples; the last k-tile skips its nine requests behind wave-uniform
+            // branches instead, which cost no registers)
+            const uint32_t koff = (uint32_t)(kt + 1) * ROWB;
             const bool half = a.khalf && !more;
             uint4 xf[MI];
             auto k_half = [&](const int ch, const bool with_dma) {
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
                     for (int i = 0; i < MI; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf),
                                                                             __builtin_bit_cast(bf16x8, xf[i]), acc[i][j], 0, 0, 0);
-                    if (with_dma) issue_piece(fill, koff, j);
-                    if (with_dma && NI < 9 && j == NI - 1) issue_piece(fill, koff, 8);  // (nine pieces, eight column blocks)
+                    if (with_dma && more) issue_piece(fill, koff, j);
+                    if (with_dma && more && NI < 9 && j == NI - 1) issue_piece(fill, koff, 8);  // (nine pieces, eight column blocks)
                     wf = wn_;
                 }
             };
