@@ -52,6 +52,11 @@ constexpr int EPI_QKNORM_TILED = 4;  // internal: SWIFTK_EPI_QKNORM with the win
 #ifndef SWIFTK_X_PF2
 #define SWIFTK_X_PF2 1
 #endif
+// timing probe with WRONG results: read only every n-th W fragment from LDS (n = 2: 10 instead of 15 ds_read_b128 per 44 MFMAs,
+// the ratio a one-wave-per-SIMD 128 x 176 register tile would have) -- does the plateau move with LDS reads per MFMA?
+#ifndef SWIFTK_X_FEWREADS
+#define SWIFTK_X_FEWREADS 0
+#endif
 // cache policy of the bf16 output tiles' 16-B stores: 0 = default, 1 = nt, 2 = sc1 (write-through, line not kept in the
 // XCD's L2), 3 = sc0 sc1.  The outputs are written once and never re-read by the kernel; a round of 32 tiles per XCD writes
 // 5.8 MB through a 4 MB L2 that should be holding the W panel the XCD re-reads every round.
@@ -548,7 +553,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 for (int j = 0; j < NI; ++j) {
 #if SWIFTK_X_PF2
                     uint4 wn_ = wf1;
+#if SWIFTK_X_FEWREADS  // timing probe, WRONG results: only every FEWREADS-th W fragment is read, the others reuse the previous one
+                    if (j + 2 < NI && (j + 2) % SWIFTK_X_FEWREADS == 0) wf1 = *reinterpret_cast<const uint4*>(s + woff + (j + 2) * 16 * ROWB + ch);
+#else
                     if (j + 2 < NI) wf1 = *reinterpret_cast<const uint4*>(s + woff + (j + 2) * 16 * ROWB + ch);
+#endif
 #else
                     uint4 wn_ = wf;
                     if (j + 1 < NI) wn_ = *reinterpret_cast<const uint4*>(s + woff + (j + 1) * 16 * ROWB + ch);
