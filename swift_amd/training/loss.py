@@ -83,12 +83,12 @@ def _engine(net) -> SwinTrainEngine:
     return eng
 
 
-def _memory_budget(dev) -> float:
-    """Bytes this process may plan with: 75 % of the device, less what OTHER processes hold on it right now (a second rank
-    sharing the GPU in a test, the parent of a benchmark child)."""
+def _memory_budget(dev, frac: float = 0.75) -> float:
+    """Bytes this process may plan with: ``frac`` of the device, less what OTHER processes hold on it right now (a second
+    rank sharing the GPU in a test, the parent of a benchmark child)."""
     free, total = torch.cuda.mem_get_info(dev)
     others = max(0, total - free - torch.cuda.memory_reserved(dev))
-    return 0.75 * total - others
+    return frac * total - others
 
 
 def _plan_once(cache: dict, key, decide: Callable[[], int], what: str, dev) -> int:
@@ -291,14 +291,18 @@ class CRPSLoss(_LossBase):
 
     @staticmethod
     def _n_keep(eng, B, calls, dev) -> int:
-        """How many trailing network calls keep their activations: SWIFTK_CRPS_KEEP if set, else what fits into 75 % of the
-        device's memory beside the iteration's own working set (measured: 2.2 activation sets -- rollout states, one
-        step's backward temporaries, gradients, optimiser state): 6 of the 8 calls of BASELINE configs[4] at local batch 8
-        on 288 GB (195 GiB peak), 2 at batch 16, none at batch 32."""
+        """How many trailing network calls keep their activations: SWIFTK_CRPS_KEEP if set.  ALL of them when the iteration
+        then fits into 85 % of the device (no recompute slot is needed in that case; measured working set beside the kept
+        sets: 0.75 activation sets, planned as 1.2 -- BASELINE configs[4] at local batch 8: 8 of 8, 218 GiB peak of 288).
+        Otherwise what fits into 75 % beside 2.2 activation sets (rollout states, the recompute slot, one step's backward
+        temporaries, gradients, optimiser state): 2 at batch 16, none at batch 32."""
         env = os.environ.get("SWIFTK_CRPS_KEEP")
         if env is not None:
             return max(0, min(calls, int(env)))
-        return max(0, min(calls, int(_memory_budget(dev) / max(1, eng.activation_bytes(B)) - 2.2)))
+        act = max(1, eng.activation_bytes(B))
+        if (calls + 1.2) * act <= _memory_budget(dev, 0.85):
+            return calls
+        return max(0, min(calls, int(_memory_budget(dev) / act - 2.2)))
 
     def _forcings(self, idx, aux_host, i, dev):
         f = torch.stack([self.dataset.get_forcings(int(j) + int(i * float(dt) * 10 // 6)) for j, dt in zip(idx, aux_host)], 0)
