@@ -60,6 +60,13 @@ constexpr int EPI_QKNORM_TILED = 4;  // internal: SWIFTK_EPI_QKNORM with the win
 // cache policy of the bf16 output tiles' 16-B stores: 0 = default, 1 = nt, 2 = sc1 (write-through, line not kept in the
 // XCD's L2), 3 = sc0 sc1.  The outputs are written once and never re-read by the kernel; a round of 32 tiles per XCD writes
 // 5.8 MB through a 4 MB L2 that should be holding the W panel the XCD re-reads every round.
+// SWIGLU_BWD: pull the tile's saved pre-activations (256 rows x 11 lines, 360 KB) into the XCD's L2 during the tile's last
+// k-tile (six 4-byte-per-lane LDS-DMA requests per wave into a scratch area), so the epilogue's 16-B reads -- two groups
+// of four in flight per lane, twelve groups per tile -- wait for L2 instead of HBM.  Measured 659 against 594 us per launch at
+// local batch 8 (profiles/r03p_gemm_ab_hpf.txt): off.
+#ifndef SWIFTK_X_HPF
+#define SWIFTK_X_HPF 0
+#endif
 #ifndef SWIFTK_X_STORE
 #define SWIFTK_X_STORE 0
 #endif
@@ -361,7 +368,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     constexpr int WP = B_BYTES / 1024;          // W pieces per stage: 40 / 44 / 48 = 5, 5.5, 6 per wave
     constexpr int HD = 8 * NI;                  // QKNORM: head_dim (a wave tile = two head vectors)
     constexpr bool TOUCH = SWIFTK_X_TOUCH > 0 && NI <= 11 && sizeof(T) == 2;  // (384-wide tiles use all 160 KiB of LDS)
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (TOUCH ? 256 : 0)];
+    constexpr bool HPF = SWIFTK_X_HPF > 0 && EPI == SWIFTK_EPI_SWIGLU_BWD && NI <= 11 && sizeof(T) == 2;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (TOUCH || HPF ? 256 : 0)];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wv >> 1, wn = wv & 1;
@@ -475,10 +483,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     // workgroups by eighths of a tile time (phase = tile row + tile column inside the XCD's 8 x 4 window: the four
     // workgroups sharing an A panel stay within half a tile of each other, the eight sharing a W panel cover all phases)
     // spreads the epilogues over the whole tile period for the rest of the launch.
-    if (g.stagger > 0) {
-        const int ph = ((vid % gm) + (vid / gm)) & 7;
+    // (negative step: phase = XCD number -- the XCDs share no L2, so nothing pulls them back into step once they are apart,
+    // while the 32 workgroups of one XCD stay together on their shared panels)
+    if (g.stagger != 0) {
+        const int ph = g.stagger > 0 ? (((vid % gm) + (vid / gm)) & 7) : (int)(blockIdx.x & 7);
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-        const uint64_t wait = (uint64_t)ph * (uint64_t)g.stagger;
+        const uint64_t wait = (uint64_t)ph * (uint64_t)(g.stagger > 0 ? g.stagger : -g.stagger);
         while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
     }
 #if SWIFTK_X_PRIO
@@ -522,6 +532,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 #if SWIFTK_GEMM_INSTR
         if (g.dbg & 8) koff = 0;  // timing experiment: every stage re-reads k-tile 0 (L2-resident after a tile's first trip)
 #endif
+        const char* hpf_base = nullptr;  // SWIGLU_BWD look-ahead: this wave's 32 rows of the tile's saved pre-activations
+        int hpf_rows = 0, hpf_cols = 0;
+        if constexpr (HPF) {
+            if (last_k) {  // (t_m0 / t_n0 still name the tile being computed: set_sources(next tile) comes below)
+                const int rb = min(t_m0 + wv * 32, (int)g.M - 1);
+                hpf_rows = min(31, (int)g.M - 1 - rb);
+                hpf_cols = (int)g.N * 4 - 4 - t_n0 * 4;  // last byte offset a request may start at, relative to the tile's first column
+                hpf_base = reinterpret_cast<const char*>(g.ep1) + ((int64_t)rb * g.pos_rows + 2 * t_n0) * 2;
+            }
+        }
         if (last_k) {
             const int ntile = tile + stride;
             if (ntile < ntiles) set_sources(ntile);
@@ -569,6 +589,14 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 #else
                     if (with_dma && j < 10) issue_piece(fill, koff, j);
 #endif
+                    if constexpr (HPF) {
+                        if (with_dma && last_k && j < 6) {  // line li of the wave's 32 rows x 11 lines (row-major), one per lane
+                            int el = lane;
+                            asm volatile("" : "+v"(el));
+                            const int li = min(el + 64 * j, 351), r = li / 11, cl = li - 11 * r;
+                            dma_touch(lds0 + 2 * STAGE, hpf_base, (uint32_t)(min(r, hpf_rows) * (int)g.pos_rows * 2 + min(cl * 128, hpf_cols)));
+                        }
+                    }
                     if constexpr (TOUCH) {
                         if (with_touch && j == 2) {
                             if (wv < 4) dma_touch(lds0 + 2 * STAGE, g.A + (int64_t)t_m0 * g.lda_b, (uint32_t)(min(tr1, g.M - 1 - t_m0) * (int)g.lda_b) + toff);
@@ -1099,7 +1127,8 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     if (g_stagger_permille > 0 && dtype == SWIFTK_BF16 && ksplit == 1) {
         const double tile_s = 2.0 * 256.0 * (32.0 * ni) * (double)K / 5.3e12;
         const int64_t tiles = ((M + 255) / 256) * g.ntn;
-        if (tiles >= 4 * 256) g.stagger = (int)(tile_s * 1e8 / 8.0 * g_stagger_permille / 1000.0);
+        const int pm = g_stagger_permille % 10000;  // key 7 values >= 10000: per-XCD phases
+        if (tiles >= 4 * 256) g.stagger = (int)(tile_s * 1e8 / 8.0 * pm / 1000.0) * (g_stagger_permille >= 10000 ? -1 : 1);
     }
     g.t_gh = g.t_gw = g.t_sh = g.t_sw = g.t_heads = 0;
     if (tiling) {

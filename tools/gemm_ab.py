@@ -39,6 +39,8 @@ torch.manual_seed(0)
 scale = torch.full((12,), 2.3, device=dev)
 shapes = [("qkv_tiled", 3168, 1088, 1056, "tiled"), ("wo", 1056, 1088, 1056, _lib.EPI_NONE),
           ("w1+swiglu", 5632, 1088, 1056, _lib.EPI_SWIGLU), ("w2", 1056, 2816, 2816, _lib.EPI_NONE)]
+if os.environ.get("GEMM_AB_TRAIN"):  # the training-only epilogue: d(hidden) = dY W2 through the saved (gate, up) pre-activations
+    shapes = [("swiglu_bwd", 2816, 1088, 1056, _lib.EPI_SWIGLU_BWD)]
 for sname, N, K, Kalg, epi in shapes:
     a = torch.randn(M, K, device=dev).bfloat16()
     if K > Kalg:
@@ -46,7 +48,8 @@ for sname, N, K, Kalg, epi in shapes:
     w = (torch.randn(N, K, device=dev) * 0.03).bfloat16()
     if K > Kalg:
         w[:, Kalg:] = 0
-    ncol = N // 2 if epi == _lib.EPI_SWIGLU else N
+    ncol = N // 2 if epi == _lib.EPI_SWIGLU else (2 * N if epi == _lib.EPI_SWIGLU_BWD else N)
+    H = torch.randn(M, 2 * N, device=dev).bfloat16() if epi == _lib.EPI_SWIGLU_BWD else None
     outs = {n: torch.zeros(M, ncol, dtype=torch.bfloat16, device=dev) for n in names}
 
     def run(n):
@@ -58,7 +61,7 @@ for sname, N, K, Kalg, epi in shapes:
                                          88, 8, 8, st())
         else:
             rc = h.swiftk_gemm(a.data_ptr(), K, w.data_ptr(), K, o.data_ptr(), ncol, M, N, Kalg, _lib.BF16, _lib.BF16, epi, None,
-                               None, 0, st())
+                               H.data_ptr() if H is not None else None, 2 * N if H is not None else 0, st())
         assert rc == 0, (n, sname, rc)
 
     res = {n: [] for n in names}
