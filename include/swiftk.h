@@ -151,7 +151,8 @@ int swiftk_linear_small(const float* x, int64_t ldx, const float* W, int64_t ldw
 /*
  * Residual rollout update in physical units, fused with re-standardisation:
  *   phys[b][c] = xstd[b][c]*sx[c] + mx[c] + y[b][c]*st[c];  xstd[b][c] = (phys[b][c] - mx[c]) / sx[c]
- * Replaces generate.py:120-131 with data/era5.py:110-166.
+ * Replaces generate.py:120-131 with data/era5.py:110-166.  st == NULL selects the non-residual form of generate.py:132-136
+ * (a dataset whose targets are states, not tendencies): phys = y*sx + mx; xstd = y.
  */
 int swiftk_rollout_update(float* xstd, const float* y, float* phys, const float* mx, const float* sx, const float* st,
                           int B, int C, int64_t hw, void* stream);

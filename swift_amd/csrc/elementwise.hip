@@ -502,10 +502,18 @@ __global__ __launch_bounds__(256) void rollout_update_kernel(float* __restrict__
                                                              int C, int64_t hw4, int64_t total4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int c = (int)((i / hw4) % C);
-        const float m = mx[c], s = sx[c], t = st[c];
-        const float4 xv = reinterpret_cast<const float4*>(xstd)[i];
+        const float m = mx[c], s = sx[c];
         const float4 yv = reinterpret_cast<const float4*>(y)[i];
         float4 p, q;
+        if (!st) {  // non-residual dataset (generate.py:132-136): the network output IS the next standardised state
+#pragma clang fp contract(off)  // two roundings, as the reference's `v * s + m`: no fused multiply-add
+            p.x = yv.x * s + m; p.y = yv.y * s + m; p.z = yv.z * s + m; p.w = yv.w * s + m;
+            if (phys) reinterpret_cast<float4*>(phys)[i] = p;
+            reinterpret_cast<float4*>(xstd)[i] = yv;
+            continue;
+        }
+        const float t = st[c];
+        const float4 xv = reinterpret_cast<const float4*>(xstd)[i];
         p.x = (xv.x * s + m) + yv.x * t; p.y = (xv.y * s + m) + yv.y * t;
         p.z = (xv.z * s + m) + yv.z * t; p.w = (xv.w * s + m) + yv.w * t;
         q.x = (p.x - m) / s; q.y = (p.y - m) / s; q.z = (p.z - m) / s; q.w = (p.w - m) / s;
@@ -663,7 +671,7 @@ extern "C" int swiftk_linear_small(const float* x, int64_t ldx, const float* W, 
 
 extern "C" int swiftk_rollout_update(float* xstd, const float* y, float* phys, const float* mx, const float* sx,
                                      const float* st, int B, int C, int64_t hw, void* stream) {
-    if (!xstd || !y || !mx || !sx || !st || B <= 0 || C <= 0 || hw <= 0) return SWIFTK_EINVAL;
+    if (!xstd || !y || !mx || !sx || B <= 0 || C <= 0 || hw <= 0) return SWIFTK_EINVAL;  // (st == NULL: non-residual form)
     if (hw % 4) return SWIFTK_ESHAPE;
     if (((uintptr_t)xstd & 15) || ((uintptr_t)y & 15) || (phys && ((uintptr_t)phys & 15))) return SWIFTK_EALIGN;
     const int64_t total4 = (int64_t)B * C * hw / 4;

@@ -201,11 +201,12 @@ def linear_small(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
 
 
 def rollout_update(xstd: torch.Tensor, y: torch.Tensor, mx, sx, st, phys: Optional[torch.Tensor] = None) -> None:
-    """In place: phys = xstd*sx + mx + y*st ; xstd = (phys - mx)/sx  (per channel)."""
-    _dev(xstd, y, mx, sx, st, phys)
+    """In place: phys = xstd*sx + mx + y*st ; xstd = (phys - mx)/sx  (per channel).  ``st=None``: the non-residual form of
+    generate.py:132-136, phys = y*sx + mx ; xstd = y."""
+    _dev(xstd, y, mx, sx, phys, *(() if st is None else (st,)))
     B, Cc, H, W = xstd.shape
     assert xstd.is_contiguous() and y.is_contiguous() and (phys is None or phys.is_contiguous())
-    check(lib().swiftk_rollout_update(xstd.data_ptr(), y.data_ptr(), _ptr(phys), mx.data_ptr(), sx.data_ptr(), st.data_ptr(),
+    check(lib().swiftk_rollout_update(xstd.data_ptr(), y.data_ptr(), _ptr(phys), mx.data_ptr(), sx.data_ptr(), _ptr(st),
                                       B, Cc, H * W, _stream()), "swiftk_rollout_update")
 
 

@@ -37,14 +37,21 @@ class RolloutEngine:
         kw = dict(num_steps=1, sigma_min=0.02, sigma_max=200.0, auxiliary=interval / 10.0)  # generate.py:255-260
         kw.update(solver_kwargs)
         self.sampler = sampler_factory(solver, net, denoise_dtype=denoise_dtype, **kw)
-        self.residual = getattr(dataset, "residual", False)
-        if not self.residual:
-            raise NotImplementedError("non-residual datasets (generate.py:133-137) are not on the forecast path built here")
+        self.residual = getattr(dataset, "residual", False)  # generate.py:76
         self._stats = None
 
     def stats(self, device):
+        """(mean_x, std_x, std_t) for ``ops.rollout_update``; std_t is None for a non-residual dataset (generate.py:132-136:
+        the output is the next standardised state, the trajectory gets ``unstandardize_x`` of it -- with the SST channel, if
+        present, zeroed by ``zero_field`` at the default delta)."""
         if self._stats is None or self._stats[0].device != device:
-            self._stats = self.dataset.rollout_stats(self.interval, device)
+            mx, sx, st = self.dataset.rollout_stats(self.interval if self.residual else 6, device)
+            if not self.residual:
+                if "sea_surface_temperature" in self.dataset.variables:
+                    sx = sx.clone()
+                    sx[list(self.dataset.variables).index("sea_surface_temperature")] = 0.0
+                st = None
+            self._stats = (mx, sx, st)
         return self._stats
 
     def stage_forcings(self, ic_indices: Sequence[int], steps: int, device) -> torch.Tensor:

@@ -27,8 +27,6 @@ def _lat_weights(dataset, H: int, device) -> torch.Tensor:
 @torch.no_grad()
 def RMSE_rollout(sampler: Callable[..., torch.Tensor], dataloader, dataset, target_interval: int, device: torch.device,
                  rng: Optional[torch.Generator] = None, num_batches: Optional[int] = None, pipeline_engine: bool = False):
-    if not dataset.residual:
-        raise NotImplementedError("the rollout kernels implement the residual (tendency) update of the shipped configs")
     per_day = 4
     nv = dataset.n_target_channels
     agg = 0.0
@@ -36,6 +34,8 @@ def RMSE_rollout(sampler: Callable[..., torch.Tensor], dataloader, dataset, targ
     if num_batches is None:
         num_batches = len(dataloader)
     mx, sx, st = dataset.rollout_stats(6, device)
+    if not dataset.residual:  # validate.py:88-96, 112-114: the output is the next state; physical units through unstandardize_x
+        st = None
     w_lat = None
     for _ in range(num_batches):
         X, TS, idx = next(dataloader)
@@ -49,7 +49,7 @@ def RMSE_rollout(sampler: Callable[..., torch.Tensor], dataloader, dataset, targ
         for i in range(target_interval):
             forc = dataset.standardize_x(torch.stack([dataset.get_forcings(int(j) + i) for j in idx], 0)).to(device).float()
             Y = sampler((X, forc.contiguous()), generator=rng)
-            ops.rollout_update(X, Y, mx, sx, st, phys=phys)           # phys = unstd(X) + unstd_t(Y); X <- std(phys)
+            ops.rollout_update(X, Y, mx, sx, st, phys=phys)           # residual: phys = unstd(X) + unstd_t(Y); X <- std(phys)
             if (i + 1) % per_day == 0 or i == 0:
                 day = (i + 1) // per_day
                 sq.zero_()

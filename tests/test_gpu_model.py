@@ -262,6 +262,38 @@ def test_rollout_vs_oracle(dev):
     assert torch.equal(t_all[1], t_one[0])
 
 
+def test_rollout_non_residual_dataset_vs_oracle(dev):
+    """generate.py:132-136 / validate.py:112-116: a dataset whose targets are states (residual=False) -- the network output is
+    the next standardised state and the trajectory holds ``unstandardize_x`` of it (bit-exact: one multiply, one add)."""
+    from oracle import rollout as oroll
+    from oracle import sampler as osamp
+    from swift_amd.data.era5 import SyntheticERA5Dataset
+    from swift_amd.rollout import RolloutEngine
+    net, onet = build(SMALLB, 10, dev)
+    ds = SyntheticERA5Dataset([f"v{i}" for i in range(69)], ["f0", "f1", "f2"], img_resolution=(64, 64), length=32,
+                              seed=10, random_stats=True, residual=False)
+    steps, B, idx = 3, 2, [0, 5]
+    X0 = det_normal((B, 69, 64, 64), 10, "X0")
+    lats = [det_normal((B, 69, 64, 64), 10, f"lat{i}") for i in range(steps)]
+    eng = RolloutEngine(net, ds, interval=6)
+    forc = eng.stage_forcings(idx, steps, dev)
+    traj = eng.run(X0.to(dev), forc, steps, latents=lambda i: lats[i].to(dev))
+    stats = oroll.Stats(ds.x_means, ds.x_stds, {6: ds.x_stds[:69]}, n_vars=69, n_forc=3)
+    it = iter(lats)
+    osampler = lambda c: osamp.scm_solver(onet, next(it), c, 0.6, num_steps=1, sigma_min=0.02, sigma_max=200.0)
+    ref = oroll.rollout(osampler, stats, X0, lambda i: torch.stack([ds.get_forcings(j + i) for j in idx], 0), steps, residual=False)
+    e = rel_l2(traj.cpu(), ref)
+    print(f"3-step non-residual rollout fp32: rel-L2 {e:.3e}")
+    assert traj.shape == ref.shape and e < FP32_TOL
+    # the update itself, bit for bit: phys = y * sx + mx (two roundings), state = y
+    from swift_amd import ops
+    mx, sx, st = eng.stats(dev)
+    assert st is None
+    y, x, phys = det_normal((B, 69, 64, 64), 10, "y").to(dev), det_normal((B, 69, 64, 64), 10, "x").to(dev), torch.empty(B, 69, 64, 64, device=dev)
+    ops.rollout_update(x, y, mx, sx, None, phys=phys)
+    assert torch.equal(x, y) and torch.equal(phys, y * sx.view(1, -1, 1, 1) + mx.view(1, -1, 1, 1))
+
+
 def test_swiftb_full_step_vs_reference_golden(dev):
     """BASELINE config 1 on the GPU: Swift-B, 1 member x 1 IC x 1 step, fp32 engine vs the reference's output."""
     from swift_amd.generating.factory import sampler_factory
