@@ -248,18 +248,20 @@ int swiftk_modnorm_bwd(const void* y, int64_t ldy, const float* g, void* dy, int
                        void* stream);
 
 /* Backward of SWIFTK_EPI_QKNORM: qkvh / dqkvh [M, ld] (normalised values and their gradients), rn [M, 3*heads] the
- * 1/max(|.|,1e-12) factors the epilogue stored through ep1 -> dqkv [M, ldo] (raw projections), dscale[heads] += . */
+ * 1/max(|.|,1e-12) factors the epilogue stored through ep1 -> dqkv [M, ldo] (raw projections), dscale[heads] += .
+ * In place: dqkvh == dqkv (row stride ldo; the attention backward wrote straight into the next GEMM's operand buffer) --
+ * v's gradient passes through unchanged, so only the q-hat / k-hat vectors are read and rewritten (2/3 of the vectors). */
 int swiftk_qknorm_bwd(const void* qkvh, const void* dqkvh, int64_t ld, const float* rn, void* dqkv, int64_t ldo,
                       const float* scale, float* dscale, int64_t M, int heads, int head_dim, int dtype, void* stream);
 
 /* Backward of the attention core (bf16, head_dim 88, PRENORM layout): dqkvh = d(q-hat | k-hat | v). */
 int swiftk_window_attention_bwd(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo, void* dqkvh, int B,
                                 int gh, int gw, int heads, int head_dim, int shift_h, int shift_w, int dtype, void* stream);
-/* Same, with the per-head logit scale parameter [heads] (or NULL): where exp(min(scale, ln 100)) <= 48 bounds |logit| (q-hat and
+/* Same, with dqkvh's own row stride ldd (>= 3*heads*head_dim) and the per-head logit scale parameter [heads] (or NULL): where exp(min(scale, ln 100)) <= 48 bounds |logit| (q-hat and
  * k-hat arrive normalised), the softmax is rebuilt without a row-maximum sweep, as in the forward kernel. */
 int swiftk_window_attention_bwd_scaled(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo, void* dqkvh,
-                                       const float* scale, int B, int gh, int gw, int heads, int head_dim, int shift_h,
-                                       int shift_w, int dtype, void* stream);
+                                       int64_t ldd, const float* scale, int B, int gh, int gw, int heads, int head_dim,
+                                       int shift_h, int shift_w, int dtype, void* stream);
 
 /* out[c] += sum_r src[r][c]  (period == 0), or out[(r % period)][c] += src[r][c]  (bias / pos_embed gradients) */
 int swiftk_colsum(const float* src, int64_t lds, float* out, int64_t rows, int cols, int64_t period, void* stream);

@@ -26,8 +26,8 @@ struct BwdArgs {
     const bf16_t* qkvh;   // [B, ntok, ldq]  q-hat | k-hat | v per head
     const bf16_t* o;      // [B, ntok, ldo]  forward output
     const bf16_t* d_o;    // [B, ntok, ldo]  upstream gradient
-    bf16_t* dqkvh;        // [B, ntok, ldq]  gradient w.r.t. q-hat | k-hat | v
-    int64_t ldq, ldo;
+    bf16_t* dqkvh;        // [B, ntok, ldd]  gradient w.r.t. q-hat | k-hat | v
+    int64_t ldq, ldo, ldd;
     int gh, gw, heads, sh, sw, nwx, nw;
 };
 
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
     const bf16_t* my_qkv = a.qkvh + (tok0 + my_tok) * a.ldq + head * 3 * HD;
     const bf16_t* my_o = a.o + (tok0 + my_tok) * a.ldo + head * HD;
     const bf16_t* my_do = a.d_o + (tok0 + my_tok) * a.ldo + head * HD;
-    bf16_t* my_dqkv = a.dqkvh + (tok0 + my_tok) * a.ldq + head * 3 * HD;
+    bf16_t* my_dqkv = a.dqkvh + (tok0 + my_tok) * a.ldd + head * 3 * HD;
 
     // ---------------------------------------------------------------- pass A images: K -> imgA, V -> imgB
     if (tid < 256) {
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
                     const int row = c / 11, cc = c - row * 11;
                     const uint4 v = *reinterpret_cast<const uint4*>(oslab + row * ROW88 + cc * 16);
                     const int tok = wtoken(a, w_, wv * 32 + rnd * 16 + row);
-                    *reinterpret_cast<uint4*>(a.dqkvh + (tok0_ + tok) * a.ldq + col0 + cc * 8) = v;
+                    *reinterpret_cast<uint4*>(a.dqkvh + (tok0_ + tok) * a.ldd + col0 + cc * 8) = v;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -591,21 +591,21 @@ static bool ntok_bytes_ok(const BwdArgs& a) {    // per-lane 32-bit source offse
 extern "C" int swiftk_window_attention_bwd(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo,
                                            void* dqkvh, int B, int gh, int gw, int heads, int head_dim, int shift_h,
                                            int shift_w, int dtype, void* stream) {
-    return swiftk_window_attention_bwd_scaled(qkvh, ldq, o, d_o, ldo, dqkvh, nullptr, B, gh, gw, heads, head_dim, shift_h, shift_w,
+    return swiftk_window_attention_bwd_scaled(qkvh, ldq, o, d_o, ldo, dqkvh, ldq, nullptr, B, gh, gw, heads, head_dim, shift_h, shift_w,
                                               dtype, stream);
 }
 
 extern "C" int swiftk_window_attention_bwd_scaled(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo,
-                                                  void* dqkvh, const float* scale, int B, int gh, int gw, int heads, int head_dim,
-                                                  int shift_h, int shift_w, int dtype, void* stream) {
+                                                  void* dqkvh, int64_t ldd, const float* scale, int B, int gh, int gw, int heads,
+                                                  int head_dim, int shift_h, int shift_w, int dtype, void* stream) {
     if (!qkvh || !o || !d_o || !dqkvh || B <= 0 || heads <= 0) return SWIFTK_EINVAL;
     if (dtype != SWIFTK_BF16) return SWIFTK_ESHAPE;  // training runs under bf16 autocast (trainer.py:191)
     if (head_dim != 80 && head_dim != 88 && head_dim != 96) return SWIFTK_ESHAPE;
     if (gh <= 0 || gw <= 0 || gh % 16 || gw % 16) return SWIFTK_ESHAPE;
     if (shift_h < 0 || shift_w < 0 || shift_h >= gh || shift_w >= gw) return SWIFTK_ESHAPE;
-    if (ldq < 3 * heads * head_dim || ldo < heads * head_dim) return SWIFTK_ESHAPE;
+    if (ldq < 3 * heads * head_dim || ldo < heads * head_dim || ldd < 3 * heads * head_dim) return SWIFTK_ESHAPE;
     if (((uintptr_t)qkvh & 15) || ((uintptr_t)o & 15) || ((uintptr_t)d_o & 15) || ((uintptr_t)dqkvh & 15) || (ldq * 2) % 16 ||
-        (ldo * 2) % 16)
+        (ldo * 2) % 16 || (ldd * 2) % 16)
         return SWIFTK_EALIGN;
     BwdArgs a;
     a.qkvh = static_cast<const bf16_t*>(qkvh);
@@ -614,6 +614,7 @@ extern "C" int swiftk_window_attention_bwd_scaled(const void* qkvh, int64_t ldq,
     a.dqkvh = static_cast<bf16_t*>(dqkvh);
     a.ldq = ldq;
     a.ldo = ldo;
+    a.ldd = ldd;
     a.gh = gh;
     a.gw = gw;
     a.heads = heads;

@@ -283,16 +283,18 @@ __global__ __launch_bounds__(256) void modnorm_bwd_cols_kernel(const T* __restri
 // walking its own 176 B, made 11 requests of 16 scattered bytes per lane and ran at 60 % of this form's rate).  The dot
 // product is a 4-step butterfly inside the 16-lane group; UNR vectors per group are in flight at once.
 template <typename T>
-__global__ __launch_bounds__(256) void qknorm_bwd_kernel(const T* __restrict__ qkvh, const T* __restrict__ dqkvh,
-                                                         int64_t ld, const float* __restrict__ rn, T* __restrict__ dqkv,
+__global__ __launch_bounds__(256) void qknorm_bwd_kernel(const T* __restrict__ qkvh, const T* dqkvh,
+                                                         int64_t ld, const float* __restrict__ rn, T* dqkv,
                                                          int64_t ldo, const float* __restrict__ scale,
-                                                         float* __restrict__ dscale, int64_t M, int heads, int hd) {
+                                                         float* __restrict__ dscale, int64_t M, int heads, int hd, int inplace) {
     constexpr int PER = 16 / (int)sizeof(T);  // elements per 16-B chunk
     constexpr int UNR = 4;
     __shared__ float sacc[64];
     if (threadIdx.x < 64) sacc[threadIdx.x] = 0.f;
     __syncthreads();
-    const int nvec = 3 * heads, nch = hd / PER;
+    // in place (dqkv == dqkvh, ldo == ld: the attention backward wrote straight into the GEMM operand buffer): v's gradient is
+    // already where it belongs, only the q-hat / k-hat vectors are walked
+    const int nvec = (inplace ? 2 : 3) * heads, nch = hd / PER;
     const int64_t total = M * nvec;
     const int sub = threadIdx.x & 15;                                   // chunk of the vector
     const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;  // 16-lane group
@@ -308,12 +310,13 @@ __global__ __launch_bounds__(256) void qknorm_bwd_kernel(const T* __restrict__ q
             r[u] = 0.f;
             if (i < total && live) {
                 const int64_t m = i / nvec;
-                const int v = (int)(i - m * nvec);
-                const int64_t off = m * ld + (int64_t)v * hd + sub * PER;
-                rd[u] = *reinterpret_cast<const uint4*>(dqkvh + off);
+                const int vv = (int)(i - m * nvec);
+                const int v = inplace ? (vv >> 1) * 3 + (vv & 1) : vv;
+                const int64_t col = (int64_t)v * hd + sub * PER;
+                rd[u] = *reinterpret_cast<const uint4*>(dqkvh + m * (inplace ? ldo : ld) + col);
                 if (v % 3 != 2) {
-                    ra[u] = *reinterpret_cast<const uint4*>(qkvh + off);
-                    r[u] = rn[i];
+                    ra[u] = *reinterpret_cast<const uint4*>(qkvh + m * ld + col);
+                    r[u] = rn[m * (3 * heads) + v];
                 }
             }
         }
@@ -322,7 +325,8 @@ __global__ __launch_bounds__(256) void qknorm_bwd_kernel(const T* __restrict__ q
             const int64_t i = i0 + u * ngrp;
             if (i >= total) break;  // (group-uniform)
             const int64_t m = i / nvec;
-            const int v = (int)(i - m * nvec), kind = v % 3, h = v / 3;
+            const int vv = (int)(i - m * nvec);
+            const int v = inplace ? (vv >> 1) * 3 + (vv & 1) : vv, kind = v % 3, h = v / 3;
             T* o = dqkv + m * ldo + (int64_t)v * hd + sub * PER;
             if (kind == 2) {
                 if (live) *reinterpret_cast<uint4*>(o) = rd[u];
@@ -725,14 +729,15 @@ extern "C" int swiftk_qknorm_bwd(const void* qkvh, const void* dqkvh, int64_t ld
                                  void* stream) {
     if (!qkvh || !dqkvh || !rn || !dqkv || !scale || !dscale || M <= 0) return SWIFTK_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int grid = grid_for(M * 3 * heads * 4);  // sixteen lanes per vector, four vectors per group and trip
+    const int inplace = (qkvh != dqkvh && dqkvh == dqkv) ? 1 : 0;  // the gradient buffer then has row stride ldo
+    const int grid = grid_for(M * (inplace ? 2 : 3) * heads * 4);  // sixteen lanes per vector, four vectors per group and trip
     DT_SWITCH(dtype,
               hipLaunchKernelGGL(qknorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(qkvh),
                                  static_cast<const bf16_t*>(dqkvh), ld, rn, static_cast<bf16_t*>(dqkv), ldo, scale, dscale, M,
-                                 heads, head_dim),
+                                 heads, head_dim, inplace),
               hipLaunchKernelGGL(qknorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(qkvh),
                                  static_cast<const float*>(dqkvh), ld, rn, static_cast<float*>(dqkv), ldo, scale, dscale, M,
-                                 heads, head_dim));
+                                 heads, head_dim, inplace));
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

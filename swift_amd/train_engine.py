@@ -369,14 +369,15 @@ class SwinTrainEngine:
             datt = torch.empty(M, self.kd, dtype=_BF, device=dev)
             _gemm(dy1, W["wo_t"], datt)  # N = d columns written, row stride kd
             self._wgrad(dy1, A["att"], d, d, G(att.wo.weight))
-            dqkvh = torch.empty(M, 3 * d, dtype=_BF, device=dev)
+            # d(q-hat | k-hat | v) lands in the to_qkv data-gradient GEMM's operand buffer (row stride kqkv); the QK-norm backward
+            # then rewrites the q-hat / k-hat vectors in place -- v's gradient is already final
+            dqkv = _padded(M, self.kqkv, 3 * d)
             sh = A["shift"]
             check(L.swiftk_window_attention_bwd_scaled(A["qkvh"].data_ptr(), 3 * d, A["att"].data_ptr(), datt.data_ptr(), self.kd,
-                                                       dqkvh.data_ptr(), W["scale"].data_ptr(), B, gh, gw, heads, self.hd, sh[0],
-                                                       sh[1], BF16, _s()), "swiftk_window_attention_bwd")
-            dqkv = _padded(M, self.kqkv, 3 * d)
+                                                       dqkv.data_ptr(), self.kqkv, W["scale"].data_ptr(), B, gh, gw, heads, self.hd,
+                                                       sh[0], sh[1], BF16, _s()), "swiftk_window_attention_bwd")
             dscale = torch.zeros(heads, dtype=torch.float32, device=dev)
-            check(L.swiftk_qknorm_bwd(A["qkvh"].data_ptr(), dqkvh.data_ptr(), 3 * d, A["rn"].data_ptr(), dqkv.data_ptr(), self.kqkv,
+            check(L.swiftk_qknorm_bwd(A["qkvh"].data_ptr(), dqkv.data_ptr(), 3 * d, A["rn"].data_ptr(), dqkv.data_ptr(), self.kqkv,
                                       W["scale"].data_ptr(), dscale.data_ptr(), M, heads, self.hd, BF16, _s()), "swiftk_qknorm_bwd")
             G(att.scale).add_(dscale.view_as(att.scale))
             _gemm(dqkv, W["qkv_t"], dx, EPI_ACCUM)

@@ -233,10 +233,27 @@ def test_window_attention_bwd(dev, shift, B):
     assert rel_l2(dpre.float().cpu(), d_old.float().cpu()) < 1e-2
     # with the logit scales at hand, heads whose bound is <= 48 skip the row-maximum sweep (offset 0): same gradients
     d_s = torch.empty_like(pre)
-    assert L.swiftk_window_attention_bwd_scaled(pre.data_ptr(), 3168, o.data_ptr(), do.data_ptr(), 1056, d_s.data_ptr(),
+    assert L.swiftk_window_attention_bwd_scaled(pre.data_ptr(), 3168, o.data_ptr(), do.data_ptr(), 1056, d_s.data_ptr(), 3168,
                                                 scale.to(dev).data_ptr(), B, grid[0], grid[1], heads, hd, shift[0], shift[1],
                                                 _lib.BF16, s()) == 0
     assert rel_l2(d_s.float().cpu(), dpre.float().cpu()) < 1e-2
+    # the training engine's form: gradients written with their own row stride (the next GEMM's k-padded operand buffer) ...
+    d_p = torch.full((B, n, 3200), 7.0, dtype=torch.bfloat16, device=dev)
+    assert L.swiftk_window_attention_bwd_scaled(pre.data_ptr(), 3168, o.data_ptr(), do.data_ptr(), 1056, d_p.data_ptr(), 3200,
+                                                scale.to(dev).data_ptr(), B, grid[0], grid[1], heads, hd, shift[0], shift[1],
+                                                _lib.BF16, s()) == 0
+    assert torch.equal(d_p[..., :3168], d_s) and bool((d_p[..., 3168:] == 7.0).all())
+    # ... and the QK-norm backward in place on it (q-hat / k-hat vectors rewritten, v untouched) == the out-of-place call
+    rn = (torch.rand(B * n, 3 * heads, device=dev) + 0.5).contiguous()
+    sc = scale.to(dev).float().contiguous()
+    ds_a, ds_b = torch.zeros(heads, device=dev), torch.zeros(heads, device=dev)
+    out_a = torch.full((B, n, 3200), 7.0, dtype=torch.bfloat16, device=dev)
+    assert L.swiftk_qknorm_bwd(pre.data_ptr(), d_s.data_ptr(), 3168, rn.data_ptr(), out_a.data_ptr(), 3200, sc.data_ptr(),
+                               ds_a.data_ptr(), B * n, heads, hd, _lib.BF16, s()) == 0
+    assert L.swiftk_qknorm_bwd(pre.data_ptr(), d_p.data_ptr(), 3168, rn.data_ptr(), d_p.data_ptr(), 3200, sc.data_ptr(),
+                               ds_b.data_ptr(), B * n, heads, hd, _lib.BF16, s()) == 0
+    assert torch.equal(out_a, d_p)
+    assert torch.allclose(ds_a, ds_b, rtol=1e-4, atol=1e-4 * float(ds_a.abs().max()))
     for part, name in enumerate("qkv"):
         assert rel_l2(d_s.float().cpu().view(B, n, heads, 3, hd)[..., part, :], gr[..., part, :]) < 2.5e-2, name
 

@@ -21,7 +21,7 @@ st = lambda: torch.cuda.current_stream().cuda_stream
 scale = torch.log(torch.full((heads,), 10.0, device=dev))
 def run(k, scaled=False):
     L.swiftk_set_tuning(9, k)
-    rc = L.swiftk_window_attention_bwd_scaled(pre.data_ptr(), 3168, o.data_ptr(), do.data_ptr(), 1088, outs[k].data_ptr(),
+    rc = L.swiftk_window_attention_bwd_scaled(pre.data_ptr(), 3168, o.data_ptr(), do.data_ptr(), 1088, outs[k].data_ptr(), 3168,
                                               scale.data_ptr() if scaled else None, B, gh, gw, heads, hd, 8, 8, _lib.BF16, st())
     assert rc == 0
 res = {0: [], 1: []}
