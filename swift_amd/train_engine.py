@@ -376,10 +376,10 @@ class SwinTrainEngine:
             check(L.swiftk_window_attention_bwd_scaled(A["qkvh"].data_ptr(), 3 * d, A["att"].data_ptr(), datt.data_ptr(), self.kd,
                                                        dqkv.data_ptr(), self.kqkv, W["scale"].data_ptr(), B, gh, gw, heads, self.hd,
                                                        sh[0], sh[1], BF16, _s()), "swiftk_window_attention_bwd")
-            dscale = torch.zeros(heads, dtype=torch.float32, device=dev)
+            gscale = G(att.scale)  # [heads, 1, 1] fp32, contiguous: the kernel accumulates (atomicAdd) straight into it
+            assert gscale.is_contiguous() and gscale.numel() == heads
             check(L.swiftk_qknorm_bwd(A["qkvh"].data_ptr(), dqkv.data_ptr(), 3 * d, A["rn"].data_ptr(), dqkv.data_ptr(), self.kqkv,
-                                      W["scale"].data_ptr(), dscale.data_ptr(), M, heads, self.hd, BF16, _s()), "swiftk_qknorm_bwd")
-            G(att.scale).add_(dscale.view_as(att.scale))
+                                      W["scale"].data_ptr(), gscale.data_ptr(), M, heads, self.hd, BF16, _s()), "swiftk_qknorm_bwd")
             _gemm(dqkv, W["qkv_t"], dx, EPI_ACCUM)
             self._wgrad(dqkv, A["xT_in"], 3 * d, d, G(att.to_qkv.weight))
             if grads_final is not None:  # everything of layer i except its modulation Linears (those follow in _embed_bwd)
