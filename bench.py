@@ -476,13 +476,40 @@ def parity_engine_leg(net, ds, dev, lib, X0, forc, units, nb: int = 8, steps: in
     lib.swiftk_profile_gemm(-1, 0)
     rate = nb * steps / dt
     att_s = ms.value / max(n.value, 1) * 1e-3
+    # the split-bf16 engine in the exact engine's place (fp32 activations, GEMMs as three bf16 MFMA products; to_qkv and the
+    # patch embedding stay exact): same units, same noise; its distance from the exact engine after one step
+    split = None
+    mod = getattr(net, "module", net)
+    try:
+        x_e, x_s = X0[:nb].clone(), X0[:nb].clone()
+        z1 = torch.randn(x_e.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+        ops.rollout_update(x_e, eng.sampler((x_e, F), latents=z1), mx, sx, st, phys=phys)
+        mod.model.fp32_engine = "bf16x3"
+        ops.rollout_update(x_s, eng.sampler((x_s, F), latents=z1), mx, sx, st, phys=phys)
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        r3 = nb * steps / (time.perf_counter() - t0)
+        split = {"value": r3, "unit": "sample-steps/s", "vs_exact_engine": r3 / rate,
+                 "rel_l2_vs_exact_engine_after_1_step": float((x_s.double() - x_e.double()).norm() / x_e.double().norm()),
+                 "what": "SWIFTK_FP32_ENGINE=bf16x3: the fp32 engine's kernels with every GEMM but to_qkv and the patch embedding as "
+                         "three bf16 MFMA products of (hi, lo)-split operands (swiftk_split3); 7.9e-5 rel-L2 vs the reference "
+                         "golden on the Swift-B step (exact engine 4.0e-5; tests/test_gpu_model.py)"}
+    except Exception as e:  # noqa: BLE001 -- an optional leg must not take the line down
+        split = {"error": f"{type(e).__name__}: {e}"[:200]}
+    finally:
+        mod.model.fp32_engine = None
     return {"dtype": "f32", "what": "exact-fp32 MFMA engine (v_mfma_f32_16x16x4_f32 / 32x32x2_f32), 1e-4 parity configuration "
             "(tests/test_gpu_model.py: 1.1e-5 rel-L2 vs the reference golden)", "units_per_step": nb, "steps": steps,
             "value": rate, "unit": "sample-steps/s", "tflops": FLOP_PER_EVAL * rate / 1e12,
             "frac_of_fp32_matrix_peak": FLOP_PER_EVAL * rate / PEAK_F32,
             "attention_kernel": "attn_f32_kernel<88>", "attention_avg_launch_ms": att_s * 1e3, "attention_launches": int(n.value),
             "attention_mfma_tflops": nb * 8.858e9 / att_s / 1e12 if att_s > 0 else None,
-            "attention_mfma_frac": nb * 8.858e9 / att_s / PEAK_F32 if att_s > 0 else None}
+            "attention_mfma_frac": nb * 8.858e9 / att_s / PEAK_F32 if att_s > 0 else None,
+            "split_bf16_engine": split}
 
 
 def drift_leg(net, ds, dev, X0, forc, units, nb: int = 2, marks=(1, 10, 60)):

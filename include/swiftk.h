@@ -34,6 +34,7 @@ extern "C" {
 
 #define SWIFTK_F32 0
 #define SWIFTK_BF16 1
+#define SWIFTK_BF16X3 2 /* swiftk_model.dtype only: fp32 activations, every GEMM as three bf16 products (swiftk_split3) */
 
 #define SWIFTK_EINVAL (-1)   /* bad argument (null pointer, negative size) */
 #define SWIFTK_ESHAPE (-2)   /* shape not supported by the gfx950 kernels   */
@@ -331,6 +332,12 @@ int swiftk_axpby_per_sample(float* out, const float* a, const float* x, const fl
 int swiftk_channel_axpy(float* out, const float* x, const float* y, const float* coef, int B, int C, int64_t hw,
                         void* stream);
 
+/* fp32 -> three bf16 column blocks of `cols` columns each (cols % 4 == 0, ldd >= 3*cols, the rest of a row zero):
+ * hi = bf16(v), lo = bf16(v - hi).  order 0: [hi | lo | hi] (activations), order 1: [hi | hi | lo] (weights) -- the operand
+ * layout of the SWIFTK_BF16X3 engine: swiftk_gemm over K' = 3*cols on these is hi hi' + lo hi' + hi lo' in fp32 accumulators,
+ * an fp32-grade product (measured 4.5e-6 relative against fp64) at the bf16 MFMA rate / 3. */
+int swiftk_split3(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int order, void* stream);
+
 /* fp32 -> dtype copy with row padding: dst[r][c] = src[r][c] for c < cols, 0 for cols <= c < ldd. */
 int swiftk_cast_pad(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype,
                     void* stream);
@@ -365,7 +372,11 @@ typedef struct swiftk_layer {
 } swiftk_layer;
 
 typedef struct swiftk_model {
-    int32_t dtype;                 /* SWIFTK_F32 | SWIFTK_BF16 */
+    int32_t dtype;                 /* SWIFTK_F32 | SWIFTK_BF16 | SWIFTK_BF16X3 (fp32 activations and k-paddings as for SWIFTK_F32;
+                                      GEMM weights stored by swiftk_split3(order 1) with row stride
+                                      swiftk_gemm_k_pad(SWIFTK_BF16, 3*K), except those whose GEMM stays on the
+                                      exact-fp32 kernel -- swiftk_set_tuning(11, mask), default qkv_w and pe_w --
+                                      which are fp32 operands as for SWIFTK_F32) */
     int32_t H, W, p1, p2;          /* image and patch size      */
     int32_t in_ch, out_ch;         /* 141, 69                   */
     int32_t depth, dim, heads;     /* 12, 1056, 12              */

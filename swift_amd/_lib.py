@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SWIFTK_LIB") or os.path.join(_HERE, "csrc", "libswiftk.so")
 
 F32, BF16 = 0, 1
+BF16X3 = 2  # swiftk_model.dtype only: fp32 activations, every GEMM as three bf16 products (include/swiftk.h)
 EPI_NONE, EPI_BIAS_POS, EPI_SWIGLU, EPI_QKNORM, EPI_ACCUM, EPI_SWIGLU_BOTH, EPI_SWIGLU_BWD = 0, 1, 2, 3, 5, 6, 7
 ATTN_PRENORM, ATTN_NO_PIPE, ATTN_TILED = 1, 2, 4
 PROF_ATTENTION = 100
@@ -70,6 +71,7 @@ _SIGS = {
     "swiftk_linear_small": ([_p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _p], _i),
     "swiftk_rollout_update": ([_p, _p, _p, _p, _p, _p, _i, _i, _l, _p], _i),
     "swiftk_cast_pad": ([_p, _l, _p, _l, _l, _l, _i, _p], _i),
+    "swiftk_split3": ([_p, _l, _p, _l, _l, _l, _i, _p], _i),
     "swiftk_axpby": ([_p, _f, _p, _f, _p, _l, _p], _i),
     "swiftk_unit_checksum": ([_p, _p, _p, _i, _l, _p], _i),
     "swiftk_timestep_embed_jvp": ([_p, _p, _p, _p, _i, _i, _f, _p], _i),

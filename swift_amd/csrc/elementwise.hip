@@ -544,6 +544,35 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
     }
 }
 
+// fp32 -> three bf16 column blocks: hi = bf16(v), lo = bf16(v - hi) (v = hi + lo to 2^-17 relative).  order 0 (activations):
+// [hi | lo | hi], order 1 (weights): [hi | hi | lo], so that the ordinary bf16 GEMM over K' = 3 cols computes
+// hi hi' + lo hi' + hi lo' with fp32 accumulation (the lo lo' term, 2^-18, is dropped); columns [3 cols, ldd) zero.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, int64_t lds, bf16_t* __restrict__ dst,
+                                                     int64_t ldd, int64_t rows, int64_t cols, int order) {
+    const int64_t c4 = cols >> 2, p4 = (ldd - 3 * cols) >> 2, per = c4 + p4, total = rows * per;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / per, c = i - r * per;
+        bf16_t* d = dst + r * ldd;
+        if (c >= c4) {  // zero padding behind the three blocks
+            *reinterpret_cast<uint2*>(d + 3 * cols + 4 * (c - c4)) = make_uint2(0u, 0u);
+            continue;
+        }
+        const float4 v = *reinterpret_cast<const float4*>(src + r * lds + 4 * c);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        bf16_t hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = f2bf(f[e]);
+            lo[e] = f2bf(f[e] - bf2f(hi[e]));
+        }
+        const uint2 H = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+        const uint2 Lo = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+        *reinterpret_cast<uint2*>(d + 4 * c) = H;
+        *reinterpret_cast<uint2*>(d + cols + 4 * c) = order == 0 ? Lo : H;
+        *reinterpret_cast<uint2*>(d + 2 * cols + 4 * c) = order == 0 ? H : Lo;
+    }
+}
+
 inline int grid_for(int64_t work_items, int per_block = 256, int cap = 256 * 16) {
     int64_t g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -694,6 +723,17 @@ extern "C" int swiftk_cast_pad(const float* src, int64_t lds, void* dst, int64_t
                            cols);
     else
         return SWIFTK_EINVAL;
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_split3(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int order,
+                             void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || lds < cols || ldd < 3 * cols || (order != 0 && order != 1)) return SWIFTK_EINVAL;
+    if (cols % 4 || ldd % 4 || lds % 4) return SWIFTK_ESHAPE;
+    if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return SWIFTK_EALIGN;
+    hipLaunchKernelGGL(split3_kernel, dim3(grid_for(rows * ((ldd - 2 * cols) >> 2))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       src, lds, static_cast<bf16_t*>(dst), ldd, rows, cols, order);
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

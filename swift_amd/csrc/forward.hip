@@ -4,6 +4,7 @@
 #include "common.h"
 
 int g_fwd_tiled = 1;  // tuning key 5 (A/B only): 0 keeps q/k/v row-major between to_qkv and attention
+int g_x3_exact = 17;  // tuning key 11: SWIFTK_BF16X3 GEMMs kept on the exact-fp32 kernel (bit 0 to_qkv, 1 wo, 2 w1, 3 w2, 4 patch embed, 5 head)
 int g_fwd_fused = 1;  // tuning key 8 (A/B only): 0 = to_qkv and window attention as two kernels (q/k/v window-tiled through HBM)
 
 namespace {
@@ -18,14 +19,14 @@ __global__ __launch_bounds__(256) void zero_cols_kernel(char* p, int64_t ld_b, i
 }
 
 struct Layout {
-    int64_t emb, h1, lat, mod, ape, x, xt, qkv, att, y, hmid, tok, total;
+    int64_t emb, h1, lat, mod, ape, x, xt, qkv, att, y, hmid, tok, a3, total;
 };
 
 inline int64_t al(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
 bool model_ok(const swiftk_model* m) {
     if (!m || !m->layers_host) return false;
-    if (m->dtype != SWIFTK_F32 && m->dtype != SWIFTK_BF16) return false;
+    if (m->dtype != SWIFTK_F32 && m->dtype != SWIFTK_BF16 && m->dtype != SWIFTK_BF16X3) return false;
     if (m->depth <= 0 || m->dim <= 0 || m->heads <= 0 || m->dim % m->heads) return false;
     if (m->H % m->p1 || m->W % m->p2) return false;
     if (m->wh != 16 || m->ww != 16) return false;
@@ -51,6 +52,12 @@ Layout make_layout(const swiftk_model* m, int B) {
     L.y = o; o += al(M * d * es);
     L.hmid = o; o += al(M * m->kmlp * es);
     L.tok = o; o += al(M * (int64_t)((m->out_ch * m->p1 * m->p2 + 3) & ~3) * 4);
+    L.a3 = o;
+    if (m->dtype == SWIFTK_BF16X3) {  // the split GEMM operand [M, k_pad(3 K)] bf16 of the widest GEMM input
+        const int64_t kin = (int64_t)m->in_ch * m->p1 * m->p2;
+        const int64_t kmax = kin > m->mlp ? (kin > d ? kin : d) : (m->mlp > d ? m->mlp : d);
+        o += al(M * swiftk_gemm_k_pad(SWIFTK_BF16, 3 * ((kmax + 3) & ~(int64_t)3)) * 2);
+    }
     L.total = o;
     return L;
 }
@@ -81,7 +88,10 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     if (workspace_bytes < L.total) return SWIFTK_EWORKSPACE;
     char* ws = static_cast<char*>(workspace);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int dt = m->dtype;
+    // SWIFTK_BF16X3: every kernel but the GEMMs runs exactly as in the fp32 engine; a GEMM's fp32 input is first split into
+    // [hi | lo | hi] bf16 blocks (swiftk_split3) and multiplied with the [hi | hi | lo] weight on the bf16 MFMA kernel
+    const bool x3 = m->dtype == SWIFTK_BF16X3;
+    const int dt = x3 ? SWIFTK_F32 : m->dtype;
     const int64_t es = dt == SWIFTK_BF16 ? 2 : 4;
     const int gh = m->H / m->p1, gw = m->W / m->p2, d = m->dim, hd = m->dim / m->heads;
     const int64_t ntok = (int64_t)gh * gw, M = ntok * B;
@@ -93,6 +103,18 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     float* x = reinterpret_cast<float*>(ws + L.x);
     float* tok = reinterpret_cast<float*>(ws + L.tok);
     void *ape = ws + L.ape, *xT = ws + L.xt, *qkv = ws + L.qkv, *att = ws + L.att, *y = ws + L.y, *hmid = ws + L.hmid;
+    void* a3 = ws + L.a3;
+    // C = epilogue(A W^T) over the M token rows: `kpass` is the K handed to swiftk_gemm in the one-product engines (the padded
+    // width, or the valid one when it ends half-way into the last k-tile), `kvalid` the number of meaningful columns of A
+    auto G = [&](const void* A, int64_t lda, const void* Wm, void* Cm, int64_t ldc, int64_t N, int64_t kpass, int64_t kvalid,
+                 int out_dt, int epi, const float* e0, const float* e1, int64_t pr, bool exact = false) -> int {
+        if (!x3 || exact) return swiftk_gemm(A, lda, Wm, lda, Cm, ldc, M, N, kpass, dt, out_dt, epi, e0, e1, pr, stream);
+        const int64_t kv = (kvalid + 3) & ~(int64_t)3;  // (columns [kvalid, kv) of A are zero k-padding; the weight has them too)
+        const int64_t ld3 = swiftk_gemm_k_pad(SWIFTK_BF16, 3 * kv);
+        RUN(swiftk_split3(static_cast<const float*>(A), lda, a3, ld3, M, kv, 0, stream));
+        const int64_t k3 = ((3 * kv) % 64 == 32 && ld3 >= 3 * kv + 32) ? 3 * kv : ld3;
+        return swiftk_gemm(a3, ld3, Wm, ld3, Cm, ldc, M, N, k3, SWIFTK_BF16, SWIFTK_F32, epi, e0, e1, pr, stream);
+    };
 
     // time / auxiliary embedding -> latent -> all 2*depth modulation vectors in one pass (swinv2.py:316-321, :85)
     RUN(swiftk_timestep_embed(t, m->aux_dim > 0 ? aux : nullptr, m->freqs, m->aux_w, m->aux_b, emb, B, d, m->aux_dim,
@@ -115,8 +137,8 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
 
     // patch embedding (+bias +pos_embed) into the fp32 residual stream, plus its GEMM-operand copy
     RUN(swiftk_patchify(src0, c0, s0, src1, c1, s1, src2, c2, s2, ape, m->kpe, B, m->H, m->W, m->p1, m->p2, dt, stream));
-    RUN(swiftk_gemm(ape, m->kpe, m->pe_w, m->kpe, x, d, M, d, m->kpe, dt, SWIFTK_F32, SWIFTK_EPI_BIAS_POS, m->pe_b, m->pos,
-                    ntok, stream));
+    RUN(G(ape, m->kpe, m->pe_w, x, d, d, m->kpe, (int64_t)m->in_ch * m->p1 * m->p2, SWIFTK_F32, SWIFTK_EPI_BIAS_POS, m->pe_b, m->pos,
+          ntok, (g_x3_exact & 16) != 0));
     RUN(swiftk_cast_pad(x, d, xT, m->kd, M, d, dt, stream));
     if (m->kd > d) {  // K-padding columns of the attention output must be finite (they meet zero weight columns)
         hipLaunchKernelGGL(zero_cols_kernel, dim3(1024), dim3(256), 0, st, static_cast<char*>(att), m->kd * es, d * es,
@@ -152,27 +174,25 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
                                         shifted ? m->sw : 0, dt, SWIFTK_ATTN_PRENORM | SWIFTK_ATTN_TILED, stream));
         } else {
-            RUN(swiftk_gemm(xT, m->kd, ly.qkv_w, m->kd, qkv, 3 * d, M, 3 * d, kdv, dt, dt,
-                            fuse_norm ? SWIFTK_EPI_QKNORM : SWIFTK_EPI_NONE, fuse_norm ? ly.scale : nullptr, nullptr,
-                            fuse_norm ? hd : 0, stream));
+            // (SWIFTK_BF16X3 keeps to_qkv -- and the patch embedding -- on the exact-fp32 kernel by default: the cosine logits
+            // multiply q-hat . k-hat by up to 100, so the split product's 4.5e-6 would reach the softmax as 4.5e-4)
+            RUN(G(xT, m->kd, ly.qkv_w, qkv, 3 * d, 3 * d, kdv, d, dt, fuse_norm ? SWIFTK_EPI_QKNORM : SWIFTK_EPI_NONE,
+                  fuse_norm ? ly.scale : nullptr, nullptr, fuse_norm ? hd : 0, (g_x3_exact & 1) != 0));
             RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
                                         shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
         }
-        RUN(swiftk_gemm(att, m->kd, ly.wo_w, m->kd, y, d, M, d, kdv, dt, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, stream));
+        RUN(G(att, m->kd, ly.wo_w, y, d, d, kdv, d, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (g_x3_exact & 2) != 0));
         RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok,
                                     1e-6f, dt, stream));
-        RUN(swiftk_gemm(xT, m->kd, ly.w1_w, m->kd, hmid, m->kmlp, M, 2 * m->mlp, kdv, dt, dt, SWIFTK_EPI_SWIGLU, nullptr,
-                        nullptr, 0, stream));
-        RUN(swiftk_gemm(hmid, m->kmlp, ly.w2_w, m->kmlp, y, d, M, d, m->kmlp, dt, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0,
-                        stream));
+        RUN(G(xT, m->kd, ly.w1_w, hmid, m->kmlp, 2 * m->mlp, kdv, d, dt, SWIFTK_EPI_SWIGLU, nullptr, nullptr, 0, (g_x3_exact & 4) != 0));
+        RUN(G(hmid, m->kmlp, ly.w2_w, y, d, d, m->kmlp, m->mlp, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (g_x3_exact & 8) != 0));
         RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d,
                                     ntok, 1e-6f, dt, stream));
     }
 
     // the head's output width rounded up to the GEMM's N granularity (head_w carries zero rows there: 69 -> 72 for 1x1 patches)
     const int po4 = (m->out_ch * m->p1 * m->p2 + 3) & ~3;
-    RUN(swiftk_gemm(xT, m->kd, m->head_w, m->kd, tok, po4, M, po4, kdv, dt, SWIFTK_F32, SWIFTK_EPI_NONE, nullptr, nullptr, 0,
-                    stream));
+    RUN(G(xT, m->kd, m->head_w, tok, po4, po4, kdv, d, SWIFTK_F32, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (g_x3_exact & 32) != 0));
     RUN(swiftk_unpatchify_affine(tok, po4, xt, alpha, beta, out, B, m->out_ch, m->H, m->W, m->p1, m->p2, stream));
     return 0;
 }

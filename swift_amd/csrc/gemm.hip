@@ -1028,6 +1028,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 7: g_stagger_permille = value; return 0;
         case 8: g_fwd_fused = value; return 0;
         case 9: g_attn_bwd_pipe = value; return 0;
+        case 11: g_x3_exact = value; return 0;
     }
     return SWIFTK_EINVAL;
 }

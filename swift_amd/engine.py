@@ -14,16 +14,21 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Sequence
 
 import torch
 
 from . import ops
-from ._lib import Layer, Model, SwiftkError, check, lib
+from ._lib import BF16X3, Layer, Model, SwiftkError, check, lib
 
 
 class SwinEngine:
-    def __init__(self, module, dtype: torch.dtype):
+    def __init__(self, module, dtype):
+        """``dtype``: torch.bfloat16 (bf16 MFMA engine), torch.float32 (exact-fp32 MFMA engine) or the string "bf16x3" --
+        the fp32 engine's kernels with every GEMM computed as three bf16 products of (hi, lo)-split operands
+        (``swiftk_split3``; GEMM error 4.5e-6 against fp64 where exact fp32 has 6e-7 and plain bf16 2e-3), at 2.4-2.7 x the
+        fp32 GEMM rate."""
         self.module = module
         self.dtype = dtype
         self._stamp = None
@@ -43,7 +48,15 @@ class SwinEngine:
         dev = m.pos_embed.device
         if dev.type != "cuda":
             raise SwiftkError("SwinV2 parameters must live on the GPU (module.to('cuda')); there is no CPU path")
-        dt = self.dtype
+        x3 = self.dtype == "bf16x3"
+        # which GEMMs of the bf16x3 engine stay on the exact-fp32 kernel (bit 0 to_qkv, 1 wo, 2 w1, 3 w2, 4 patch embed, 5 head)
+        # Default 17: the cosine logits multiply q-hat . k-hat by up to 100, and an error in the patch embedding passes through
+        # every layer -- measured on Swift-B against the reference: all GEMMs split 2.8e-4, these two exact 7.9e-5 (exact
+        # engine 4.0e-5); 68 against 47 sample-steps/s for the exact engine at 8 units per step.
+        exact_mask = int(os.environ.get("SWIFTK_X3_EXACT", "17"))
+        if x3:
+            lib().swiftk_set_tuning(11, exact_mask)
+        dt = torch.float32 if x3 else self.dtype  # activations, k-paddings and every non-GEMM kernel
         d, heads, depth, mlp = m.dim, m.heads, m.depth, m.mlp_dim
         p1, p2 = m.patch_size
         # int(8/3 * dim) is odd for some widths (1280 -> 3413): one zero (gate, up) row pair makes w1's N a multiple of 4;
@@ -57,8 +70,11 @@ class SwinEngine:
             keep.append(t)
             return t.data_ptr()
 
-        def gemm_w(t, k):
-            t = ops.pad_cols(t.detach(), k, dt)
+        def gemm_w(t, k, exact=False):
+            if x3 and not exact:  # [hi | hi | lo] blocks over the valid columns (rounded up to 4), row stride k_pad(bf16, 3 K)
+                t = ops.split3(t.detach(), 1, cols=(t.shape[1] + 3) // 4 * 4)
+            else:
+                t = ops.pad_cols(t.detach(), k, dt)
             keep.append(t)
             return t.data_ptr()
 
@@ -69,10 +85,10 @@ class SwinEngine:
             w1i = w1.view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)  # rows: gate_0, up_0, gate_1, up_1, ...
             if mlp_e != mlp:
                 w1i = torch.cat([w1i, w1i.new_zeros(2, d)], 0)
-            layers[i].qkv_w = gemm_w(att.to_qkv.weight, kd)
-            layers[i].wo_w = gemm_w(att.wo.weight, kd)
-            layers[i].w1_w = gemm_w(w1i, kd)
-            layers[i].w2_w = gemm_w(ff.w2.weight, kmlp)
+            layers[i].qkv_w = gemm_w(att.to_qkv.weight, kd, exact=bool(exact_mask & 1))
+            layers[i].wo_w = gemm_w(att.wo.weight, kd, exact=bool(exact_mask & 2))
+            layers[i].w1_w = gemm_w(w1i, kd, exact=bool(exact_mask & 4))
+            layers[i].w2_w = gemm_w(ff.w2.weight, kmlp, exact=bool(exact_mask & 8))
             layers[i].scale = f32(att.scale.reshape(-1))
             layers[i].ln1_g, layers[i].ln1_b = f32(att.norm.norm.weight), f32(att.norm.norm.bias)
             layers[i].ln2_g, layers[i].ln2_b = f32(ff.norm.norm.weight), f32(ff.norm.norm.bias)
@@ -83,7 +99,7 @@ class SwinEngine:
         freqs = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32, device=dev) / half)  # swinv2.py:48-50
 
         mo = Model()
-        mo.dtype = ops.dtype_code(dt)
+        mo.dtype = BF16X3 if x3 else ops.dtype_code(dt)
         mo.H, mo.W = m.image_size
         mo.p1, mo.p2 = p1, p2
         mo.in_ch, mo.out_ch = m.in_channels, m.out_channels
@@ -94,7 +110,7 @@ class SwinEngine:
         mo.has_logvar = int(m.logvar_embed is not None)
         mo.timestep_weight = float(m.timestep_weight)
         mo.kd, mo.kmlp, mo.kpe = kd, kmlp, kpe
-        mo.pe_w = gemm_w(m.patch_embed.emb.weight, kpe)
+        mo.pe_w = gemm_w(m.patch_embed.emb.weight, kpe, exact=bool(exact_mask & 16))
         mo.pe_b = f32(m.patch_embed.emb.bias)
         mo.pos = f32(m.pos_embed.reshape(-1, d))
         mo.freqs = f32(freqs)
@@ -108,7 +124,7 @@ class SwinEngine:
         hw = m.head.head[0].weight.detach()
         if hw.shape[0] % 4:  # GEMM N granularity: zero rows (1x1 patches: 69 -> 72 output columns, the extra ones unused)
             hw = torch.cat([hw, hw.new_zeros(4 - hw.shape[0] % 4, hw.shape[1])], 0)
-        mo.head_w = gemm_w(hw, kd)
+        mo.head_w = gemm_w(hw, kd, exact=bool(exact_mask & 32))
         mo.layers_host = C.cast(layers, C.POINTER(Layer))
         keep.append(layers)
         self.model, self._keep, self._stamp = mo, keep, stamp

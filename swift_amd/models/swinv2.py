@@ -14,6 +14,7 @@ autocast selects the bf16-MFMA engine, anything else the exact-fp32 engine.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Sequence, Union
 
 import torch
@@ -155,8 +156,14 @@ class SwinV2(AbstractNetwork):
             return torch.bfloat16
         return torch.float32
 
-    def engine(self, dtype: Optional[torch.dtype] = None) -> SwinEngine:
+    def engine(self, dtype=None) -> SwinEngine:
+        """The engine of a compute dtype: bf16 under bf16 autocast, else the exact-fp32 engine -- or, when
+        ``SWIFTK_FP32_ENGINE=bf16x3`` (or ``module.fp32_engine = "bf16x3"``), the split-bf16 engine in its place: fp32
+        activations, every GEMM as three bf16 MFMA products (about twice the exact engine's throughput; parity with the
+        reference measured at a few 1e-5 instead of 1e-5, tests/test_gpu_model.py)."""
         dtype = dtype or self.compute_dtype()
+        if dtype == torch.float32 and (getattr(self, "fp32_engine", None) or os.environ.get("SWIFTK_FP32_ENGINE", "exact")) == "bf16x3":
+            dtype = "bf16x3"
         if dtype not in self._engines:
             self._engines[dtype] = SwinEngine(self, dtype)
         return self._engines[dtype]

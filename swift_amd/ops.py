@@ -56,6 +56,21 @@ def pad_cols(w: torch.Tensor, k: int, dtype: torch.dtype, out: Optional[torch.Te
     return out
 
 
+def split3(w: torch.Tensor, order: int, cols: Optional[int] = None) -> torch.Tensor:
+    """fp32 [rows, c] -> bf16 [rows, k_pad(bf16, 3 * cols)]: the three-block (hi / lo) operand of the bf16x3 engine
+    (``swiftk_split3``; order 0 = activations [hi | lo | hi], 1 = weights [hi | hi | lo]).  ``cols`` >= c: zero columns are
+    appended first (valid K rounded up to the split's granularity of 4)."""
+    _dev(w)
+    w = w.contiguous().float()
+    cols = cols or w.shape[1]
+    if cols != w.shape[1]:
+        w = torch.nn.functional.pad(w, (0, cols - w.shape[1]))
+    out = torch.empty(w.shape[0], k_pad(torch.bfloat16, 3 * cols), dtype=torch.bfloat16, device=w.device)
+    check(lib().swiftk_split3(w.data_ptr(), w.shape[1], out.data_ptr(), out.shape[1], w.shape[0], cols, order, _stream()),
+          "swiftk_split3")
+    return out
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *, n_out: Optional[int] = None,
          out_dtype: Optional[torch.dtype] = None, epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None,
          pos: Optional[torch.Tensor] = None, head_dim: int = 0) -> torch.Tensor:

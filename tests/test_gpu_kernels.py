@@ -451,3 +451,29 @@ def test_race_screen_pipelined_kernels(dev):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "stress.py"), "12"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "RACE SCREEN: CLEAN" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("K", [1056, 564, 144])
+def test_split3_and_three_product_gemm(dev, K):
+    """swiftk_split3: hi = bf16(v), lo = bf16(v - hi) in three column blocks ([hi | lo | hi] activations, [hi | hi | lo] weights,
+    zero padding behind); the ordinary bf16 GEMM over them is an fp32-grade product (the bf16x3 engine's GEMM)."""
+    from swift_amd import ops
+    M, N = 512, 352
+    a, w = rnd((M, K), 70), rnd((N, K), 71, 0.03)
+    a3, w3 = ops.split3(a.to(dev), 0), ops.split3(w.to(dev), 1)
+    ld = ops.k_pad(torch.bfloat16, 3 * K)
+    assert a3.shape == (M, ld) and w3.shape == (N, ld) and a3.dtype == torch.bfloat16
+    hi = a.bfloat16()
+    lo = (a - hi.float()).bfloat16()
+    assert torch.equal(a3[:, :K].cpu(), hi) and torch.equal(a3[:, K:2 * K].cpu(), lo) and torch.equal(a3[:, 2 * K:3 * K].cpu(), hi)
+    whi = w.bfloat16()
+    assert torch.equal(w3[:, :K].cpu(), whi) and torch.equal(w3[:, K:2 * K].cpu(), whi)
+    assert torch.equal(w3[:, 2 * K:3 * K].cpu(), (w - whi.float()).bfloat16())
+    assert float(a3[:, 3 * K:].float().abs().sum()) == 0.0 and float(w3[:, 3 * K:].float().abs().sum()) == 0.0
+    assert float(((hi.float() + lo.float()) - a).abs().max() / a.abs().max()) < 2.0 ** -15
+    c = ops.gemm(a3, w3, out_dtype=torch.float32)
+    ref = a.double() @ w.double().t()
+    e3 = float((c.cpu().double() - ref).norm() / ref.norm())
+    e1 = float(((hi.double() @ whi.double().t()) - ref).norm() / ref.norm())
+    print(f"K = {K}: three-product GEMM rel-L2 {e3:.2e} against fp64 (one bf16 product: {e1:.2e})")
+    assert e3 < 1e-5 and e1 > 1e-3
