@@ -16,12 +16,20 @@ every key owns its pool -- except keys the caller declares ``transient``: their 
 sequence of this cache runs (backward passes: input gradients are copied or accumulated at once), so they share one pool
 and with it their temporaries (several GB per backward pass at Swift-B).
 
+Garbage collection: a cyclic-GC pass that happens to start INSIDE a capture can finalise objects of an earlier, invalidated
+capture (graph executables, pool blocks), and the runtime aborts the process when such a release is issued on a capturing
+stream (observed: SIGABRT in ``test_graph_pools_survive_growing_rollouts_and_moved_gradients`` once unrelated host code shifted
+the collector's schedule).  ``capture()`` therefore keeps the collector off from capture begin to capture end; whatever became
+garbage meanwhile is collected by the next ordinary pass, outside any capture.
+
 Requirements on ``fn``: no host synchronisation, no Python-side dependence on tensor VALUES, every scalar kernel argument
 constant for the key, and every buffer it reads besides ``inputs`` at a fixed address (the engines keep their operand
 copies in persistent buffers for this).  ``SWIFTK_TRAIN_GRAPHS=0`` disables capture (everything runs eagerly).
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import os
 from typing import Callable, Dict, Sequence
 
@@ -30,6 +38,19 @@ import torch
 
 def enabled() -> bool:
     return os.environ.get("SWIFTK_TRAIN_GRAPHS", "1") != "0" and torch.cuda.is_available()
+
+
+@contextlib.contextmanager
+def capture(graph: "torch.cuda.CUDAGraph", pool=None):
+    """``torch.cuda.graph`` with the cyclic garbage collector held off for the duration of the capture (see the module text)."""
+    was_on = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, pool=pool):
+            yield
+    finally:
+        if was_on:
+            gc.enable()
 
 
 class GraphCache:
@@ -63,7 +84,7 @@ class GraphCache:
                 pool = self._transient_pool
             else:
                 pool = torch.cuda.graph_pool_handle()  # outputs outlive other keys' replays: a pool of its own
-            with torch.cuda.graph(graph, pool=pool):
+            with capture(graph, pool=pool):
                 out = fn(*static_in)
             ent = self._graphs[key] = (graph, static_in, out)
             self.generation[key] = self.generation.get(key, 0) + 1

@@ -15,30 +15,33 @@ from ..config import instantiate
 from .abstract import AbstractNetwork
 
 
-def _2d_resolution(x):
-    if isinstance(x, int):
-        return np.array([x, x], dtype=int)
-    x = np.asarray(x, dtype=int)
-    assert x.shape[0] == 2
-    return x
+def _2d_resolution(x) -> np.ndarray:
+    """An int or an (H, W) pair -> ``np.array([H, W])``, the type callers of the reference read from ``net.img_resolution``
+    (precond.py:9-18)."""
+    hw = np.broadcast_to(np.asarray(x, dtype=int).reshape(-1), (2,)) if np.ndim(x) == 0 else np.asarray(x, dtype=int)
+    if hw.shape != (2,):
+        raise AssertionError(f"img_resolution must be an int or a pair, got {x!r}")
+    return np.array(hw)
 
 
 def _process_auxiliary(auxiliary, auxiliary_dim, batch_size, device):
-    """scalar / [1] / [B] / None -> [B|1, auxiliary_dim]  (precond.py:21-31)."""
-    if auxiliary_dim == 0:
+    """scalar / [1] / [B] / None -> [B|1, auxiliary_dim]  (precond.py:21-31).  None stands for a zero lead time (one row that the
+    network broadcasts); a Python number is materialised by a fill kernel rather than a pageable host-to-device copy (capturable
+    into a HIP graph); tensors on another device are brought over without a host stall."""
+    if not auxiliary_dim:
         return None
+    dev = torch.device(device)
     if auxiliary is None:
-        return torch.zeros([1, auxiliary_dim], device=device)
-    if not isinstance(auxiliary, torch.Tensor):
-        if isinstance(auxiliary, (int, float)):  # a fill kernel instead of a pageable host->device copy: graph-capturable
-            auxiliary = torch.full((), float(auxiliary), dtype=torch.float32, device=device)
-        else:
-            auxiliary = torch.tensor(auxiliary, device=device)
-    if auxiliary.device != torch.device(device):  # (the trainer keeps lead times on the host; pinned loader batches copy asynchronously)
-        auxiliary = auxiliary.to(device, non_blocking=True)
-    if auxiliary.dim() == 0 or (auxiliary.dim() == 1 and auxiliary.size(0) == 1):
-        auxiliary = auxiliary.repeat(batch_size)
-    return auxiliary.reshape(-1, auxiliary_dim)
+        return torch.zeros(1, auxiliary_dim, device=dev)
+    if isinstance(auxiliary, (int, float)):
+        aux = torch.full((), float(auxiliary), dtype=torch.float32, device=dev)
+    else:
+        aux = auxiliary if torch.is_tensor(auxiliary) else torch.as_tensor(auxiliary)
+        if aux.device != dev:  # (the trainer keeps lead times on the host; pinned loader batches copy asynchronously)
+            aux = aux.to(dev, non_blocking=True)
+    if aux.numel() == 1 and aux.dim() <= 1:  # one value for the whole batch
+        aux = aux.reshape(1).expand(batch_size)
+    return aux.reshape(-1, auxiliary_dim)
 
 
 class PassPrecond(torch.nn.Module):

@@ -22,7 +22,7 @@ from typing import Callable, Optional, Sequence
 
 import torch
 
-from . import ops
+from . import graphs, ops
 from .generating.factory import sampler_factory
 
 
@@ -81,7 +81,7 @@ class RolloutEngine:
             X.copy_(keep)
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with graphs.capture(graph):
             Y = self.sampler((X, forc), latents=z)
             ops.rollout_update(X, Y, mx, sx, st, phys=phys)
         X.copy_(keep)

@@ -12,6 +12,8 @@ matmuls); the O(n) element-wise glue (momentum lerp, ``bA + cA^2``, ``aX + BX``,
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.distributed as dist
 
@@ -61,21 +63,20 @@ def _transpose_into(src: torch.Tensor, rows: int, cols: int, dst: torch.Tensor) 
 
 
 def zeropower_via_newtonschulz5(G: torch.Tensor, steps: int = 5) -> torch.Tensor:
-    """muon.py:5-35 for one 2-D matrix on the GPU; returns bf16 of G's shape."""
+    """Quintic Newton-Schulz iteration X <- aX + (bA + cA^2)X, A = XX^T, on G / |G|_F (muon.py:5-35) for one 2-D matrix on the
+    GPU; wide orientation inside (rows <= cols), bf16 throughout, returns bf16 of G's shape."""
     assert G.ndim == 2 and G.is_cuda
     a, b, c = NS_COEFFS
-    X = G.to(_BF)
-    tall = G.size(0) > G.size(1)
-    if tall:
-        X = X.mT
-    X = X / (X.norm(dim=(-2, -1), keepdim=True) + 1e-7)
-    m, n = X.shape  # m <= n
+    tall = G.shape[0] > G.shape[1]
+    X = G.to(_BF).mT if tall else G.to(_BF)
+    X = X / (X.norm() + 1e-7)  # Frobenius norm, in bf16 as the reference takes it
+    m, n = X.shape
     if m % 4 or n % 4 or m < 16:
         # degenerate "matrices" the reference's rule also sends through Muon (the [1, heads, 1, 1] logit scale viewed as
-        # 1 x heads): a few dozen FLOPs, below the GEMM's shape granularity -> plain rocBLAS matmul
+        # 1 x heads): a few dozen FLOPs, below the GEMM's shape granularity -> plain library matmul
         for _ in range(steps):
-            A = X @ X.mT
-            X = a * X + (b * A + c * A @ A) @ X
+            gram = X @ X.mT
+            X = a * X + (b * gram + c * (gram @ gram)) @ X
         return X.mT if tall else X
     km, kn = ops.k_pad(_BF, m), ops.k_pad(_BF, n)
     dev = G.device
@@ -96,43 +97,80 @@ def zeropower_via_newtonschulz5(G: torch.Tensor, steps: int = 5) -> torch.Tensor
 
 
 def muon_update(grad: torch.Tensor, momentum: torch.Tensor, beta: float = 0.95, ns_steps: int = 5, nesterov: bool = True):
-    """muon.py:38-45 (grad is consumed: the Nesterov blend is written into it, as the reference does)."""
-    momentum.lerp_(grad, 1 - beta)
-    update = grad.lerp_(momentum, beta) if nesterov else momentum
-    if update.ndim == 4:
-        update = update.view(len(update), -1)
-    update = zeropower_via_newtonschulz5(update, steps=ns_steps)
-    update = update * max(1, grad.size(-2) / grad.size(-1)) ** 0.5
-    return update
+    """The Muon direction of one parameter (muon.py:38-45): gradient EMA, Nesterov look-ahead (written into ``grad``, which the
+    reference consumes the same way), orthogonalisation of the matrix view, sqrt(max(1, rows / cols)) rescale."""
+    momentum.mul_(beta).add_(grad, alpha=1.0 - beta)
+    direction = grad.mul_(1.0 - beta).add_(momentum, alpha=beta) if nesterov else momentum
+    matrix = direction.flatten(1) if direction.ndim == 4 else direction
+    ortho = zeropower_via_newtonschulz5(matrix, steps=ns_steps)  # (module-level lookup: tests swap in a CPU orthogonaliser)
+    return ortho * math.sqrt(max(1.0, grad.shape[-2] / grad.shape[-1]))
 
 
 def adam_update(grad, buf1, buf2, step, betas, eps):
-    """muon.py:149-154."""
-    buf1.lerp_(grad, 1 - betas[0])
-    buf2.lerp_(grad.square(), 1 - betas[1])
-    buf1c = buf1 / (1 - betas[0] ** step)
-    buf2c = buf2 / (1 - betas[1] ** step)
-    return buf1c / (buf2c.sqrt() + eps)
+    """Bias-corrected Adam direction (muon.py:149-154); ``buf1`` / ``buf2`` are the running first / second moments."""
+    b1, b2 = betas
+    buf1.mul_(b1).add_(grad, alpha=1.0 - b1)
+    buf2.mul_(b2).addcmul_(grad, grad, value=1.0 - b2)
+    return (buf1 / (1.0 - b1 ** step)) / ((buf2 / (1.0 - b2 ** step)).sqrt_() + eps)
+
+
+# per-group hyper-parameters the reference fills in (muon.py:172-184); the key set of a group is checked against them
+_GROUP_DEFAULTS = {
+    True: {"lr": 0.02, "momentum": 0.95, "weight_decay": 0},
+    False: {"lr": 3e-4, "betas": (0.9, 0.95), "eps": 1e-10, "weight_decay": 0},
+}
 
 
 class MuonWithAuxAdam(torch.optim.Optimizer):
+    """Param groups flagged ``use_muon`` (2-D+ transformer weights) take the Muon step, the others an AdamW-style step.  State
+    keys as in the reference (``momentum_buffer`` / ``exp_avg``, ``exp_avg_sq``, ``step``) so optimiser checkpoints carry over."""
+
     def __init__(self, param_groups, **kwargs):
-        param_groups = [dict(g) for g in param_groups]
-        for group in param_groups:
-            assert "use_muon" in group
-            if group["use_muon"]:
-                group["params"] = sorted(group["params"], key=lambda x: x.size(), reverse=True)
-                group["lr"] = group.get("lr", 0.02)
-                group["momentum"] = group.get("momentum", 0.95)
-                group["weight_decay"] = group.get("weight_decay", 0)
-                assert set(group.keys()) == {"params", "lr", "momentum", "weight_decay", "use_muon"}
-            else:
-                group["lr"] = group.get("lr", 3e-4)
-                group["betas"] = group.get("betas", (0.9, 0.95))
-                group["eps"] = group.get("eps", 1e-10)
-                group["weight_decay"] = group.get("weight_decay", 0)
-                assert set(group.keys()) == {"params", "lr", "betas", "eps", "weight_decay", "use_muon"}
-        super().__init__(param_groups, dict())
+        groups = []
+        for given in param_groups:
+            if "use_muon" not in given:
+                raise AssertionError("every param group must say use_muon=True/False (muon.py:170)")
+            kind = bool(given["use_muon"])
+            group = {**_GROUP_DEFAULTS[kind], **given}
+            if set(group) != set(_GROUP_DEFAULTS[kind]) | {"params", "use_muon"}:
+                raise AssertionError(f"unexpected keys in a {'Muon' if kind else 'Adam'} group: {sorted(group)}")
+            if kind:  # largest first: the rounds of the rank round-robin then hold parameters of similar cost
+                group["params"] = sorted(group["params"], key=lambda q: q.size(), reverse=True)
+            groups.append(group)
+        super().__init__(groups, dict())
+
+    def _muon_group(self, group, world: int, rank: int, multi: bool) -> None:
+        params = group["params"]
+        decay = 1.0 - group["lr"] * group["weight_decay"]
+        for base in range(0, len(params), world):  # round `base // world`: rank r owns params[base + r]
+            mine = base + rank
+            if mine < len(params):
+                p = params[mine]
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                st = self.state[p]
+                if "momentum_buffer" not in st:
+                    st["momentum_buffer"] = torch.zeros_like(p)
+                step = muon_update(p.grad, st["momentum_buffer"], beta=group["momentum"])
+                p.mul_(decay).add_(step.reshape(p.shape).to(p.dtype), alpha=-group["lr"])
+            if multi:
+                # the reference all-gathers the round's parameters (muon.py:234-237), which needs one shape per round;
+                # rounds here may mix shapes (12 x w1 then 12 x to_qkv on 8 ranks), so every parameter of the round is
+                # broadcast from the rank that owns it
+                for r in range(min(world, len(params) - base)):
+                    dist.broadcast(params[base + r].data, src=r)
+
+    def _adam_group(self, group) -> None:
+        decay = 1.0 - group["lr"] * group["weight_decay"]
+        for p in group["params"]:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            st = self.state[p]
+            if not st:
+                st["exp_avg"], st["exp_avg_sq"], st["step"] = torch.zeros_like(p), torch.zeros_like(p), 0
+            st["step"] += 1
+            p.mul_(decay).add_(adam_update(p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], group["betas"], group["eps"]),
+                               alpha=-group["lr"])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -144,36 +182,7 @@ class MuonWithAuxAdam(torch.optim.Optimizer):
         world, rank = (dist.get_world_size(), dist.get_rank()) if multi else (1, 0)
         for group in self.param_groups:
             if group["use_muon"]:
-                params = group["params"]
-                for base in range(0, len(params), world):
-                    if base + rank < len(params):
-                        p = params[base + rank]
-                        if p.grad is None:
-                            p.grad = torch.zeros_like(p)
-                        state = self.state[p]
-                        if len(state) == 0:
-                            state["momentum_buffer"] = torch.zeros_like(p)
-                        update = muon_update(p.grad, state["momentum_buffer"], beta=group["momentum"])
-                        p.mul_(1 - group["lr"] * group["weight_decay"])
-                        p.add_(update.reshape(p.shape).to(p.dtype), alpha=-group["lr"])
-                    if multi:
-                        # the reference all-gathers the round's parameters (muon.py:234-237), which needs one shape per
-                        # round; rounds here may mix shapes (12 x w1 then 12 x to_qkv on 8 ranks), so every parameter of
-                        # the round is broadcast from the rank that owns it
-                        for r in range(world):
-                            if base + r < len(params):
-                                dist.broadcast(params[base + r].data, src=r)
+                self._muon_group(group, world, rank, multi)
             else:
-                for p in group["params"]:
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-                    state = self.state[p]
-                    if len(state) == 0:
-                        state["exp_avg"] = torch.zeros_like(p)
-                        state["exp_avg_sq"] = torch.zeros_like(p)
-                        state["step"] = 0
-                    state["step"] += 1
-                    update = adam_update(p.grad, state["exp_avg"], state["exp_avg_sq"], state["step"], group["betas"], group["eps"])
-                    p.mul_(1 - group["lr"] * group["weight_decay"])
-                    p.add_(update, alpha=-group["lr"])
+                self._adam_group(group)
         return loss
