@@ -237,9 +237,9 @@ class Trainer:
         # other optimisers (MuonWithAuxAdam, anything a config names): the reference's sequence on torch ops
         torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)  # trainer.py:223-231
         self.optimizer.step()
-        with torch.no_grad():  # p_ema = p_net.lerp(p_ema, beta)  (trainer.py:245-246)
-            for pe, pn in zip(self.ema.parameters(), self.net.parameters()):
-                pe.copy_(pn.detach().lerp(pe, beta))
+        with torch.no_grad():  # p_ema = p_net.lerp(p_ema, beta)  (trainer.py:245-246), all tensors in two multi-tensor launches
+            pe, pn = list(self.ema.parameters()), [q.detach() for q in self.net.parameters()]
+            torch._foreach_copy_(pe, torch._foreach_lerp(pn, pe, beta))
 
     def train_step(self, x, t, idx, delta, global_nimg: int, steps: int = 1):
         """One optimisation step on a prepared batch; returns the (rank-local) loss value."""
