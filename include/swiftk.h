@@ -215,6 +215,13 @@ int swiftk_gemm_qkv_tiled(const void* A, int64_t lda, const void* W, int64_t ldw
                           const float* scale, int B, int gh, int gw, int heads, int head_dim, int shift_h, int shift_w,
                           void* stream);
 
+/* Batched product: C_b[M, N] = A_b[M, K] * W_b[N, K]^T for b < batch, matrix b of each operand at `stride_*` ELEMENTS from
+ * matrix b-1 (bf16 operands, bf16 or fp32 result, K % 64 == 0 with zero-padded rows, N % 4 == 0).  One launch; made for the
+ * Newton-Schulz products of MuonWithAuxAdam over the same-shape weights of all layers (reference
+ * training/optimizers/muon.py:5-35 runs them as batched torch matmuls too when given a 3-D tensor). */
+int swiftk_gemm_batched(const void* A, int64_t lda, int64_t stride_a, const void* W, int64_t ldw, int64_t stride_w, void* C,
+                        int64_t ldc, int64_t stride_c, int batch, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype,
+                        void* stream);
 /* slabs[s][M, ldc] (fp32) = A[M, K_s] * W[N, K_s]^T for the s-th of `ksplit` equal k-ranges; slab s starts at
  * slabs + s*slab_stride.  Same operand rules as swiftk_gemm; M % 8 == 0, N % 8 == 0. */
 int swiftk_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, float* slabs, int64_t ldc, int64_t slab_stride,

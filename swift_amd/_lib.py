@@ -85,6 +85,7 @@ _SIGS = {
     "swiftk_scm_target": ([_p, _p, _p, _p, _p, _f, _f, _p, _p, _i, _l, _p], _i),
     "swiftk_gemm_qkv_tiled": ([_p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_qkv_attention_fused": ([_p, _l, _p, _l, _p, _p, _l, _l, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "swiftk_gemm_batched": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _i, _l, _l, _l, _i, _i, _p], _i),
     "swiftk_gemm_splitk": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _l, _i, _i, _p], _i),
     "swiftk_gemm_tn_splitk": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _l, _i, _p], _i),
     "swiftk_reduce_slabs": ([_p, _l, _l, _i, _p, _l, _l, _l, _i, _p], _i),

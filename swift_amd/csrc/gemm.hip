@@ -99,6 +99,7 @@ struct GemmArgs {
     int stagger;       // persistent kernel: start-up delay step in 10-ns ticks (workgroup phase p waits p x stagger); 0 = off
     int ksplit;        // persistent kernel: k-ranges per output tile (1 = plain)
     int64_t c_split;   // elements between the fp32 slabs of consecutive splits
+    int64_t batch_a, batch_w, batch_c;  // one-tile-per-workgroup kernel only: byte steps of A / W / C per blockIdx.y (batched GEMM)
     // QKNORM only: window-tiled output [sample][window][head][q|k|v][256][88] (t_gw = 0: plain row-major C)
     int t_gh, t_gw, t_sh, t_sw, t_heads;
 };
@@ -227,6 +228,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
     }
     const int m0 = (tile / g.ntn) * BM;
     const int n0 = (tile % g.ntn) * BN;
+    // batched form (swiftk_gemm_batched): matrix blockIdx.y of a stack with constant steps
+    g.A += (int64_t)blockIdx.y * g.batch_a;
+    g.W += (int64_t)blockIdx.y * g.batch_w;
+    g.C += (int64_t)blockIdx.y * g.batch_c;
 
     // ---- per-lane source pointers of the LDS-DMA pieces (k-tile 0) ----
     const int prow = lane >> 3;      // row inside an 8-row piece
@@ -1120,6 +1125,7 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     g.dbg = g_dbg;
     g.ksplit = ksplit;
     g.c_split = c_split;
+    g.batch_a = g.batch_w = g.batch_c = 0;
     g.khalf = khalf;
     g.touch = 0;  // (unused: the look-ahead is a build-time switch, its requests clamp against the matrix edges)
     // estimated time of one output tile at ~1.35 PFLOP/s chip-wide (5.3 TFLOP/s per CU), in 10-ns ticks; the stagger only
@@ -1147,6 +1153,51 @@ extern "C" int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ld
                            int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, const float* ep0, const float* ep1,
                            int64_t pos_rows, void* stream) {
     return gemm_impl(A, lda, W, ldw, C, ldc, M, N, K, dtype, out_dtype, epilogue, ep0, ep1, pos_rows, 1, 0, stream);
+}
+
+// C_b = A_b W_b^T for b < batch, every matrix of a stack at a constant step from the previous one: one launch of the
+// one-tile-per-workgroup kernel with blockIdx.y = b.  For many SMALL products (the Newton-Schulz iterations of Muon over the
+// twelve same-shape weights of a layer class: 15 output tiles each) the batch fills the chip where a single product needs
+// split-K slabs and a reduction pass to do so.
+extern "C" int swiftk_gemm_batched(const void* A, int64_t lda, int64_t stride_a, const void* W, int64_t ldw, int64_t stride_w, void* C,
+                                   int64_t ldc, int64_t stride_c, int batch, int64_t M, int64_t N, int64_t K, int dtype,
+                                   int out_dtype, void* stream) {
+    if (!A || !W || !C || batch <= 0 || batch > 65535 || M <= 0 || N <= 0 || K <= 0) return SWIFTK_EINVAL;
+    if (dtype != SWIFTK_BF16 || (out_dtype != SWIFTK_BF16 && out_dtype != SWIFTK_F32)) return SWIFTK_EINVAL;
+    const int os = out_dtype == SWIFTK_BF16 ? 2 : 4;
+    if (K % 64 || N % 4 || lda < K || ldw < K || ldc < N) return SWIFTK_ESHAPE;
+    if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SWIFTK_ESHAPE;
+    if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || (lda * 2) % 16 || (ldw * 2) % 16 || (stride_a * 2) % 16 || (stride_w * 2) % 16)
+        return SWIFTK_EALIGN;
+    if (((uintptr_t)C % (4 * os)) || (ldc * os) % (4 * os) || (stride_c * os) % (4 * os)) return SWIFTK_EALIGN;
+    GemmArgs g;
+    g.A = static_cast<const char*>(A);
+    g.W = static_cast<const char*>(W);
+    g.C = static_cast<char*>(C);
+    g.lda_b = lda * 2;
+    g.ldw_b = ldw * 2;
+    g.ldc = ldc;
+    g.M = (int)M;
+    g.N = (int)N;
+    g.K = (int)K;
+    g.ep0 = g.ep1 = nullptr;
+    g.pos_rows = 0;
+    g.ni = 11;
+    g.ntn = (int)((N + BN - 1) / BN);
+    g.dbg = 0;
+    g.khalf = g.touch = g.stagger = 0;
+    g.ksplit = 1;
+    g.c_split = 0;
+    g.batch_a = stride_a * 2;
+    g.batch_w = stride_w * 2;
+    g.batch_c = stride_c * os;
+    g.t_gh = g.t_gw = g.t_sh = g.t_sw = g.t_heads = 0;
+    const dim3 grid((unsigned)(((M + BM - 1) / BM) * g.ntn), (unsigned)batch);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (out_dtype == SWIFTK_BF16) hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t, SWIFTK_EPI_NONE>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<bf16_t, float, SWIFTK_EPI_NONE>), grid, dim3(NT), 0, st, g);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int swiftk_gemm_qkv_tiled(const void* A, int64_t lda, const void* W, int64_t ldw, void* qkv_tiled, int64_t K,

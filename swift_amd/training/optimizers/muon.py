@@ -96,6 +96,46 @@ def zeropower_via_newtonschulz5(G: torch.Tensor, steps: int = 5) -> torch.Tensor
     return X.mT if tall else X
 
 
+def _gemm_stack(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, n: int, k: int) -> torch.Tensor:
+    """out[l][:, :n] = a[l][:, :k] @ w[l][:n, :k]^T for every matrix l of three [L, rows, ld] bf16 stacks: ONE launch
+    (``swiftk_gemm_batched``).  Twelve same-shape products fill the chip by themselves (180 output tiles for the 1056-wide
+    squares), where a single one needs the split-K slabs and the reduction pass of ``_gemm_bf16``."""
+    check(lib().swiftk_gemm_batched(a.data_ptr(), a.stride(1), a.stride(0), w.data_ptr(), w.stride(1), w.stride(0), out.data_ptr(),
+                                    out.stride(1), out.stride(0), a.shape[0], a.shape[1], n, k, ops.dtype_code(_BF),
+                                    ops.dtype_code(_BF), _s()), "swiftk_gemm_batched")
+    return out
+
+
+def zeropower_stack(G: torch.Tensor, steps: int = 5) -> torch.Tensor:
+    """``zeropower_via_newtonschulz5`` for a stack [L, rows, cols] of same-shape matrices at once (the reference's routine
+    takes batches as well, muon.py:13-35): per iteration three batched GEMM launches, L transposes and four element-wise
+    launches for the whole stack instead of that many per matrix.  rows, cols multiples of 4, min(rows, cols) >= 16."""
+    assert G.ndim == 3 and G.is_cuda
+    a, b, c = NS_COEFFS
+    tall = G.shape[1] > G.shape[2]
+    X = G.to(_BF).mT if tall else G.to(_BF)
+    X = X / (X.norm(dim=(-2, -1), keepdim=True) + 1e-7)
+    L, m, n = X.shape
+    assert m % 4 == 0 and n % 4 == 0 and m >= 16
+    km, kn = ops.k_pad(_BF, m), ops.k_pad(_BF, n)
+    dev = G.device
+    Xb = torch.zeros(L, m, kn, dtype=_BF, device=dev)
+    Xb[:, :, :n] = X
+    XT = torch.zeros(L, n, km, dtype=_BF, device=dev)
+    A, A2 = torch.zeros(L, m, km, dtype=_BF, device=dev), torch.zeros(L, m, km, dtype=_BF, device=dev)
+    BX = torch.zeros(L, m, kn, dtype=_BF, device=dev)
+    for _ in range(steps):
+        _gemm_stack(Xb, Xb, A, m, kn)                # A = X X^T
+        _gemm_stack(A, A, A2, m, km)                 # A A   (A symmetric)
+        B = b * A + c * A2
+        for l in range(L):
+            _transpose_into(Xb[l], m, n, XT[l])      # operand form of X for B X
+        _gemm_stack(B, XT, BX, n, km)                # B X
+        Xb = a * Xb + BX
+    X = Xb[:, :, :n]
+    return X.mT if tall else X
+
+
 def muon_update(grad: torch.Tensor, momentum: torch.Tensor, beta: float = 0.95, ns_steps: int = 5, nesterov: bool = True):
     """The Muon direction of one parameter (muon.py:38-45): gradient EMA, Nesterov look-ahead (written into ``grad``, which the
     reference consumes the same way), orthogonalisation of the matrix view, sqrt(max(1, rows / cols)) rescale."""
@@ -160,6 +200,36 @@ class MuonWithAuxAdam(torch.optim.Optimizer):
                 for r in range(min(world, len(params) - base)):
                     dist.broadcast(params[base + r].data, src=r)
 
+    def _muon_group_stacked(self, group) -> None:
+        """One rank, parameters on the GPU: the same update with the same-shape matrices of the group (the twelve layers' w1,
+        w2, to_qkv, wo) walked TOGETHER -- multi-tensor launches for the momentum / Nesterov blend and the parameter update, the
+        stacked orthogonaliser in between.  Issued matrix by matrix the step is ~5,000 launches of 5-25 us (65 ms at Swift-B)."""
+        beta, lr = group["momentum"], group["lr"]
+        decay = 1.0 - lr * group["weight_decay"]
+        classes = {}
+        for p in group["params"]:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            if "momentum_buffer" not in self.state[p]:
+                self.state[p]["momentum_buffer"] = torch.zeros_like(p)
+            classes.setdefault(tuple(p.shape), []).append(p)
+        for shape, ps in classes.items():
+            rows, cols = shape[0], max(1, math.prod(shape[1:])) if len(shape) == 4 else (shape[-1] if len(shape) > 1 else 1)
+            if len(ps) < 2 or len(shape) not in (2, 4) or rows % 4 or cols % 4 or min(rows, cols) < 16:
+                for p in ps:  # lone or degenerate shapes (the [1, heads, 1, 1] logit scales): matrix by matrix
+                    step = muon_update(p.grad, self.state[p]["momentum_buffer"], beta=beta)
+                    p.mul_(decay).add_(step.reshape(p.shape).to(p.dtype), alpha=-lr)
+                continue
+            grads, bufs = [p.grad for p in ps], [self.state[p]["momentum_buffer"] for p in ps]
+            torch._foreach_mul_(bufs, beta)                       # gradient EMA ...
+            torch._foreach_add_(bufs, grads, alpha=1.0 - beta)
+            torch._foreach_mul_(grads, 1.0 - beta)                # ... and the Nesterov look-ahead, written into the gradients
+            torch._foreach_add_(grads, bufs, alpha=beta)
+            ortho = zeropower_stack(torch.stack([g.reshape(rows, cols) for g in grads]))
+            scaled = (ortho * math.sqrt(max(1.0, shape[-2] / shape[-1]))).float()
+            torch._foreach_mul_(ps, decay)
+            torch._foreach_add_(ps, [u.reshape(shape) for u in scaled.unbind(0)], alpha=-lr)
+
     def _adam_group(self, group) -> None:
         decay = 1.0 - group["lr"] * group["weight_decay"]
         for p in group["params"]:
@@ -181,7 +251,9 @@ class MuonWithAuxAdam(torch.optim.Optimizer):
         multi = dist.is_available() and dist.is_initialized()  # (a one-rank group broadcasts to itself: same code path)
         world, rank = (dist.get_world_size(), dist.get_rank()) if multi else (1, 0)
         for group in self.param_groups:
-            if group["use_muon"]:
+            if group["use_muon"] and world == 1 and all(p.is_cuda for p in group["params"]):
+                self._muon_group_stacked(group)  # nothing to exchange: same-shape matrices orthogonalised together
+            elif group["use_muon"]:
                 self._muon_group(group, world, rank, multi)
             else:
                 self._adam_group(group)

@@ -585,6 +585,45 @@ def test_muon_with_aux_adam_vs_reference_golden(dev):
     assert e < 3e-2 and float(sv.max()) < 1.7 and float((sv > 0.5).double().mean()) > 0.8  # most of the spectrum pushed to ~1
 
 
+def test_muon_stacked_step_vs_matrix_by_matrix(dev):
+    """One rank: MuonWithAuxAdam orthogonalises the same-shape matrices of a group TOGETHER (swiftk_gemm_batched, multi-tensor
+    momentum / update launches).  Against the matrix-by-matrix update on a copy: the same step up to bf16 noise through the five
+    quintic iterations (a different GEMM kernel sums in a different order), and the batched GEMM itself against fp64."""
+    from swift_amd import _lib
+    from swift_amd.training.optimizers import muon as pm
+    L = _lib.lib()
+    a = (rnd((3, 320, 192), 90) * 0.3).to(dev).to(BF)
+    w = (rnd((3, 96, 192), 91) * 0.3).to(dev).to(BF)
+    out = torch.zeros(3, 320, 104, dtype=BF, device=dev)
+    assert L.swiftk_gemm_batched(a.data_ptr(), 192, 320 * 192, w.data_ptr(), 192, 96 * 192, out.data_ptr(), 104, 320 * 104, 3, 320, 96,
+                                 192, _lib.BF16, _lib.BF16, s()) == 0
+    ref = torch.einsum("lmk,lnk->lmn", a.double().cpu(), w.double().cpu())
+    assert rel_l2(out[:, :, :96].double().cpu(), ref) < 4e-3 and float(out[:, :, 96:].float().abs().max()) == 0.0
+    # (128, 1024): the matrix-by-matrix path sums such a contraction over split-K slabs, the stacked one in a single k-loop;
+    # the small ones take the same arithmetic order in both (bit-equal)
+    shapes = [(64, 160)] * 3 + [(128, 1024)] * 2 + [(96, 32)] * 2 + [(1, 12, 1, 1), (48, 48)]
+
+    def make():
+        ps = [torch.nn.Parameter((rnd(sh, 80 + i) * 0.05).to(dev)) for i, sh in enumerate(shapes)]
+        return ps, pm.MuonWithAuxAdam([dict(params=ps, use_muon=True, lr=0.02, weight_decay=0.01)])
+
+    def run(stacked):
+        ps, opt = make()
+        if not stacked:
+            opt._muon_group_stacked = lambda group: opt._muon_group(group, 1, 0, False)
+        for st in range(3):
+            for i, q in enumerate(ps):
+                q.grad = rnd(q.shape, 900 + 10 * st + i).to(dev)
+            before = [q.detach().clone() for q in ps]
+            opt.step()
+        return [q.detach() - b for q, b in zip(ps, before)]  # the third step taken
+
+    for i, (u, v) in enumerate(zip(run(True), run(False))):
+        e = rel_l2(u.float().cpu(), v.float().cpu())
+        print(f"param {i} {tuple(u.shape)}: stacked vs matrix-by-matrix step rel-L2 {e:.2e}")
+        assert e < 5e-2
+
+
 def test_trainer_trajectory_vs_oracle_net_and_oracle_trainer(dev, tmp_path, monkeypatch):
     """Three optimisation steps of ``Trainer.train_step`` (multistep-CRPS loss, bf16 autocast, fused AdamW + EMA kernel,
     LR warm-up then cosine) against the CPU oracle, step by step:
