@@ -93,7 +93,10 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
     """generate.py:48-154 with (member, IC) units instead of members as the sharded work item."""
     dump = getattr(args, "dump", "numpy")
     if dump == "numpy":
-        store = np.lib.format.open_memmap(ofile, mode="r+")
+        store = np.lib.format.open_memmap(ofile, mode="r+")  # shape / data offset of the .npy the launcher created
+        store_fd = os.open(ofile, os.O_WRONLY)
+        store_off, store_shape = int(store.offset), tuple(store.shape)   # [samples, members, steps + 1, nv, H, W] float32
+        del store
     else:
         from .utils import zarrlite
         var_channels = zarrlite.variable_channels(list(dataset.variables))
@@ -120,6 +123,12 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
     copy_stream = torch.cuda.Stream(device=device) if on_gpu else None
     pinned = [None, None]
     pending = None  # (copy-done event, pinned buffer view, units)
+    # GPU path: the output leaves STEP BY STEP -- as soon as a lead step of the batch is enqueued its [B, nv, H, W] slab is copied
+    # on the side stream into one of RING pinned slabs (RING x 0.87 GB at 96 units, instead of two whole pinned trajectories:
+    # 2 x 52 GB for 60 steps) and written from there while the following steps compute; at the end of a batch only its last
+    # slabs are still on their way, so a job of ONE batch (12 members x 8 ICs on a GPU) overlaps its output as well
+    RING = 4
+    ring, ring_busy, ring_pos = [None], [None] * RING, [0]
 
     t_host = [0.0, 0.0]  # seconds in input staging / output writes (host side)
 
@@ -130,14 +139,62 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
         t1 = time.time()
         h = host.numpy()
         if dump == "numpy":
-            for k, (m, ic) in enumerate(us):    # buffer is step-major [steps+1, B, ...]
-                store[ic, m] = h[:, k]
+            # buffer is step-major [steps+1, B, ...]: every (step, unit) slab is contiguous on both sides, so the store is filled
+            # by positional writes from the loader threads (pwrite releases the GIL; assigning into a memory map of the file
+            # page-faults its way through fresh pages at ~3 GB/s however many threads share the mapping -- less than one GPU
+            # produces: 330 sample-steps/s x 9 MB)
+            slab = int(np.prod(store_shape[3:])) * 4
+            per_unit = store_shape[2] * slab
+
+            def put(kmi):
+                k, (m, ic) = kmi
+                base = store_off + (ic * store_shape[1] + m) * per_unit
+                for i in range(h.shape[0]):
+                    os.pwrite(store_fd, memoryview(h[i, k]).cast("B"), base + i * slab)
+
+            list(loaders.map(put, enumerate(us)))
         else:  # one chunk file per unit and variable: independent files, written by a few threads
             list(loaders.map(lambda kmi: zarrlite.write_unit(ofile, var_channels, kmi[1][1], kmi[1][0], h[:, kmi[0]]),
                              enumerate(us)))
-        if dump == "numpy":
-            store.flush()
         t_host[1] += time.time() - t1
+
+    def flush_step(ev, host, us, j):
+        ev.synchronize()
+        t1 = time.time()
+        h = host.numpy()  # [B, nv, H, W] of lead step j
+        if dump == "numpy":
+            slab = int(np.prod(store_shape[3:])) * 4
+            per_unit = store_shape[2] * slab
+            list(loaders.map(lambda kmi: os.pwrite(store_fd, memoryview(h[kmi[0]]).cast("B"),
+                                                   store_off + (kmi[1][1] * store_shape[1] + kmi[1][0]) * per_unit + j * slab),
+                             enumerate(us)))
+        else:
+            list(loaders.map(lambda kmi: zarrlite.write_unit_step(ofile, var_channels, kmi[1][1], kmi[1][0], j, h[kmi[0]]),
+                             enumerate(us)))
+        t_host[1] += time.time() - t1
+
+    def stream_out(us):
+        """after_step hook of RolloutEngine.run for one batch."""
+        def hook(j, slab_dev):
+            B_ = slab_dev.shape[0]
+            if ring[0] is None or ring[0].shape[1] < B_:
+                for f in ring_busy:
+                    if f is not None:
+                        f.result()
+                ring[0] = torch.empty(RING, B_, *slab_dev.shape[1:], dtype=torch.float32, pin_memory=True)
+            slot = ring_pos[0] % RING
+            ring_pos[0] += 1
+            if ring_busy[slot] is not None:
+                ring_busy[slot].result()  # the writer is done with this slab (back-pressure when the store is slower than the GPU)
+            host = ring[0][slot, :B_]
+            ready, ev = torch.cuda.Event(), torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                host.copy_(slab_dev, non_blocking=True)
+                ev.record(copy_stream)
+            ring_busy[slot] = writer.submit(flush_step, ev, host, us, j)
+        return hook
 
     def stage(s):
         """Host-side inputs of the batch starting at unit s (pinned tensors; runs on the reader thread, one batch ahead)."""
@@ -180,10 +237,16 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
         units, X0, forc, truth = nxt.result()
         nxt = reader.submit(stage, starts[bi + 1]) if bi + 1 < len(starts) else None
         X0, forc = X0.to(device, non_blocking=True), forc.to(device, non_blocking=True)
-        traj = engine.run(X0, forc, steps, seeds=[unit_seed(m, indices[ic]) for m, ic in units])  # [B, steps+1, ...] view
+        traj = engine.run(X0, forc, steps, seeds=[unit_seed(m, indices[ic]) for m, ic in units],  # [B, steps+1, ...] view
+                          **({"after_step": stream_out(units)} if on_gpu else {}))
         dev_buf = traj.transpose(0, 1)      # the contiguous step-major buffer behind it
         if want_metrics:
             batch_metrics(units, dev_buf, truth)
+        if on_gpu:
+            dev_buf.record_stream(copy_stream)  # its last slabs may still be on their way to the host
+            done += len(units)
+            dist.log0(f"rank 0: {done}/{len(mine)} units")
+            continue
         if on_gpu:
             ready = torch.cuda.Event()
             ready.record()
@@ -208,9 +271,14 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
         dist.log0(f"rank 0: {done}/{len(mine)} units")
     if pending is not None:
         pending.result()
+    for f in ring_busy:
+        if f is not None:
+            f.result()
     writer.shutdown()
     reader.shutdown()
     loaders.shutdown()
+    if dump == "numpy":
+        os.close(store_fd)
     dist.log0(f"host side: {t_host[0]:.2f} s staging inputs, {t_host[1]:.2f} s writing outputs")
     if want_metrics:
         return collect_metrics(metric_sums, n_ic, steps, nv, members, dataset, interval, device, os.path.dirname(ofile))

@@ -90,13 +90,15 @@ class RolloutEngine:
     @torch.no_grad()
     def run(self, X0: torch.Tensor, forcings: torch.Tensor, steps: int, *, seeds: Optional[Sequence[int]] = None,
             latents: Optional[Callable[[int], torch.Tensor]] = None, out: Optional[torch.Tensor] = None,
-            keep_trajectory: bool = True) -> torch.Tensor:
+            keep_trajectory: bool = True, after_step: Optional[Callable[[int, torch.Tensor], None]] = None) -> torch.Tensor:
         """Roll ``steps`` lead steps from the standardised state X0 [B, n_vars, H, W] (device, fp32).
 
         ``forcings`` [steps, B, n_forc, H, W] standardised, on the device.  ``latents(i)`` overrides the
         noise of step i (tests); otherwise unit b draws from ``torch.Generator`` seeded ``seeds[b]``.
         Returns the physical trajectory as a [B, steps+1, n_vars, H, W] view of a step-major buffer
         ``out`` [steps+1, B, ...] (or the final physical state if ``keep_trajectory`` is False).
+        ``after_step(j, out[j])`` is called on the host as soon as lead step j (0 = the initial state) has been ENQUEUED:
+        the caller may queue a device-to-host copy of that slab behind it (output streaming, generate.py:129).
         """
         dev = X0.device
         B, nv, H, W = X0.shape
@@ -106,6 +108,8 @@ class RolloutEngine:
             if out is None:  # step-major so that every lead step is one contiguous [B, C, H, W] block
                 out = torch.empty(steps + 1, B, nv, H, W, dtype=torch.float32, device=dev)
             out[0] = self.dataset.unstandardize_x(X.clone())
+            if after_step is not None:
+                after_step(0, out[0])
         gens = None
         if latents is None:
             seeds = list(seeds) if seeds is not None else list(range(B))
@@ -120,4 +124,6 @@ class RolloutEngine:
                     z[b].normal_(generator=g)
             Y = self.sampler((X, forcings[i]), latents=z)
             ops.rollout_update(X, Y, mx, sx, st, phys=out[i + 1] if keep_trajectory else phys)
+            if keep_trajectory and after_step is not None:
+                after_step(i + 1, out[i + 1])
         return out.transpose(0, 1) if keep_trajectory else phys

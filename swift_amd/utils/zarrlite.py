@@ -155,6 +155,21 @@ def write_unit(ofile: str, var_channels: Dict[str, List[int]], sample: int, memb
             write_chunk(ofile, var, (sample, member, 0, 0, 0, 0), traj[None, None][:, :, :, ch])
 
 
+def write_unit_step(ofile: str, var_channels: Dict[str, List[int]], sample: int, member: int, step: int, fields: np.ndarray) -> None:
+    """Lead step ``step`` of one (sample, member) unit, ``fields [C, H, W]``: written in place into the unit's chunk files
+    (chunk batch 1, uncompressed: a chunk file is the raw ``[steps+1, (levels,) H, W]`` block, so a step is one contiguous
+    range of it).  A chunk becomes complete when its last step has been written; ``write_unit`` is the all-at-once form."""
+    for var, ch in var_channels.items():
+        chunks, dt = _chunk_meta(ofile, var)
+        data = np.ascontiguousarray(fields[ch[0]] if len(chunks) == 5 else fields[ch], dtype=dt)
+        name = ".".join(str(int(i)) for i in ((sample, member) + (0,) * (len(chunks) - 2)))
+        fd = os.open(os.path.join(ofile, var, name), os.O_WRONLY | os.O_CREAT, 0o644)
+        try:
+            os.pwrite(fd, memoryview(data).cast("B"), int(step) * data.nbytes)
+        finally:
+            os.close(fd)
+
+
 def _has_level(ofile: str, var: str) -> bool:
     return len(_chunk_meta(ofile, var)[0]) == 6
 
