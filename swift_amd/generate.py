@@ -204,17 +204,24 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
         state = getattr(dataset, "get_state", None)  # one read per IC; dataset[j] would also read j's training target
         x0 = {int(j): (dataset.standardize_x(state(int(j))) if state else dataset[int(j)][0][0][:nv]) for j in set(ics)}
         X0 = torch.stack([x0[int(j)] for j in ics], 0)
-        forc = engine.stage_forcings(ics, steps, "cpu")
+        # GPU path: forcings are staged step by step behind the rollout's back (the first batch starts after step 0's slab, not
+        # after all `steps` of them); the CPU stand-in of the host-logic tests takes the whole tensor
+        forc = engine.stage_forcings_lazily(ics, steps, device, stagers) if on_gpu else engine.stage_forcings(ics, steps, "cpu")
         truth = None
         if want_metrics:  # verifying fields of every lead step, physical units, one copy per IC of the batch
             uniq = sorted(set(ic for _, ic in units))
             get = state if state else (lambda j: dataset.unstandardize_x(dataset[j][0][0][:nv]))
             jobs = [int(indices[ic]) + (i + 1) * interval // 6 for ic in uniq for i in range(steps)]
-            fields = list(loaders.map(get, jobs))  # file reads / field synthesis in parallel (numpy and h5 release the GIL)
-            truth = torch.stack(fields, 0).view(len(uniq), steps, *fields[0].shape)
+
+            def load_truth():  # file reads / field synthesis in parallel (numpy and h5 release the GIL)
+                fields = list(loaders.map(get, jobs))
+                tt = torch.stack(fields, 0).view(len(uniq), steps, *fields[0].shape)
+                return tt.pin_memory() if on_gpu else tt
+
+            # needed only once the batch has been rolled out: on the GPU path it loads while the rollout runs
+            truth = stagers.submit(load_truth) if on_gpu else load_truth()
         if on_gpu:
-            X0, forc = X0.pin_memory(), forc.pin_memory()
-            truth = None if truth is None else truth.pin_memory()
+            X0 = X0.pin_memory()
         t_host[0] += time.time() - t1
         return units, X0, forc, truth
 
@@ -223,6 +230,8 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
         from .eval.metrics import ensemble_sums
         lat = dataset.get_lat_lon()[0]
         uniq = sorted(set(ic for _, ic in units))
+        if hasattr(truth, "result"):
+            truth = truth.result()
         for k, ic in enumerate(uniq):
             slots = [b for b, (_, i) in enumerate(units) if i == ic]
             assert len(slots) == members and slots == list(range(slots[0], slots[0] + members))
@@ -231,12 +240,15 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
 
     reader = ThreadPoolExecutor(max_workers=1)
     loaders = ThreadPoolExecutor(max_workers=8)
+    stagers = ThreadPoolExecutor(max_workers=4)  # forcing slabs, step by step (their own pool: output writes must not queue behind them)
     starts = list(range(mine.start, mine.stop, batch))
     nxt = reader.submit(stage, starts[0]) if starts else None
     for bi, s in enumerate(starts):
         units, X0, forc, truth = nxt.result()
         nxt = reader.submit(stage, starts[bi + 1]) if bi + 1 < len(starts) else None
-        X0, forc = X0.to(device, non_blocking=True), forc.to(device, non_blocking=True)
+        X0 = X0.to(device, non_blocking=True)
+        if not on_gpu:
+            forc = forc.to(device, non_blocking=True)
         traj = engine.run(X0, forc, steps, seeds=[unit_seed(m, indices[ic]) for m, ic in units],  # [B, steps+1, ...] view
                           **({"after_step": stream_out(units)} if on_gpu else {}))
         dev_buf = traj.transpose(0, 1)      # the contiguous step-major buffer behind it
@@ -277,6 +289,7 @@ def rollout_and_save(engine: RolloutEngine, dataset, indices, members: int, step
     writer.shutdown()
     reader.shutdown()
     loaders.shutdown()
+    stagers.shutdown()
     if dump == "numpy":
         os.close(store_fd)
     dist.log0(f"host side: {t_host[0]:.2f} s staging inputs, {t_host[1]:.2f} s writing outputs")

@@ -30,6 +30,29 @@ def unit_seed(member: int, ic: int) -> int:
     return (int(member) * 1_000_003 + int(ic) * 7919 + 12345) & 0x7FFFFFFF
 
 
+class LazyForcings:
+    """Indexable like the [steps, B, n_forc, H, W] tensor of ``RolloutEngine.stage_forcings``; slab i is staged by a pool
+    thread (pinned when the target is a GPU) and copied to the device when it is asked for."""
+
+    def __init__(self, engine, ic_indices, steps: int, device, pool):
+        self.engine, self.steps, self.device = engine, int(steps), torch.device(device)
+        self.uniq = sorted(set(int(j) for j in ic_indices))  # members of one IC share its forcings: read each file once
+        self.pos = torch.tensor([self.uniq.index(int(j)) for j in ic_indices])
+        self.futs = [pool.submit(self._stage, i) for i in range(self.steps)]  # in step order: slab 0 comes first
+
+    def _stage(self, i: int) -> torch.Tensor:
+        eng = self.engine
+        f = torch.stack([eng.dataset.get_forcings(j + int(i * eng.interval // 6)) for j in self.uniq], 0)
+        f = eng.dataset.standardize_x(f)[self.pos].contiguous()
+        return f.pin_memory() if self.device.type == "cuda" else f
+
+    def __len__(self) -> int:
+        return self.steps
+
+    def __getitem__(self, i: int) -> torch.Tensor:
+        return self.futs[i].result().to(self.device, non_blocking=True)
+
+
 class RolloutEngine:
     def __init__(self, net, dataset, interval: int = 6, solver: str = "scm", denoise_dtype: torch.dtype = torch.float32,
                  **solver_kwargs):
@@ -63,6 +86,12 @@ class RolloutEngine:
             f = torch.stack([self.dataset.get_forcings(j + int(i * self.interval // 6)) for j in uniq], 0)
             rows.append(self.dataset.standardize_x(f))
         return torch.stack(rows, 0)[:, pos].contiguous().to(device, non_blocking=True)
+
+    def stage_forcings_lazily(self, ic_indices: Sequence[int], steps: int, device, pool) -> "LazyForcings":
+        """The same slabs as ``stage_forcings``, produced step by step on ``pool`` (a thread pool) and handed over one lead step
+        at a time: ``run`` indexes ``forcings[i]`` when it reaches step i, so a rollout starts as soon as step 0's forcings are
+        staged instead of after all ``steps`` of them (60 file reads per IC for the 15-day job)."""
+        return LazyForcings(self, ic_indices, steps, device, pool)
 
     @torch.no_grad()
     def capture_step(self, X: torch.Tensor, forc: torch.Tensor, z: torch.Tensor, phys: torch.Tensor) -> "torch.cuda.CUDAGraph":
