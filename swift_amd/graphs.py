@@ -46,7 +46,11 @@ def capture(graph: "torch.cuda.CUDAGraph", pool=None):
     was_on = gc.isenabled()
     gc.disable()
     try:
-        with torch.cuda.graph(graph, pool=pool):
+        # thread_local: only THIS thread's calls are policed during the capture.  The default ("global") also invalidates it
+        # when any other thread touches the runtime -- the DataLoader's pin-memory thread allocating a pinned batch, the
+        # writer / reader threads of `generate` -- which is what a real training run does all the time
+        # (hipErrorStreamCaptureInvalidated in the first captured pass of `python -m swift_amd.train` at Swift-B).
+        with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
             yield
     finally:
         if was_on:

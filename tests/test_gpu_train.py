@@ -585,6 +585,41 @@ def test_muon_with_aux_adam_vs_reference_golden(dev):
     assert e < 3e-2 and float(sv.max()) < 1.7 and float((sv > 0.5).double().mean()) > 0.8  # most of the spectrum pushed to ~1
 
 
+def test_graph_capture_survives_other_threads_using_the_runtime(dev):
+    """A real training run captures its launch sequences while the DataLoader's pin-memory thread allocates pinned batches and
+    copies them to the device; under torch's default capture mode ("global") such a call from ANOTHER thread invalidates the
+    capture (hipErrorStreamCaptureInvalidated in the first captured pass of `python -m swift_amd.train` at Swift-B).
+    ``graphs.capture`` polices the capturing thread only."""
+    import threading
+    from swift_amd import graphs, ops
+    stop = threading.Event()
+    seen = []
+
+    def pinner():  # what torch.utils.data's pin_memory thread does, as fast as it can
+        side = torch.cuda.Stream(device=dev)
+        while not stop.is_set():
+            h = torch.empty(1 << 18).pin_memory()
+            with torch.cuda.stream(side):
+                seen.append(h.to(dev, non_blocking=True).sum())
+            side.synchronize()
+            del seen[:-4]
+
+    th = threading.Thread(target=pinner, daemon=True)
+    th.start()
+    try:
+        a, w = rnd((512, 1088), 3).to(dev).to(BF), rnd((352, 1088), 4).to(dev).to(BF)
+        for rep in range(12):
+            cache = graphs.GraphCache()
+            fn = lambda x: (ops.gemm(x, w) * 2.0,)
+            ref = fn(a)[0].clone()
+            for _ in range(3):  # eager, capture + replay, replay
+                out = cache.call(("k", rep), fn, [a])[0]
+            assert cache._graphs and torch.equal(out, ref)
+    finally:
+        stop.set()
+        th.join(timeout=20)
+
+
 def test_muon_stacked_step_vs_matrix_by_matrix(dev):
     """One rank: MuonWithAuxAdam orthogonalises the same-shape matrices of a group TOGETHER (swiftk_gemm_batched, multi-tensor
     momentum / update launches).  Against the matrix-by-matrix update on a copy: the same step up to bf16 noise through the five
