@@ -209,6 +209,8 @@ def _yaml_load(text):
 def _parse_value(s: str):
     if len(s) > 1 and s.isdigit() and s[0] == "0":  # run ids like 000 / 001 stay strings (resume=000)
         return s
+    if re.fullmatch(r"\d{8}_\d{6}", s):  # a run directory named by its start time (HYDRA_RUN_ID unset); YAML would read an integer
+        return s
     try:
         return _yaml_load(s)
     except yaml.YAMLError:

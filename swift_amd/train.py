@@ -34,7 +34,7 @@ def resume_setup(cfg: Cfg):
     if cfg.get("resume") is None:
         return cfg, None
     finetune = cfg.get("finetune")
-    run_dir = cfg.resume
+    run_dir = str(cfg.resume)  # (a bare number would be taken for a file descriptor by os.path.isdir)
     if not os.path.isdir(run_dir):
         run_dir = os.path.join(os.path.dirname(os.getcwd()), str(cfg.resume))
     assert os.path.isdir(run_dir), FileNotFoundError(f"{run_dir} is not a directory")

@@ -329,6 +329,8 @@ def test_finetune_keeps_its_own_optimizer_and_cli_floats():
     c = compose(CFG, "train", ["optimizer=adamw", "optimizer.lr=1e-4", "trainer.lr_min_factor=3E-4", "resume=007", "seed=12"])
     assert c.optimizer.lr == 1e-4 and isinstance(c.optimizer.lr, float) and c.trainer.lr_min_factor == 3e-4
     assert c.resume == "007" and c.seed == 12
+    # a run directory named by its start time (HYDRA_RUN_ID unset) is a run id too, not the integer YAML 1.1 reads into it
+    assert compose(CFG, "train", ["resume=20261003_180414"]).resume == "20261003_180414"
 
 
 def test_distill_sets_scm_distillation_flag():
