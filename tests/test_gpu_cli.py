@@ -198,3 +198,47 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert d2["checksum"]["last_step_first_units"] == d1["checksum"]["last_step_first_units"]
     assert d2["checksum"]["last_step_all_units_sum"] != d1["checksum"]["last_step_all_units_sum"]
     assert d2["value"] == pytest.approx(2 * 4 * 3 / (d2["ms_per_step"] * 3 / 1e3), rel=1e-3)
+
+
+@pytest.mark.timeout(900)
+def test_train_and_generate_cli_at_swiftb_size_with_loader_workers(tmp_path):
+    """The entry points as a user runs them -- full Swift-B, the data config's own loader workers and pin-memory thread, run
+    directory named by its start time -- for a few dozen iterations.  The small CLI tests above run with `data.data_workers=0`;
+    only at this size and with the loader threads alive did two faults show: the first captured launch sequence invalidated by
+    the pin-memory thread (graphs.capture), and `resume=<start-time id>` read as an integer (config._parse_value)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    big = ["data=era5-synthetic-1.4", "data.batch_size=8", "data.dataset.length=64", "trainer.total_kimg=0.16",
+           "trainer.kimg_per_tick=0.08", "trainer.val_ticks=null", "trainer.checkpoint_ticks=1", "trainer.lr_rampup_kimg=0"]
+    e = {k: v for k, v in os.environ.items() if k != "HYDRA_RUN_ID"}
+    e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
+    p = subprocess.run([sys.executable, "-m", "swift_amd.train", "experiment=era5-swinv2-1.4-scm"] + big, cwd=str(tmp_path), env=e,
+                       capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    runs = sorted(os.listdir(tmp_path / "results" / "era5-swinv2-1.4-scm"))
+    assert len(runs) == 1 and len(runs[0]) == 15 and runs[0][8] == "_", runs  # YYYYMMDD_HHMMSS
+    rdir = tmp_path / "results" / "era5-swinv2-1.4-scm" / runs[0]
+    lines = [yaml.safe_load(l) for l in open(rdir / "stats.jsonl")]
+    assert len(lines) >= 2 and all(np.isfinite(l["train/loss"]) for l in lines)
+    per_iter = lines[-1]["train/dt/kimg"] * 8 / 1000.0
+    print(f"sCM + MuonWithAuxAdam through the CLI, Swift-B, local batch 8: {per_iter:.3f} s per iteration")
+    assert per_iter < 0.5  # (0.16-0.19 s measured; tools/train_bench.py without a loader: 0.155)
+    assert sorted(os.listdir(rdir / "checkpoints"))
+    # multistep-CRPS finetune resumed from the start-time id, two iterations
+    e2 = dict(e, HYDRA_RUN_ID="ft")
+    p = subprocess.run([sys.executable, "-m", "swift_amd.train", "experiment=era5-swinv2-1.4-scm", f"resume={runs[0]}", "finetune=multistep",
+                        "finetune.finetune.intervals=[{steps: 4, kimg: 0.016}]", "data=era5-synthetic-1.4", "data.batch_size=8",
+                        "data.dataset.length=64", "trainer.kimg_per_tick=0.008", "trainer.val_ticks=null",
+                        "trainer.checkpoint_ticks=null"], cwd=str(tmp_path), env=e2, capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    cfg2 = yaml.safe_load(open(tmp_path / "results" / "era5-swinv2-1.4-scm" / "ft" / ".hydra" / "config.yaml"))
+    assert cfg2["loss"]["_target_"].endswith("CRPSLoss")
+    # the 15-day job's per-GPU share, shortened: 12 members x 2 ICs x 6 steps from the run's checkpoint, zarr + metrics
+    e3 = dict(e)
+    p = subprocess.run([sys.executable, "-m", "swift_amd.generate", "--input", str(rdir), "--members", "12", "--steps", "6", "--samples",
+                        "2", "--batch", "12", "--dtype", "bf16", "--metrics"], cwd=str(tmp_path), env=e3, capture_output=True, text=True,
+                       timeout=800)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    outs = os.listdir(rdir / "output" / sorted(os.listdir(rdir / "output"))[0])
+    assert "evaluation_metrics.json" in outs and any(o.endswith(".zarr") for o in outs)
