@@ -434,8 +434,9 @@ def training_leg():
     torch.cuda.empty_cache()
     out = {}
     tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "train_bench.py")
-    for name, args in (("crps_finetune_steps4", ["--loss", "crps", "--iters", "3"]), ("scm_pretrain", ["--loss", "scm", "--iters", "3"]),
-                       ("scm_pretrain_muon", ["--loss", "scm", "--opt", "muon", "--iters", "3"])):  # the experiment's own optimiser
+    # (six timed iterations each: with three, the first replays after the capture weighed 0.75-0.92 s on the CRPS figure)
+    for name, args in (("crps_finetune_steps4", ["--loss", "crps", "--iters", "6"]), ("scm_pretrain", ["--loss", "scm", "--iters", "6"]),
+                       ("scm_pretrain_muon", ["--loss", "scm", "--opt", "muon", "--iters", "6"])):  # the experiment's own optimiser
         try:
             p = subprocess.run([sys.executable, tool] + args, capture_output=True, text=True, timeout=600)
             rec = json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{")))
