@@ -62,10 +62,12 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None,
                     help="(member, IC) units per GPU per step (default 96 = configs[3]'s per-GPU share; 24 in --rollout mode)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"],
+                    help="bf16 = BASELINE configs[1]'s dtype (default); f32 = exact-fp32 engine; bf16x3 = fp32-grade split-bf16 engine")
     ap.add_argument("--cpu-steps", type=int, default=3, help="samples of the CPU baseline, median reported (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip parity_engine / bf16_vs_fp32 / cpu_baseline legs")
-    ap.add_argument("--graph", action="store_true", help="replay the step as one HIP graph (pays off below ~8 units per step)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the WHOLE step (noise draw included) as one HIP graph (pays off below ~8 units per step)")
     ap.add_argument("--solver", default="scm", choices=["scm", "2s", "dpm"],
                     help="scm = BASELINE configs[1] (default, the metric's workload); 2s / dpm = configs[2], multi-step ODE sampler")
     ap.add_argument("--num-steps", type=int, default=None, help="solver steps (default: 1 for scm, 20 for 2s, 8 for dpm)")
@@ -168,18 +170,20 @@ def cpu_baseline(state, samples: int):
                        f"{med:.2f} s per sample-step (all: {', '.join(f'{t:.2f}' for t in ts)})")
 
 
-def unit_inputs(units, dev):
-    """Initial standardised states [B, 69, H, W] and one forcing slab [B, 3, H, W]; keyed by the unit's IC, so the members of
-    an IC share them (as they share the dataset's files) and a unit's inputs do not depend on the rank that holds it."""
+def unit_inputs(units, dev, slabs: int = 1):
+    """Initial standardised states [B, 69, H, W] and the pre-staged forcings [slabs, B, 3, H, W] (one slab
+    per lead step, resident before the timed region); keyed by the unit's IC, so the members of an IC share them (as they
+    share the dataset's files) and a unit's inputs do not depend on the rank that holds it."""
     import torch
     X = torch.empty(len(units), NV, *IMG, device=dev)
-    F = torch.empty(len(units), NF, *IMG, device=dev)
+    F = torch.empty(slabs, len(units), NF, *IMG, device=dev)
     cache = {}
     for b, (ic, _m) in enumerate(units):
         if ic not in cache:
             g = torch.Generator(device=dev).manual_seed(1234 + ic)
-            cache[ic] = (torch.randn(NV, *IMG, generator=g, device=dev), torch.randn(NF, *IMG, generator=g, device=dev))
-        X[b], F[b] = cache[ic]
+            cache[ic] = (torch.randn(NV, *IMG, generator=g, device=dev), torch.randn(slabs, NF, *IMG, generator=g, device=dev))
+        X[b] = cache[ic][0]
+        F[:, b] = cache[ic][1]
     return X, F
 
 
@@ -199,6 +203,13 @@ def main():
     # checksum all-gather, barriers, the max-over-ranks of the timing) through a one-rank RCCL communicator instead of
     # skipping them.  SWIFTK_SINGLE_RANK_GROUP=0 turns that off; an RCCL that cannot initialise is recorded, not fatal, at N = 1.
     rccl_error = None
+    rccl_log = None
+    if sdist.get_world_size() > 1 or os.environ.get("SWIFTK_RCCL_LOG"):
+        # the first time N > 1 ranks meet, the record should show what RCCL built (ranks, channels, ring / tree orders)
+        rccl_log = f"/tmp/swiftk_rccl.{os.getpid()}"
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log + ".%h.%p.log")
     try:
         rank = sdist.setup_torch(single_rank_group=os.environ.get("SWIFTK_SINGLE_RANK_GROUP", "1") != "0")
     except Exception as e:  # noqa: BLE001
@@ -217,7 +228,7 @@ def main():
     lib = _lib.lib()
     for kv in filter(None, os.environ.get("SWIFTK_TUNE", "").split(",")):  # kernel A/B knobs, e.g. "3:8" (swiftk_set_tuning)
         lib.swiftk_set_tuning(*(int(x) for x in kv.split(":")))
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "bf16x3": "bf16x3"}[a.dtype]
     B, K, W = a.batch, a.steps, a.warmup
 
     net, state = build_net(dev, rank, grouped)
@@ -231,6 +242,8 @@ def main():
             "collectives": "weight broadcast, per-step all-gather of per-unit fp64 checksums, barriers, all-reduce(MAX) of the timing" if grouped else None}
     if rccl_error:
         rccl["error"] = rccl_error
+    if rccl_log and rank == 0:
+        rccl["topology_log"] = rccl_topology(rccl_log + ".*.log")
 
     def sync():
         torch.cuda.synchronize()
@@ -249,10 +262,14 @@ def main():
 
     # this rank's units: a contiguous block of the flattened IC-major (IC, member) space
     units = [(u // MEMBERS, u % MEMBERS) for u in range(rank * B, rank * B + B)]
-    X, forc = unit_inputs(units, dev)
+    n_slabs = W + K + 2  # one forcing slab per lead step of the run (warm-up, timed steps, the attention leg's two)
+    X, forc_all = unit_inputs(units, dev, n_slabs)
+    forc = forc_all[0].clone()  # the first slab, for the legs that roll a few units out on their own
     X0 = X.clone()
     mx, sx, st = eng.stats(dev)
-    gens = [torch.Generator(device=dev).manual_seed(unit_seed(m, ic)) for ic, m in units]
+    # latent noise: ONE launch per step for the whole batch, keyed by (unit seed, lead step, element) -- swiftk_unit_noise
+    seeds = torch.tensor([unit_seed(m, ic) for ic, m in units], dtype=torch.int64, device=dev)
+    lead = torch.zeros(1, dtype=torch.int64, device=dev)  # device-side lead-step counter (what a captured step reads)
     phys = torch.empty_like(X)
     z = torch.empty_like(X)
     ck = torch.zeros(B, dtype=torch.float64, device=dev)
@@ -271,18 +288,19 @@ def main():
         step_no[0] += 1
 
     def step():
-        for b, gg in enumerate(gens):
-            z[b].normal_(generator=gg)
-        Y = eng.sampler((X, forc), latents=z)
+        i = step_no[0]
+        ops.unit_noise(z, seeds, 0, step_dev=lead)
+        ops.counter_add(lead, 1)
+        Y = eng.sampler((X, forc_all[i % n_slabs]), latents=z)
         ops.rollout_update(X, Y, mx, sx, st, phys=phys)
         collect()
 
-    if a.graph:  # noise stays outside the graph (per-unit generators); everything else of the step is one replay
-        graph = eng.capture_step(X, forc, z, phys)
+    if a.graph:  # the whole step is one replay: noise draw (device-side lead-step counter), network, state update
+        fslab = forc_all[0].clone()  # static address inside the graph; the step's slab is copied in before the replay
+        graph = eng.capture_step(X, fslab, z, phys, seeds=seeds, step=lead)
 
         def step():  # noqa: F811
-            for b, gg in enumerate(gens):
-                z[b].normal_(generator=gg)
+            fslab.copy_(forc_all[step_no[0] % n_slabs])
             graph.replay()
             collect()
 
@@ -334,7 +352,7 @@ def main():
         M = B * 64 * 128
         flop_launch = 2.0 * M * mlp2 * 1056  # algorithmic: K = 1056, not the padded 1088
         avg_s = (tot_ms.value / max(n_launch.value, 1)) * 1e-3
-        peak = PEAK_BF16 if a.dtype == "bf16" else PEAK_F32
+        peak = PEAK_BF16 if a.dtype == "bf16" else PEAK_F32  # (bf16x3 is priced against the fp32 matrix peak it stands in for)
         ach = flop_launch / avg_s if avg_s > 0 else 0.0
         line = {
             "metric": "6h forecast steps/sec (members x ICs) on 128x256x69 ERA5",
@@ -355,6 +373,8 @@ def main():
                        f"Swift-B {a.solver} sampler, num_steps {nsteps} = {evals} network evaluations per sample-step, 128x256x69 "
                        "(BASELINE configs[2])", "units_per_gpu_per_step": B, "units": f"IC-major (IC, member) pairs, {MEMBERS} members per IC",
                        "hip_graph": bool(a.graph), "params": 225980976,
+                       "noise": "swiftk_unit_noise: Philox4x32-10 + Box-Muller keyed by (member, IC, lead step), one launch per step",
+                       "forcings": f"{n_slabs} pre-staged slabs [B, 3, 128, 256], one per lead step",
                        "parallelism": f"units sharded over {world} GPU(s), no data-path collective on the state"},
             "rccl": rccl,
             "checksum": {"what": "fixed-order fp64 sum of each unit's physical state [69,128,256], all-gathered every step",
@@ -379,7 +399,7 @@ def main():
             # operand read once, the attention output written once, the weight once.  SWIFTK_TUNE=8:0 restores the two-kernel
             # path, whose attention kernel is HBM-bound (69.2 MB per sample-layer, 128 flop/B < ridge 312).
             att_s = att_ms.value / att_n.value * 1e-3
-            fused = os.environ.get("SWIFTK_TUNE", "").find("8:0") < 0
+            fused = lib.swiftk_get_tuning(8) != 0  # read back from the library: the kernel that actually ran
             if fused:
                 flop = B * (2.0 * 8192 * 3168 * 1056 + 8.858e9)
                 bytes_ = B * 8192 * 2 * 1056 * 2.0 + 3168 * 1056 * 2.0
@@ -402,8 +422,15 @@ def main():
                     "note": "arithmetic intensity 128 flop/B < ridge 312: the HBM roofline caps MFMA utilisation at 41 % in bf16; the "
                             "MFMA-bound regime is the fp32 engine's kernel (parity_engine.attention_mfma_frac)"}
         if world == 1 and not a.no_extras and a.solver == "scm" and nsteps == 1:
-            line["parity_engine"] = parity_engine_leg(eng.net, ds, dev, lib, X0, forc, units)
-            line["bf16_vs_fp32"] = drift_leg(eng.net, ds, dev, X0, forc, units)
+            for key, leg in (("batch_sweep", lambda: batch_sweep_leg(eng.net, ds, dev, X0, forc, units, dtype)),
+                             ("config3_2s", lambda: config3_leg(eng.net, ds, dev, X0, forc, units, dtype)),
+                             ("rollout_12x8x60", lambda: rollout_leg(a, eng, dev, B, sync)),
+                             ("parity_engine", lambda: parity_engine_leg(eng.net, ds, dev, lib, X0, forc, units)),
+                             ("bf16_vs_fp32", lambda: drift_leg(eng.net, ds, dev, X0, forc, units))):
+                try:
+                    line[key] = leg()
+                except Exception as e:  # noqa: BLE001 -- a reported extra must not take the metric's line down
+                    line[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not a.no_extras and a.cpu_steps > 0:
             line["cpu_baseline"] = cpu_baseline(state, a.cpu_steps)
             line["vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
@@ -411,7 +438,7 @@ def main():
             # the children plan their resident activations around what other processes hold: hand the forecast path's
             # buffers (workspace for 96 units, states, engines) back first
             import gc
-            del X, X0, forc, phys, z, eng
+            del X, X0, forc, forc_all, phys, z, eng
             for e in list(getattr(net.model, "_engines", {}).values()):
                 e._ws = None
             gc.collect()
@@ -446,25 +473,49 @@ def training_leg():
     return out
 
 
-def parity_engine_leg(net, ds, dev, lib, X0, forc, units, nb: int = 8, steps: int = 4):
-    """The exact-fp32 engine (the configuration that meets the 1e-4 tolerance) on the first `nb` units of the workload."""
+def _stepper(eng, dev, X0, forc, units, nb):
+    """(step, X): `step()` advances the first nb units by one lead step (noise draw, network, state update) on `eng`."""
     import torch
 
-    from swift_amd import _lib, ops
-    from swift_amd.rollout import RolloutEngine, unit_seed
+    from swift_amd import ops
+    from swift_amd.rollout import unit_seed
+
+    mx, sx, st = eng.stats(dev)
+    X, F = X0[:nb].clone(), forc[:nb].contiguous()
+    seeds = torch.tensor([unit_seed(m, ic) for ic, m in units[:nb]], dtype=torch.int64, device=dev)
+    z, phys = torch.empty_like(X), torch.empty_like(X)
+    n = [0]
+
+    def step():
+        ops.unit_noise(z, seeds, n[0])
+        n[0] += 1
+        ops.rollout_update(X, eng.sampler((X, F), latents=z), mx, sx, st, phys=phys)
+
+    return step, X
+
+
+def _rate(step, nb, steps):
+    import torch
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return nb * steps / (time.perf_counter() - t0)
+
+
+def parity_engine_leg(net, ds, dev, lib, X0, forc, units, nb: int = 8, steps: int = 4):
+    """The exact-fp32 engine (the configuration that meets the 1e-4 tolerance) on the first `nb` units of the workload, and
+    the split-bf16 engine (`--dtype bf16x3`) beside it."""
+    import torch
+
+    from swift_amd import _lib
+    from swift_amd.rollout import RolloutEngine
 
     nb = min(nb, X0.shape[0])
     eng = RolloutEngine(net, ds, interval=6, solver="scm", denoise_dtype=torch.float32, num_steps=1)
-    mx, sx, st = eng.stats(dev)
-    X, F = X0[:nb].clone(), forc[:nb].contiguous()
-    gens = [torch.Generator(device=dev).manual_seed(unit_seed(m, ic)) for ic, m in units[:nb]]
-    z, phys = torch.empty_like(X), torch.empty_like(X)
-
-    def step():
-        for b, gg in enumerate(gens):
-            z[b].normal_(generator=gg)
-        ops.rollout_update(X, eng.sampler((X, F), latents=z), mx, sx, st, phys=phys)
-
+    step, Xe = _stepper(eng, dev, X0, forc, units, nb)
     step()
     lib.swiftk_profile_gemm(_lib.PROF_ATTENTION, 0)
     torch.cuda.synchronize()
@@ -478,35 +529,24 @@ def parity_engine_leg(net, ds, dev, lib, X0, forc, units, nb: int = 8, steps: in
     lib.swiftk_profile_gemm(-1, 0)
     rate = nb * steps / dt
     att_s = ms.value / max(n.value, 1) * 1e-3
-    # the split-bf16 engine in the exact engine's place (fp32 activations, GEMMs as three bf16 MFMA products; to_qkv and the
-    # patch embedding stay exact): same units, same noise; its distance from the exact engine after one step
     split = None
-    mod = getattr(net, "module", net)
-    try:
-        x_e, x_s = X0[:nb].clone(), X0[:nb].clone()
-        z1 = torch.randn(x_e.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
-        ops.rollout_update(x_e, eng.sampler((x_e, F), latents=z1), mx, sx, st, phys=phys)
-        mod.model.fp32_engine = "bf16x3"
-        ops.rollout_update(x_s, eng.sampler((x_s, F), latents=z1), mx, sx, st, phys=phys)
-        step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        r3 = nb * steps / (time.perf_counter() - t0)
+    try:  # same units, same noise: distance after one step, then the rate
+        eng3 = RolloutEngine(net, ds, interval=6, solver="scm", denoise_dtype="bf16x3", num_steps=1)
+        s_e, x_e = _stepper(eng, dev, X0, forc, units, nb)
+        s_3, x_3 = _stepper(eng3, dev, X0, forc, units, nb)
+        s_e()
+        s_3()
+        rel = float((x_3.double() - x_e.double()).norm() / x_e.double().norm())
+        r3 = _rate(s_3, nb, steps)
         split = {"value": r3, "unit": "sample-steps/s", "vs_exact_engine": r3 / rate,
-                 "rel_l2_vs_exact_engine_after_1_step": float((x_s.double() - x_e.double()).norm() / x_e.double().norm()),
-                 "what": "SWIFTK_FP32_ENGINE=bf16x3: the fp32 engine's kernels with every GEMM but to_qkv and the patch embedding as "
-                         "three bf16 MFMA products of (hi, lo)-split operands (swiftk_split3); 7.9e-5 rel-L2 vs the reference "
-                         "golden on the Swift-B step (exact engine 4.0e-5; tests/test_gpu_model.py)"}
+                 "rel_l2_vs_exact_engine_after_1_step": rel,
+                 "what": "--dtype bf16x3: the fp32 engine's kernels with every GEMM as bf16 MFMA products of (hi, lo)-split operands "
+                         "(swiftk_split3); within 1e-4 rel-L2 of the reference golden on the Swift-B step (tests/test_gpu_model.py)"}
     except Exception as e:  # noqa: BLE001 -- an optional leg must not take the line down
         split = {"error": f"{type(e).__name__}: {e}"[:200]}
-    finally:
-        mod.model.fp32_engine = None
     return {"dtype": "f32", "what": "exact-fp32 MFMA engine (v_mfma_f32_16x16x4_f32 / 32x32x2_f32), 1e-4 parity configuration "
-            "(tests/test_gpu_model.py: 1.1e-5 rel-L2 vs the reference golden)", "units_per_step": nb, "steps": steps,
-            "value": rate, "unit": "sample-steps/s", "tflops": FLOP_PER_EVAL * rate / 1e12,
+            "(tests/test_gpu_model.py: rel-L2 vs the reference golden and vs the reference run in fp64)", "units_per_step": nb,
+            "steps": steps, "value": rate, "unit": "sample-steps/s", "tflops": FLOP_PER_EVAL * rate / 1e12,
             "frac_of_fp32_matrix_peak": FLOP_PER_EVAL * rate / PEAK_F32,
             "attention_kernel": "attn_f32_kernel<88>", "attention_avg_launch_ms": att_s * 1e3, "attention_launches": int(n.value),
             "attention_mfma_tflops": nb * 8.858e9 / att_s / 1e12 if att_s > 0 else None,
@@ -518,23 +558,17 @@ def drift_leg(net, ds, dev, X0, forc, units, nb: int = 2, marks=(1, 10, 60)):
     """bf16 engine vs fp32 engine over an autoregressive rollout of the same units with the same noise."""
     import torch
 
-    from swift_amd import ops
-    from swift_amd.rollout import RolloutEngine, unit_seed
+    from swift_amd.rollout import RolloutEngine
 
     nb = min(nb, X0.shape[0])
     out = {}
     states = {}
     for name, dt_ in (("f32", torch.float32), ("bf16", torch.bfloat16)):
         eng = RolloutEngine(net, ds, interval=6, solver="scm", denoise_dtype=dt_, num_steps=1)
-        mx, sx, st = eng.stats(dev)
-        X, F = X0[:nb].clone(), forc[:nb].contiguous()
-        gens = [torch.Generator(device=dev).manual_seed(unit_seed(m, ic)) for ic, m in units[:nb]]
-        z, phys = torch.empty_like(X), torch.empty_like(X)
+        step, X = _stepper(eng, dev, X0, forc, units, nb)
         snaps = {}
         for i in range(1, max(marks) + 1):
-            for b, gg in enumerate(gens):
-                z[b].normal_(generator=gg)
-            ops.rollout_update(X, eng.sampler((X, F), latents=z), mx, sx, st, phys=phys)
+            step()
             if i in marks:
                 snaps[i] = X.clone()
         states[name] = snaps
@@ -544,6 +578,89 @@ def drift_leg(net, ds, dev, X0, forc, units, nb: int = 2, marks=(1, 10, 60)):
     out["what"] = (f"standardised state of {nb} units, bf16 engine vs exact-fp32 engine, same initial state, forcings and noise; "
                    "random-weight Swift-B (logit scales up to 100), one staged forcing slab")
     return out
+
+
+def batch_sweep_leg(net, ds, dev, X0, forc, units, dtype, sizes=(1, 4, 8, 16, 32), steps: int = 6):
+    """the sCM 1-step sampler at {1, 4, 8, 16, 32} units per step (eager launches and, for the
+    launch-bound sizes, the whole step replayed as one HIP graph)."""
+    import torch
+
+    from swift_amd import ops
+    from swift_amd.rollout import RolloutEngine, unit_seed
+
+    eng = RolloutEngine(net, ds, interval=6, solver="scm", denoise_dtype=dtype, num_steps=1)
+    out = {}
+    for nb in sizes:
+        if nb > X0.shape[0]:
+            continue
+        step, _ = _stepper(eng, dev, X0, forc, units, nb)
+        rec = {"eager": _rate(step, nb, steps)}
+        if nb <= 8:
+            X, F = X0[:nb].clone(), forc[:nb].contiguous()
+            z, phys = torch.empty_like(X), torch.empty_like(X)
+            seeds = torch.tensor([unit_seed(m, ic) for ic, m in units[:nb]], dtype=torch.int64, device=dev)
+            lead = torch.zeros(1, dtype=torch.int64, device=dev)
+            g = eng.capture_step(X, F, z, phys, seeds=seeds, step=lead)
+            rec["hip_graph"] = _rate(g.replay, nb, steps)
+            del g
+        rec["best"] = max(rec.values())
+        rec["frac_of_dense_mfma_peak"] = FLOP_PER_EVAL * rec["best"] / PEAK_BF16
+        out[str(nb)] = rec
+    out["unit"] = "sample-steps/s"
+    out["what"] = "Swift-B sCM 1-step sampler, units per step as keyed; whole step (noise, network, state update) per unit-step"
+    return out
+
+
+def config3_leg(net, ds, dev, X0, forc, units, dtype, sizes=(1, 8)):
+    """BASELINE configs[2]: the multi-step ODE sampler (dpm_solver_2s, num_steps 20 = 39 network evaluations per sample-step)."""
+    import torch
+
+    from swift_amd.rollout import RolloutEngine
+
+    eng = RolloutEngine(net, ds, interval=6, solver="2s", denoise_dtype=dtype, num_steps=20)
+    out = {}
+    for nb in sizes:
+        if nb > X0.shape[0]:
+            continue
+        step, _ = _stepper(eng, dev, X0, forc, units, nb)
+        r = _rate(step, nb, 2)
+        out[str(nb)] = {"value": r, "network_evals_per_s": 39 * r, "frac_of_dense_mfma_peak": FLOP_PER_EVAL * 39 * r / PEAK_BF16}
+    out["unit"] = "sample-steps/s (one sample-step = 39 Swift-B evaluations)"
+    out["what"] = "dpm_solver_2s, num_steps 20, sigma 0.02..200 (solver/2s.yaml), units per step as keyed, eager launches"
+    return out
+
+
+def rollout_leg(a, eng, dev, B, sync):
+    """The per-GPU share of BASELINE configs[3] (12 members x 8 ICs x 60 six-hour steps = 5,760 sample-steps) through
+    RolloutEngine.run, inside the driver-run line: the north-star loop itself (lead-step-indexed forcings, counter-based noise,
+    state resident), where the headline loop above is its per-step body."""
+    import copy
+    a2 = copy.copy(a)
+    a2.rollout = "12x8x60"
+    r = rollout_mode(a2, eng, dev, 0, 1, B, None, None, sync)
+    return {"value": r["value"], "unit": r["unit"], "timed_region_s": r["timed_region_s"], "workload": r["config"]["workload"],
+            "batch": B, "frac_of_dense_mfma_peak": r["e2e"]["frac_of_dense_mfma_peak"], "checksum": r["checksum"]["all_units_sum"]}
+
+
+def rccl_topology(log_glob: str, max_lines: int = 14):
+    """What RCCL said about the communicator it built (NCCL_DEBUG=INFO, subsystems INIT + GRAPH, written to a file so that
+    stdout keeps its one JSON line): rank count, channels, the ring / tree orders it chose.  Best effort: [] when nothing
+    was logged."""
+    import glob
+    import re
+    keep = []
+    pat = re.compile(r"(nranks|nRanks|Channel|Ring|Tree|Trees|Connected|comm 0x|Using network|P2P|xGMI|XGMI|Algo|algo|Proto)")
+    for path in sorted(glob.glob(log_glob))[:1]:
+        try:
+            with open(path, errors="replace") as f:
+                for ln in f:
+                    if pat.search(ln):
+                        keep.append(re.sub(r"^\S+:\d+:\d+ \[\d+\] ", "", ln.strip())[:200])
+                        if len(keep) >= max_lines:
+                            break
+        except OSError:
+            pass
+    return keep
 
 
 def rollout_mode(a, eng, dev, rank, world, B, dtype, rccl, sync):

@@ -116,6 +116,21 @@ int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, void* xcopy, i
                             float eps, int dtype, void* stream);
 
 /*
+ * The same update on the bf16 engine's PAIR form of the residual stream: x is two bf16 tensors, x_hi = bf16(x) and
+ * x_lo = bf16(x - x_hi) (x = hi + lo to 2^-17 relative), so x_hi IS the next GEMM's operand and no separate operand copy
+ * is written: 10 bytes per element (y, hi, lo in; hi, lo out) where the fp32 stream + bf16 copy move 14.
+ * Replaces src/swift/models/swinv2.py:83-86 (ModulatedNorm) + :211-212 (residual) in the bf16 engine.
+ *   y [M, ldy] bf16   x_hi [M, ldh] bf16 (in/out; columns >= d untouched)   x_lo [M, ldl] bf16 (in/out)
+ *   rows_per_sample must be a multiple of 16 (SWIFTK_ESHAPE otherwise: callers keep the fp32-stream form)
+ */
+int swiftk_modnorm_residual_pair(const void* y, int64_t ldy, void* x_hi, int64_t ldh, void* x_lo, int64_t ldl,
+                                 const float* gamma, const float* beta, const float* mod, int64_t ldmod, int64_t M, int d,
+                                 int64_t rows_per_sample, float eps, void* stream);
+/* fp32 [rows, lds] -> the pair form: hi [rows, ldh] bf16 with columns [cols, ldh) zeroed (GEMM k-padding), lo [rows, ldl]. */
+int swiftk_split_pair(const float* src, int64_t lds, void* hi, int64_t ldh, void* lo, int64_t ldl, int64_t rows,
+                      int64_t cols, void* stream);
+
+/*
  * Channel-concat + patchify of up to three NCHW fp32 sources into the GEMM
  * operand of the patch embedding: A[b*gh*gw + gy*gw + gx][(i1*p2 + i2)*C + c]
  * = scale_s * src_s[b][c - c0_s][gy*p1 + i1][gx*p2 + i2]; pad columns zeroed.
@@ -148,6 +163,22 @@ int swiftk_timestep_embed(const float* t, const float* aux, const float* freqs, 
  */
 int swiftk_linear_small(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* out,
                         int64_t ldo, int B, int N, int K, int act, void* stream);
+
+/*
+ * Latent noise of one forecast step for B units, as ONE launch: out[b][e] ~ N(0, 1), a pure function of
+ * (seeds[b], step, e) -- Philox4x32-10 keyed by the unit's 64-bit seed, counter (e / 4, 0, step lo, step hi), two
+ * Box-Muller pairs per counter (24-bit uniforms).  step = (*step_dev if step_dev else 0) + step_add: a captured step
+ * graph reads the lead step from device memory and advances it with swiftk_counter_add.
+ * Replaces `torch.randn(shape, generator=g)` of src/swift/generating/factory.py:52-56 for production rollouts, where
+ * src/swift/generate.py:83 seeds one torch generator per member and consumes it in batch order (so a unit's noise would
+ * depend on the sharding); parity tests inject the reference's latents explicitly.
+ *   out [B, n_per_unit] fp32 (n_per_unit % 4 == 0)    seeds [B] int64 DEVICE    step_dev DEVICE int64 or NULL
+ *   mode 0 = normals; 1 = the generator's raw 32-bit words in the fp32 container (bit-exact test of the integer part)
+ */
+int swiftk_unit_noise(float* out, const int64_t* seeds, const int64_t* step_dev, int64_t step_add, int B,
+                      int64_t n_per_unit, int mode, void* stream);
+/* *counter += value on the stream (the lead-step counter of a captured forecast step). */
+int swiftk_counter_add(int64_t* counter, int64_t value, void* stream);
 
 /*
  * Residual rollout update in physical units, fused with re-standardisation:
@@ -190,8 +221,13 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * swiftk_swinv2_forward (1), key 6 = swiftk_modnorm_residual: bit 0 non-temporal residual-stream accesses, bit 1 chunked
  * kernel (3), key 7 = start-up stagger of the persistent GEMM's workgroups in 1/1000 of an eighth of a tile time (0),
  * key 8 = to_qkv + window attention as one kernel in swiftk_swinv2_forward (1; key 4 bits 8..15 = that kernel's ablations,
- * bits 16.. = those of the persistent attention backward), key 9 = persistent attention backward for head_dim 88 (1). */
+ * bits 16.. = those of the persistent attention backward), key 9 = persistent attention backward for head_dim 88 (1),
+ * key 12 = bf16 forward keeps the residual stream as a (hi, lo) bf16 pair (1; 0 = fp32 stream + bf16 operand copy). */
 int swiftk_set_tuning(int key, int value);
+/* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
+ * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default
+ * swiftk_model.x3_exact mask (17). */
+int swiftk_get_tuning(int key);
 int swiftk_profile_collect(double* total_ms_host, int64_t* launches_host);
 
 /* ------------------------------------------------------------------------ *
@@ -382,7 +418,7 @@ typedef struct swiftk_model {
     int32_t dtype;                 /* SWIFTK_F32 | SWIFTK_BF16 | SWIFTK_BF16X3 (fp32 activations and k-paddings as for SWIFTK_F32;
                                       GEMM weights stored by swiftk_split3(order 1) with row stride
                                       swiftk_gemm_k_pad(SWIFTK_BF16, 3*K), except those whose GEMM stays on the
-                                      exact-fp32 kernel -- swiftk_set_tuning(11, mask), default qkv_w and pe_w --
+                                      exact-fp32 kernel -- the x3_exact mask below --
                                       which are fp32 operands as for SWIFTK_F32) */
     int32_t H, W, p1, p2;          /* image and patch size      */
     int32_t in_ch, out_ch;         /* 141, 69                   */
@@ -391,6 +427,9 @@ typedef struct swiftk_model {
     int32_t wh, ww, sh, sw;        /* window 16x16, shift 8x8   */
     int32_t aux_dim;
     int32_t has_logvar;
+    int32_t x3_exact;              /* SWIFTK_BF16X3 only: GEMMs whose weights were packed as fp32 operands (bit 0 to_qkv, 1 wo,
+                                      2 w1, 3 w2, 4 patch embed, 5 head); a property of THIS model's weight buffers, set by
+                                      whoever packed them (swiftk_get_tuning(11) is the library's default: 17) */
     float timestep_weight;
     int64_t kd;                    /* swiftk_gemm_k_pad(dtype, dim)            */
     int64_t kmlp;                  /* swiftk_gemm_k_pad(dtype, mlp)            */

@@ -190,11 +190,31 @@ def modulated_norm(x, t_lat, p, prefix, eps=1e-6):
     return x * (1 + scale[:, None, :]) + shift[:, None, :]
 
 
-def cosine_window_attention(qkv, scale, heads, naive: bool = False):
+def bf16_round(x: torch.Tensor) -> torch.Tensor:
+    """Round to the nearest bf16 value (ties to even), keep the fp32 container: the operand rounding of a bf16 matrix
+    product whose accumulation stays fp32 (torch autocast on the reference side, bf16 MFMA on the product side)."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def linear_bf16(x, w, b=None):
+    """F.linear with both operands rounded to bf16 and fp32 accumulation (what ``autocast(bf16)`` makes of models/swinv2.py's
+    nn.Linear calls, minus the rounding of the OUTPUT, which callers apply where the product stores bf16)."""
+    return F.linear(bf16_round(x), bf16_round(w), b)
+
+
+def cosine_window_attention(qkv, scale, heads, naive: bool = False, emulate_bf16: bool = False):
     """qkv [Bw, n, heads*3*hd] with per-head channel blocks [q|k|v] -> [Bw, n, heads*hd].
 
     models/swinv2.py:119-136: q = normalize(q)*exp(min(scale, ln 100)),
     k = normalize(k), softmax(q k^T) v with softmax scale 1.0; no mask, no bias.
+
+    ``emulate_bf16``: the norm and the softmax stay fp32 (as under autocast), the operands of the two contractions are
+    rounded to bf16 -- q-hat*tau, k-hat, v, and the un-normalised probabilities e = exp(S - offset), whose row sum is taken
+    over the ROUNDED values (the matrix pipe sums what it multiplies).  The offset is the row maximum (True) or, with
+    ``emulate_bf16="offset0"``, zero for heads whose logit bound tau = exp(min(scale, ln 100)) is <= 48 (|S| <= tau because
+    q-hat, k-hat are unit vectors, so exp cannot overflow) and the row maximum otherwise: two equally valid roundings of the
+    same formula -- softmax is shift-invariant -- whose distance from each other is the noise floor of ANY bf16
+    implementation of this network (tests/test_gpu_model.py calibrates the bf16 engine's bound on it).
     """
     Bw, n, c3 = qkv.shape
     hd = c3 // (3 * heads)
@@ -203,7 +223,14 @@ def cosine_window_attention(qkv, scale, heads, naive: bool = False):
     tau = torch.clamp(scale, max=math.log(1.0 / 0.01)).exp()
     q = q / q.norm(dim=-1, keepdim=True).clamp_min(1e-12) * tau
     k = k / k.norm(dim=-1, keepdim=True).clamp_min(1e-12)
-    if naive:
+    if emulate_bf16:
+        s = bf16_round(q) @ bf16_round(k).transpose(-2, -1)
+        off = s.amax(dim=-1, keepdim=True)
+        if emulate_bf16 == "offset0":
+            off = torch.where(tau <= 48.0, torch.zeros_like(tau), off)
+        e = bf16_round((s - off).exp())
+        o = (e @ bf16_round(v)) / e.sum(dim=-1, keepdim=True)
+    elif naive:
         o = (q @ k.transpose(-2, -1)).softmax(dim=-1) @ v
     else:
         o = F.scaled_dot_product_attention(q, k, v, scale=1.0)
@@ -221,11 +248,17 @@ def latent_embedding(cfg: SwinCfg, p: dict, t: torch.Tensor, auxiliary: Optional
     return F.silu(F.linear(h, p["latent_embed.l2.weight"], p["latent_embed.l2.bias"]))
 
 
-def transformer_layer(cfg: SwinCfg, p: dict, i: int, x, lat, jvp: bool = False, taps: Optional[dict] = None):
+def transformer_layer(cfg: SwinCfg, p: dict, i: int, x, lat, jvp: bool = False, taps: Optional[dict] = None,
+                      emulate_bf16: bool = False):
     """One (attention, feed-forward) pair on the residual stream x [B, n, d].
 
     models/swinv2.py:186-212 (layer loop), :105-139 (attention), :89-102 (SwiGLU).
+
+    ``emulate_bf16``: the four large Linears take bf16-rounded operands and (like an autocast nn.Linear) return a bf16-rounded
+    branch output ``y``; LayerNorm, the modulation, the residual stream and its additions stay fp32.
     """
+    if emulate_bf16:
+        return _transformer_layer_bf16(cfg, p, i, x, lat, taps, emulate_bf16)
     B, n, d = x.shape
     a, f = f"transformer.layers.{i}.0.", f"transformer.layers.{i}.1."
     shift = cfg.shift_size if (any(cfg.shift_size) and i % 2 != 0) else (0, 0)
@@ -250,6 +283,30 @@ def transformer_layer(cfg: SwinCfg, p: dict, i: int, x, lat, jvp: bool = False, 
     return x + y
 
 
+def _transformer_layer_bf16(cfg: SwinCfg, p: dict, i: int, x, lat, taps, mode=True):
+    """transformer_layer with the roundings a bf16 matrix pipe applies (see there); same index maps."""
+    B, n, d = x.shape
+    a, f = f"transformer.layers.{i}.0.", f"transformer.layers.{i}.1."
+    shift = cfg.shift_size if (any(cfg.shift_size) and i % 2 != 0) else (0, 0)
+    idx = window_token_index(cfg.grid, cfg.window_size, shift).to(x.device)
+    nW, wn = idx.shape
+    qkv = linear_bf16(x, p[a + "to_qkv.weight"])  # fp32 accumulators: the cosine norm reads them unrounded
+    qkv_w = qkv[:, idx.reshape(-1)].reshape(B * nW, wn, -1)
+    o_w = cosine_window_attention(qkv_w, p[a + "scale"], cfg.heads, emulate_bf16=mode)
+    o = torch.empty(B, n, o_w.shape[-1], dtype=o_w.dtype, device=x.device)
+    o[:, idx.reshape(-1)] = o_w.reshape(B, nW * wn, -1)
+    if taps is not None:
+        taps[f"qkv{i}"] = qkv
+        taps[f"attn{i}"] = o
+    y = bf16_round(linear_bf16(o, p[a + "wo.weight"]))
+    x = x + modulated_norm(y, lat, p, a + "norm.")
+    h = linear_bf16(x, p[f + "w1.weight"])
+    m = cfg.mlp_dim
+    h = F.silu(h[..., :m]) * h[..., m:]
+    y = bf16_round(linear_bf16(h, p[f + "w2.weight"]))
+    return x + modulated_norm(y, lat, p, f + "norm.")
+
+
 def swinv2_forward(
     cfg: SwinCfg,
     p: dict,
@@ -259,9 +316,17 @@ def swinv2_forward(
     jvp: bool = False,
     return_logvar: bool = False,
     taps: Optional[dict] = None,
+    emulate_bf16: bool = False,
 ):
-    """models/swinv2.py:305-330.  x [B,Cin,H,W], t [B] or scalar, aux [B,aux_dim]."""
-    tok = F.linear(patchify(x, cfg.patch_size), p["patch_embed.emb.weight"], p["patch_embed.emb.bias"])
+    """models/swinv2.py:305-330.  x [B,Cin,H,W], t [B] or scalar, aux [B,aux_dim].
+
+    ``emulate_bf16`` (TEST YARDSTICK for the bf16 engine, not a reference code path): the operands of the patch embedding, of
+    the four Linears per layer, of QK^T / PV and of the head are rounded to bf16, every accumulation, LayerNorm, softmax,
+    the time-embedding MLP, the modulation Linears and the residual stream stay fp32.  It is what the reference's
+    ``autocast(bfloat16)`` computes, with the fp32 islands a hand-written bf16 engine keeps (small Linears, patch-embedding
+    and head outputs)."""
+    lin = linear_bf16 if emulate_bf16 else F.linear
+    tok = lin(patchify(x, cfg.patch_size), p["patch_embed.emb.weight"], p["patch_embed.emb.bias"])
     tok = tok + p["pos_embed"]
     if t.dim() == 0 or (t.dim() == 1 and t.size(0) == 1):
         t = t.repeat(tok.size(0))
@@ -270,10 +335,10 @@ def swinv2_forward(
         taps["tok0"] = tok
         taps["lat"] = lat
     for i in range(cfg.depth):
-        tok = transformer_layer(cfg, p, i, tok, lat, jvp=jvp, taps=taps)
+        tok = transformer_layer(cfg, p, i, tok, lat, jvp=jvp, taps=taps, emulate_bf16=emulate_bf16)
         if taps is not None:
             taps[f"x{i}"] = tok
-    out = unpatchify(F.linear(tok, p["head.head.0.weight"]), cfg.patch_size, cfg.grid)
+    out = unpatchify(lin(tok, p["head.head.0.weight"]), cfg.patch_size, cfg.grid)
     if cfg.logvar and return_logvar:
         lv = F.linear(lat, p["logvar_embed.weight"], p["logvar_embed.bias"]).squeeze(-1)
         return out, lv
@@ -312,8 +377,11 @@ class OracleNet:
         self.img_resolution = tuple(cfg.img_resolution)
         self.auxiliary_dim = cfg.auxiliary_dim
         self.sigma_data, self.sigma_min, self.sigma_max = sigma_data, sigma_min, sigma_max
+        self.emulate_bf16 = False  # tests set it to get the bf16-operand yardstick through samplers and rollouts
 
     def __call__(self, x, t, condition=None, auxiliary=None, **kw):
+        if self.emulate_bf16:
+            kw.setdefault("emulate_bf16", self.emulate_bf16)
         aux = process_auxiliary(auxiliary, self.auxiliary_dim, x.size(0), x.device)
         arg = x
         if condition is not None and self.condition_channels > 0:

@@ -49,7 +49,7 @@ class OptHyper(C.Structure):
 class Model(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ("dtype", "H", "W", "p1", "p2", "in_ch", "out_ch", "depth", "dim", "heads", "mlp",
-                                  "wh", "ww", "sh", "sw", "aux_dim", "has_logvar")]
+                                  "wh", "ww", "sh", "sw", "aux_dim", "has_logvar", "x3_exact")]
         + [("timestep_weight", C.c_float)]
         + [(n, C.c_int64) for n in ("kd", "kmlp", "kpe")]
         + [(n, C.c_void_p) for n in ("pe_w", "pe_b", "pos", "freqs", "aux_w", "aux_b", "l1_w", "l1_b", "l2_w", "l2_b",
@@ -65,6 +65,10 @@ _SIGS = {
     "swiftk_gemm": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _i, _i, _i, _p, _p, _l, _p], _i),
     "swiftk_window_attention": ([_p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_modnorm_residual": ([_p, _l, _p, _p, _l, _p, _p, _p, _l, _l, _i, _l, _f, _i, _p], _i),
+    "swiftk_modnorm_residual_pair": ([_p, _l, _p, _l, _p, _l, _p, _p, _p, _l, _l, _i, _l, _f, _p], _i),
+    "swiftk_split_pair": ([_p, _l, _p, _l, _p, _l, _l, _l, _p], _i),
+    "swiftk_unit_noise": ([_p, _p, _p, _l, _i, _l, _i, _p], _i),
+    "swiftk_counter_add": ([_p, _l, _p], _i),
     "swiftk_patchify": ([_p, _i, _f, _p, _i, _f, _p, _i, _f, _p, _l, _i, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_unpatchify_affine": ([_p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_timestep_embed": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p], _i),
@@ -107,6 +111,7 @@ _SIGS = {
     "swiftk_adamw_ema_step": ([_p, _i, _p, _p, _p, C.POINTER(OptHyper), _p], _i),
     "swiftk_profile_gemm": ([_i, _l], _i),
     "swiftk_set_tuning": ([_i, _i], _i),
+    "swiftk_get_tuning": ([_i], _i),
     "swiftk_profile_collect": ([C.POINTER(C.c_double), C.POINTER(C.c_int64)], _i),
     "swiftk_workspace_bytes": ([C.POINTER(Model), _i], _l),
     "swiftk_swinv2_forward": ([C.POINTER(Model), _p, _i, _f, _p, _i, _f, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p,

@@ -93,6 +93,9 @@ __global__ __launch_bounds__(256) void modnorm_kernel(const T* __restrict__ y, i
 #define SWIFTK_MN_ROWS 16
 #endif
 constexpr int MN_ROWS = SWIFTK_MN_ROWS;
+#ifndef SWIFTK_MNP_OCC
+#define SWIFTK_MNP_OCC 3  // pair kernel: 168 VGPRs = three waves per SIMD
+#endif
 #ifndef SWIFTK_MN_OCC
 #define SWIFTK_MN_OCC 2
 #endif
@@ -207,6 +210,160 @@ __global__ __launch_bounds__(256, SWIFTK_MN_OCC) void modnorm_chunk_kernel(const
         if (row + 4 >= row_end) break;
         if (row + 8 < row_end) load_row(row + 8, ya, xa);
         finish_row(row + 4, yb, xb);
+    }
+}
+
+
+// Pair form of the bf16 engine's residual stream (round 4): x is held as two bf16 tensors, hi = bf16(x) and
+// lo = bf16(x - hi) (x = hi + lo to 2^-17 relative), so that hi IS the next GEMM's operand -- no separate operand copy.
+// Bytes per element: y 2 + hi 2 + lo 2 in, hi 2 + lo 2 out = 10 (the fp32 stream + bf16 copy moved 14).  Same chunk
+// scheme as modnorm_chunk_kernel: a workgroup owns MN_ROWS rows, P / Q folded once into LDS, two rows in flight per wave;
+// the residual waits packed (8 registers per slot for hi and lo, as the fp32 form's 8).
+__device__ __forceinline__ uint4 load_q(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 load_q_nt(const bf16_t* p) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+    const u4 a = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
+    return make_uint4(a[0], a[1], a[2], a[3]);
+}
+__device__ __forceinline__ void store_q_nt(bf16_t* p, const uint4& q) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+    __builtin_nontemporal_store(u4{q.x, q.y, q.z, q.w}, reinterpret_cast<u4*>(p));
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(256, SLOTS == 3 ? SWIFTK_MNP_OCC : 2) void modnorm_pair_kernel(const bf16_t* __restrict__ y, int64_t ldy,
+                                                            bf16_t* __restrict__ xh, int64_t ldh, bf16_t* __restrict__ xl,
+                                                            int64_t ldl, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ mod,
+                                                            int64_t ldmod, int64_t M, int d, int64_t rps, float eps, int nt) {
+    const bool NT = nt & 1;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int nc = d >> 3;
+    const int64_t row0 = (int64_t)blockIdx.x * MN_ROWS + wv;
+    const int64_t row_end = min((int64_t)(blockIdx.x + 1) * MN_ROWS, M);
+    __shared__ __attribute__((aligned(16))) float sP[2048], sQ[2048];
+    const int64_t blk_sample = ((int64_t)blockIdx.x * MN_ROWS) / rps;
+    {
+        const float* mrow = mod + blk_sample * ldmod;
+        for (int c = threadIdx.x; c < nc; c += 256) {
+            float g[8], bt[8], sc[8], sh[8], p[8], q[8];
+            load8<float>(gamma + 8 * c, g);
+            load8<float>(beta + 8 * c, bt);
+            load8<float>(mrow + 8 * c, sc);
+            load8<float>(mrow + d + 8 * c, sh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                p[e] = g[e] * (1.0f + sc[e]);
+                q[e] = bt[e] * (1.0f + sc[e]) + sh[e];
+            }
+            store8<float>(sP + 8 * c, p);
+            store8<float>(sQ + 8 * c, q);
+        }
+    }
+    __syncthreads();
+    if (row0 >= row_end) return;
+    struct Row { uint4 y[SLOTS], h[SLOTS], l[SLOTS]; };
+    Row ra, rb;
+    auto load_row = [&](int64_t row, Row& r) {
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                r.y[i] = NT ? load_q_nt(y + row * ldy + 8 * c) : load_q(y + row * ldy + 8 * c);
+                r.h[i] = load_q(xh + row * ldh + 8 * c);
+                r.l[i] = NT ? load_q_nt(xl + row * ldl + 8 * c) : load_q(xl + row * ldl + 8 * c);
+            }
+        }
+    };
+    auto finish_row = [&](int64_t row, Row& r) {
+        float v[SLOTS][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i)
+            if (lane + 64 * i < nc) {
+                raw8<bf16_t> t;
+                t.q = r.y[i];
+                unpack_raw(t, v[i]);
+                sum += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+            }
+        const float mean = wave_sum(sum) / (float)d;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i)
+            if (lane + 64 * i < nc) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[i][e] -= mean;
+                    sq += v[i][e] * v[i][e];
+                }
+            }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)d + eps);
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                float P[8], Q[8], hi[8], lo[8];
+                load8<float>(sP + 8 * c, P);
+                load8<float>(sQ + 8 * c, Q);
+                raw8<bf16_t> t;
+                t.q = r.h[i];
+                unpack_raw(t, hi);
+                t.q = r.l[i];
+                unpack_raw(t, lo);
+                uint32_t oh[4], ol[4];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xn = (hi[e] + lo[e]) + ((v[i][e] * rstd) * P[e] + Q[e]);
+                    const bf16_t h = f2bf(xn);
+                    const bf16_t l = f2bf(xn - bf2f(h));
+                    if (e & 1) {
+                        oh[e >> 1] |= (uint32_t)h << 16;
+                        ol[e >> 1] |= (uint32_t)l << 16;
+                    } else {
+                        oh[e >> 1] = h;
+                        ol[e >> 1] = l;
+                    }
+                }
+                *reinterpret_cast<uint4*>(xh + row * ldh + 8 * c) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+                if (NT) store_q_nt(xl + row * ldl + 8 * c, make_uint4(ol[0], ol[1], ol[2], ol[3]));
+                else *reinterpret_cast<uint4*>(xl + row * ldl + 8 * c) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+            }
+        }
+    };
+    load_row(row0, ra);
+    for (int64_t row = row0; row < row_end; row += 8) {
+        if (row + 4 < row_end) load_row(row + 4, rb);
+        finish_row(row, ra);
+        if (row + 4 >= row_end) break;
+        if (row + 8 < row_end) load_row(row + 8, ra);
+        finish_row(row + 4, rb);
+    }
+}
+
+// fp32 -> (hi, lo) bf16 pair, hi with zeroed k-padding columns [cols, ldh) (it is a GEMM operand), lo [rows, ldl]
+__global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict__ src, int64_t lds, bf16_t* __restrict__ hi,
+                                                         int64_t ldh, bf16_t* __restrict__ lo, int64_t ldl, int64_t rows,
+                                                         int64_t cols) {
+    const int64_t per = ldh >> 2, total = rows * per;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / per, c = i - r * per;
+        if (4 * c >= cols) {
+            *reinterpret_cast<uint2*>(hi + r * ldh + 4 * c) = make_uint2(0u, 0u);
+            continue;
+        }
+        const float4 v = *reinterpret_cast<const float4*>(src + r * lds + 4 * c);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        bf16_t h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = f2bf(f[e]);
+            l[e] = f2bf(f[e] - bf2f(h[e]));
+        }
+        *reinterpret_cast<uint2*>(hi + r * ldh + 4 * c) =
+            make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+        *reinterpret_cast<uint2*>(lo + r * ldl + 4 * c) =
+            make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
     }
 }
 
@@ -573,6 +730,54 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ s
     }
 }
 
+// --------------------------------------------------------------------------------- latent noise
+// Counter-based N(0, 1) stream keyed by (unit seed, lead step, element): Philox4x32-10 (Salmon et al., SC'11; the
+// Random123 constants) with key = the unit's 64-bit seed and counter = (element / 4, 0, step lo, step hi); the four 32-bit
+// outputs feed two Box-Muller pairs.  A unit's noise therefore depends on nothing but (seed, step, element) -- not on the
+// rank, the batch it sits in or the order of launches -- and the whole draw is one launch that a captured step can hold
+// (the step number is read from device memory).  Replaces the latents of generating/factory.py:52-56 for production
+// rollouts (generate.py:83 seeds a torch generator per member and consumes it in batch order).
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c[0]), l0 = 0xD2511F53u * c[0];
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c[2]), l1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = h1 ^ c[1] ^ k0, n2 = h0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = l1; c[2] = n2; c[3] = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void unit_noise_kernel(float* __restrict__ out, const int64_t* __restrict__ seeds,
+                                                         const int64_t* __restrict__ step_dev, int64_t step_add, int64_t n4,
+                                                         int mode) {
+    const int b = blockIdx.y;
+    const uint64_t seed = (uint64_t)seeds[b];
+    const uint64_t step = (uint64_t)((step_dev ? *step_dev : 0) + step_add);
+    float* o = out + (int64_t)b * n4 * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        float4 z;
+        if (mode == 1) {  // raw generator output (bit-exact check of the integer part against the oracle)
+            z = make_float4(__uint_as_float(c[0]), __uint_as_float(c[1]), __uint_as_float(c[2]), __uint_as_float(c[3]));
+        } else {
+            // 24-bit uniforms strictly inside (0, 1): (k + 0.5) 2^-24 is exact in fp32
+            const float u0 = ((float)(c[0] >> 8) + 0.5f) * 0x1p-24f, u1 = ((float)(c[1] >> 8) + 0.5f) * 0x1p-24f;
+            const float u2 = ((float)(c[2] >> 8) + 0.5f) * 0x1p-24f, u3 = ((float)(c[3] >> 8) + 0.5f) * 0x1p-24f;
+            const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+            float sa, ca, sb, cb;
+            sincospif(2.0f * u1, &sa, &ca);
+            sincospif(2.0f * u3, &sb, &cb);
+            z = make_float4(ra * ca, ra * sa, rb * cb, rb * sb);
+        }
+        *reinterpret_cast<float4*>(o + 4 * i) = z;
+    }
+}
+
+__global__ void counter_add_kernel(int64_t* p, int64_t v) { *p += v; }
+
 inline int grid_for(int64_t work_items, int per_block = 256, int cap = 256 * 16) {
     int64_t g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -609,6 +814,40 @@ extern "C" int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, voi
         return SWIFTK_EINVAL;
     }
 #undef SWIFTK_MODNORM
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_modnorm_residual_pair(const void* y, int64_t ldy, void* x_hi, int64_t ldh, void* x_lo, int64_t ldl,
+                                            const float* gamma, const float* beta, const float* mod, int64_t ldmod, int64_t M,
+                                            int d, int64_t rows_per_sample, float eps, void* stream) {
+    if (!y || !x_hi || !x_lo || !gamma || !beta || !mod || M <= 0 || d <= 0 || rows_per_sample <= 0) return SWIFTK_EINVAL;
+    if (d % 8 || d > 2048 || rows_per_sample % MN_ROWS) return SWIFTK_ESHAPE;
+    if (ldy < d || ldh < d || ldl < d) return SWIFTK_ESHAPE;
+    if (((uintptr_t)y & 15) || (ldy * 2) % 16 || ((uintptr_t)x_hi & 15) || (ldh * 2) % 16 || ((uintptr_t)x_lo & 15) ||
+        (ldl * 2) % 16 || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)mod & 15) || (ldmod % 4))
+        return SWIFTK_EALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int cgrid = (int)((M + MN_ROWS - 1) / MN_ROWS);
+    if (d <= 3 * 512)
+        hipLaunchKernelGGL((modnorm_pair_kernel<3>), dim3(cgrid), dim3(256), 0, st, static_cast<const bf16_t*>(y), ldy,
+                           static_cast<bf16_t*>(x_hi), ldh, static_cast<bf16_t*>(x_lo), ldl, gamma, beta, mod, ldmod, M, d,
+                           rows_per_sample, eps, g_modnorm_nt);
+    else
+        hipLaunchKernelGGL((modnorm_pair_kernel<4>), dim3(cgrid), dim3(256), 0, st, static_cast<const bf16_t*>(y), ldy,
+                           static_cast<bf16_t*>(x_hi), ldh, static_cast<bf16_t*>(x_lo), ldl, gamma, beta, mod, ldmod, M, d,
+                           rows_per_sample, eps, g_modnorm_nt);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_split_pair(const float* src, int64_t lds, void* hi, int64_t ldh, void* lo, int64_t ldl, int64_t rows,
+                                 int64_t cols, void* stream) {
+    if (!src || !hi || !lo || rows <= 0 || cols <= 0) return SWIFTK_EINVAL;
+    if (cols % 4 || ldh % 4 || ldl % 4 || lds % 4 || ldh < cols || ldl < cols || lds < cols) return SWIFTK_ESHAPE;
+    if (((uintptr_t)src & 15) || ((uintptr_t)hi & 7) || ((uintptr_t)lo & 7)) return SWIFTK_EALIGN;
+    hipLaunchKernelGGL(split_pair_kernel, dim3(grid_for(rows * (ldh >> 2))), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                       lds, static_cast<bf16_t*>(hi), ldh, static_cast<bf16_t*>(lo), ldl, rows, cols);
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }
@@ -734,6 +973,25 @@ extern "C" int swiftk_split3(const float* src, int64_t lds, void* dst, int64_t l
     if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return SWIFTK_EALIGN;
     hipLaunchKernelGGL(split3_kernel, dim3(grid_for(rows * ((ldd - 2 * cols) >> 2))), dim3(256), 0, static_cast<hipStream_t>(stream),
                        src, lds, static_cast<bf16_t*>(dst), ldd, rows, cols, order);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_unit_noise(float* out, const int64_t* seeds, const int64_t* step, int64_t step_add, int B,
+                                 int64_t n_per_unit, int mode, void* stream) {
+    if (!out || !seeds || B <= 0 || n_per_unit <= 0 || (mode != 0 && mode != 1)) return SWIFTK_EINVAL;
+    if (n_per_unit % 4 || B > 65535) return SWIFTK_ESHAPE;
+    if ((uintptr_t)out & 15) return SWIFTK_EALIGN;
+    const int64_t n4 = n_per_unit / 4;
+    hipLaunchKernelGGL(unit_noise_kernel, dim3(grid_for(n4, 256, 1024), B), dim3(256), 0, static_cast<hipStream_t>(stream), out,
+                       seeds, step, step_add, n4, mode);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_counter_add(int64_t* counter, int64_t value, void* stream) {
+    if (!counter) return SWIFTK_EINVAL;
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), counter, value);
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

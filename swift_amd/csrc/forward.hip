@@ -4,7 +4,9 @@
 #include "common.h"
 
 int g_fwd_tiled = 1;  // tuning key 5 (A/B only): 0 keeps q/k/v row-major between to_qkv and attention
-int g_x3_exact = 17;  // tuning key 11: SWIFTK_BF16X3 GEMMs kept on the exact-fp32 kernel (bit 0 to_qkv, 1 wo, 2 w1, 3 w2, 4 patch embed, 5 head)
+int g_x3_exact = 17;  // tuning key 11: the DEFAULT mask a host binding copies into swiftk_model.x3_exact when it packs the weights
+                      // (the forward reads the model's own field, never this global: ADVICE r3)
+int g_fwd_pair = 1;   // tuning key 12: bf16 engine keeps the residual stream as a (hi, lo) bf16 pair (hi = the GEMM operand)
 int g_fwd_fused = 1;  // tuning key 8 (A/B only): 0 = to_qkv and window attention as two kernels (q/k/v window-tiled through HBM)
 
 namespace {
@@ -19,7 +21,7 @@ __global__ __launch_bounds__(256) void zero_cols_kernel(char* p, int64_t ld_b, i
 }
 
 struct Layout {
-    int64_t emb, h1, lat, mod, ape, x, xt, qkv, att, y, hmid, tok, a3, total;
+    int64_t emb, h1, lat, mod, ape, x, xt, xlo, qkv, att, y, hmid, tok, a3, total;
 };
 
 inline int64_t al(int64_t v) { return (v + 255) & ~(int64_t)255; }
@@ -47,6 +49,7 @@ Layout make_layout(const swiftk_model* m, int B) {
     L.ape = o; o += al(M * m->kpe * es);
     L.x = o; o += al(M * d * 4);
     L.xt = o; o += al(M * m->kd * es);
+    L.xlo = o; o += m->dtype == SWIFTK_BF16 ? al(M * d * 2) : 0;  // low half of the pair-form residual stream
     L.qkv = o; o += al(M * 3 * d * es);
     L.att = o; o += al(M * m->kd * es);
     L.y = o; o += al(M * d * es);
@@ -91,6 +94,7 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     // SWIFTK_BF16X3: every kernel but the GEMMs runs exactly as in the fp32 engine; a GEMM's fp32 input is first split into
     // [hi | lo | hi] bf16 blocks (swiftk_split3) and multiplied with the [hi | hi | lo] weight on the bf16 MFMA kernel
     const bool x3 = m->dtype == SWIFTK_BF16X3;
+    const int x3_exact = m->x3_exact;  // which GEMMs keep fp32 operands: fixed when the weights were packed
     const int dt = x3 ? SWIFTK_F32 : m->dtype;
     const int64_t es = dt == SWIFTK_BF16 ? 2 : 4;
     const int gh = m->H / m->p1, gw = m->W / m->p2, d = m->dim, hd = m->dim / m->heads;
@@ -138,8 +142,12 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     // patch embedding (+bias +pos_embed) into the fp32 residual stream, plus its GEMM-operand copy
     RUN(swiftk_patchify(src0, c0, s0, src1, c1, s1, src2, c2, s2, ape, m->kpe, B, m->H, m->W, m->p1, m->p2, dt, stream));
     RUN(G(ape, m->kpe, m->pe_w, x, d, d, m->kpe, (int64_t)m->in_ch * m->p1 * m->p2, SWIFTK_F32, SWIFTK_EPI_BIAS_POS, m->pe_b, m->pos,
-          ntok, (g_x3_exact & 16) != 0));
-    RUN(swiftk_cast_pad(x, d, xT, m->kd, M, d, dt, stream));
+          ntok, (x3_exact & 16) != 0));
+    // bf16 engine: from here on the residual stream is the pair (xT = hi, xlo = lo); the fp32 x is not touched again
+    const bool pair = dt == SWIFTK_BF16 && g_fwd_pair && ntok % 16 == 0 && d % 8 == 0 && d <= 2048;
+    void* xlo = ws + L.xlo;
+    if (pair) RUN(swiftk_split_pair(x, d, xT, m->kd, xlo, d, M, d, stream));
+    else RUN(swiftk_cast_pad(x, d, xT, m->kd, M, d, dt, stream));
     if (m->kd > d) {  // K-padding columns of the attention output must be finite (they meet zero weight columns)
         hipLaunchKernelGGL(zero_cols_kernel, dim3(1024), dim3(256), 0, st, static_cast<char*>(att), m->kd * es, d * es,
                            (m->kd - d) * es, M);
@@ -177,22 +185,30 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             // (SWIFTK_BF16X3 keeps to_qkv -- and the patch embedding -- on the exact-fp32 kernel by default: the cosine logits
             // multiply q-hat . k-hat by up to 100, so the split product's 4.5e-6 would reach the softmax as 4.5e-4)
             RUN(G(xT, m->kd, ly.qkv_w, qkv, 3 * d, 3 * d, kdv, d, dt, fuse_norm ? SWIFTK_EPI_QKNORM : SWIFTK_EPI_NONE,
-                  fuse_norm ? ly.scale : nullptr, nullptr, fuse_norm ? hd : 0, (g_x3_exact & 1) != 0));
+                  fuse_norm ? ly.scale : nullptr, nullptr, fuse_norm ? hd : 0, (x3_exact & 1) != 0));
             RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
                                         shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
         }
-        RUN(G(att, m->kd, ly.wo_w, y, d, d, kdv, d, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (g_x3_exact & 2) != 0));
-        RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok,
-                                    1e-6f, dt, stream));
-        RUN(G(xT, m->kd, ly.w1_w, hmid, m->kmlp, 2 * m->mlp, kdv, d, dt, SWIFTK_EPI_SWIGLU, nullptr, nullptr, 0, (g_x3_exact & 4) != 0));
-        RUN(G(hmid, m->kmlp, ly.w2_w, y, d, d, m->kmlp, m->mlp, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (g_x3_exact & 8) != 0));
-        RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d,
-                                    ntok, 1e-6f, dt, stream));
+        RUN(G(att, m->kd, ly.wo_w, y, d, d, kdv, d, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (x3_exact & 2) != 0));
+        if (pair)
+            RUN(swiftk_modnorm_residual_pair(y, d, xT, m->kd, xlo, d, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M,
+                                             d, ntok, 1e-6f, stream));
+        else
+            RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok,
+                                        1e-6f, dt, stream));
+        RUN(G(xT, m->kd, ly.w1_w, hmid, m->kmlp, 2 * m->mlp, kdv, d, dt, SWIFTK_EPI_SWIGLU, nullptr, nullptr, 0, (x3_exact & 4) != 0));
+        RUN(G(hmid, m->kmlp, ly.w2_w, y, d, d, m->kmlp, m->mlp, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (x3_exact & 8) != 0));
+        if (pair)
+            RUN(swiftk_modnorm_residual_pair(y, d, xT, m->kd, xlo, d, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, ldmod,
+                                             M, d, ntok, 1e-6f, stream));
+        else
+            RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d,
+                                        ntok, 1e-6f, dt, stream));
     }
 
     // the head's output width rounded up to the GEMM's N granularity (head_w carries zero rows there: 69 -> 72 for 1x1 patches)
     const int po4 = (m->out_ch * m->p1 * m->p2 + 3) & ~3;
-    RUN(G(xT, m->kd, m->head_w, tok, po4, po4, kdv, d, SWIFTK_F32, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (g_x3_exact & 32) != 0));
+    RUN(G(xT, m->kd, m->head_w, tok, po4, po4, kdv, d, SWIFTK_F32, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (x3_exact & 32) != 0));
     RUN(swiftk_unpatchify_affine(tok, po4, xt, alpha, beta, out, B, m->out_ch, m->H, m->W, m->p1, m->p2, stream));
     return 0;
 }

@@ -232,7 +232,17 @@ class SyntheticERA5Dataset(_ERA5Base):
         return np.datetime64("2020-01-01T00:00:00") + np.timedelta64(6 * int(idx), "h")
 
     def get_forcings(self, idx: int) -> torch.Tensor:
-        return self._fields(idx, "forc", len(self.forcings))
+        # a small most-recently-used cache stands in for the OS page cache an h5-backed dataset has: the multistep loss asks
+        # for the same (index, lead step) files again and again (loss.py:378-392), and a forcing slab is 393 KB
+        cache = self.__dict__.setdefault("_forc_cache", {})
+        idx = int(idx)
+        f = cache.pop(idx, None)
+        if f is None:
+            f = self._fields(idx, "forc", len(self.forcings))
+            if len(cache) >= 256:
+                cache.pop(next(iter(cache)))
+        cache[idx] = f  # (re-inserted last: dict order = recency)
+        return f.clone()
 
     def get_state(self, idx: int) -> torch.Tensor:
         return self._fields(idx, "state", len(self.variables))

@@ -80,11 +80,21 @@ def setup_torch(backend: Optional[str] = None, timeout_s: int = 1800, single_ran
             os.environ.setdefault("MASTER_PORT", "29500")
         if be == "nccl":
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())  # eager communicator: init errors surface here
-        with _stdout_to_stderr():  # RCCL prints a version banner on C stdout when its first communicator comes up
-            dist.init_process_group(be, **kw)
-            if be == "nccl":
-                dist.barrier()
-                torch.cuda.synchronize()
+        try:
+            with _stdout_to_stderr():  # RCCL prints a version banner on C stdout when its first communicator comes up
+                dist.init_process_group(be, **kw)
+                if be == "nccl":
+                    dist.barrier()
+                    torch.cuda.synchronize()
+        except Exception:
+            # a group that came up but cannot carry a barrier must not stay behind: collectives_active() would report it
+            # and every later collective would run on a broken communicator
+            if dist.is_initialized():
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001 -- the original error is the one to report
+                    pass
+            raise
     return get_rank()
 
 

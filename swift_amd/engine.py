@@ -53,9 +53,7 @@ class SwinEngine:
         # Default 17: the cosine logits multiply q-hat . k-hat by up to 100, and an error in the patch embedding passes through
         # every layer -- measured on Swift-B against the reference: all GEMMs split 2.8e-4, these two exact 7.9e-5 (exact
         # engine 4.0e-5); 68 against 47 sample-steps/s for the exact engine at 8 units per step.
-        exact_mask = int(os.environ.get("SWIFTK_X3_EXACT", "17"))
-        if x3:
-            lib().swiftk_set_tuning(11, exact_mask)
+        exact_mask = int(os.environ.get("SWIFTK_X3_EXACT", "17"))  # travels in the model descriptor (mo.x3_exact), per engine
         dt = torch.float32 if x3 else self.dtype  # activations, k-paddings and every non-GEMM kernel
         d, heads, depth, mlp = m.dim, m.heads, m.depth, m.mlp_dim
         p1, p2 = m.patch_size
@@ -108,6 +106,7 @@ class SwinEngine:
         mo.sh, mo.sw = m.shift_size
         mo.aux_dim = m.auxiliary_dim
         mo.has_logvar = int(m.logvar_embed is not None)
+        mo.x3_exact = exact_mask if x3 else 0
         mo.timestep_weight = float(m.timestep_weight)
         mo.kd, mo.kmlp, mo.kpe = kd, kmlp, kpe
         mo.pe_w = gemm_w(m.patch_embed.emb.weight, kpe, exact=bool(exact_mask & 16))

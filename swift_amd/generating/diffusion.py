@@ -13,12 +13,34 @@ ablation_sampler, scm_solve2) are out of scope.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Callable, Optional, Sequence
 
 import torch
 
 from .. import ops
+
+
+@contextlib.contextmanager
+def engine_for(module, dtype, device_type: str = "cuda"):
+    """Select the compute engine of ``denoise_dtype`` for the calls inside the block: torch.bfloat16 = the bf16 MFMA engine
+    (through autocast, as the reference's ``autocast(dtype=denoise_dtype)``, diffusion.py:457), torch.float32 = the
+    exact-fp32 engine, the string "bf16x3" = the fp32-grade engine built from three bf16 products per GEMM (fp32
+    activations; what ``generate --dtype bf16x3`` runs)."""
+    model = getattr(module, "model", module)
+    x3 = isinstance(dtype, str) and dtype == "bf16x3"
+    if isinstance(dtype, str) and not x3:
+        raise ValueError(f"denoise_dtype {dtype!r}: expected torch.float32, torch.bfloat16 or 'bf16x3'")
+    prev = getattr(model, "fp32_engine", None)
+    if x3:
+        model.fp32_engine = "bf16x3"
+    try:
+        with torch.autocast(device_type, enabled=(dtype == torch.bfloat16), dtype=torch.bfloat16):
+            yield
+    finally:
+        if x3:
+            model.fp32_engine = prev
 
 
 def _log_sigma_grid(num_steps: int, sigma_min: float, sigma_max: float, sigma_data: float) -> torch.Tensor:
@@ -56,7 +78,7 @@ class DiffusionSampler:
         tt = torch.full((B,), float(t_scalar), dtype=torch.float32, device=dev)
         a = torch.full((B,), float(alpha), dtype=torch.float32, device=dev)
         b = torch.full((B,), float(beta), dtype=torch.float32, device=dev)
-        with torch.autocast(dev.type, enabled=(dtype == torch.bfloat16), dtype=torch.bfloat16):
+        with engine_for(self._module(), dtype, dev.type):
             return self.net(x_t, tt, condition, auxiliary, x_scale=1.0 / sd, xt=x_t, alpha=a, beta=b)
 
     @torch.no_grad()
@@ -95,7 +117,7 @@ class DiffusionSampler:
                 tt = torch.full((B,), float(t), dtype=torch.float32, device=dev)
                 a = torch.ones(B, dtype=torch.float32, device=dev)
                 b = torch.full((B,), 0.5 * dt, dtype=torch.float32, device=dev)
-                with torch.autocast(dev.type, enabled=(denoise_dtype == torch.bfloat16), dtype=torch.bfloat16):
+                with engine_for(self._module(), denoise_dtype, dev.type):
                     x_t = self.net(x_e, tt, condition, auxiliary, x_scale=1.0 / sd, xt=half, alpha=a, beta=b)
             else:
                 x_t = x_e

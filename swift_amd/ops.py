@@ -225,6 +225,48 @@ def rollout_update(xstd: torch.Tensor, y: torch.Tensor, mx, sx, st, phys: Option
                                       B, Cc, H * W, _stream()), "swiftk_rollout_update")
 
 
+def unit_noise(out: torch.Tensor, seeds: torch.Tensor, step=0, step_dev: Optional[torch.Tensor] = None, raw: bool = False) -> torch.Tensor:
+    """out[b] ~ N(0, 1), a pure function of (seeds[b], step, element): the counter-based latent stream of production rollouts
+    (Philox4x32-10 + Box-Muller, ``swiftk_unit_noise``; replaces the per-member torch generator of generate.py:83 /
+    factory.py:52-56).  ``seeds`` int64 [B] on the device; the lead step is ``step`` plus ``*step_dev`` (device int64 scalar)
+    when given -- a captured step reads it from memory.  ``raw``: the generator's 32-bit words instead (tests)."""
+    _dev(out, seeds, step_dev)
+    assert out.is_contiguous() and out.dtype == torch.float32 and seeds.dtype == torch.int64 and seeds.numel() == out.shape[0]
+    assert step_dev is None or step_dev.dtype == torch.int64
+    check(lib().swiftk_unit_noise(out.data_ptr(), seeds.data_ptr(), _ptr(step_dev), int(step), out.shape[0],
+                                  out[0].numel(), 1 if raw else 0, _stream()), "swiftk_unit_noise")
+    return out
+
+
+def counter_add(counter: torch.Tensor, value: int = 1) -> None:
+    """counter (device int64 scalar) += value on the current stream."""
+    _dev(counter)
+    assert counter.dtype == torch.int64 and counter.numel() == 1
+    check(lib().swiftk_counter_add(counter.data_ptr(), int(value), _stream()), "swiftk_counter_add")
+
+
+def split_pair(x: torch.Tensor, ldh: int):
+    """fp32 [M, d] -> (hi bf16 [M, ldh] with zeroed pad columns, lo bf16 [M, d]): the bf16 engine's residual-stream form."""
+    _dev(x)
+    assert x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 2
+    M, d = x.shape
+    hi = torch.empty(M, ldh, dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty(M, d, dtype=torch.bfloat16, device=x.device)
+    check(lib().swiftk_split_pair(x.data_ptr(), d, hi.data_ptr(), ldh, lo.data_ptr(), d, M, d, _stream()), "swiftk_split_pair")
+    return hi, lo
+
+
+def modnorm_residual_pair(y: torch.Tensor, x_hi: torch.Tensor, x_lo: torch.Tensor, gamma, beta, mod: torch.Tensor,
+                          rows_per_sample: int, d: int, eps: float = 1e-6) -> None:
+    """In place on the pair (x_hi, x_lo): x += LayerNorm(y) * (1 + scale_b) + shift_b (swinv2.py:83-86, 211-212)."""
+    _dev(y, x_hi, x_lo, gamma, beta, mod)
+    assert y.dtype == x_hi.dtype == x_lo.dtype == torch.bfloat16 and mod.dtype == torch.float32
+    M = y.shape[0]
+    check(lib().swiftk_modnorm_residual_pair(y.data_ptr(), y.stride(0), x_hi.data_ptr(), x_hi.stride(0), x_lo.data_ptr(),
+                                             x_lo.stride(0), gamma.data_ptr(), beta.data_ptr(), mod.data_ptr(), mod.stride(0),
+                                             M, d, rows_per_sample, float(eps), _stream()), "swiftk_modnorm_residual_pair")
+
+
 def axpby(a: float, x: torch.Tensor, b: float, y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = a*x + b*y on fp32 device tensors of equal shape (out may alias x or y)."""
     _dev(x, y, out)

@@ -11,10 +11,12 @@ What changes relative to the reference loop, and why it is the same computation:
   * unstandardise-x + unstandardise-t + add + re-standardise (generate.py:120-131) is one kernel;
   * the work unit is a (member, IC) pair, not a member: any contiguous block of the flattened
     member x IC space can run as one batch, which is what lets 12 members fill 8 GPUs.
-Noise: each unit gets its own generator seeded from (member, IC index) so results do not depend
-on how units are sharded or batched (the reference seeds per member and consumes the stream in
-batch order, generate.py:83 -- that coupling is deliberately not reproduced; parity tests inject
-latents explicitly).
+Noise: a counter-based stream keyed by (unit seed = f(member, IC index), lead step, element) --
+``swiftk_unit_noise``, Philox4x32-10 + Box-Muller, ONE launch per step for the whole batch -- so
+results do not depend on how units are sharded or batched, and the draw can sit inside a captured
+step (the reference seeds a torch generator per member and consumes it in batch order,
+generate.py:83 -- that coupling is deliberately not reproduced; parity tests inject latents
+explicitly, and ``sampler(X, generator=g)`` still draws exactly like factory.py:52-56).
 """
 from __future__ import annotations
 
@@ -27,7 +29,24 @@ from .generating.factory import sampler_factory
 
 
 def unit_seed(member: int, ic: int) -> int:
-    return (int(member) * 1_000_003 + int(ic) * 7919 + 12345) & 0x7FFFFFFF
+    """The 64-bit Philox key of a (member, IC) unit: member in the high word, the IC's dataset index in the low one --
+    collision-free, independent of rank and batch."""
+    return ((int(member) & 0x7FFFFFFF) << 32) | (int(ic) & 0xFFFFFFFF)
+
+
+def update_stats(dataset, interval: int, device):
+    """(mean_x, std_x, std_t) for ``ops.rollout_update``, shared by the generate rollout and the in-training validation
+    rollout.  std_t is None for a non-residual dataset (generate.py:132-136, validate.py:112-116: the output is the next
+    standardised state, the trajectory gets ``unstandardize_x`` of it -- with the SST channel, if present, zeroed by
+    ``zero_field`` at the default delta, data/era5.py:135-170)."""
+    residual = getattr(dataset, "residual", False)
+    mx, sx, st = dataset.rollout_stats(int(interval) if residual else 6, device)
+    if not residual:
+        if "sea_surface_temperature" in dataset.variables:
+            sx = sx.clone()
+            sx[list(dataset.variables).index("sea_surface_temperature")] = 0.0
+        st = None
+    return mx, sx, st
 
 
 class LazyForcings:
@@ -64,17 +83,9 @@ class RolloutEngine:
         self._stats = None
 
     def stats(self, device):
-        """(mean_x, std_x, std_t) for ``ops.rollout_update``; std_t is None for a non-residual dataset (generate.py:132-136:
-        the output is the next standardised state, the trajectory gets ``unstandardize_x`` of it -- with the SST channel, if
-        present, zeroed by ``zero_field`` at the default delta)."""
+        """``update_stats`` of this engine's dataset and interval, cached per device."""
         if self._stats is None or self._stats[0].device != device:
-            mx, sx, st = self.dataset.rollout_stats(self.interval if self.residual else 6, device)
-            if not self.residual:
-                if "sea_surface_temperature" in self.dataset.variables:
-                    sx = sx.clone()
-                    sx[list(self.dataset.variables).index("sea_surface_temperature")] = 0.0
-                st = None
-            self._stats = (mx, sx, st)
+            self._stats = update_stats(self.dataset, self.interval, device)
         return self._stats
 
     def stage_forcings(self, ic_indices: Sequence[int], steps: int, device) -> torch.Tensor:
@@ -94,26 +105,43 @@ class RolloutEngine:
         return LazyForcings(self, ic_indices, steps, device, pool)
 
     @torch.no_grad()
-    def capture_step(self, X: torch.Tensor, forc: torch.Tensor, z: torch.Tensor, phys: torch.Tensor) -> "torch.cuda.CUDAGraph":
+    def capture_step(self, X: torch.Tensor, forc: torch.Tensor, z: torch.Tensor, phys: torch.Tensor,
+                     seeds: Optional[torch.Tensor] = None, step: Optional[torch.Tensor] = None) -> "torch.cuda.CUDAGraph":
         """One forecast step (sampler + residual state update) recorded as a HIP graph over the caller's static tensors:
-        replaying it advances ``X`` in place from the noise currently in ``z`` and the forcings in ``forc``.  For the
-        launch-bound regime (a few units per step: ~100 launches per network evaluation against ~5 ms of kernels);
-        at 8+ units per step the launch queue already runs ahead of the kernels."""
+        replaying it advances ``X`` in place from the noise in ``z`` and the forcings in ``forc``.  With ``seeds`` (device
+        int64 [B]) and ``step`` (device int64 scalar) the latent draw is part of the graph too: every replay fills ``z`` for
+        lead step ``*step`` (``swiftk_unit_noise``) and advances the counter, so the WHOLE step is one replay; without them
+        the caller fills ``z`` before replaying.  For the launch-bound regime (a few units per step: ~100 launches per
+        network evaluation against ~5 ms of kernels); at 8+ units per step the launch queue already runs ahead of the kernels."""
         mx, sx, st = self.stats(X.device)
+        draw = seeds is not None
+        if draw and step is None:
+            raise ValueError("capture_step(seeds=...) needs the device step counter as well")
+
+        def body():
+            if draw:
+                ops.unit_noise(z, seeds, 0, step_dev=step)
+                ops.counter_add(step, 1)
+            Y = self.sampler((X, forc), latents=z)
+            ops.rollout_update(X, Y, mx, sx, st, phys=phys)
+
         side = torch.cuda.Stream(device=X.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up outside the capture: operand preparation, workspace allocation
             keep = X.clone()
+            step0 = step.clone() if draw else None
             for _ in range(2):
-                Y = self.sampler((X, forc), latents=z)
-                ops.rollout_update(X, Y, mx, sx, st, phys=phys)
+                body()
             X.copy_(keep)
+            if draw:
+                step.copy_(step0)
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with graphs.capture(graph):
-            Y = self.sampler((X, forc), latents=z)
-            ops.rollout_update(X, Y, mx, sx, st, phys=phys)
+            body()
         X.copy_(keep)
+        if draw:
+            step.copy_(step0)
         return graph
 
     @torch.no_grad()
@@ -123,7 +151,8 @@ class RolloutEngine:
         """Roll ``steps`` lead steps from the standardised state X0 [B, n_vars, H, W] (device, fp32).
 
         ``forcings`` [steps, B, n_forc, H, W] standardised, on the device.  ``latents(i)`` overrides the
-        noise of step i (tests); otherwise unit b draws from ``torch.Generator`` seeded ``seeds[b]``.
+        noise of step i (tests); otherwise unit b's latent of lead step i is the counter-based draw keyed by
+        (``seeds[b]``, i) -- one ``swiftk_unit_noise`` launch per step for the whole batch.
         Returns the physical trajectory as a [B, steps+1, n_vars, H, W] view of a step-major buffer
         ``out`` [steps+1, B, ...] (or the final physical state if ``keep_trajectory`` is False).
         ``after_step(j, out[j])`` is called on the host as soon as lead step j (0 = the initial state) has been ENQUEUED:
@@ -139,18 +168,14 @@ class RolloutEngine:
             out[0] = self.dataset.unstandardize_x(X.clone())
             if after_step is not None:
                 after_step(0, out[0])
-        gens = None
+        seeds_dev = zbuf = None
         if latents is None:
             seeds = list(seeds) if seeds is not None else list(range(B))
-            gens = [torch.Generator(device=dev).manual_seed(int(s)) for s in seeds]
+            seeds_dev = torch.tensor([int(s) for s in seeds], dtype=torch.int64, device=dev)
+            zbuf = torch.empty(B, nv, H, W, dtype=torch.float32, device=dev)
         phys = torch.empty_like(X)
         for i in range(steps):
-            if latents is not None:
-                z = latents(i)
-            else:
-                z = torch.empty(B, nv, H, W, dtype=torch.float32, device=dev)
-                for b, g in enumerate(gens):
-                    z[b].normal_(generator=g)
+            z = latents(i) if latents is not None else ops.unit_noise(zbuf, seeds_dev, i)
             Y = self.sampler((X, forcings[i]), latents=z)
             ops.rollout_update(X, Y, mx, sx, st, phys=out[i + 1] if keep_trajectory else phys)
             if keep_trajectory and after_step is not None:

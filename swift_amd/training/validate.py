@@ -16,6 +16,7 @@ import torch
 
 from .. import ops
 from .._lib import check, lib
+from ..rollout import update_stats
 
 
 def _lat_weights(dataset, H: int, device) -> torch.Tensor:
@@ -33,9 +34,9 @@ def RMSE_rollout(sampler: Callable[..., torch.Tensor], dataloader, dataset, targ
     sep = np.zeros([nv, target_interval // per_day + 1])
     if num_batches is None:
         num_batches = len(dataloader)
-    mx, sx, st = dataset.rollout_stats(6, device)
-    if not dataset.residual:  # validate.py:88-96, 112-114: the output is the next state; physical units through unstandardize_x
-        st = None
+    # validate.py:88-96, 112-116 -- one helper with the generate rollout, so that the non-residual branch (state targets; SST
+    # zeroed by zero_field) cannot drift apart between the two loops
+    mx, sx, st = update_stats(dataset, 6, device)
     w_lat = None
     for _ in range(num_batches):
         X, TS, idx = next(dataloader)

@@ -205,6 +205,82 @@ def test_modnorm_residual(dev, dt, rps):
     assert (xc[:, d:].float() == 7.0).all()  # pad columns untouched
 
 
+@pytest.mark.parametrize("rps", [512, 48])
+def test_modnorm_residual_pair(dev, rps):
+    """The bf16 engine's residual stream as a (hi, lo) bf16 pair (swiftk_split_pair, swiftk_modnorm_residual_pair): the split is
+    exact bf16 arithmetic (bit-equal to torch), the update is the oracle's ModulatedNorm + residual (swinv2.py:83-86, 211-212)
+    on x = hi + lo, stored back to 2^-17 relative, and hi is what a bf16 cast of the new x gives."""
+    from oracle.swinv2 import modulated_norm
+    from swift_amd import ops
+    B, d = 3, 1056
+    M = B * rps
+    y, x = rnd((M, d), 12, 2.0) + 0.5, rnd((M, d), 13)
+    p = {"n.norm.weight": 1 + 0.1 * rnd((d,), 14), "n.norm.bias": 0.1 * rnd((d,), 15),
+         "n.modulation.weight": 0.02 * rnd((2 * d, d), 16), "n.modulation.bias": 0.1 * rnd((2 * d,), 17)}
+    lat = rnd((B, d), 18)
+    ld = ops.k_pad(torch.bfloat16, d)
+    hi, lo = ops.split_pair(x.to(dev), ld)
+    xh = x.bfloat16()
+    assert torch.equal(hi[:, :d].cpu(), xh) and torch.equal(lo.cpu(), (x - xh.float()).bfloat16())
+    assert (hi[:, d:].float() == 0).all()
+    mod = torch.nn.functional.linear(lat, p["n.modulation.weight"], p["n.modulation.bias"])  # [B, 2d]: scale | shift
+    yd = to_dt(y, torch.bfloat16, dev)
+    hi[:, d:] = 7.0
+    ops.modnorm_residual_pair(yd, hi, lo, p["n.norm.weight"].to(dev), p["n.norm.bias"].to(dev), mod.to(dev), rps, d)
+    x_in = xh.float() + (x - xh.float()).bfloat16().float()
+    ref = x_in.view(B, rps, d) + modulated_norm(yd.float().cpu().view(B, rps, d), lat, p, "n.")
+    got = hi[:, :d].float().cpu() + lo.float().cpu()
+    e = rel_l2(got, ref.view(M, d))
+    print(f"pair ModulatedNorm (rows per sample {rps}): hi + lo vs oracle rel-L2 {e:.2e}")
+    assert e < 1e-5
+    assert float((got - ref.view(M, d)).abs().max() / ref.abs().max()) < 2.0 ** -15
+    # hi is the bf16 operand of the new x: lo stays within half an ulp of hi; re-rounding hi + lo differs only where lo rounded
+    # up to exactly half an ulp (a tie, ~2^-9 of the elements, half of which resolve the other way)
+    assert float((hi[:, :d].cpu() != got.bfloat16()).float().mean()) < 3e-3
+    assert float((lo.float().abs().cpu() > 2.0 ** -8 * hi[:, :d].float().abs().cpu() + 1e-30).float().mean()) == 0.0
+    assert (hi[:, d:].float() == 7.0).all()                  # pad columns untouched
+    # against the fp32-stream kernel on the same inputs: the operand copies agree except where x sits within 2^-17 of a tie
+    xd, xc = x_in.to(dev).clone(), torch.zeros(M, ld, dtype=torch.bfloat16, device=dev)
+    ops.modnorm_residual(yd, xd, p["n.norm.weight"].to(dev), p["n.norm.bias"].to(dev), mod.to(dev), rps, xcopy=xc)
+    assert float((xc[:, :d] != hi[:, :d]).float().mean()) < 1e-3
+    assert rel_l2(got, xd.cpu()) < 1e-5
+
+
+def test_unit_noise_vs_oracle(dev):
+    """swiftk_unit_noise: the generator's words bit for bit against the numpy Philox4x32-10 of oracle/noise.py (which
+    tests/test_oracle_golden.py pins to Random123's known answers), the normals against its Box-Muller, and the properties a
+    rollout relies on: a pure function of (seed, step, element) whatever the batch, moments of N(0, 1)."""
+    from oracle import noise as onoise
+    from swift_amd import ops
+    n = 69 * 32 * 64
+    seeds = [12345, (7 << 40) + 99, 2 ** 63 - 1, 0]
+    sd = torch.tensor(seeds, dtype=torch.int64, device=dev)
+    out = torch.empty(len(seeds), n, device=dev)
+    for step in (0, 3, (1 << 33) + 5):
+        ops.unit_noise(out, sd, step, raw=True)
+        bits = out.view(torch.int32).cpu().numpy().view(np.uint32)
+        for b, s_ in enumerate(seeds):
+            assert np.array_equal(bits[b], onoise.unit_bits(s_, step, n)), (b, step)
+        ops.unit_noise(out, sd, step)
+        z = out.cpu().numpy()
+        for b, s_ in enumerate(seeds):
+            ref = onoise.unit_noise(s_, step, n)
+            assert np.abs(z[b] - ref).max() < 2e-5, (b, step, np.abs(z[b] - ref).max())
+    # device-side step counter (what a captured step reads) == host-side step; one unit alone == the same unit in a batch
+    ctr = torch.tensor([3], dtype=torch.int64, device=dev)
+    a = ops.unit_noise(torch.empty(len(seeds), n, device=dev), sd, 0, step_dev=ctr).clone()
+    ops.unit_noise(out, sd, 3)
+    assert torch.equal(a, out)
+    ops.counter_add(ctr, 2)
+    assert int(ctr.item()) == 5
+    one = ops.unit_noise(torch.empty(1, n, device=dev), sd[2:3], 3)
+    assert torch.equal(one[0], out[2])
+    big = ops.unit_noise(torch.empty(2, 69 * 128 * 256, device=dev), sd[:2], 11)
+    assert abs(float(big.mean())) < 2e-3 and abs(float(big.var()) - 1.0) < 3e-3
+    assert abs(float((big[0] * big[1]).mean())) < 3e-3 and abs(float((big[0, :-1] * big[0, 1:]).mean())) < 3e-3
+    assert float(big.abs().max()) < 6.5 and torch.isfinite(big).all()
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_patchify_three_sources(dev, dt):
     from oracle.swinv2 import patchify
@@ -395,6 +471,23 @@ def test_fused_qkv_attention(dev, shift, B):
     ref = torch.empty(B, n, heads * hd)
     ref[:, idx.reshape(-1)] = ow.permute(0, 2, 1, 3).reshape(B, n, -1)
     assert rel_l2(fused.float().cpu(), ref) < 1.2e-2
+    # (c) the ORACLE as the yardstick, nothing from the HIP library in the reference value: to_qkv by F.linear on the same
+    # bf16-valued operands, then oracle.cosine_window_attention over the oracle's window index map (swinv2.py:119-136,
+    # 185-208) -- in exact fp32 (distance = the kernel's bf16 rounding of q-hat / k-hat / v / P) and with the oracle's
+    # bf16-operand emulation (distance = two independent roundings of the same quantities)
+    import torch.nn.functional as F
+    from oracle.swinv2 import cosine_window_attention
+    af, wf = ad[:, :d].float().cpu(), wd[:, :d].float().cpu()
+    qkv = F.linear(af, wf).view(B, n, -1)
+    sc = scale.cpu().view(1, heads, 1, 1)
+    for emu, tol in ((False, 1.2e-2), (True, 1.2e-2)):
+        ow = cosine_window_attention(qkv[:, idx.reshape(-1)].reshape(B * idx.shape[0], 256, -1), sc, heads, naive=True,
+                                     emulate_bf16=emu)
+        oref = torch.empty(B, n, heads * hd)
+        oref[:, idx.reshape(-1)] = ow.reshape(B, idx.numel(), -1)
+        e = rel_l2(fused.float().cpu(), oref)
+        print(f"fused to_qkv + attention vs oracle (emulate_bf16={emu}), shift {shift}, B {B}: rel-L2 {e:.3e}")
+        assert e < tol
 
 
 def test_fused_qkv_attention_rejects_what_it_cannot_run(dev):

@@ -217,6 +217,111 @@ def test_gradient_allreduce_world2_equals_single_process(tmp_path):
     assert torch.equal(torch.load(solo), a)
 
 
+WORLD8_WORKER = textwrap.dedent("""
+    import os, sys, types, json, numpy as np, torch
+    sys.path.insert(0, %(root)r)
+    from swift_amd import dist
+    from swift_amd.generate import create_empty_numpy, rollout_and_save, select_indices
+    from swift_amd.data.era5 import SyntheticERA5Dataset
+    from swift_amd.rollout import unit_seed
+
+    class FakeEngine:   # stands in for RolloutEngine: a deterministic function of (X0, forcings, seed), CPU only
+        interval = 6
+        seen = []
+        def stage_forcings(self, ics, steps, device):
+            return torch.stack([torch.stack([ds.get_forcings(j + i) for j in ics]) for i in range(steps)])
+        def run(self, X0, forc, steps, seeds=None, **kw):
+            FakeEngine.seen += [int(s) for s in seeds]
+            out = [X0]
+            for i in range(steps):
+                z = torch.stack([torch.randn(X0.shape[1:], generator=torch.Generator().manual_seed((int(s) + i) %% (2 ** 62)))
+                                 for s in seeds])
+                out.append(0.9 * out[-1] + 0.1 * z + forc[i].mean(dim=1, keepdim=True))
+            return torch.stack(out, 1)
+
+    dist.setup_torch(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ds = SyntheticERA5Dataset(["t2m", "z_500"], ["f0"], img_resolution=(2, 4), length=200, seed=5)
+    members, ics, steps = 12, 64, 2                     # BASELINE configs[3]'s unit space: 12 x 64 = 768
+    idx = select_indices(len(ds), ics, steps, 6)
+    ofile = sys.argv[1]
+    dist.run_on_rank0(create_empty_numpy, ofile, len(idx), 2, (2, 4), members, steps)
+    args = types.SimpleNamespace(dump="numpy", batch=96)
+    rollout_and_save(FakeEngine(), ds, idx, members, steps, ofile, torch.device("cpu"), args)
+    mine = dist.shard_units(members * ics, rank, world)
+    assert len(FakeEngine.seen) == len(mine) == (768 // world), (len(FakeEngine.seen), len(mine))
+    want = [unit_seed(u %% members, idx[u // members]) for u in mine]     # IC-major: unit u = ic * members + member
+    assert FakeEngine.seen == want
+    json.dump({"rank": rank, "first": mine[0], "n": len(mine)}, open(ofile + f".rank{rank}.json", "w"))
+    dist.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+""")
+
+
+@pytest.mark.timeout(600)
+def test_generate_world8_is_the_configs3_partition(tmp_path):
+    """BASELINE configs[3] on the node it names: 12 members x 64 ICs = 768 (member, IC) units over EIGHT ranks = 96 contiguous
+    IC-major units each (8 whole ICs per rank), written into one store that equals the one-rank store.  gloo on CPU with a
+    stand-in engine -- the partition, the seeds each rank asks for and the shared store are what an 8-GPU run adds."""
+    import json
+    script = tmp_path / "w8.py"
+    script.write_text(WORLD8_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    one = str(tmp_path / "one.npy")
+    subprocess.run([sys.executable, str(script), one], check=True, env={**env, "WORLD_SIZE": "1", "RANK": "0"}, timeout=300)
+    a = np.load(one)
+    assert a.shape == (64, 12, 3, 2, 2, 4) and np.isfinite(a).all()
+    out = str(tmp_path / "w8.npy")
+    port = str(29500 + (os.getpid() + 8) % 90)
+    procs = [subprocess.Popen([sys.executable, str(script), out],
+                              env={**env, "WORLD_SIZE": "8", "RANK": str(r), "LOCAL_RANK": str(r), "MASTER_PORT": port})
+             for r in range(8)]
+    assert [p.wait(timeout=400) for p in procs] == [0] * 8
+    np.testing.assert_array_equal(a, np.load(out))
+    recs = [json.load(open(out + f".rank{r}.json")) for r in range(8)]
+    assert [r["n"] for r in recs] == [96] * 8 and [r["first"] for r in recs] == [96 * r for r in range(8)]
+
+
+@pytest.mark.timeout(600)
+def test_gradient_allreduce_world8_equals_single_process(tmp_path):
+    """BASELINE configs[4]'s group size: 8 ranks x local batch 1 with the early announcements + one averaged all-reduce ==
+    1 process x batch 8."""
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(DDP_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    one, eight = str(tmp_path / "g1.pt"), str(tmp_path / "g8.pt")
+    subprocess.run([sys.executable, str(script), one], check=True, env={**env, "WORLD_SIZE": "1", "RANK": "0"}, timeout=200)
+    port = str(29700 + os.getpid() % 90)
+    procs = [subprocess.Popen([sys.executable, str(script), eight],
+                              env={**env, "WORLD_SIZE": "8", "RANK": str(r), "LOCAL_RANK": str(r), "MASTER_PORT": port})
+             for r in range(8)]
+    assert [p.wait(timeout=400) for p in procs] == [0] * 8
+    a, b = torch.load(one), torch.load(eight)
+    assert a.abs().sum() > 0 and torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_rollout_update_stats_non_residual_sst():
+    """One helper feeds generate's and the validation rollout's update kernel: a non-residual dataset gets
+    std_t = None, and sea_surface_temperature -- zeroed by zero_field in the reference (data/era5.py:135-170) -- a zero
+    un-standardisation scale in BOTH loops."""
+    from swift_amd.data.era5 import SyntheticERA5Dataset
+    from swift_amd.rollout import RolloutEngine, update_stats
+    names = ["t2m", "sea_surface_temperature", "z_500"]
+    for residual in (True, False):
+        ds = SyntheticERA5Dataset(names, ["f0"], img_resolution=(4, 8), length=16, seed=3, random_stats=True, residual=residual)
+        mx, sx, st = update_stats(ds, 6, "cpu")
+        assert (st is None) == (not residual)
+        if residual:
+            assert float(mx[1]) == 0.0 and float(sx[1]) == 1.0 and float(st[1]) == 0.0
+        else:
+            assert float(sx[1]) == 0.0 and float(sx[0]) != 0.0 and float(sx[2]) != 0.0
+        eng = RolloutEngine.__new__(RolloutEngine)
+        eng.dataset, eng.interval, eng.residual, eng._stats = ds, 6, residual, None
+        got = eng.stats(torch.device("cpu"))
+        assert all((a is None and b is None) or torch.equal(a, b) for a, b in zip(got, (mx, sx, st)))
+
+
 MUON_WORKER = textwrap.dedent("""
     import os, sys, torch
     sys.path.insert(0, %(root)r)

@@ -640,7 +640,48 @@ def fx_swiftb_2s_bf16():
     save("swiftb_2s_bf16", seed=seed, fingerprint=state_fingerprint(state), bf16_autocast_rel_sub=rel)
 
 
-ALL = dict(swiftb_2s_bf16=fx_swiftb_2s_bf16, scm_distill_tiny=fx_scm_distill_tiny, index_streams=fx_index_streams, era5_tiny=fx_era5_tiny, swiftb_long=fx_swiftb_long, trainer_tiny=fx_trainer_tiny, metrics_tiny=fx_metrics_tiny, val_tiny=fx_val_tiny, muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
+def fx_swiftb_fp64():
+    """The fp64 truth for BASELINE configs[1] and [2] at full size: the reference itself with ``net.double()``, fp64 inputs
+    and fp64 default dtype (so the solvers' time grids and ``timestep_embedding`` are fp64 too) -- the same seeded weights
+    and inputs as swiftb_step / swiftb_long, which are fp32 values and upcast exactly.  Stored: the sub-sampled fp64
+    outputs and how far the reference's OWN fp32 run (the stored swiftb_step / swiftb_long sub-samples) is from them.
+    The yardstick that tells fp32 rounding noise from a defect in tests/test_gpu_model.py."""
+    from swift.generating.diffusion import DiffusionSampler
+    import time
+    c, seed = SWIFTB, 1234
+    net, state = build_ref_net(c, seed)
+    nv, nf = c["n_vars"], c["n_forc"]
+    cond = det_normal((1, nv + nf, *c["img"]), seed, "cond").double()
+    lat = det_normal((1, nv, *c["img"]), seed, "lat").double()
+    torch.set_default_dtype(torch.float64)
+    try:
+        net = net.double()
+        S = DiffusionSampler(net)
+        t0 = time.time()
+        with torch.no_grad():
+            y1 = S.scm_solver(lat, condition=cond, num_steps=1, sigma_min=0.02, sigma_max=200.0, auxiliary=0.6,
+                              denoise_dtype=torch.float64)
+            print(f"reference fp64 scm step: {time.time() - t0:.1f} s", flush=True)
+            assert y1.dtype == torch.float64
+            t0 = time.time()
+            y2 = S.dpm_solver_2s(lat, condition=cond, num_steps=20, sigma_min=0.02, sigma_max=200.0, auxiliary=0.6,
+                                 denoise_dtype=torch.float64)
+            print(f"reference fp64 dpm_solver_2s (39 evaluations): {time.time() - t0:.1f} s", flush=True)
+            assert y2.dtype == torch.float64
+    finally:
+        torch.set_default_dtype(torch.float32)
+    y1s, y2s = y1[0, ::4, ::8, ::8], y2[0, ::4, ::8, ::8]
+    r1 = torch.from_numpy(np.load(os.path.join(OUT, "swiftb_step.npz"))["y_sub"]).double()
+    r2 = torch.from_numpy(np.load(os.path.join(OUT, "swiftb_long.npz"))["y2s_sub"]).double()
+    d1 = float((r1 - y1s).norm() / y1s.norm())
+    d2 = float((r2 - y2s).norm() / y2s.norm())
+    print(f"reference fp32 vs fp64 (sub-sample): scm step {d1:.3e}, dpm_solver_2s {d2:.3e}")
+    save("swiftb_fp64", seed=seed, fingerprint=state_fingerprint(state), y1_sub=y1s, y2s_sub=y2s,
+         ref_fp32_vs_fp64_step=d1, ref_fp32_vs_fp64_2s=d2,
+         y1_norm=float(y1.norm()), y2s_norm=float(y2.norm()))
+
+
+ALL = dict(swiftb_fp64=fx_swiftb_fp64, swiftb_2s_bf16=fx_swiftb_2s_bf16, scm_distill_tiny=fx_scm_distill_tiny, index_streams=fx_index_streams, era5_tiny=fx_era5_tiny, swiftb_long=fx_swiftb_long, trainer_tiny=fx_trainer_tiny, metrics_tiny=fx_metrics_tiny, val_tiny=fx_val_tiny, muon_tiny=fx_muon_tiny, swinv2_tiny=fx_swinv2_tiny, swinv2_smallb=fx_swinv2_smallb, attention_hd88=fx_attention_hd88,
            samplers_tiny=fx_samplers_tiny, rollout_tiny=fx_rollout_tiny, losses_tiny=fx_losses_tiny,
            swiftb_step=fx_swiftb_step, weights_aux=fx_weights_aux)
 
