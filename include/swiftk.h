@@ -88,6 +88,19 @@ int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
                 void* stream);
 
 /*
+ * swiftk_gemm for fp32 operands with TWO-LEVEL accumulation: the MFMA chain restarts every `chunk_k` k (a multiple of 32)
+ * and the partial sums meet in fp32 through `scratch` (caller-owned, >= swiftk_gemm_chunk_scratch_bytes(), 16-B aligned;
+ * a workgroup-private slab that stays cache-resident).  One chain over K = 1056 .. 2816 ends 1.8 x further from the fp64
+ * product than ATen's blocked CPU sgemm (tools/fp32_bisect.py); chains of 256 bring the exact-fp32 engine to the reference's
+ * own fp32 accuracy.  Same epilogues, same results up to summation order.  Replaces F.linear of
+ * src/swift/models/swinv2.py:119,137,99-100,229,239 in the exact-fp32 engine.
+ */
+int swiftk_gemm_chunked(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                        int64_t K, int dtype, int out_dtype, int epilogue, const float* ep0, const float* ep1,
+                        int64_t pos_rows, int chunk_k, void* scratch, int64_t scratch_bytes, void* stream);
+int64_t swiftk_gemm_chunk_scratch_bytes(void);
+
+/*
  * Shifted-window cosine attention, fused: window gather (+cyclic roll), L2
  * normalisation of q and k, per-head logit scale exp(min(s, ln 100)), softmax
  * over the 256 keys of the window, P V, scatter back to token order.
@@ -222,7 +235,8 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * kernel (3), key 7 = start-up stagger of the persistent GEMM's workgroups in 1/1000 of an eighth of a tile time (0),
  * key 8 = to_qkv + window attention as one kernel in swiftk_swinv2_forward (1; key 4 bits 8..15 = that kernel's ablations,
  * bits 16.. = those of the persistent attention backward), key 9 = persistent attention backward for head_dim 88 (1),
- * key 12 = bf16 forward keeps the residual stream as a (hi, lo) bf16 pair (1; 0 = fp32 stream + bf16 operand copy). */
+ * key 12 = bf16 forward keeps the residual stream as a (hi, lo) bf16 pair (1; 0 = fp32 stream + bf16 operand copy),
+ * key 13 = chain length (in k) of the fp32-operand GEMMs' two-level accumulation in swiftk_swinv2_forward (256; 0 = off). */
 int swiftk_set_tuning(int key, int value);
 /* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
  * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default

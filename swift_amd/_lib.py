@@ -63,6 +63,8 @@ _SIGS = {
     "swiftk_version": ([], C.c_int),
     "swiftk_gemm_k_pad": ([_i, _l], _l),
     "swiftk_gemm": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _i, _i, _i, _p, _p, _l, _p], _i),
+    "swiftk_gemm_chunked": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _i, _i, _i, _p, _p, _l, _i, _p, _l, _p], _i),
+    "swiftk_gemm_chunk_scratch_bytes": ([], _l),
     "swiftk_window_attention": ([_p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_modnorm_residual": ([_p, _l, _p, _p, _l, _p, _p, _p, _l, _l, _i, _l, _f, _i, _p], _i),
     "swiftk_modnorm_residual_pair": ([_p, _l, _p, _l, _p, _l, _p, _p, _p, _l, _l, _i, _l, _f, _p], _i),

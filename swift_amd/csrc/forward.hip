@@ -7,6 +7,7 @@ int g_fwd_tiled = 1;  // tuning key 5 (A/B only): 0 keeps q/k/v row-major betwee
 int g_x3_exact = 17;  // tuning key 11: the DEFAULT mask a host binding copies into swiftk_model.x3_exact when it packs the weights
                       // (the forward reads the model's own field, never this global: ADVICE r3)
 int g_fwd_pair = 1;   // tuning key 12: bf16 engine keeps the residual stream as a (hi, lo) bf16 pair (hi = the GEMM operand)
+int g_f32_chunk_k = 256;  // tuning key 13: fp32-operand GEMMs of the forward accumulate in chains of this many k (0 = one chain over K)
 int g_fwd_fused = 1;  // tuning key 8 (A/B only): 0 = to_qkv and window attention as two kernels (q/k/v window-tiled through HBM)
 
 namespace {
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(256) void zero_cols_kernel(char* p, int64_t ld_b, i
 }
 
 struct Layout {
-    int64_t emb, h1, lat, mod, ape, x, xt, xlo, qkv, att, y, hmid, tok, a3, total;
+    int64_t emb, h1, lat, mod, ape, x, xt, xlo, qkv, att, y, hmid, tok, kscr, a3, total;
 };
 
 inline int64_t al(int64_t v) { return (v + 255) & ~(int64_t)255; }
@@ -55,6 +56,8 @@ Layout make_layout(const swiftk_model* m, int B) {
     L.y = o; o += al(M * d * es);
     L.hmid = o; o += al(M * m->kmlp * es);
     L.tok = o; o += al(M * (int64_t)((m->out_ch * m->p1 * m->p2 + 3) & ~3) * 4);
+    L.kscr = o;
+    if (m->dtype != SWIFTK_BF16) o += al(swiftk_gemm_chunk_scratch_bytes());  // parked accumulators of the fp32-operand GEMMs
     L.a3 = o;
     if (m->dtype == SWIFTK_BF16X3) {  // the split GEMM operand [M, k_pad(3 K)] bf16 of the widest GEMM input
         const int64_t kin = (int64_t)m->in_ch * m->p1 * m->p2;
@@ -112,6 +115,9 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     // width, or the valid one when it ends half-way into the last k-tile), `kvalid` the number of meaningful columns of A
     auto G = [&](const void* A, int64_t lda, const void* Wm, void* Cm, int64_t ldc, int64_t N, int64_t kpass, int64_t kvalid,
                  int out_dt, int epi, const float* e0, const float* e1, int64_t pr, bool exact = false) -> int {
+        if (dt == SWIFTK_F32 && (!x3 || exact) && g_f32_chunk_k > 0)  // exact fp32 product: two-level accumulation (gemm.hip)
+            return swiftk_gemm_chunked(A, lda, Wm, lda, Cm, ldc, M, N, kpass, dt, out_dt, epi, e0, e1, pr, g_f32_chunk_k, ws + L.kscr,
+                                       swiftk_gemm_chunk_scratch_bytes(), stream);
         if (!x3 || exact) return swiftk_gemm(A, lda, Wm, lda, Cm, ldc, M, N, kpass, dt, out_dt, epi, e0, e1, pr, stream);
         const int64_t kv = (kvalid + 3) & ~(int64_t)3;  // (columns [kvalid, kv) of A are zero k-padding; the weight has them too)
         const int64_t ld3 = swiftk_gemm_k_pad(SWIFTK_BF16, 3 * kv);

@@ -111,6 +111,11 @@ struct GemmArgs {
     int64_t batch_a, batch_w, batch_c;  // one-tile-per-workgroup kernel only: byte steps of A / W / C per blockIdx.y (batched GEMM)
     // QKNORM only: window-tiled output [sample][window][head][q|k|v][256][88] (t_gw = 0: plain row-major C)
     int t_gh, t_gw, t_sh, t_sw, t_heads;
+    // fp32 operands, persistent kernel: two-level accumulation.  Every `kchunk` k-tiles a workgroup parks its accumulators in
+    // its private slab of `kscr` (lane-major float4s: blockIdx.x, wave, (i, j), lane) and restarts from zero; a tile's last
+    // k-tile adds the parked sum back before the epilogue.  0 = one chain over the whole K range.
+    float* kscr;
+    int kchunk;
 };
 
 template <typename T>
@@ -481,6 +486,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 #pragma unroll
     for (int p = 0; p < 10; ++p) issue_piece(lds0, (uint32_t)kt * ROWB, p);
     int par = 0;
+    bool have_part = false;  // (fp32 operands, kchunk > 0) this tile has a partial sum parked in the workgroup's scratch slab
     // dbg bit 32 (timing experiment, EPI_NONE only): wave 0 of every 32nd workgroup logs s_memtime at five points of each tile
     // into the buffer passed as ep1 -- [wg/32][tile][8] uint64: loop top of the first k-step, last MFMA issued, epilogue
     // barrier passed, stores issued, next loop top passed, sum of the k-steps' vmcnt(0) waits, sum of their barrier waits
@@ -630,13 +636,72 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             }
         }
         par ^= 1;
-        if (!last_k) {
+        // Two-level accumulation (fp32 operands, g.kchunk > 0).  One MFMA chain over K = 1056 .. 2816 rounds 264 .. 704 times
+        // at the growing partial sum's magnitude and ends 1.8 x further from the fp64 product than the CPU's blocked sgemm
+        // (tools/fp32_bisect.py: the GEMMs are the ONLY op family of the fp32 engine less accurate than ATen's).  Chains of
+        // `kchunk` k-tiles, summed through the workgroup's cache-resident scratch slab, bring that to the CPU's level; a
+        // 256 x 352 fp32 tile takes ~300 us, parking 352 KB a few times per tile is not measurable.  Written like the ACCUM
+        // epilogue (groups of four blocks, the next group's loads in flight) and placed behind the k-step's own wait, so the
+        // k-loop's register allocation is the plain kernel's.
+        auto chunk_io = [&](const bool rd, const bool wr) {
+            int elane = lane;  // (opaque copy: hipcc otherwise hoists the 44 slab addresses above the k-loop and spills them)
+            asm volatile("" : "+v"(elane));
+            float4* scr = reinterpret_cast<float4*>(g.kscr) + ((int64_t)blockIdx.x * 8 + wv) * (MI * NI) * 64 + elane;
+            constexpr int JH = 4, GPI = (NI + JH - 1) / JH, NG = MI * GPI;
+            float4 buf[2][JH];
+            auto load_group = [&](int gidx, float4 (&b)[JH]) {
+                const int i = gidx / GPI, jh = (gidx - i * GPI) * JH;
+#pragma unroll
+                for (int jj = 0; jj < JH; ++jj) {
+                    b[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (jh + jj < NI && rd) b[jj] = scr[(i * NI + jh + jj) * 64];
+                }
+            };
+            load_group(0, buf[0]);
+#pragma unroll
+            for (int gidx = 0; gidx < NG; ++gidx) {
+                if (gidx + 1 < NG) load_group(gidx + 1, buf[(gidx + 1) & 1]);
+                const int i = gidx / GPI, jh = (gidx - i * GPI) * JH;
+#pragma unroll
+                for (int jj = 0; jj < JH; ++jj) {
+                    if (jh + jj < NI) {
+                        const int j = jh + jj;
+                        const float4 o = buf[gidx & 1][jj];
+                        f32x4 v = acc[i][j];
+                        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                        if (wr) {
+                            scr[(i * NI + j) * 64] = make_float4(v[0], v[1], v[2], v[3]);
+                            v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        acc[i][j] = v;
+                    }
+                }
+            }
+        };
+        bool chain_end = last_k;
+        if constexpr (sizeof(T) == 4) chain_end = last_k || (g.kchunk > 0 && (kt + 1 - k_begin(tile)) % g.kchunk == 0);
+        if (!chain_end) {
             ++kt;
             // (a k-tile that is not its tile's last is never the half one: both k-halves ran, so with the look-ahead on its two
             // requests are this wave's youngest VMEM operations and stay in flight)
             if constexpr (TOUCH) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             continue;
+        }
+        if constexpr (sizeof(T) == 4) {
+            // end of a chain that is not the tile's last: park the partial sum (added to what is parked already);
+            // the tile's last chain: add what the earlier ones parked, then the epilogue proper.  ONE call site.
+            if (have_part || !last_k) {
+                chunk_io(have_part, !last_k);
+                have_part = !last_k;
+            }
+            if (!last_k) {
+                ++kt;
+                // VMEM retires in issue order: the next stage's DMA pieces are older than the park's MI x NI stores, so leaving
+                // exactly those outstanding is enough -- they drain under the next chain's MFMAs
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NI) : "memory");
+                continue;
+            }
         }
         bool interior = false;
         // ---- epilogue of `tile`: lane holds C[m][nb .. nb+3] for m = ..+r16, nb = ..+4*(lane>>4) ----
@@ -1044,6 +1109,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 9: g_attn_bwd_pipe = value; return 0;
         case 11: g_x3_exact = value; return 0;
         case 12: g_fwd_pair = value; return 0;
+        case 13: g_f32_chunk_k = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -1062,6 +1128,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 9: return g_attn_bwd_pipe;
         case 11: return g_x3_exact;
         case 12: return g_fwd_pair;
+        case 13: return g_f32_chunk_k;
     }
     return SWIFTK_EINVAL;
 }
@@ -1095,7 +1162,8 @@ extern "C" int64_t swiftk_gemm_k_pad(int dtype, int64_t k) {
 
 static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
                      int64_t K, int dtype, int out_dtype, int epilogue, const float* ep0, const float* ep1, int64_t pos_rows,
-                     int ksplit, int64_t c_split, void* stream, const int* tiling = nullptr) {
+                     int ksplit, int64_t c_split, void* stream, const int* tiling = nullptr, float* kscr = nullptr,
+                     int kchunk = 0) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || ksplit < 1) return SWIFTK_EINVAL;
     if (ksplit > 1 && (out_dtype != SWIFTK_F32 || epilogue != SWIFTK_EPI_NONE || c_split < M * ldc)) return SWIFTK_EINVAL;
     if (epilogue == SWIFTK_EPI_ACCUM && out_dtype != SWIFTK_F32) return SWIFTK_EINVAL;
@@ -1165,6 +1233,14 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
         const int pm = g_stagger_permille % 10000;  // key 7 values >= 10000: per-XCD phases
         if (tiles >= 4 * 256) g.stagger = (int)(tile_s * 1e8 / 8.0 * pm / 1000.0) * (g_stagger_permille >= 10000 ? -1 : 1);
     }
+    g.kscr = kscr;
+    g.kchunk = 0;
+    if (kscr && dtype == SWIFTK_F32 && ksplit == 1 && kchunk > 0) {
+        // chains of equal length: K = 1056 (33 k-tiles) at a nominal 8 tiles -> 4 chains of 9, 9, 9, 6 (three parks per tile),
+        // not 8, 8, 8, 8, 1
+        const int nkt = (int)(K / tile_k), chains = nkt / kchunk > 1 ? nkt / kchunk : 1;
+        g.kchunk = chains > 1 ? (nkt + chains - 1) / chains : 0;
+    }
     g.t_gh = g.t_gw = g.t_sh = g.t_sw = g.t_heads = 0;
     if (tiling) {
         g.t_gh = tiling[0]; g.t_gw = tiling[1]; g.t_sh = tiling[2]; g.t_sw = tiling[3]; g.t_heads = tiling[4];
@@ -1181,6 +1257,22 @@ extern "C" int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ld
                            int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, const float* ep0, const float* ep1,
                            int64_t pos_rows, void* stream) {
     return gemm_impl(A, lda, W, ldw, C, ldc, M, N, K, dtype, out_dtype, epilogue, ep0, ep1, pos_rows, 1, 0, stream);
+}
+
+extern "C" int64_t swiftk_gemm_chunk_scratch_bytes(void) {
+    // persistent grid x 8 waves x (4 x 12) accumulator tiles x 64 lanes x 16 B (the widest tile geometry)
+    return (int64_t)(g_persist_wgs > 256 ? g_persist_wgs : 256) * 8 * (MI * 12) * 64 * 16;
+}
+
+extern "C" int swiftk_gemm_chunked(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
+                                   int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, const float* ep0,
+                                   const float* ep1, int64_t pos_rows, int chunk_k, void* scratch, int64_t scratch_bytes,
+                                   void* stream) {
+    if (dtype != SWIFTK_F32 || chunk_k <= 0 || chunk_k % 32) return SWIFTK_EINVAL;
+    if (!scratch || ((uintptr_t)scratch & 15)) return SWIFTK_EALIGN;
+    if (scratch_bytes < swiftk_gemm_chunk_scratch_bytes()) return SWIFTK_EWORKSPACE;
+    return gemm_impl(A, lda, W, ldw, C, ldc, M, N, K, dtype, out_dtype, epilogue, ep0, ep1, pos_rows, 1, 0, stream, nullptr,
+                     static_cast<float*>(scratch), chunk_k / 32);
 }
 
 // C_b = A_b W_b^T for b < batch, every matrix of a stack at a constant step from the previous one: one launch of the
@@ -1216,6 +1308,8 @@ extern "C" int swiftk_gemm_batched(const void* A, int64_t lda, int64_t stride_a,
     g.khalf = g.touch = g.stagger = 0;
     g.ksplit = 1;
     g.c_split = 0;
+    g.kscr = nullptr;
+    g.kchunk = 0;
     g.batch_a = stride_a * 2;
     g.batch_w = stride_w * 2;
     g.batch_c = stride_c * os;

@@ -90,6 +90,30 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *
     return out
 
 
+_chunk_scratch = {}
+
+
+def gemm_chunked(a: torch.Tensor, w: torch.Tensor, *, chunk_k: int = 256, out_dtype: Optional[torch.dtype] = None,
+                 epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None,
+                 head_dim: int = 0) -> torch.Tensor:
+    """``gemm`` for fp32 operands with two-level accumulation (``swiftk_gemm_chunked``): MFMA chains of ``chunk_k``, partial
+    sums met in fp32 through a scratch slab -- the exact-fp32 engine's product."""
+    _dev(a, w, bias, pos)
+    M, K = a.shape
+    N = w.shape[0]
+    assert a.dtype == w.dtype == torch.float32 and w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
+    need = int(lib().swiftk_gemm_chunk_scratch_bytes())
+    scr = _chunk_scratch.get(a.device)
+    if scr is None or scr.numel() < need:
+        scr = _chunk_scratch[a.device] = torch.empty(need, dtype=torch.uint8, device=a.device)
+    out = torch.empty(M, N // 2 if epilogue == EPI_SWIGLU else N, dtype=out_dtype or torch.float32, device=a.device)
+    check(lib().swiftk_gemm_chunked(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+                                    dtype_code(a.dtype), dtype_code(out.dtype), epilogue, _ptr(bias), _ptr(pos),
+                                    (head_dim if epilogue == EPI_QKNORM else 0) if pos is None else pos.shape[0], int(chunk_k),
+                                    scr.data_ptr(), scr.numel(), _stream()), "swiftk_gemm_chunked")
+    return out
+
+
 def gemm_qkv_tiled(a: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, B: int, grid: Tuple[int, int], heads: int,
                    shift: Tuple[int, int] = (0, 0), out: Optional[torch.Tensor] = None, k: Optional[int] = None,
                    head_dim: int = 88) -> torch.Tensor:

@@ -113,6 +113,38 @@ def test_gemm_swiglu_backward_epilogue(dev, H):
     assert bool(dh[:, 2 * H:].isnan().all())
 
 
+@pytest.mark.parametrize("K", [1056, 2816, 576])
+def test_gemm_fp32_two_level_accumulation(dev, K):
+    """swiftk_gemm_chunked (round 4): fp32 operands, MFMA chains of 256 k met through a scratch slab.  The plain kernel's
+    single chain over K ends measurably further from the fp64 product than the chained form (tools/fp32_bisect.py traced the
+    exact engine's 1.8 x excess over the CPU's fp32 error to it); both stay inside the per-op tolerance, the epilogues see
+    the same accumulators."""
+    from swift_amd import ops
+    M, N = 2048 + 24, 704
+    a, w = rnd((M, K), 41), rnd((N, K), 42, 0.05)
+    ad, wd = a.to(dev), w.to(dev)
+    ref = a.double() @ w.double().T
+    plain, chained = ops.gemm(ad, wd), ops.gemm_chunked(ad, wd, chunk_k=256)
+    e_p, e_c = rel_l2(plain.cpu(), ref), rel_l2(chained.cpu(), ref)
+    e_cpu = rel_l2(a @ w.T, ref)
+    print(f"fp32 GEMM K={K}: rel-L2 vs fp64: one chain {e_p:.2e}, chains of 256 {e_c:.2e}, CPU sgemm {e_cpu:.2e}")
+    assert e_p < F32_TOL and e_c < F32_TOL
+    assert e_c < (0.8 * e_p if K > 1000 else 1.05 * e_p)
+    assert rel_l2(chained.cpu(), plain.cpu()) < 2e-6
+    # several tiles per workgroup (the parked slab is re-used tile after tile) and a ragged last row tile
+    M2 = 256 * 300 + 40
+    a2 = rnd((M2, 192), 43).to(dev)
+    w2 = rnd((352, 192), 44, 0.05).to(dev)
+    assert rel_l2(ops.gemm_chunked(a2, w2, chunk_k=64).cpu(), a2.cpu().double() @ w2.cpu().double().T) < F32_TOL
+    # fused epilogues take the merged accumulators
+    H = 352
+    w1 = rnd((2 * H, K), 45, 0.03)
+    wi = w1.view(2, H, K).permute(1, 0, 2).reshape(2 * H, K).contiguous()
+    c = ops.gemm_chunked(ad, wi.to(dev), epilogue=ops.EPI_SWIGLU)
+    h = a.double() @ w1.double().T
+    assert rel_l2(c.cpu(), torch.nn.functional.silu(h[:, :H]) * h[:, H:]) < F32_TOL
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N", [1056, 1280, 1536])
 def test_gemm_accumulate(dev, dt, N):

@@ -41,7 +41,8 @@ def hip_linear(a, w, b=None):
     if id(w) not in wcache:
         wcache[id(w)] = ops.pad_cols(w.to(dev), kp, torch.float32)
     a2 = ops.pad_cols(a.reshape(-1, K).to(dev), kp, torch.float32)
-    y = ops.gemm(a2, wcache[id(w)], out_dtype=torch.float32).cpu().reshape(*a.shape[:-1], w.shape[0])
+    y = (ops.gemm_chunked(a2, wcache[id(w)], chunk_k=CHUNK) if CHUNK else ops.gemm(a2, wcache[id(w)], out_dtype=torch.float32))
+    y = y.cpu().reshape(*a.shape[:-1], w.shape[0])
     return y if b is None else y + b
 def hip_attn(qkv, scale, heads_, naive=False, emulate_bf16=False):
     Bw = qkv.shape[0]
@@ -60,14 +61,21 @@ def run(lin=lin0, att=att0, norm=norm0):
             return onet(x, t, cond, 0.6)
     finally:
         F.linear, osw.cosine_window_attention, osw.modulated_norm = lin0, att0, norm0
-res = {"cpu": rel(run()), "+gemm": rel(run(lin=hip_linear)), "+attn": rel(run(att=hip_attn)), "+norm": rel(run(norm=hip_norm)),
-       "+gemm+attn+norm": rel(run(hip_linear, hip_attn, hip_norm))}
+CHUNK = 256
+res = {"cpu": rel(run()), "+gemm (chains of 256 k)": rel(run(lin=hip_linear))}
+CHUNK = 0
+res.update({"+gemm (one chain)": rel(run(lin=hip_linear)), "+attn": rel(run(att=hip_attn)), "+norm": rel(run(norm=hip_norm)),
+       "+gemm+attn+norm": rel(run(hip_linear, hip_attn, hip_norm))})
 mcfg = dict(_target_="swift.models.swinv2.SwinV2", window_size=[16, 16], shift_size=[8, 8], patch_size=[2, 2], depth=depth, dim=dim, heads=heads)
 net = PassPrecond(mcfg, img_resolution=list(img), img_channels=nv, condition_channels=nv + nf, auxiliary_dim=1)
 net.load_state_dict(state)
 net = net.to(dev).eval()
+from swift_amd import _lib
 with torch.no_grad():
-    res["engine"] = rel(net(x.to(dev), t.to(dev), cond.to(dev), 0.6))
+    res["engine (chains of 256 k)"] = rel(net(x.to(dev), t.to(dev), cond.to(dev), 0.6))
+    _lib.lib().swiftk_set_tuning(13, 0)
+    res["engine (one chain)"] = rel(net(x.to(dev), t.to(dev), cond.to(dev), 0.6))
+    _lib.lib().swiftk_set_tuning(13, 256)
 print(f"depth {depth}, rel-L2 against the fp64 oracle:")
 for k, v in res.items():
-    print(f"  {k:18s} {v:.3e}  ({v / res['cpu']:.2f} x cpu)")
+    print(f"  {k:26s} {v:.3e}  ({v / res['cpu']:.2f} x cpu)")
