@@ -2,6 +2,7 @@
 // patchify / un-patchify with the concat and the sampler update folded in, the tiny
 // time-embedding MLP, the rollout state update and operand casts.
 #include "common.h"
+#include <type_traits>
 
 int g_modnorm_nt = 3;  // tuning key 6: bit 0 = stream the fp32 residual with non-temporal loads / stores, bit 1 = chunked kernel
 
@@ -230,9 +231,26 @@ __device__ __forceinline__ void store_q_nt(bf16_t* p, const uint4& q) {
     __builtin_nontemporal_store(u4{q.x, q.y, q.z, q.w}, reinterpret_cast<u4*>(p));
 }
 
-template <int SLOTS>
+
+// 8-bit low part of the pair form: x = hi + l8 * ulp(hi) / 256 with l8 = rint((x - hi) * 256 / ulp(hi)) in [-127, 127]
+// (|x - hi| <= ulp / 2), ulp(hi) = 2^(E - 134) for hi's biased exponent E: x is held to ulp / 512 = 2^-17 relative, the
+// bf16 low part's accuracy, in one byte.  E < 16 (|hi| < 2^-111): the low part is dropped (scale factors out of range).
+__device__ __forceinline__ float lo8_unit(uint32_t hi_bits16) {  // ulp(hi) / 256 as a float
+    const int E = (int)((hi_bits16 >> 7) & 0xFFu);
+    return E >= 16 ? __uint_as_float((uint32_t)(E - 15) << 23) : 0.0f;
+}
+__device__ __forceinline__ float lo8_inv_unit(uint32_t hi_bits16) {  // 256 / ulp(hi)
+    const int E = (int)((hi_bits16 >> 7) & 0xFFu);
+    return E >= 16 ? __uint_as_float((uint32_t)(269 - E) << 23) : 0.0f;
+}
+__device__ __forceinline__ int lo8_encode(float x, bf16_t h) {
+    const float q = rintf((x - bf2f(h)) * lo8_inv_unit(h));
+    return (int)fminf(fmaxf(q, -127.0f), 127.0f);
+}
+
+template <int SLOTS, bool LO8>
 __global__ __launch_bounds__(256, SLOTS == 3 ? SWIFTK_MNP_OCC : 2) void modnorm_pair_kernel(const bf16_t* __restrict__ y, int64_t ldy,
-                                                            bf16_t* __restrict__ xh, int64_t ldh, bf16_t* __restrict__ xl,
+                                                            bf16_t* __restrict__ xh, int64_t ldh, void* __restrict__ xl_,
                                                             int64_t ldl, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ mod,
                                                             int64_t ldmod, int64_t M, int d, int64_t rps, float eps, int nt) {
@@ -263,7 +281,10 @@ __global__ __launch_bounds__(256, SLOTS == 3 ? SWIFTK_MNP_OCC : 2) void modnorm_
     }
     __syncthreads();
     if (row0 >= row_end) return;
-    struct Row { uint4 y[SLOTS], h[SLOTS], l[SLOTS]; };
+    bf16_t* xl = static_cast<bf16_t*>(xl_);   // bf16 low parts ...
+    int8_t* xl8 = static_cast<int8_t*>(xl_);  // ... or one signed byte each (LO8)
+    using LoT = typename std::conditional<LO8, uint2, uint4>::type;  // a slot's low parts: 8 bytes or 8 bf16
+    struct Row { uint4 y[SLOTS], h[SLOTS]; LoT l[SLOTS]; };
     Row ra, rb;
     auto load_row = [&](int64_t row, Row& r) {
 #pragma unroll
@@ -272,7 +293,11 @@ __global__ __launch_bounds__(256, SLOTS == 3 ? SWIFTK_MNP_OCC : 2) void modnorm_
             if (c < nc) {
                 r.y[i] = NT ? load_q_nt(y + row * ldy + 8 * c) : load_q(y + row * ldy + 8 * c);
                 r.h[i] = load_q(xh + row * ldh + 8 * c);
-                r.l[i] = NT ? load_q_nt(xl + row * ldl + 8 * c) : load_q(xl + row * ldl + 8 * c);
+                if constexpr (LO8) {
+                    r.l[i] = *reinterpret_cast<const uint2*>(xl8 + row * ldl + 8 * c);
+                } else {
+                    r.l[i] = NT ? load_q_nt(xl + row * ldl + 8 * c) : load_q(xl + row * ldl + 8 * c);
+                }
             }
         }
     };
@@ -309,25 +334,41 @@ __global__ __launch_bounds__(256, SLOTS == 3 ? SWIFTK_MNP_OCC : 2) void modnorm_
                 raw8<bf16_t> t;
                 t.q = r.h[i];
                 unpack_raw(t, hi);
-                t.q = r.l[i];
-                unpack_raw(t, lo);
-                uint32_t oh[4], ol[4];
+                if constexpr (LO8) {
+                    const uint32_t hb[4] = {r.h[i].x, r.h[i].y, r.h[i].z, r.h[i].w};
+                    const uint32_t lb[2] = {r.l[i].x, r.l[i].y};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t h16 = (e & 1) ? (hb[e >> 1] >> 16) : (hb[e >> 1] & 0xFFFFu);
+                        const int l8 = (int)(int8_t)((lb[e >> 2] >> (8 * (e & 3))) & 0xFFu);
+                        lo[e] = (float)l8 * lo8_unit(h16);
+                    }
+                } else {
+                    const LoT lq = r.l[i];
+                    t.q = make_uint4(lq.x, lq.y, reinterpret_cast<const uint32_t*>(&lq)[LO8 ? 0 : 2], reinterpret_cast<const uint32_t*>(&lq)[LO8 ? 1 : 3]);
+                    unpack_raw(t, lo);
+                }
+                uint32_t oh[4], ol[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float xn = (hi[e] + lo[e]) + ((v[i][e] * rstd) * P[e] + Q[e]);
                     const bf16_t h = f2bf(xn);
-                    const bf16_t l = f2bf(xn - bf2f(h));
-                    if (e & 1) {
-                        oh[e >> 1] |= (uint32_t)h << 16;
-                        ol[e >> 1] |= (uint32_t)l << 16;
+                    if (e & 1) oh[e >> 1] |= (uint32_t)h << 16;
+                    else oh[e >> 1] = h;
+                    if constexpr (LO8) {
+                        ol[e >> 2] |= ((uint32_t)lo8_encode(xn, h) & 0xFFu) << (8 * (e & 3));
                     } else {
-                        oh[e >> 1] = h;
-                        ol[e >> 1] = l;
+                        const bf16_t l = f2bf(xn - bf2f(h));
+                        ol[e >> 1] |= (uint32_t)l << ((e & 1) ? 16 : 0);
                     }
                 }
                 *reinterpret_cast<uint4*>(xh + row * ldh + 8 * c) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
-                if (NT) store_q_nt(xl + row * ldl + 8 * c, make_uint4(ol[0], ol[1], ol[2], ol[3]));
-                else *reinterpret_cast<uint4*>(xl + row * ldl + 8 * c) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+                if constexpr (LO8) {
+                    *reinterpret_cast<uint2*>(xl8 + row * ldl + 8 * c) = make_uint2(ol[0], ol[1]);
+                } else {
+                    if (NT) store_q_nt(xl + row * ldl + 8 * c, make_uint4(ol[0], ol[1], ol[2], ol[3]));
+                    else *reinterpret_cast<uint4*>(xl + row * ldl + 8 * c) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+                }
             }
         }
     };
@@ -343,8 +384,9 @@ __global__ __launch_bounds__(256, SLOTS == 3 ? SWIFTK_MNP_OCC : 2) void modnorm_
 
 // fp32 -> (hi, lo) bf16 pair, hi with zeroed k-padding columns [cols, ldh) (it is a GEMM operand), lo [rows, ldl]
 __global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict__ src, int64_t lds, bf16_t* __restrict__ hi,
-                                                         int64_t ldh, bf16_t* __restrict__ lo, int64_t ldl, int64_t rows,
-                                                         int64_t cols) {
+                                                         int64_t ldh, void* __restrict__ lo_, int64_t ldl, int64_t rows,
+                                                         int64_t cols, int lo8) {
+    bf16_t* lo = static_cast<bf16_t*>(lo_);
     const int64_t per = ldh >> 2, total = rows * per;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / per, c = i - r * per;
@@ -362,8 +404,15 @@ __global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict
         }
         *reinterpret_cast<uint2*>(hi + r * ldh + 4 * c) =
             make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-        *reinterpret_cast<uint2*>(lo + r * ldl + 4 * c) =
-            make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+        if (lo8) {
+            uint32_t b = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b |= ((uint32_t)lo8_encode(f[e], h[e]) & 0xFFu) << (8 * e);
+            *reinterpret_cast<uint32_t*>(static_cast<int8_t*>(lo_) + r * ldl + 4 * c) = b;
+        } else {
+            *reinterpret_cast<uint2*>(lo + r * ldl + 4 * c) =
+                make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+        }
     }
 }
 
@@ -819,35 +868,38 @@ extern "C" int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, voi
 }
 
 extern "C" int swiftk_modnorm_residual_pair(const void* y, int64_t ldy, void* x_hi, int64_t ldh, void* x_lo, int64_t ldl,
-                                            const float* gamma, const float* beta, const float* mod, int64_t ldmod, int64_t M,
-                                            int d, int64_t rows_per_sample, float eps, void* stream) {
+                                            int lo_bits, const float* gamma, const float* beta, const float* mod, int64_t ldmod,
+                                            int64_t M, int d, int64_t rows_per_sample, float eps, void* stream) {
     if (!y || !x_hi || !x_lo || !gamma || !beta || !mod || M <= 0 || d <= 0 || rows_per_sample <= 0) return SWIFTK_EINVAL;
+    if (lo_bits != 16 && lo_bits != 8) return SWIFTK_EINVAL;
     if (d % 8 || d > 2048 || rows_per_sample % MN_ROWS) return SWIFTK_ESHAPE;
     if (ldy < d || ldh < d || ldl < d) return SWIFTK_ESHAPE;
-    if (((uintptr_t)y & 15) || (ldy * 2) % 16 || ((uintptr_t)x_hi & 15) || (ldh * 2) % 16 || ((uintptr_t)x_lo & 15) ||
-        (ldl * 2) % 16 || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)mod & 15) || (ldmod % 4))
+    const int lb = lo_bits / 8;
+    if (((uintptr_t)y & 15) || (ldy * 2) % 16 || ((uintptr_t)x_hi & 15) || (ldh * 2) % 16 || ((uintptr_t)x_lo & (8 * lb - 1)) ||
+        (ldl * lb) % (8 * lb) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)mod & 15) || (ldmod % 4))
         return SWIFTK_EALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int cgrid = (int)((M + MN_ROWS - 1) / MN_ROWS);
-    if (d <= 3 * 512)
-        hipLaunchKernelGGL((modnorm_pair_kernel<3>), dim3(cgrid), dim3(256), 0, st, static_cast<const bf16_t*>(y), ldy,
-                           static_cast<bf16_t*>(x_hi), ldh, static_cast<bf16_t*>(x_lo), ldl, gamma, beta, mod, ldmod, M, d,
-                           rows_per_sample, eps, g_modnorm_nt);
-    else
-        hipLaunchKernelGGL((modnorm_pair_kernel<4>), dim3(cgrid), dim3(256), 0, st, static_cast<const bf16_t*>(y), ldy,
-                           static_cast<bf16_t*>(x_hi), ldh, static_cast<bf16_t*>(x_lo), ldl, gamma, beta, mod, ldmod, M, d,
-                           rows_per_sample, eps, g_modnorm_nt);
+#define SWIFTK_MNP(SL, L8)                                                                                                     \
+    hipLaunchKernelGGL((modnorm_pair_kernel<SL, L8>), dim3(cgrid), dim3(256), 0, st, static_cast<const bf16_t*>(y), ldy,        \
+                       static_cast<bf16_t*>(x_hi), ldh, x_lo, ldl, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps, g_modnorm_nt)
+    if (d <= 3 * 512) {
+        if (lo_bits == 8) SWIFTK_MNP(3, true); else SWIFTK_MNP(3, false);
+    } else {
+        if (lo_bits == 8) SWIFTK_MNP(4, true); else SWIFTK_MNP(4, false);
+    }
+#undef SWIFTK_MNP
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int swiftk_split_pair(const float* src, int64_t lds, void* hi, int64_t ldh, void* lo, int64_t ldl, int64_t rows,
-                                 int64_t cols, void* stream) {
-    if (!src || !hi || !lo || rows <= 0 || cols <= 0) return SWIFTK_EINVAL;
+extern "C" int swiftk_split_pair(const float* src, int64_t lds, void* hi, int64_t ldh, void* lo, int64_t ldl, int lo_bits,
+                                 int64_t rows, int64_t cols, void* stream) {
+    if (!src || !hi || !lo || rows <= 0 || cols <= 0 || (lo_bits != 16 && lo_bits != 8)) return SWIFTK_EINVAL;
     if (cols % 4 || ldh % 4 || ldl % 4 || lds % 4 || ldh < cols || ldl < cols || lds < cols) return SWIFTK_ESHAPE;
     if (((uintptr_t)src & 15) || ((uintptr_t)hi & 7) || ((uintptr_t)lo & 7)) return SWIFTK_EALIGN;
     hipLaunchKernelGGL(split_pair_kernel, dim3(grid_for(rows * (ldh >> 2))), dim3(256), 0, static_cast<hipStream_t>(stream), src,
-                       lds, static_cast<bf16_t*>(hi), ldh, static_cast<bf16_t*>(lo), ldl, rows, cols);
+                       lds, static_cast<bf16_t*>(hi), ldh, lo, ldl, rows, cols, lo_bits == 8 ? 1 : 0);
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

@@ -6,7 +6,7 @@
 int g_fwd_tiled = 1;  // tuning key 5 (A/B only): 0 keeps q/k/v row-major between to_qkv and attention
 int g_x3_exact = 17;  // tuning key 11: the DEFAULT mask a host binding copies into swiftk_model.x3_exact when it packs the weights
                       // (the forward reads the model's own field, never this global: ADVICE r3)
-int g_fwd_pair = 1;   // tuning key 12: bf16 engine keeps the residual stream as a (hi, lo) bf16 pair (hi = the GEMM operand)
+int g_fwd_pair = 2;   // tuning key 12: bf16 engine's residual stream: 2 = (bf16 hi, int8 lo) pair, 1 = (bf16 hi, bf16 lo), 0 = fp32 + copy
 int g_f32_chunk_k = 256;  // tuning key 13: fp32-operand GEMMs of the forward accumulate in chains of this many k (0 = one chain over K)
 int g_fwd_fused = 1;  // tuning key 8 (A/B only): 0 = to_qkv and window attention as two kernels (q/k/v window-tiled through HBM)
 
@@ -152,7 +152,8 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     // bf16 engine: from here on the residual stream is the pair (xT = hi, xlo = lo); the fp32 x is not touched again
     const bool pair = dt == SWIFTK_BF16 && g_fwd_pair && ntok % 16 == 0 && d % 8 == 0 && d <= 2048;
     void* xlo = ws + L.xlo;
-    if (pair) RUN(swiftk_split_pair(x, d, xT, m->kd, xlo, d, M, d, stream));
+    const int lo_bits = g_fwd_pair == 1 ? 16 : 8;
+    if (pair) RUN(swiftk_split_pair(x, d, xT, m->kd, xlo, d, lo_bits, M, d, stream));
     else RUN(swiftk_cast_pad(x, d, xT, m->kd, M, d, dt, stream));
     if (m->kd > d) {  // K-padding columns of the attention output must be finite (they meet zero weight columns)
         hipLaunchKernelGGL(zero_cols_kernel, dim3(1024), dim3(256), 0, st, static_cast<char*>(att), m->kd * es, d * es,
@@ -197,7 +198,7 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
         }
         RUN(G(att, m->kd, ly.wo_w, y, d, d, kdv, d, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (x3_exact & 2) != 0));
         if (pair)
-            RUN(swiftk_modnorm_residual_pair(y, d, xT, m->kd, xlo, d, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M,
+            RUN(swiftk_modnorm_residual_pair(y, d, xT, m->kd, xlo, d, lo_bits, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M,
                                              d, ntok, 1e-6f, stream));
         else
             RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok,
@@ -205,7 +206,7 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
         RUN(G(xT, m->kd, ly.w1_w, hmid, m->kmlp, 2 * m->mlp, kdv, d, dt, SWIFTK_EPI_SWIGLU, nullptr, nullptr, 0, (x3_exact & 4) != 0));
         RUN(G(hmid, m->kmlp, ly.w2_w, y, d, d, m->kmlp, m->mlp, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (x3_exact & 8) != 0));
         if (pair)
-            RUN(swiftk_modnorm_residual_pair(y, d, xT, m->kd, xlo, d, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, ldmod,
+            RUN(swiftk_modnorm_residual_pair(y, d, xT, m->kd, xlo, d, lo_bits, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, ldmod,
                                              M, d, ntok, 1e-6f, stream));
         else
             RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d,

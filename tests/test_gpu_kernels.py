@@ -237,11 +237,13 @@ def test_modnorm_residual(dev, dt, rps):
     assert (xc[:, d:].float() == 7.0).all()  # pad columns untouched
 
 
+@pytest.mark.parametrize("lo_bits", [8, 16])
 @pytest.mark.parametrize("rps", [512, 48])
-def test_modnorm_residual_pair(dev, rps):
-    """The bf16 engine's residual stream as a (hi, lo) bf16 pair (swiftk_split_pair, swiftk_modnorm_residual_pair): the split is
-    exact bf16 arithmetic (bit-equal to torch), the update is the oracle's ModulatedNorm + residual (swinv2.py:83-86, 211-212)
-    on x = hi + lo, stored back to 2^-17 relative, and hi is what a bf16 cast of the new x gives."""
+def test_modnorm_residual_pair(dev, rps, lo_bits):
+    """The bf16 engine's residual stream as a pair -- hi = bf16(x) plus a bf16 or an int8 low part (swiftk_split_pair,
+    swiftk_modnorm_residual_pair): the split is exact bf16 arithmetic (bit-equal to torch), the update is the oracle's
+    ModulatedNorm + residual (swinv2.py:83-86, 211-212) on the value the pair stands for, stored back to 2^-17 relative, and hi
+    is what a bf16 cast of the new x gives."""
     from oracle.swinv2 import modulated_norm
     from swift_amd import ops
     B, d = 3, 1056
@@ -251,25 +253,30 @@ def test_modnorm_residual_pair(dev, rps):
          "n.modulation.weight": 0.02 * rnd((2 * d, d), 16), "n.modulation.bias": 0.1 * rnd((2 * d,), 17)}
     lat = rnd((B, d), 18)
     ld = ops.k_pad(torch.bfloat16, d)
-    hi, lo = ops.split_pair(x.to(dev), ld)
+    hi, lo = ops.split_pair(x.to(dev), ld, lo_bits)
     xh = x.bfloat16()
-    assert torch.equal(hi[:, :d].cpu(), xh) and torch.equal(lo.cpu(), (x - xh.float()).bfloat16())
-    assert (hi[:, d:].float() == 0).all()
+    assert torch.equal(hi[:, :d].cpu(), xh) and (hi[:, d:].float() == 0).all()
+    if lo_bits == 16:
+        assert torch.equal(lo.cpu(), (x - xh.float()).bfloat16())
+    else:
+        assert lo.dtype == torch.int8 and int(lo.abs().max()) <= 127
+    x_in = ops.pair_value(hi, lo, d).cpu()
+    assert float(((x_in - x).abs() / x.abs().clamp_min(1e-20)).max()) < 2.0 ** -15
     mod = torch.nn.functional.linear(lat, p["n.modulation.weight"], p["n.modulation.bias"])  # [B, 2d]: scale | shift
     yd = to_dt(y, torch.bfloat16, dev)
     hi[:, d:] = 7.0
     ops.modnorm_residual_pair(yd, hi, lo, p["n.norm.weight"].to(dev), p["n.norm.bias"].to(dev), mod.to(dev), rps, d)
-    x_in = xh.float() + (x - xh.float()).bfloat16().float()
     ref = x_in.view(B, rps, d) + modulated_norm(yd.float().cpu().view(B, rps, d), lat, p, "n.")
-    got = hi[:, :d].float().cpu() + lo.float().cpu()
+    got = ops.pair_value(hi, lo, d).cpu()
     e = rel_l2(got, ref.view(M, d))
-    print(f"pair ModulatedNorm (rows per sample {rps}): hi + lo vs oracle rel-L2 {e:.2e}")
+    print(f"pair ModulatedNorm (rows per sample {rps}, {lo_bits}-bit low part): pair value vs oracle rel-L2 {e:.2e}")
     assert e < 1e-5
     assert float((got - ref.view(M, d)).abs().max() / ref.abs().max()) < 2.0 ** -15
     # hi is the bf16 operand of the new x: lo stays within half an ulp of hi; re-rounding hi + lo differs only where lo rounded
     # up to exactly half an ulp (a tie, ~2^-9 of the elements, half of which resolve the other way)
     assert float((hi[:, :d].cpu() != got.bfloat16()).float().mean()) < 3e-3
-    assert float((lo.float().abs().cpu() > 2.0 ** -8 * hi[:, :d].float().abs().cpu() + 1e-30).float().mean()) == 0.0
+    if lo_bits == 16:
+        assert float((lo.float().abs().cpu() > 2.0 ** -8 * hi[:, :d].float().abs().cpu() + 1e-30).float().mean()) == 0.0
     assert (hi[:, d:].float() == 7.0).all()                  # pad columns untouched
     # against the fp32-stream kernel on the same inputs: the operand copies agree except where x sits within 2^-17 of a tie
     xd, xc = x_in.to(dev).clone(), torch.zeros(M, ld, dtype=torch.bfloat16, device=dev)

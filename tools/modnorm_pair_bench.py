@@ -16,22 +16,25 @@ x0 = torch.randn(M, d, device=dev)
 gamma, beta = 1 + 0.1 * torch.randn(d, device=dev), 0.1 * torch.randn(d, device=dev)
 mod = 0.3 * torch.randn(B, 48 * d, device=dev)[:, 4 * d:6 * d]
 xc = torch.zeros(M, ld, dtype=torch.bfloat16, device=dev)
-hi, lo = ops.split_pair(x0, ld)
+hi, lo = ops.split_pair(x0, ld, 16)
+hi8, lo8 = ops.split_pair(x0, ld, 8)
 x = x0.clone()
 def f32(): ops.modnorm_residual(y, x, gamma, beta, mod, 8192, xcopy=xc)
 def pair(): ops.modnorm_residual_pair(y, hi, lo, gamma, beta, mod, 8192, d)
-f32(); pair(); torch.cuda.synchronize()
-print("after one call: hi == bf16 copy of the fp32 stream on", float((hi[:, :d] == xc[:, :d]).float().mean()), "of the elements; "
-      "rel-L2 of hi + lo vs fp32 stream", float(((hi[:, :d].float() + lo.float()) - x).norm() / x.norm()))
-res = {"fp32 stream (14 B/elt)": [], "pair (10 B/elt)": []}
+def pair8(): ops.modnorm_residual_pair(y, hi8, lo8, gamma, beta, mod, 8192, d)
+f32(); pair(); pair8(); torch.cuda.synchronize()
+for nm, (h_, l_) in (("bf16 low part", (hi, lo)), ("int8 low part", (hi8, lo8))):
+    print(f"after one call, {nm}: hi == bf16 copy of the fp32 stream on", float((h_[:, :d] == xc[:, :d]).float().mean()),
+          "of the elements; rel-L2 of the pair's value vs fp32 stream", float((ops.pair_value(h_, l_, d) - x).norm() / x.norm()))
+res = {"fp32 stream (14 B/elt)": [], "pair, bf16 lo (10 B/elt)": [], "pair, int8 lo (8 B/elt)": []}
 for rnd in range(R):
-    order = list(zip(res, (f32, pair)))
+    order = list(zip(res, (f32, pair, pair8)))
     for name, fn in (order if rnd % 2 == 0 else order[::-1]):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5): fn()
         e1.record(); torch.cuda.synchronize(); res[name].append(e0.elapsed_time(e1) / 5)
-for (name, t), bpe in zip(res.items(), (14.0, 10.0)):
+for (name, t), bpe in zip(res.items(), (14.0, 10.0, 8.0)):
     t = sorted(t); med = t[len(t) // 2]
     print(f"{name}: median {med*1e3:8.1f} us  min {t[0]*1e3:8.1f} us  {M*d*bpe/med/1e6:7.1f} GB/s of algorithmic bytes", flush=True)
