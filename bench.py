@@ -409,9 +409,16 @@ def main():
                     "frac": flop / att_s / PEAK_BF16, "traffic": traffic.get("qkv_attn_fused"), "launches": int(att_n.value),
                     "avg_launch_ms": att_s * 1e3, "flop_per_launch": flop, "algorithmic_bytes_per_launch": bytes_,
                     "attention_core_flop_per_launch": B * 8.858e9,
-                    "note": "MFMA utilisation over the fused FLOPs (window attention's QK^T / PV run on the tile the to_qkv k-loop just "
-                            "produced, q/k/v stay in LDS); replaces swiftk_gemm_qkv_tiled + swiftk_window_attention, which moved "
-                            "10 GB of q/k/v per layer through HBM at 96 units"}
+                    "note": "frac = fused FLOPs / time / the 2.5 PF dense peak (a 2.4 GHz figure).  SQ counters of this kernel at 96 units "
+                            "(profiles/r04a_qkv_attn_sq_counters_report.txt): MFMA pipe busy 0.53 of the SIMD cycles at an effective "
+                            "clock of 1.92 GHz under this load (0.53 x 1.92 / 2.4 = 0.43); the attention core alone (fused minus a build "
+                            "with the core skipped, 0.73 ms of the 5.9) runs at 0.63 MFMA-busy with 4.5 VALU instructions per MFMA and "
+                            "no LDS bank conflicts, the to_qkv k-loop around it at 0.51 -- the plain to_qkv GEMM's 0.50.  The 6.5 x "
+                            "fabric traffic (traffic vs algorithmic_bytes_per_launch: weight slabs re-streamed per window) is not the "
+                            "limiter (head-grouped order: +2 % time, profiles/r03e_*_ab8.txt).  Replaces swiftk_gemm_qkv_tiled + "
+                            "swiftk_window_attention, which moved 10 GB of q/k/v per layer through HBM at 96 units",
+                    "mfma_pipe_busy": {"kernel": 0.532, "attention_core": 0.628, "to_qkv_k_loop": 0.512, "plain_to_qkv_gemm": 0.504,
+                                       "effective_clock_ghz": 1.92, "source": "profiles/r04a_qkv_attn_sq_counters_report.txt (rocprofv3 --pmc, 96 units)"}}
             else:
                 att_bytes, att_flop = B * 8192 * 4 * 1056 * 2.0, B * 8.858e9
                 line["attention_roofline"] = {

@@ -115,7 +115,9 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     // width, or the valid one when it ends half-way into the last k-tile), `kvalid` the number of meaningful columns of A
     auto G = [&](const void* A, int64_t lda, const void* Wm, void* Cm, int64_t ldc, int64_t N, int64_t kpass, int64_t kvalid,
                  int out_dt, int epi, const float* e0, const float* e1, int64_t pr, bool exact = false) -> int {
-        if (dt == SWIFTK_F32 && (!x3 || exact) && g_f32_chunk_k > 0)  // exact fp32 product: two-level accumulation (gemm.hip)
+        // the exact-fp32 engine's products: two-level accumulation (gemm.hip).  The split engine's two exact GEMMs keep one chain:
+        // its error is the (hi, lo) split's 2^-17, not the chain's
+        if (dt == SWIFTK_F32 && !x3 && g_f32_chunk_k > 0)
             return swiftk_gemm_chunked(A, lda, Wm, lda, Cm, ldc, M, N, kpass, dt, out_dt, epi, e0, e1, pr, g_f32_chunk_k, ws + L.kscr,
                                        swiftk_gemm_chunk_scratch_bytes(), stream);
         if (!x3 || exact) return swiftk_gemm(A, lda, Wm, lda, Cm, ldc, M, N, kpass, dt, out_dt, epi, e0, e1, pr, stream);
