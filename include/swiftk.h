@@ -141,6 +141,13 @@ int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, void* xcopy, i
 int swiftk_modnorm_residual_pair(const void* y, int64_t ldy, void* x_hi, int64_t ldh, void* x_lo, int64_t ldl, int lo_bits,
                                  const float* gamma, const float* beta, const float* mod, int64_t ldmod, int64_t M, int d,
                                  int64_t rows_per_sample, float eps, void* stream);
+/* The same with the branch output given as the SUM of two fp32 slabs y_slabs and y_slabs + slab_stride ([M, ldy] each): what
+ * swiftk_gemm_splitk(..., ksplit = 2) leaves.  At one unit per step wo / w2 have 96 output tiles for 256 CUs; two k-ranges
+ * per tile fill three quarters of the chip and the norm kernel does the reduction on its way (swiftk_swinv2_forward,
+ * tuning key 14). */
+int swiftk_modnorm_residual_pair_slabs(const float* y_slabs, int64_t ldy, int64_t slab_stride, void* x_hi, int64_t ldh, void* x_lo,
+                                       int64_t ldl, int lo_bits, const float* gamma, const float* beta, const float* mod,
+                                       int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps, void* stream);
 /* fp32 [rows, lds] -> the pair form: hi [rows, ldh] bf16 with columns [cols, ldh) zeroed (GEMM k-padding), lo [rows, ldl]
  * (bf16 or int8 by lo_bits, ldl in elements). */
 int swiftk_split_pair(const float* src, int64_t lds, void* hi, int64_t ldh, void* lo, int64_t ldl, int lo_bits, int64_t rows,
@@ -240,7 +247,8 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * bits 16.. = those of the persistent attention backward), key 9 = persistent attention backward for head_dim 88 (1),
  * key 12 = residual stream of the bf16 forward: 2 = (bf16 hi, int8 lo) pair (default), 1 = (bf16 hi, bf16 lo) pair, 0 = fp32
  * stream + bf16 operand copy,
- * key 13 = chain length (in k) of the fp32-operand GEMMs' two-level accumulation in swiftk_swinv2_forward (256; 0 = off). */
+ * key 13 = chain length (in k) of the fp32-operand GEMMs' two-level accumulation in swiftk_swinv2_forward (256; 0 = off),
+ * key 14 = split-K wo / w2 at one unit per step (1). */
 int swiftk_set_tuning(int key, int value);
 /* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
  * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default

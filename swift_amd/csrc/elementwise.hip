@@ -248,8 +248,10 @@ __device__ __forceinline__ int lo8_encode(float x, bf16_t h) {
     return (int)fminf(fmaxf(q, -127.0f), 127.0f);
 }
 
-template <int SLOTS, bool LO8>
-__global__ __launch_bounds__(256, SLOTS == 3 ? SWIFTK_MNP_OCC : 2) void modnorm_pair_kernel(const bf16_t* __restrict__ y, int64_t ldy,
+// YF32: y arrives as TWO fp32 slabs (y and y + yslab, row stride ldy) whose sum is the branch output -- the split-K form of wo / w2
+// at one or two units per step, where 96 output tiles cannot fill 256 CUs (forward.hip)
+template <int SLOTS, bool LO8, bool YF32>
+__global__ __launch_bounds__(256, (SLOTS == 3 && !YF32) ? SWIFTK_MNP_OCC : ((SLOTS == 4 && YF32) ? 1 : 2)) void modnorm_pair_kernel(const void* __restrict__ y_, int64_t ldy, int64_t yslab,
                                                             bf16_t* __restrict__ xh, int64_t ldh, void* __restrict__ xl_,
                                                             int64_t ldl, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ mod,
@@ -281,17 +283,28 @@ __global__ __launch_bounds__(256, SLOTS == 3 ? SWIFTK_MNP_OCC : 2) void modnorm_
     }
     __syncthreads();
     if (row0 >= row_end) return;
+    const bf16_t* y = static_cast<const bf16_t*>(y_);
+    const float* yf = static_cast<const float*>(y_);
     bf16_t* xl = static_cast<bf16_t*>(xl_);   // bf16 low parts ...
     int8_t* xl8 = static_cast<int8_t*>(xl_);  // ... or one signed byte each (LO8)
     using LoT = typename std::conditional<LO8, uint2, uint4>::type;  // a slot's low parts: 8 bytes or 8 bf16
-    struct Row { uint4 y[SLOTS], h[SLOTS]; LoT l[SLOTS]; };
+    using YT = typename std::conditional<YF32, raw8<float>, uint4>::type;  // a slot of y: 8 bf16, or the 8 summed floats
+    struct Row { YT y[SLOTS]; uint4 h[SLOTS]; LoT l[SLOTS]; };
     Row ra, rb;
     auto load_row = [&](int64_t row, Row& r) {
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const int c = lane + 64 * i;
             if (c < nc) {
-                r.y[i] = NT ? load_q_nt(y + row * ldy + 8 * c) : load_q(y + row * ldy + 8 * c);
+                if constexpr (YF32) {
+                    raw8<float> s0, s1;
+                    load_raw(yf + row * ldy + 8 * c, s0);
+                    load_raw(yf + yslab + row * ldy + 8 * c, s1);
+                    r.y[i].a = make_float4(s0.a.x + s1.a.x, s0.a.y + s1.a.y, s0.a.z + s1.a.z, s0.a.w + s1.a.w);
+                    r.y[i].b = make_float4(s0.b.x + s1.b.x, s0.b.y + s1.b.y, s0.b.z + s1.b.z, s0.b.w + s1.b.w);
+                } else {
+                    r.y[i] = NT ? load_q_nt(y + row * ldy + 8 * c) : load_q(y + row * ldy + 8 * c);
+                }
                 r.h[i] = load_q(xh + row * ldh + 8 * c);
                 if constexpr (LO8) {
                     r.l[i] = *reinterpret_cast<const uint2*>(xl8 + row * ldl + 8 * c);
@@ -307,9 +320,13 @@ __global__ __launch_bounds__(256, SLOTS == 3 ? SWIFTK_MNP_OCC : 2) void modnorm_
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i)
             if (lane + 64 * i < nc) {
-                raw8<bf16_t> t;
-                t.q = r.y[i];
-                unpack_raw(t, v[i]);
+                if constexpr (YF32) {
+                    unpack_raw(r.y[i], v[i]);
+                } else {
+                    raw8<bf16_t> t;
+                    t.q = r.y[i];
+                    unpack_raw(t, v[i]);
+                }
                 sum += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
             }
         const float mean = wave_sum(sum) / (float)d;
@@ -833,6 +850,36 @@ inline int grid_for(int64_t work_items, int per_block = 256, int cap = 256 * 16)
     return (int)(g > cap ? cap : g);
 }
 
+
+// y_slab == 0: y is bf16 [M, ldy]; y_slab > 0: y is the sum of two fp32 slabs [M, ldy] that many elements apart
+static int modnorm_pair_impl(const void* y, int64_t ldy, int64_t y_slab, void* x_hi, int64_t ldh, void* x_lo, int64_t ldl,
+                             int lo_bits, const float* gamma, const float* beta, const float* mod, int64_t ldmod, int64_t M, int d,
+                             int64_t rows_per_sample, float eps, void* stream) {
+    if (!y || !x_hi || !x_lo || !gamma || !beta || !mod || M <= 0 || d <= 0 || rows_per_sample <= 0) return SWIFTK_EINVAL;
+    if (lo_bits != 16 && lo_bits != 8) return SWIFTK_EINVAL;
+    if (d % 8 || d > 2048 || rows_per_sample % MN_ROWS) return SWIFTK_ESHAPE;
+    if (ldy < d || ldh < d || ldl < d) return SWIFTK_ESHAPE;
+    const int lb = lo_bits / 8, ys = y_slab ? 4 : 2;
+    if (((uintptr_t)y & 15) || (ldy * ys) % 16 || ((uintptr_t)x_hi & 15) || (ldh * 2) % 16 || ((uintptr_t)x_lo & (8 * lb - 1)) ||
+        (ldl * lb) % (8 * lb) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)mod & 15) || (ldmod % 4))
+        return SWIFTK_EALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int cgrid = (int)((M + MN_ROWS - 1) / MN_ROWS);
+#define SWIFTK_MNP(SL, L8, YF)                                                                                                  \
+    hipLaunchKernelGGL((modnorm_pair_kernel<SL, L8, YF>), dim3(cgrid), dim3(256), 0, st, y, ldy, y_slab,                          \
+                       static_cast<bf16_t*>(x_hi), ldh, x_lo, ldl, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps, g_modnorm_nt)
+#define SWIFTK_MNP2(SL)                                                                   \
+    do {                                                                                   \
+        if (y_slab) { if (lo_bits == 8) SWIFTK_MNP(SL, true, true); else SWIFTK_MNP(SL, false, true); }   \
+        else { if (lo_bits == 8) SWIFTK_MNP(SL, true, false); else SWIFTK_MNP(SL, false, false); }        \
+    } while (0)
+    if (d <= 3 * 512) SWIFTK_MNP2(3); else SWIFTK_MNP2(4);
+#undef SWIFTK_MNP2
+#undef SWIFTK_MNP
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, void* xcopy, int64_t ldc, const float* gamma,
@@ -870,27 +917,16 @@ extern "C" int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, voi
 extern "C" int swiftk_modnorm_residual_pair(const void* y, int64_t ldy, void* x_hi, int64_t ldh, void* x_lo, int64_t ldl,
                                             int lo_bits, const float* gamma, const float* beta, const float* mod, int64_t ldmod,
                                             int64_t M, int d, int64_t rows_per_sample, float eps, void* stream) {
-    if (!y || !x_hi || !x_lo || !gamma || !beta || !mod || M <= 0 || d <= 0 || rows_per_sample <= 0) return SWIFTK_EINVAL;
-    if (lo_bits != 16 && lo_bits != 8) return SWIFTK_EINVAL;
-    if (d % 8 || d > 2048 || rows_per_sample % MN_ROWS) return SWIFTK_ESHAPE;
-    if (ldy < d || ldh < d || ldl < d) return SWIFTK_ESHAPE;
-    const int lb = lo_bits / 8;
-    if (((uintptr_t)y & 15) || (ldy * 2) % 16 || ((uintptr_t)x_hi & 15) || (ldh * 2) % 16 || ((uintptr_t)x_lo & (8 * lb - 1)) ||
-        (ldl * lb) % (8 * lb) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)mod & 15) || (ldmod % 4))
-        return SWIFTK_EALIGN;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int cgrid = (int)((M + MN_ROWS - 1) / MN_ROWS);
-#define SWIFTK_MNP(SL, L8)                                                                                                     \
-    hipLaunchKernelGGL((modnorm_pair_kernel<SL, L8>), dim3(cgrid), dim3(256), 0, st, static_cast<const bf16_t*>(y), ldy,        \
-                       static_cast<bf16_t*>(x_hi), ldh, x_lo, ldl, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps, g_modnorm_nt)
-    if (d <= 3 * 512) {
-        if (lo_bits == 8) SWIFTK_MNP(3, true); else SWIFTK_MNP(3, false);
-    } else {
-        if (lo_bits == 8) SWIFTK_MNP(4, true); else SWIFTK_MNP(4, false);
-    }
-#undef SWIFTK_MNP
-    SWIFTK_CHECK_LAUNCH();
-    return 0;
+    return modnorm_pair_impl(y, ldy, 0, x_hi, ldh, x_lo, ldl, lo_bits, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps, stream);
+}
+
+extern "C" int swiftk_modnorm_residual_pair_slabs(const float* y_slabs, int64_t ldy, int64_t slab_stride, void* x_hi, int64_t ldh,
+                                                  void* x_lo, int64_t ldl, int lo_bits, const float* gamma, const float* beta,
+                                                  const float* mod, int64_t ldmod, int64_t M, int d, int64_t rows_per_sample,
+                                                  float eps, void* stream) {
+    if (slab_stride <= 0 || slab_stride % 4) return SWIFTK_EINVAL;
+    return modnorm_pair_impl(y_slabs, ldy, slab_stride, x_hi, ldh, x_lo, ldl, lo_bits, gamma, beta, mod, ldmod, M, d,
+                             rows_per_sample, eps, stream);
 }
 
 extern "C" int swiftk_split_pair(const float* src, int64_t lds, void* hi, int64_t ldh, void* lo, int64_t ldl, int lo_bits,

@@ -8,6 +8,7 @@ int g_x3_exact = 17;  // tuning key 11: the DEFAULT mask a host binding copies i
                       // (the forward reads the model's own field, never this global: ADVICE r3)
 int g_fwd_pair = 2;   // tuning key 12: bf16 engine's residual stream: 2 = (bf16 hi, int8 lo) pair, 1 = (bf16 hi, bf16 lo), 0 = fp32 + copy
 int g_f32_chunk_k = 256;  // tuning key 13: fp32-operand GEMMs of the forward accumulate in chains of this many k (0 = one chain over K)
+int g_fwd_splitk = 1;  // tuning key 14: wo / w2 as two k-ranges into fp32 slabs when their tiles fill less than half the chip (one unit per step)
 int g_fwd_fused = 1;  // tuning key 8 (A/B only): 0 = to_qkv and window attention as two kernels (q/k/v window-tiled through HBM)
 
 namespace {
@@ -22,7 +23,7 @@ __global__ __launch_bounds__(256) void zero_cols_kernel(char* p, int64_t ld_b, i
 }
 
 struct Layout {
-    int64_t emb, h1, lat, mod, ape, x, xt, xlo, qkv, att, y, hmid, tok, kscr, a3, total;
+    int64_t emb, h1, lat, mod, ape, x, xt, xlo, qkv, att, y, yslab, hmid, tok, kscr, a3, total;
 };
 
 inline int64_t al(int64_t v) { return (v + 255) & ~(int64_t)255; }
@@ -36,6 +37,16 @@ bool model_ok(const swiftk_model* m) {
     if ((m->H / m->p1) % 16 || (m->W / m->p2) % 16) return false;
     if (m->dim % 4 || m->mlp % 2) return false;
     return true;
+}
+
+// bf16 engine, pair-form stream: wo / w2 have (M / 256) x (d / 352) output tiles -- 96 per unit for 256 CUs, so one unit fills
+// 37 % of a round of the persistent grid.  While two k-ranges per tile still fit ONE round the two GEMMs run as split-K into two
+// fp32 slabs which the norm kernel sums on its way: B = 1 235 -> 250 sample-steps/s (255 replayed as a graph).  Not beyond one
+// round: at three units (288 tiles, 56 % of two rounds) the split fills 75 % of three, but the norm kernel's 8 instead of 2 bytes
+// of y per element cost more than the rounds save (306 -> 272, measured).
+inline bool small_m_splitk(const swiftk_model* m, int64_t M) {
+    const int64_t tiles = ((M + 255) / 256) * ((m->dim + 351) / 352);
+    return m->dtype == SWIFTK_BF16 && g_fwd_splitk && g_fwd_pair && m->dim % 8 == 0 && 2 * tiles <= 256;
 }
 
 Layout make_layout(const swiftk_model* m, int B) {
@@ -54,6 +65,7 @@ Layout make_layout(const swiftk_model* m, int B) {
     L.qkv = o; o += al(M * 3 * d * es);
     L.att = o; o += al(M * m->kd * es);
     L.y = o; o += al(M * d * es);
+    L.yslab = o; o += small_m_splitk(m, M) ? al(2 * M * d * 4) : 0;  // two fp32 slabs of the split-K wo / w2 (one unit per step)
     L.hmid = o; o += al(M * m->kmlp * es);
     L.tok = o; o += al(M * (int64_t)((m->out_ch * m->p1 * m->p2 + 3) & ~3) * 4);
     L.kscr = o;
@@ -155,6 +167,8 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     const bool pair = dt == SWIFTK_BF16 && g_fwd_pair && ntok % 16 == 0 && d % 8 == 0 && d <= 2048;
     void* xlo = ws + L.xlo;
     const int lo_bits = g_fwd_pair == 1 ? 16 : 8;
+    const bool splitk = pair && small_m_splitk(m, M);
+    float* yslab = reinterpret_cast<float*>(ws + L.yslab);
     if (pair) RUN(swiftk_split_pair(x, d, xT, m->kd, xlo, d, lo_bits, M, d, stream));
     else RUN(swiftk_cast_pad(x, d, xT, m->kd, M, d, dt, stream));
     if (m->kd > d) {  // K-padding columns of the attention output must be finite (they meet zero weight columns)
@@ -198,6 +212,11 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
                                         shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
         }
+        if (splitk) {
+            RUN(swiftk_gemm_splitk(att, m->kd, ly.wo_w, m->kd, yslab, d, M * d, M, d, kdv, SWIFTK_BF16, 2, stream));
+            RUN(swiftk_modnorm_residual_pair_slabs(yslab, d, M * d, xT, m->kd, xlo, d, lo_bits, ly.ln1_g, ly.ln1_b,
+                                                   mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
+        } else {
         RUN(G(att, m->kd, ly.wo_w, y, d, d, kdv, d, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (x3_exact & 2) != 0));
         if (pair)
             RUN(swiftk_modnorm_residual_pair(y, d, xT, m->kd, xlo, d, lo_bits, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M,
@@ -205,7 +224,14 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
         else
             RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok,
                                         1e-6f, dt, stream));
+        }
         RUN(G(xT, m->kd, ly.w1_w, hmid, m->kmlp, 2 * m->mlp, kdv, d, dt, SWIFTK_EPI_SWIGLU, nullptr, nullptr, 0, (x3_exact & 4) != 0));
+        if (splitk) {
+            RUN(swiftk_gemm_splitk(hmid, m->kmlp, ly.w2_w, m->kmlp, yslab, d, M * d, M, d, m->kmlp, SWIFTK_BF16, 2, stream));
+            RUN(swiftk_modnorm_residual_pair_slabs(yslab, d, M * d, xT, m->kd, xlo, d, lo_bits, ly.ln2_g, ly.ln2_b,
+                                                   mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
+            continue;
+        }
         RUN(G(hmid, m->kmlp, ly.w2_w, y, d, d, m->kmlp, m->mlp, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (x3_exact & 8) != 0));
         if (pair)
             RUN(swiftk_modnorm_residual_pair(y, d, xT, m->kd, xlo, d, lo_bits, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, ldmod,

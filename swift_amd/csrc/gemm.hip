@@ -1110,6 +1110,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 11: g_x3_exact = value; return 0;
         case 12: g_fwd_pair = value; return 0;
         case 13: g_f32_chunk_k = value; return 0;
+        case 14: g_fwd_splitk = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -1129,6 +1130,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 11: return g_x3_exact;
         case 12: return g_fwd_pair;
         case 13: return g_f32_chunk_k;
+        case 14: return g_fwd_splitk;
     }
     return SWIFTK_EINVAL;
 }

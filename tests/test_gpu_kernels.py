@@ -320,6 +320,40 @@ def test_unit_noise_vs_oracle(dev):
     assert float(big.abs().max()) < 6.5 and torch.isfinite(big).all()
 
 
+@pytest.mark.parametrize("lo_bits", [8, 16])
+def test_modnorm_residual_pair_from_splitk_slabs(dev, lo_bits):
+    """Round 4, one unit per step: wo / w2 run as two k-ranges into fp32 slabs (swiftk_gemm_splitk) and the pair-form norm kernel
+    sums them on its way (swiftk_modnorm_residual_pair_slabs).  Slabs from the real split-K GEMM; against the oracle's
+    ModulatedNorm on the fp64 product, and against the one-launch GEMM + bf16 y path (which rounds y to bf16 first)."""
+    from oracle.swinv2 import modulated_norm
+    from swift_amd import _lib, ops
+    B, rps, d, K = 2, 256, 1056, 2816
+    M = B * rps
+    a, w, x = rnd((M, K), 51), rnd((d, K), 52, 0.03), rnd((M, d), 53)
+    ad, wd = to_dt(a, torch.bfloat16, dev), to_dt(w, torch.bfloat16, dev)
+    slabs = torch.full((2, M, d), float("nan"), device=dev)
+    _lib.check(_lib.lib().swiftk_gemm_splitk(ad.data_ptr(), K, wd.data_ptr(), K, slabs.data_ptr(), d, M * d, M, d, K, _lib.BF16, 2,
+                                             torch.cuda.current_stream().cuda_stream), "swiftk_gemm_splitk")
+    y64 = ad.float().cpu().double() @ wd.float().cpu().double().T
+    assert rel_l2((slabs[0] + slabs[1]).cpu(), y64) < F32_TOL
+    p = {"n.norm.weight": 1 + 0.1 * rnd((d,), 14), "n.norm.bias": 0.1 * rnd((d,), 15),
+         "n.modulation.weight": 0.02 * rnd((2 * d, d), 16), "n.modulation.bias": 0.1 * rnd((2 * d,), 17)}
+    lat = rnd((B, d), 18)
+    mod = torch.nn.functional.linear(lat, p["n.modulation.weight"], p["n.modulation.bias"]).to(dev)
+    ld = ops.k_pad(torch.bfloat16, d)
+    hi, lo = ops.split_pair(x.to(dev), ld, lo_bits)
+    x_in = ops.pair_value(hi, lo, d).cpu()
+    ops.modnorm_residual_pair_slabs(slabs, hi, lo, p["n.norm.weight"].to(dev), p["n.norm.bias"].to(dev), mod, rps, d)
+    ref = x_in.view(B, rps, d) + modulated_norm(y64.float().view(B, rps, d), lat, p, "n.")
+    got = ops.pair_value(hi, lo, d).cpu()
+    e = rel_l2(got, ref.view(M, d))
+    print(f"pair ModulatedNorm from split-K slabs ({lo_bits}-bit low part): rel-L2 vs oracle {e:.2e}")
+    assert e < 1e-5
+    hi2, lo2 = ops.split_pair(x.to(dev), ld, lo_bits)
+    ops.modnorm_residual_pair(ops.gemm(ad, wd), hi2, lo2, p["n.norm.weight"].to(dev), p["n.norm.bias"].to(dev), mod, rps, d)
+    assert rel_l2(ops.pair_value(hi2, lo2, d).cpu(), got) < 3e-3  # (y rounded to bf16 on that path)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_patchify_three_sources(dev, dt):
     from oracle.swinv2 import patchify

@@ -87,6 +87,19 @@ def test_forward_vs_reference_golden(dev):
     eemu, demu = rel_l2(yb.cpu(), yemu), rel_l2(yemu, g["y_flash"])
     print(f"forward smallb: bf16 engine vs bf16-emulating oracle {eemu:.3e} (emulation vs fp32 reference {demu:.3e})")
     assert eemu < BF16_EMU_TOL and eemu < 0.5 * e16
+    # this small grid (24 output tiles for wo / w2) takes the split-K form of those GEMMs; the large-batch form -- one launch,
+    # bf16 y, what the benchmark runs -- on the same inputs, and the fp32-stream form of the residual (tuning keys 14, 12)
+    from swift_amd import _lib
+    L = _lib.lib()
+    for key, val in ((14, 0), (12, 1), (12, 0)):
+        old = L.swiftk_get_tuning(key)
+        L.swiftk_set_tuning(key, val)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            yv = net.model(x.to(dev), t.to(dev), auxiliary=aux.to(dev))
+        L.swiftk_set_tuning(key, old)
+        ev = rel_l2(yv.cpu(), yemu)
+        print(f"  tuning {key}:{val}: bf16 engine vs bf16-emulating oracle {ev:.3e}; vs the default form {rel_l2(yv.cpu(), yb.cpu()):.3e}")
+        assert ev < BF16_EMU_TOL and not torch.equal(yv, yb)
 
 
 @pytest.mark.parametrize("name,c", [
