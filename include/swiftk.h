@@ -438,6 +438,11 @@ typedef struct swiftk_layer {
     const float* ln1_b;
     const float* ln2_g;  /* [d] ff norm.norm.weight   */
     const float* ln2_b;
+    const void* qkv_w_f32;   /* SWIFTK_BF16X3 with x3_exact bit 6 (adaptive to_qkv), else NULL: to_qkv.weight as fp32 operands
+                                [3*heads*hd, kd] beside the split form in qkv_w                                              */
+    int32_t qk_exact_pairs;  /* ... and which PAIRS of heads (bit p = heads 2p, 2p+1) are recomputed on the exact-fp32 kernel:
+                                those whose logit scale exp(min(scale, ln 100)) exceeds the packer's threshold -- the split
+                                product's 4.5e-6 reaches the softmax multiplied by that scale                                */
 } swiftk_layer;
 
 typedef struct swiftk_model {
@@ -454,7 +459,8 @@ typedef struct swiftk_model {
     int32_t aux_dim;
     int32_t has_logvar;
     int32_t x3_exact;              /* SWIFTK_BF16X3 only: GEMMs whose weights were packed as fp32 operands (bit 0 to_qkv, 1 wo,
-                                      2 w1, 3 w2, 4 patch embed, 5 head); a property of THIS model's weight buffers, set by
+                                      2 w1, 3 w2, 4 patch embed, 5 head; bit 6: to_qkv split EXCEPT the head pairs of
+                                      swiftk_layer.qk_exact_pairs); a property of THIS model's weight buffers, set by
                                       whoever packed them (swiftk_get_tuning(11) is the library's default: 17) */
     float timestep_weight;
     int64_t kd;                    /* swiftk_gemm_k_pad(dtype, dim)            */

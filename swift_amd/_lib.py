@@ -29,8 +29,9 @@ class SwiftkError(RuntimeError):
 
 
 class Layer(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in
-                ("qkv_w", "wo_w", "w1_w", "w2_w", "scale", "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+    _fields_ = ([(n, C.c_void_p) for n in
+                 ("qkv_w", "wo_w", "w1_w", "w2_w", "scale", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_w_f32")]
+                + [("qk_exact_pairs", C.c_int32)])
 
 
 OPT_MAX_GROUPS = 8

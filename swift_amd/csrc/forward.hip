@@ -209,6 +209,18 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             // multiply q-hat . k-hat by up to 100, so the split product's 4.5e-6 would reach the softmax as 4.5e-4)
             RUN(G(xT, m->kd, ly.qkv_w, qkv, 3 * d, 3 * d, kdv, d, dt, fuse_norm ? SWIFTK_EPI_QKNORM : SWIFTK_EPI_NONE,
                   fuse_norm ? ly.scale : nullptr, nullptr, fuse_norm ? hd : 0, (x3_exact & 1) != 0));
+            if (x3 && (x3_exact & 64) && !(x3_exact & 1) && fuse_norm && hd == 88 && ly.qkv_w_f32) {
+                // adaptive to_qkv of the split engine: the head pairs whose logit scale is large enough for the split product's
+                // 4.5e-6 to matter in front of the softmax are recomputed on the exact-fp32 kernel -- 528 output columns each,
+                // written over the split result (same QK-norm epilogue, the pair's two logit scales)
+                for (int pp = 0; 2 * pp < m->heads; ++pp) {
+                    if (!((ly.qk_exact_pairs >> pp) & 1)) continue;
+                    const int64_t c0 = (int64_t)pp * 6 * hd;
+                    RUN(swiftk_gemm(xT, m->kd, static_cast<const float*>(ly.qkv_w_f32) + c0 * m->kd, m->kd,
+                                    static_cast<float*>(qkv) + c0, 3 * d, M, 6 * hd, kdv, SWIFTK_F32, SWIFTK_F32, SWIFTK_EPI_QKNORM,
+                                    ly.scale + 2 * pp, nullptr, hd, stream));
+                }
+            }
             RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
                                         shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
         }

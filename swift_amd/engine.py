@@ -53,7 +53,12 @@ class SwinEngine:
         # Default 17: the cosine logits multiply q-hat . k-hat by up to 100, and an error in the patch embedding passes through
         # every layer -- measured on Swift-B against the reference: all GEMMs split 2.8e-4, these two exact 7.9e-5 (exact
         # engine 4.0e-5); 68 against 47 sample-steps/s for the exact engine at 8 units per step.
-        exact_mask = int(os.environ.get("SWIFTK_X3_EXACT", "17"))  # travels in the model descriptor (mo.x3_exact), per engine
+        # bit 6 (round 4, the default with bit 4): to_qkv split too, except the head PAIRS whose logit scale
+        # exp(min(scale, ln 100)) exceeds SWIFTK_X3_TAU (default 25) -- those are recomputed on the exact kernel (the split
+        # product's 4.5e-6 reaches the softmax multiplied by the scale: 1.1e-4 at 25, 4.5e-4 at the clamp's 100).
+        exact_mask = int(os.environ.get("SWIFTK_X3_EXACT", "80"))  # travels in the model descriptor (mo.x3_exact), per engine
+        tau_max = float(os.environ.get("SWIFTK_X3_TAU", "25"))
+        adaptive = x3 and bool(exact_mask & 64) and not (exact_mask & 1) and m.heads % 2 == 0 and (m.dim // m.heads) == 88
         dt = torch.float32 if x3 else self.dtype  # activations, k-paddings and every non-GEMM kernel
         d, heads, depth, mlp = m.dim, m.heads, m.depth, m.mlp_dim
         p1, p2 = m.patch_size
@@ -84,6 +89,14 @@ class SwinEngine:
             if mlp_e != mlp:
                 w1i = torch.cat([w1i, w1i.new_zeros(2, d)], 0)
             layers[i].qkv_w = gemm_w(att.to_qkv.weight, kd, exact=bool(exact_mask & 1))
+            if adaptive:
+                tau = torch.exp(torch.clamp(att.scale.detach().reshape(-1).float(), max=math.log(100.0))).cpu()
+                hot = 0
+                for pp in range(heads // 2):
+                    if float(tau[2 * pp:2 * pp + 2].max()) > tau_max:
+                        hot |= 1 << pp
+                layers[i].qk_exact_pairs = hot
+                layers[i].qkv_w_f32 = gemm_w(att.to_qkv.weight, kd, exact=True) if hot else None
             layers[i].wo_w = gemm_w(att.wo.weight, kd, exact=bool(exact_mask & 2))
             layers[i].w1_w = gemm_w(w1i, kd, exact=bool(exact_mask & 4))
             layers[i].w2_w = gemm_w(ff.w2.weight, kmlp, exact=bool(exact_mask & 8))
@@ -106,7 +119,7 @@ class SwinEngine:
         mo.sh, mo.sw = m.shift_size
         mo.aux_dim = m.auxiliary_dim
         mo.has_logvar = int(m.logvar_embed is not None)
-        mo.x3_exact = exact_mask if x3 else 0
+        mo.x3_exact = (exact_mask if adaptive else exact_mask & ~64) if x3 else 0
         mo.timestep_weight = float(m.timestep_weight)
         mo.kd, mo.kmlp, mo.kpe = kd, kmlp, kpe
         mo.pe_w = gemm_w(m.patch_embed.emb.weight, kpe, exact=bool(exact_mask & 16))

@@ -66,6 +66,15 @@ def test_train_then_generate_cli(tmp_path):
     assert a.shape == (3, 2, 4, 69, 64, 64) and np.isfinite(a).all()
     assert np.abs(a[:, 0] - a[:, 1])[:, 1:].max() > 0  # members differ after the first step, share the initial state
     assert np.array_equal(a[:, 0, 0], a[:, 1, 0])
+    # the same job on the fp32-grade split-bf16 engine (--dtype bf16x3, round 4): same counter-based noise, so the trajectories
+    # agree with the exact engine's to fp32-grade accuracy -- and are not bit-equal (another engine did run)
+    os.rename(f, str(f) + ".exact")
+    run(["swift_amd.generate", "--input", str(rdir), "--members", "2", "--steps", "3", "--samples", "3", "--batch", "4",
+         "--dump", "numpy", "--dtype", "bf16x3"], cwd=str(tmp_path))
+    a3 = np.load(f)
+    d3 = np.linalg.norm((a3 - a).astype(np.float64)) / np.linalg.norm(a.astype(np.float64))
+    assert np.isfinite(a3).all() and 0 < d3 < 1e-4, d3
+    os.rename(str(f) + ".exact", f)
     # the reference's DEFAULT invocation (--dump zarr, generate.py:41-43) + on-device ensemble metrics: same numbers in the
     # per-variable zarr arrays (level axis for the pressure-level variables), metrics file next to the store
     import json
@@ -153,6 +162,17 @@ def test_bench_contract_line(tmp_path):
     pe, dr = d["parity_engine"], d["bf16_vs_fp32"]
     assert pe["dtype"] == "f32" and 0.3 < pe["frac_of_fp32_matrix_peak"] < 1.0 and 0.2 < pe["attention_mfma_frac"] < 1.0
     assert 0 < dr["rel_l2_after_1_steps"] < dr["rel_l2_after_60_steps"] < 1.0
+    # round-4 objects: SURVEY 8d's batch sweep, configs[2] (39-evaluation sampler), the north-star rollout loop, the split engine
+    sw = d["batch_sweep"]
+    assert "error" not in sw and all(str(b) in sw for b in (1, 4, 8, 16)) and sw["1"]["best"] < sw["8"]["best"]
+    assert "hip_graph" in sw["1"] and sw["1"]["best"] > 100
+    c3 = d["config3_2s"]
+    assert "error" not in c3 and c3["1"]["network_evals_per_s"] == pytest.approx(39 * c3["1"]["value"])
+    ro = d["rollout_12x8x60"]
+    assert "error" not in ro and 0.5 * d["value"] < ro["value"] < 1.5 * d["value"] and np.isfinite(ro["checksum"])
+    sp = pe["split_bf16_engine"]
+    assert "error" not in sp and sp["value"] > pe["value"] and 0 < sp["rel_l2_vs_exact_engine_after_1_step"] < 1e-4
+    assert d["config"]["noise"].startswith("swiftk_unit_noise") and d["attention_roofline"]["mfma_pipe_busy"]["kernel"] > 0.5
     # the training step behind the path's weights, measured in child processes (reported extra)
     for leg, lo, hi in (("crps_finetune_steps4", 0.4, 2.0), ("scm_pretrain", 0.05, 0.5)):
         t = d["training"][leg]
