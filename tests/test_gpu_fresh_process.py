@@ -125,7 +125,9 @@ def test_rccl_single_rank_group_carries_the_collectives(tmp_path):
     rec = json.loads(next(l for l in p.stdout.splitlines() if l.startswith("RCCL_RESULT "))[len("RCCL_RESULT "):])
     print(rec)
     assert rec["backend"] == "nccl" and rec["world"] == 1 and rec["grad_norm"] > 0
-    assert rec["loss_group"] == pytest.approx(rec["loss_no_group"], rel=1e-6)
+    # (the loss mean is a sum of per-workgroup partials added by fp32 atomics: their order is the only freedom between two
+    # evaluations of the same forward; observed up to 1.4e-6 relative)
+    assert rec["loss_group"] == pytest.approx(rec["loss_no_group"], rel=5e-6)
     # same kernels, eager vs graph-replayed; the only run-to-run freedom is the order of the fp32 atomics in the loss mean
     # and the LayerNorm / bias column sums (measured 4e-5; two eager runs differ by as much, test_graph_replay_equals_eager)
     assert rec["grad_rel_diff"] < 1e-4
