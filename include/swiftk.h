@@ -132,10 +132,10 @@ int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, void* xcopy, i
  * The same update on the bf16 engine's PAIR form of the residual stream: x is held as x_hi = bf16(x), which IS the next
  * GEMM's operand (no separate operand copy is written), plus a low part --
  *   lo_bits 16: x_lo = bf16(x - x_hi)                                  (x to 2^-17 relative; 10 bytes per element and launch)
- *   lo_bits  8: x_lo = int8 rint((x - x_hi) * 256 / ulp(x_hi)), +-127  (x to ulp / 512 = 2^-17 relative;  8 bytes)
+ *   lo_bits  8: x_lo = one byte, round((x - x_hi) * 256 / ulp(x_hi)) + 128   (x to ulp / 512 = 2^-17 relative;  8 bytes)
  * where the fp32 stream + bf16 copy of swiftk_modnorm_residual move 14 (y 2, x 4 + 4, copy 2).
  * Replaces src/swift/models/swinv2.py:83-86 (ModulatedNorm) + :211-212 (residual) in the bf16 engine.
- *   y [M, ldy] bf16   x_hi [M, ldh] bf16 (in/out; columns >= d untouched)   x_lo [M, ldl] bf16 or int8 (in/out)
+ *   y [M, ldy] bf16   x_hi [M, ldh] bf16 (in/out; columns >= d untouched)   x_lo [M, ldl] bf16 or uint8 (in/out)
  *   rows_per_sample must be a multiple of 16 (SWIFTK_ESHAPE otherwise: callers keep the fp32-stream form)
  */
 int swiftk_modnorm_residual_pair(const void* y, int64_t ldy, void* x_hi, int64_t ldh, void* x_lo, int64_t ldl, int lo_bits,
@@ -149,7 +149,7 @@ int swiftk_modnorm_residual_pair_slabs(const float* y_slabs, int64_t ldy, int64_
                                        int64_t ldl, int lo_bits, const float* gamma, const float* beta, const float* mod,
                                        int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps, void* stream);
 /* fp32 [rows, lds] -> the pair form: hi [rows, ldh] bf16 with columns [cols, ldh) zeroed (GEMM k-padding), lo [rows, ldl]
- * (bf16 or int8 by lo_bits, ldl in elements). */
+ * (bf16 or uint8 by lo_bits, ldl in elements). */
 int swiftk_split_pair(const float* src, int64_t lds, void* hi, int64_t ldh, void* lo, int64_t ldl, int lo_bits, int64_t rows,
                       int64_t cols, void* stream);
 
@@ -245,7 +245,7 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * kernel (3), key 7 = start-up stagger of the persistent GEMM's workgroups in 1/1000 of an eighth of a tile time (0),
  * key 8 = to_qkv + window attention as one kernel in swiftk_swinv2_forward (1; key 4 bits 8..15 = that kernel's ablations,
  * bits 16.. = those of the persistent attention backward), key 9 = persistent attention backward for head_dim 88 (1),
- * key 12 = residual stream of the bf16 forward: 2 = (bf16 hi, int8 lo) pair (default), 1 = (bf16 hi, bf16 lo) pair, 0 = fp32
+ * key 12 = residual stream of the bf16 forward: 2 = (bf16 hi, 8-bit lo) pair (default), 1 = (bf16 hi, bf16 lo) pair, 0 = fp32
  * stream + bf16 operand copy,
  * key 13 = chain length (in k) of the fp32-operand GEMMs' two-level accumulation in swiftk_swinv2_forward (256; 0 = off),
  * key 14 = split-K wo / w2 at one unit per step (1). */

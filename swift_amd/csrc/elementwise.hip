@@ -232,21 +232,16 @@ __device__ __forceinline__ void store_q_nt(bf16_t* p, const uint4& q) {
 }
 
 
-// 8-bit low part of the pair form: x = hi + l8 * ulp(hi) / 256 with l8 = rint((x - hi) * 256 / ulp(hi)) in [-127, 127]
-// (|x - hi| <= ulp / 2), ulp(hi) = 2^(E - 134) for hi's biased exponent E: x is held to ulp / 512 = 2^-17 relative, the
-// bf16 low part's accuracy, in one byte.  E < 16 (|hi| < 2^-111): the low part is dropped (scale factors out of range).
-__device__ __forceinline__ float lo8_unit(uint32_t hi_bits16) {  // ulp(hi) / 256 as a float
-    const int E = (int)((hi_bits16 >> 7) & 0xFFu);
-    return E >= 16 ? __uint_as_float((uint32_t)(E - 15) << 23) : 0.0f;
+// 8-bit low part of the pair form: x = hi + (b - 128) * ulp(hi) / 256 with the byte b = round((x - hi) * 256 / ulp(hi)) + 128
+// in [0, 255] (|x - hi| <= ulp / 2), ulp(hi) = 2^(E - 134) for hi's biased exponent E: x is held to ulp / 512 = 2^-17 relative,
+// the bf16 low part's accuracy, in one byte.  Written for the VALU budget -- at 8 bytes per element the kernel would otherwise be
+// instruction-bound (0.5 T elements/s x ~40 operations against 33 T lane-operations/s): the scale factors are exponent
+// arithmetic (v_bfe_u32 + v_ldexp_f32, no table, no division), the byte leaves through v_cvt_pk_u8_f32 (saturating convert
+// AND insert) and arrives through v_cvt_f32_ubyteN.  |hi| < 2^-111 (E < 16): the low part under- / overflows harmlessly.
+__device__ __forceinline__ uint32_t lo8_insert(float x, float h, uint32_t E, uint32_t byte_idx, uint32_t acc) {
+    return __builtin_amdgcn_cvt_pk_u8_f32(ldexpf(x - h, 142 - (int)E) + 128.0f, byte_idx, acc);  // (the convert rounds to nearest)
 }
-__device__ __forceinline__ float lo8_inv_unit(uint32_t hi_bits16) {  // 256 / ulp(hi)
-    const int E = (int)((hi_bits16 >> 7) & 0xFFu);
-    return E >= 16 ? __uint_as_float((uint32_t)(269 - E) << 23) : 0.0f;
-}
-__device__ __forceinline__ int lo8_encode(float x, bf16_t h) {
-    const float q = rintf((x - bf2f(h)) * lo8_inv_unit(h));
-    return (int)fminf(fmaxf(q, -127.0f), 127.0f);
-}
+__device__ __forceinline__ float lo8_value(float byte_as_float, uint32_t E) { return ldexpf(byte_as_float - 128.0f, (int)E - 142); }
 
 // YF32: y arrives as TWO fp32 slabs (y and y + yslab, row stride ldy) whose sum is the branch output -- the split-K form of wo / w2
 // at one or two units per step, where 96 output tiles cannot fill 256 CUs (forward.hip)
@@ -286,7 +281,7 @@ __global__ __launch_bounds__(256, (SLOTS == 3 && !YF32) ? SWIFTK_MNP_OCC : ((SLO
     const bf16_t* y = static_cast<const bf16_t*>(y_);
     const float* yf = static_cast<const float*>(y_);
     bf16_t* xl = static_cast<bf16_t*>(xl_);   // bf16 low parts ...
-    int8_t* xl8 = static_cast<int8_t*>(xl_);  // ... or one signed byte each (LO8)
+    uint8_t* xl8 = static_cast<uint8_t*>(xl_);  // ... or one byte each (LO8)
     using LoT = typename std::conditional<LO8, uint2, uint4>::type;  // a slot's low parts: 8 bytes or 8 bf16
     using YT = typename std::conditional<YF32, raw8<float>, uint4>::type;  // a slot of y: 8 bf16, or the 8 summed floats
     struct Row { YT y[SLOTS]; uint4 h[SLOTS]; LoT l[SLOTS]; };
@@ -356,9 +351,10 @@ __global__ __launch_bounds__(256, (SLOTS == 3 && !YF32) ? SWIFTK_MNP_OCC : ((SLO
                     const uint32_t lb[2] = {r.l[i].x, r.l[i].y};
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const uint32_t h16 = (e & 1) ? (hb[e >> 1] >> 16) : (hb[e >> 1] & 0xFFFFu);
-                        const int l8 = (int)(int8_t)((lb[e >> 2] >> (8 * (e & 3))) & 0xFFu);
-                        lo[e] = (float)l8 * lo8_unit(h16);
+                        const uint32_t E = (hb[e >> 1] >> ((e & 1) ? 23 : 7)) & 0xFFu;
+                        const uint32_t w = lb[e >> 2];
+                        const float b = (float)((w >> (8 * (e & 3))) & 0xFFu);  // (selected as one v_cvt_f32_ubyteN)
+                        lo[e] = lo8_value(b, E);
                     }
                 } else {
                     const LoT lq = r.l[i];
@@ -366,17 +362,19 @@ __global__ __launch_bounds__(256, (SLOTS == 3 && !YF32) ? SWIFTK_MNP_OCC : ((SLO
                     unpack_raw(t, lo);
                 }
                 uint32_t oh[4], ol[4] = {0u, 0u, 0u, 0u};
+                float xn[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float xn = (hi[e] + lo[e]) + ((v[i][e] * rstd) * P[e] + Q[e]);
-                    const bf16_t h = f2bf(xn);
-                    if (e & 1) oh[e >> 1] |= (uint32_t)h << 16;
-                    else oh[e >> 1] = h;
+                for (int e = 0; e < 8; ++e) xn[e] = (hi[e] + lo[e]) + ((v[i][e] * rstd) * P[e] + Q[e]);
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const uint32_t ph = pack_bf16(xn[2 * e2], xn[2 * e2 + 1]);  // one v_cvt_pk_bf16_f32 per pair
+                    oh[e2] = ph;
+                    const float h0 = __uint_as_float(ph << 16), h1 = __uint_as_float(ph & 0xffff0000u);
                     if constexpr (LO8) {
-                        ol[e >> 2] |= ((uint32_t)lo8_encode(xn, h) & 0xFFu) << (8 * (e & 3));
+                        ol[e2 >> 1] = lo8_insert(xn[2 * e2], h0, (ph >> 7) & 0xFFu, (2 * e2) & 3, ol[e2 >> 1]);
+                        ol[e2 >> 1] = lo8_insert(xn[2 * e2 + 1], h1, (ph >> 23) & 0xFFu, (2 * e2 + 1) & 3, ol[e2 >> 1]);
                     } else {
-                        const bf16_t l = f2bf(xn - bf2f(h));
-                        ol[e >> 1] |= (uint32_t)l << ((e & 1) ? 16 : 0);
+                        ol[e2] = pack_bf16(xn[2 * e2] - h0, xn[2 * e2 + 1] - h1);
                     }
                 }
                 *reinterpret_cast<uint4*>(xh + row * ldh + 8 * c) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
@@ -424,8 +422,8 @@ __global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict
         if (lo8) {
             uint32_t b = 0u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b |= ((uint32_t)lo8_encode(f[e], h[e]) & 0xFFu) << (8 * e);
-            *reinterpret_cast<uint32_t*>(static_cast<int8_t*>(lo_) + r * ldl + 4 * c) = b;
+            for (int e = 0; e < 4; ++e) b = lo8_insert(f[e], bf2f(h[e]), ((uint32_t)h[e] >> 7) & 0xFFu, e, b);
+            *reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(lo_) + r * ldl + 4 * c) = b;
         } else {
             *reinterpret_cast<uint2*>(lo + r * ldl + 4 * c) =
                 make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));

@@ -270,31 +270,31 @@ def counter_add(counter: torch.Tensor, value: int = 1) -> None:
 
 
 def split_pair(x: torch.Tensor, ldh: int, lo_bits: int = 8):
-    """fp32 [M, d] -> (hi bf16 [M, ldh] with zeroed pad columns, lo [M, d] bf16 or int8): the bf16 engine's residual stream."""
+    """fp32 [M, d] -> (hi bf16 [M, ldh] with zeroed pad columns, lo [M, d] bf16 or uint8): the bf16 engine's residual stream."""
     _dev(x)
     assert x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 2 and lo_bits in (8, 16)
     M, d = x.shape
     hi = torch.empty(M, ldh, dtype=torch.bfloat16, device=x.device)
-    lo = torch.empty(M, d, dtype=torch.bfloat16 if lo_bits == 16 else torch.int8, device=x.device)
+    lo = torch.empty(M, d, dtype=torch.bfloat16 if lo_bits == 16 else torch.uint8, device=x.device)
     check(lib().swiftk_split_pair(x.data_ptr(), d, hi.data_ptr(), ldh, lo.data_ptr(), d, lo_bits, M, d, _stream()), "swiftk_split_pair")
     return hi, lo
 
 
 def pair_value(hi: torch.Tensor, lo: torch.Tensor, d: int) -> torch.Tensor:
-    """The fp32 value a pair stands for (tests, diagnostics): hi + lo, or hi + lo8 * ulp(hi) / 256 for the int8 low part."""
+    """The fp32 value a pair stands for (tests, diagnostics): hi + lo, or hi + (byte - 128) * ulp(hi) / 256 for the 8-bit low
+    part (ulp(hi) / 256 = 2^(E - 142) for hi's biased exponent E)."""
     h = hi[:, :d].float()
     if lo.dtype == torch.bfloat16:
         return h + lo.float()
     E = (hi[:, :d].contiguous().view(torch.int16).to(torch.int32) >> 7) & 0xFF
-    unit = torch.where(E >= 16, torch.exp2((E - 142).float()), torch.zeros_like(h))
-    return h + lo.float() * unit
+    return h + torch.ldexp(lo.float() - 128.0, E - 142)
 
 
 def modnorm_residual_pair(y: torch.Tensor, x_hi: torch.Tensor, x_lo: torch.Tensor, gamma, beta, mod: torch.Tensor,
                           rows_per_sample: int, d: int, eps: float = 1e-6) -> None:
     """In place on the pair (x_hi, x_lo): x += LayerNorm(y) * (1 + scale_b) + shift_b (swinv2.py:83-86, 211-212)."""
     _dev(y, x_hi, x_lo, gamma, beta, mod)
-    assert y.dtype == x_hi.dtype == torch.bfloat16 and x_lo.dtype in (torch.bfloat16, torch.int8) and mod.dtype == torch.float32
+    assert y.dtype == x_hi.dtype == torch.bfloat16 and x_lo.dtype in (torch.bfloat16, torch.uint8) and mod.dtype == torch.float32
     M = y.shape[0]
     check(lib().swiftk_modnorm_residual_pair(y.data_ptr(), y.stride(0), x_hi.data_ptr(), x_hi.stride(0), x_lo.data_ptr(),
                                              x_lo.stride(0), 16 if x_lo.dtype == torch.bfloat16 else 8, gamma.data_ptr(),

@@ -23,10 +23,10 @@ def f32(): ops.modnorm_residual(y, x, gamma, beta, mod, 8192, xcopy=xc)
 def pair(): ops.modnorm_residual_pair(y, hi, lo, gamma, beta, mod, 8192, d)
 def pair8(): ops.modnorm_residual_pair(y, hi8, lo8, gamma, beta, mod, 8192, d)
 f32(); pair(); pair8(); torch.cuda.synchronize()
-for nm, (h_, l_) in (("bf16 low part", (hi, lo)), ("int8 low part", (hi8, lo8))):
+for nm, (h_, l_) in (("bf16 low part", (hi, lo)), ("8-bit low part", (hi8, lo8))):
     print(f"after one call, {nm}: hi == bf16 copy of the fp32 stream on", float((h_[:, :d] == xc[:, :d]).float().mean()),
           "of the elements; rel-L2 of the pair's value vs fp32 stream", float((ops.pair_value(h_, l_, d) - x).norm() / x.norm()))
-res = {"fp32 stream (14 B/elt)": [], "pair, bf16 lo (10 B/elt)": [], "pair, int8 lo (8 B/elt)": []}
+res = {"fp32 stream (14 B/elt)": [], "pair, bf16 lo (10 B/elt)": [], "pair, 8-bit lo (8 B/elt)": []}
 for rnd in range(R):
     order = list(zip(res, (f32, pair, pair8)))
     for name, fn in (order if rnd % 2 == 0 else order[::-1]):
