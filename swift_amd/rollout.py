@@ -78,9 +78,22 @@ class RolloutEngine:
         self.net, self.dataset, self.interval = net, dataset, int(interval)
         kw = dict(num_steps=1, sigma_min=0.02, sigma_max=200.0, auxiliary=interval / 10.0)  # generate.py:255-260
         kw.update(solver_kwargs)
+        # re-noising draws of the multi-step consistency sampler (diffusion.py:452-455: randn_like between network calls) come
+        # from the same counter-based stream as the latents while ``run`` drives the sampler: draw k of lead step i is keyed
+        # (unit seed, i + (k << 40)), so multi-step rollouts are as independent of sharding and batching as the 1-step one
+        self._draw = None  # (seeds_dev, lead step, draw counter) while run() is inside a step with the device stream
+        if "randn_like" not in kw:
+            kw["randn_like"] = self._randn_like
         self.sampler = sampler_factory(solver, net, denoise_dtype=denoise_dtype, **kw)
         self.residual = getattr(dataset, "residual", False)  # generate.py:76
         self._stats = None
+
+    def _randn_like(self, like: torch.Tensor) -> torch.Tensor:
+        if self._draw is None:  # outside run(), or latents injected by the caller: the reference's draw
+            return torch.randn_like(like)
+        seeds_dev, step, k = self._draw
+        self._draw = (seeds_dev, step, k + 1)
+        return ops.unit_noise(torch.empty_like(like), seeds_dev, step + ((k + 1) << 40))
 
     def stats(self, device):
         """``update_stats`` of this engine's dataset and interval, cached per device."""
@@ -176,8 +189,10 @@ class RolloutEngine:
         phys = torch.empty_like(X)
         for i in range(steps):
             z = latents(i) if latents is not None else ops.unit_noise(zbuf, seeds_dev, i)
+            self._draw = None if latents is not None else (seeds_dev, i, 0)
             Y = self.sampler((X, forcings[i]), latents=z)
             ops.rollout_update(X, Y, mx, sx, st, phys=out[i + 1] if keep_trajectory else phys)
             if keep_trajectory and after_step is not None:
                 after_step(i + 1, out[i + 1])
+        self._draw = None
         return out.transpose(0, 1) if keep_trajectory else phys

@@ -296,6 +296,14 @@ def test_rollout_vs_oracle(dev):
     t_all = eng.run(X0.to(dev), forc, 2, seeds=[11, 22])
     t_one = eng.run(X0[1:].to(dev), forc[:, 1:], 2, seeds=[22])
     assert torch.equal(t_all[1], t_one[0])
+    # ... also with the multi-step consistency sampler, whose re-noising draws (diffusion.py:452-455) come from the same
+    # counter-based stream (a global torch generator would make them depend on what ran before)
+    eng3 = RolloutEngine(net, ds, interval=6, num_steps=3)
+    torch.manual_seed(1)
+    t_all = eng3.run(X0.to(dev), forc, 2, seeds=[11, 22])
+    torch.manual_seed(2)
+    t_one = eng3.run(X0[1:].to(dev), forc[:, 1:], 2, seeds=[22])
+    assert torch.equal(t_all[1], t_one[0]) and not torch.equal(t_all[0], t_all[1])
 
 
 def test_rollout_non_residual_dataset_vs_oracle(dev):
