@@ -226,8 +226,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     dev = sdist.get_torch_device()
     lib = _lib.lib()
-    for kv in filter(None, os.environ.get("SWIFTK_TUNE", "").split(",")):  # kernel A/B knobs, e.g. "3:8" (swiftk_set_tuning)
-        lib.swiftk_set_tuning(*(int(x) for x in kv.split(":")))
+    # (kernel A/B knobs: SWIFTK_TUNE=key:value,... is applied by _lib.lib() when the library is loaded)
     dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "bf16x3": "bf16x3"}[a.dtype]
     B, K, W = a.batch, a.steps, a.warmup
 

@@ -138,6 +138,12 @@ def lib() -> C.CDLL:
         for name, (args, res) in _SIGS.items():
             fn = getattr(h, name)
             fn.argtypes, fn.restype = args, res
+        # A/B knobs for measurements (include/swiftk.h: swiftk_set_tuning), e.g. SWIFTK_TUNE=13:512,8:0 -- applied once, at load,
+        # so that every entry point of the package (bench, tests, CLIs, tools) runs the same variant
+        for kv in filter(None, os.environ.get("SWIFTK_TUNE", "").split(",")):
+            k, v = (int(x) for x in kv.split(":"))
+            if h.swiftk_set_tuning(k, v) != 0:
+                raise SwiftkError(f"SWIFTK_TUNE: unknown tuning key {k}")
         _lib = h
     return _lib
 

@@ -61,7 +61,8 @@ def run(lin=lin0, att=att0, norm=norm0):
             return onet(x, t, cond, 0.6)
     finally:
         F.linear, osw.cosine_window_attention, osw.modulated_norm = lin0, att0, norm0
-CHUNK = 256
+CHUNK = int(os.environ.get("SWIFTK_CHUNK", "256"))
+CK = CHUNK
 res = {"cpu": rel(run()), "+gemm (chains of 256 k)": rel(run(lin=hip_linear))}
 CHUNK = 0
 res.update({"+gemm (one chain)": rel(run(lin=hip_linear)), "+attn": rel(run(att=hip_attn)), "+norm": rel(run(norm=hip_norm)),
@@ -76,6 +77,10 @@ with torch.no_grad():
     _lib.lib().swiftk_set_tuning(13, 0)
     res["engine (one chain)"] = rel(net(x.to(dev), t.to(dev), cond.to(dev), 0.6))
     _lib.lib().swiftk_set_tuning(13, 256)
+    if CK != 256:
+        _lib.lib().swiftk_set_tuning(13, CK)
+        res[f"engine (chains of {CK} k)"] = rel(net(x.to(dev), t.to(dev), cond.to(dev), 0.6))
+        _lib.lib().swiftk_set_tuning(13, 256)
 print(f"depth {depth}, rel-L2 against the fp64 oracle:")
 for k, v in res.items():
     print(f"  {k:26s} {v:.3e}  ({v / res['cpu']:.2f} x cpu)")
