@@ -133,7 +133,7 @@ int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, void* xcopy, i
  * GEMM's operand (no separate operand copy is written), plus a low part --
  *   lo_bits 16: x_lo = bf16(x - x_hi)                                  (x to 2^-17 relative; 10 bytes per element and launch)
  *   lo_bits  8: x_lo = one byte, round((x - x_hi) * 256 / ulp(x_hi)) + 128   (x to ulp / 512 = 2^-17 relative;  8 bytes)
- * where the fp32 stream + bf16 copy of swiftk_modnorm_residual move 14 (y 2, x 4 + 4, copy 2).
+ * where the fp32 stream + bf16 copy of swiftk_modnorm_residual move 12 (y 2, x 4 + 4, copy 2).
  * Replaces src/swift/models/swinv2.py:83-86 (ModulatedNorm) + :211-212 (residual) in the bf16 engine.
  *   y [M, ldy] bf16   x_hi [M, ldh] bf16 (in/out; columns >= d untouched)   x_lo [M, ldl] bf16 or uint8 (in/out)
  *   rows_per_sample must be a multiple of 16 (SWIFTK_ESHAPE otherwise: callers keep the fp32-stream form)

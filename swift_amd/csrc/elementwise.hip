@@ -4,7 +4,8 @@
 #include "common.h"
 #include <type_traits>
 
-int g_modnorm_nt = 3;  // tuning key 6: bit 0 = stream the fp32 residual with non-temporal loads / stores, bit 1 = chunked kernel
+int g_modnorm_nt = 3;  // tuning key 6: bit 0 = stream the fp32 residual with non-temporal loads / stores, bit 1 = chunked kernel,
+                       // bit 2 = row-per-wave pair kernel instead of the packed one (A/B)
 
 namespace {
 
@@ -94,6 +95,9 @@ __global__ __launch_bounds__(256) void modnorm_kernel(const T* __restrict__ y, i
 #define SWIFTK_MN_ROWS 16
 #endif
 constexpr int MN_ROWS = SWIFTK_MN_ROWS;
+#ifndef SWIFTK_MNPK_OCC
+#define SWIFTK_MNPK_OCC 2
+#endif
 #ifndef SWIFTK_MNP_OCC
 #define SWIFTK_MNP_OCC 3  // pair kernel: 168 VGPRs = three waves per SIMD
 #endif
@@ -395,6 +399,181 @@ __global__ __launch_bounds__(256, (SLOTS == 3 && !YF32) ? SWIFTK_MNP_OCC : ((SLO
         if (row + 8 < row_end) load_row(row + 8, ra);
         finish_row(row + 4, rb);
     }
+}
+
+// Packed form of the pair kernel (8-bit low part, bf16 y, contiguous y / lo rows) for row widths that are not a multiple of
+// 64 chunks: d = 1056 is 132 16-byte chunks = 2 x 64 + 4, so the row-per-wave form above issues every third instruction for 4
+// of its 64 lanes -- a third of the VALU work and of the memory instructions of a kernel that is instruction- as much as
+// byte-bound at 8 bytes per element.  Here a wave takes FOUR consecutive rows at a time and spreads their 4 NC chunks over its
+// lanes without gaps (chunk q = 64 s + lane of the batch = row q / NC, column chunk q % NC: 9 slots instead of 12 for NC = 132,
+// 10 instead of 12 for 160); which row(s) a slot holds and where the boundary lane sits are compile-time constants, so the row
+// statistics are static selects plus one wave reduction per row and statistic, as before.  All of a batch's loads are issued up
+// front (90 registers of packed data); y is unpacked again in each of the three passes (sum, centred squares, update) instead
+// of being kept as 72 floats.  No second batch in flight: three waves per SIMD cover the latency.
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256, SWIFTK_MNPK_OCC) void modnorm_pair_packed_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ xh, int64_t ldh,
+                                                                    uint8_t* __restrict__ xl, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, const float* __restrict__ mod,
+                                                                    int64_t ldmod, int64_t M, int64_t rps, float eps, int nt) {
+    constexpr int D = 8 * NC, NS = (4 * NC + 63) / 64;
+    // (measured, 96 units: low part non-temporal 1.465 ms, plain 1.477; hi loads non-temporal 1.555 -- hi stays cached, it is the
+    // next GEMM's operand; all forms of this kernel move their bytes at 4.5-4.9 TB/s, the rate a device copy reaches here)
+    constexpr bool lo_nt = true;
+    (void)nt;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) float sP[D], sQ[D];
+    const int64_t blk_sample = ((int64_t)blockIdx.x * MN_ROWS) / rps;
+    {
+        const float* mrow = mod + blk_sample * ldmod;
+        for (int c = threadIdx.x; c < NC; c += 256) {
+            float g[8], bt[8], sc[8], sh[8], p[8], q[8];
+            load8<float>(gamma + 8 * c, g);
+            load8<float>(beta + 8 * c, bt);
+            load8<float>(mrow + 8 * c, sc);
+            load8<float>(mrow + D + 8 * c, sh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                p[e] = g[e] * (1.0f + sc[e]);
+                q[e] = bt[e] * (1.0f + sc[e]) + sh[e];
+            }
+            store8<float>(sP + 8 * c, p);
+            store8<float>(sQ + 8 * c, q);
+        }
+    }
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * MN_ROWS + 4 * wv;  // (the launcher guarantees M % 16 == 0)
+    if (r0 >= M) return;
+    const bf16_t* yb = y + r0 * D;
+    uint8_t* lb = xl + r0 * D;
+    bf16_t* hb = xh + r0 * ldh;
+    uint4 yq[NS], hq[NS];
+    uint2 lq[NS];
+    // slot s: row R0 for the lanes below BL, row R0 + 1 from BL on (BL >= 64: one row); the batch's last slot ends at lane VL
+#define SWIFTK_SLOT(S_)                                                                                                     \
+    constexpr int s = decltype(S_)::value;                                                                                  \
+    constexpr int R0 = (64 * (s)) / NC, BL = (R0 + 1) * NC - 64 * (s), VL = 4 * NC - 64 * (s);                                \
+    const bool up = BL < 64 && lane >= BL;           /* this lane's chunk belongs to row R0 + 1 */                          \
+    const bool live = VL >= 64 || lane < VL;                                                                                \
+    const int colc = lane + 64 * (s) - R0 * NC - (up ? NC : 0); /* column chunk inside the row */                           \
+    const uint32_t hoff = (uint32_t)((R0 + (up ? 1 : 0)) * (int)ldh + 8 * colc)  /* (4 rows x ldh elements: fits 32 bits) */
+    static_for<0, NS>([&](auto S_) {
+        SWIFTK_SLOT(S_);
+        yq[s] = hq[s] = make_uint4(0u, 0u, 0u, 0u);
+        lq[s] = make_uint2(0u, 0u);
+        if (live) {
+            yq[s] = load_q_nt(yb + 8 * (64 * s + lane));
+            hq[s] = load_q(hb + hoff);
+            if (lo_nt) {
+                typedef __attribute__((ext_vector_type(2))) uint32_t u2;
+                const u2 t = __builtin_nontemporal_load(reinterpret_cast<const u2*>(lb + 8 * (64 * s + lane)));
+                lq[s] = make_uint2(t[0], t[1]);
+            } else {
+                lq[s] = *reinterpret_cast<const uint2*>(lb + 8 * (64 * s + lane));
+            }
+        }
+    });
+    auto unpack = [&](const uint4& q, float (&v)[8]) {
+        raw8<bf16_t> t;
+        t.q = q;
+        unpack_raw(t, v);
+    };
+    // pass 1: row sums (a dead lane's zeros add nothing)
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    static_for<0, NS>([&](auto S_) {
+        SWIFTK_SLOT(S_);
+        float v[8];
+        unpack(yq[s], v);
+        const float p = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        if constexpr (BL >= 64) {
+            acc[R0] += p;
+        } else {
+            const float a = up ? 0.f : p;
+            acc[R0] += a;
+            acc[R0 + 1] += p - a;
+        }
+    });
+    float mean[5];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mean[r] = wave_sum(acc[r]) * (1.0f / (float)D);
+    mean[4] = 0.f;
+    // (opaque: without it hipcc keeps the 72 unpacked floats of pass 1 alive for passes 2 and 3 -- 256 VGPRs and spills)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(yq[s].x), "+v"(yq[s].y), "+v"(yq[s].z), "+v"(yq[s].w));
+    // pass 2: centred squares
+#pragma unroll
+    for (int r = 0; r < 5; ++r) acc[r] = 0.f;
+    static_for<0, NS>([&](auto S_) {
+        SWIFTK_SLOT(S_);
+        float v[8];
+        unpack(yq[s], v);
+        const float m = (BL < 64 && up) ? mean[R0 + 1] : mean[R0];
+        float p = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float c = v[e] - m;
+            p += c * c;
+        }
+        p = live ? p : 0.f;  // (a dead lane's zeros minus the mean are not zero)
+        if constexpr (BL >= 64) {
+            acc[R0] += p;
+        } else {
+            const float a = up ? 0.f : p;
+            acc[R0] += a;
+            acc[R0 + 1] += p - a;
+        }
+    });
+    float rstd[5];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rstd[r] = rsqrtf(wave_sum(acc[r]) * (1.0f / (float)D) + eps);
+    rstd[4] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(yq[s].x), "+v"(yq[s].y), "+v"(yq[s].z), "+v"(yq[s].w));
+    // pass 3: update and store
+    static_for<0, NS>([&](auto S_) {
+        SWIFTK_SLOT(S_);
+        if (!live) return;
+        float v[8], hi[8], P[8], Q[8];
+        unpack(yq[s], v);
+        unpack(hq[s], hi);
+        load8<float>(sP + 8 * colc, P);
+        load8<float>(sQ + 8 * colc, Q);
+        const float m = (BL < 64 && up) ? mean[R0 + 1] : mean[R0];
+        const float rs = (BL < 64 && up) ? rstd[R0 + 1] : rstd[R0];
+        const uint32_t hw[4] = {hq[s].x, hq[s].y, hq[s].z, hq[s].w};
+        const uint32_t lw[2] = {lq[s].x, lq[s].y};
+        float xn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t E = (hw[e >> 1] >> ((e & 1) ? 23 : 7)) & 0xFFu;
+            const float b = (float)((lw[e >> 2] >> (8 * (e & 3))) & 0xFFu);
+            xn[e] = (hi[e] + lo8_value(b, E)) + (((v[e] - m) * rs) * P[e] + Q[e]);
+        }
+        uint32_t oh[4], ol[2] = {0u, 0u};
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const uint32_t ph = pack_bf16(xn[2 * e2], xn[2 * e2 + 1]);
+            oh[e2] = ph;
+            ol[e2 >> 1] = lo8_insert(xn[2 * e2], __uint_as_float(ph << 16), (ph >> 7) & 0xFFu, (2 * e2) & 3, ol[e2 >> 1]);
+            ol[e2 >> 1] = lo8_insert(xn[2 * e2 + 1], __uint_as_float(ph & 0xffff0000u), (ph >> 23) & 0xFFu, (2 * e2 + 1) & 3, ol[e2 >> 1]);
+        }
+        *reinterpret_cast<uint4*>(hb + hoff) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+        if (lo_nt) {
+            typedef __attribute__((ext_vector_type(2))) uint32_t u2;
+            __builtin_nontemporal_store(u2{ol[0], ol[1]}, reinterpret_cast<u2*>(lb + 8 * (64 * s + lane)));
+        } else {
+            *reinterpret_cast<uint2*>(lb + 8 * (64 * s + lane)) = make_uint2(ol[0], ol[1]);
+        }
+    });
+#undef SWIFTK_SLOT
 }
 
 // fp32 -> (hi, lo) bf16 pair, hi with zeroed k-padding columns [cols, ldh) (it is a GEMM operand), lo [rows, ldl]
@@ -863,6 +1042,19 @@ static int modnorm_pair_impl(const void* y, int64_t ldy, int64_t y_slab, void* x
         return SWIFTK_EALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int cgrid = (int)((M + MN_ROWS - 1) / MN_ROWS);
+    // row widths of 132 / 160 chunks (d = 1056 / 1280) with the 8-bit low part and contiguous y / lo rows: the packed form
+    if (!y_slab && lo_bits == 8 && ldy == d && ldl == d && M % MN_ROWS == 0 && (g_modnorm_nt & 4) == 0 && (d == 1056 || d == 1280)) {
+        if (d == 1056)
+            hipLaunchKernelGGL((modnorm_pair_packed_kernel<132>), dim3(cgrid), dim3(256), 0, st, static_cast<const bf16_t*>(y),
+                               static_cast<bf16_t*>(x_hi), ldh, static_cast<uint8_t*>(x_lo), gamma, beta, mod, ldmod, M,
+                               rows_per_sample, eps, g_modnorm_nt);
+        else
+            hipLaunchKernelGGL((modnorm_pair_packed_kernel<160>), dim3(cgrid), dim3(256), 0, st, static_cast<const bf16_t*>(y),
+                               static_cast<bf16_t*>(x_hi), ldh, static_cast<uint8_t*>(x_lo), gamma, beta, mod, ldmod, M,
+                               rows_per_sample, eps, g_modnorm_nt);
+        SWIFTK_CHECK_LAUNCH();
+        return 0;
+    }
 #define SWIFTK_MNP(SL, L8, YF)                                                                                                  \
     hipLaunchKernelGGL((modnorm_pair_kernel<SL, L8, YF>), dim3(cgrid), dim3(256), 0, st, y, ldy, y_slab,                          \
                        static_cast<bf16_t*>(x_hi), ldh, x_lo, ldl, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps, g_modnorm_nt)

@@ -265,7 +265,19 @@ def test_modnorm_residual_pair(dev, rps, lo_bits):
     mod = torch.nn.functional.linear(lat, p["n.modulation.weight"], p["n.modulation.bias"])  # [B, 2d]: scale | shift
     yd = to_dt(y, torch.bfloat16, dev)
     hi[:, d:] = 7.0
+    if lo_bits == 8:
+        # d = 1056 with the 8-bit low part runs the PACKED kernel (four rows per wave pass, no idle lanes); the row-per-wave
+        # form of the same arithmetic (tuning key 6 bit 2) must agree with it bit for bit
+        from swift_amd import _lib
+        h2, l2 = hi.clone(), lo.clone()
+        _lib.lib().swiftk_set_tuning(6, 7)
+        ops.modnorm_residual_pair(yd, h2, l2, p["n.norm.weight"].to(dev), p["n.norm.bias"].to(dev), mod.to(dev), rps, d)
+        _lib.lib().swiftk_set_tuning(6, 3)
     ops.modnorm_residual_pair(yd, hi, lo, p["n.norm.weight"].to(dev), p["n.norm.bias"].to(dev), mod.to(dev), rps, d)
+    if lo_bits == 8:
+        # (same formulas; the row sums associate differently, so a few last bits of the statistics may differ)
+        assert float((h2[:, :d] != hi[:, :d]).float().mean()) < 1e-3
+        assert rel_l2(ops.pair_value(h2, l2, d).cpu(), ops.pair_value(hi, lo, d).cpu()) < 2e-6
     ref = x_in.view(B, rps, d) + modulated_norm(yd.float().cpu().view(B, rps, d), lat, p, "n.")
     got = ops.pair_value(hi, lo, d).cpu()
     e = rel_l2(got, ref.view(M, d))
