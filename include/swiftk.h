@@ -141,6 +141,12 @@ int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, void* xcopy, i
 int swiftk_modnorm_residual_pair(const void* y, int64_t ldy, void* x_hi, int64_t ldh, void* x_lo, int64_t ldl, int lo_bits,
                                  const float* gamma, const float* beta, const float* mod, int64_t ldmod, int64_t M, int d,
                                  int64_t rows_per_sample, float eps, void* stream);
+/* The same with the new hi written to ANOTHER buffer (x_hi_in is left as it was; same row stride): the training forward keeps
+ * every layer's operand as a saved activation for the weight gradients.  8-bit low part and d = 1056 / 1280 only
+ * (SWIFTK_ESHAPE otherwise: callers keep swiftk_modnorm_residual). */
+int swiftk_modnorm_residual_pair_to(const void* y, int64_t ldy, const void* x_hi_in, void* x_hi_out, int64_t ldh, void* x_lo,
+                                    int64_t ldl, int lo_bits, const float* gamma, const float* beta, const float* mod,
+                                    int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps, void* stream);
 /* The same with the branch output given as the SUM of two fp32 slabs y_slabs and y_slabs + slab_stride ([M, ldy] each): what
  * swiftk_gemm_splitk(..., ksplit = 2) leaves.  At one unit per step wo / w2 have 96 output tiles for 256 CUs; two k-ranges
  * per tile fill three quarters of the chip and the norm kernel does the reduction on its way (swiftk_swinv2_forward,

@@ -69,6 +69,7 @@ _SIGS = {
     "swiftk_window_attention": ([_p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_modnorm_residual": ([_p, _l, _p, _p, _l, _p, _p, _p, _l, _l, _i, _l, _f, _i, _p], _i),
     "swiftk_modnorm_residual_pair": ([_p, _l, _p, _l, _p, _l, _i, _p, _p, _p, _l, _l, _i, _l, _f, _p], _i),
+    "swiftk_modnorm_residual_pair_to": ([_p, _l, _p, _p, _l, _p, _l, _i, _p, _p, _p, _l, _l, _i, _l, _f, _p], _i),
     "swiftk_modnorm_residual_pair_slabs": ([_p, _l, _l, _p, _l, _p, _l, _i, _p, _p, _p, _l, _l, _i, _l, _f, _p], _i),
     "swiftk_split_pair": ([_p, _l, _p, _l, _p, _l, _i, _l, _l, _p], _i),
     "swiftk_unit_noise": ([_p, _p, _p, _l, _i, _l, _i, _p], _i),

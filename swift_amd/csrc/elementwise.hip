@@ -419,8 +419,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 template <int NC>
-__global__ __launch_bounds__(256, SWIFTK_MNPK_OCC) void modnorm_pair_packed_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ xh, int64_t ldh,
-                                                                    uint8_t* __restrict__ xl, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256, SWIFTK_MNPK_OCC) void modnorm_pair_packed_kernel(const bf16_t* __restrict__ y, const bf16_t* xh, bf16_t* xh_out,
+                                                                    int64_t ldh, uint8_t* __restrict__ xl, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, const float* __restrict__ mod,
                                                                     int64_t ldmod, int64_t M, int64_t rps, float eps, int nt) {
     constexpr int D = 8 * NC, NS = (4 * NC + 63) / 64;
@@ -454,7 +454,8 @@ __global__ __launch_bounds__(256, SWIFTK_MNPK_OCC) void modnorm_pair_packed_kern
     if (r0 >= M) return;
     const bf16_t* yb = y + r0 * D;
     uint8_t* lb = xl + r0 * D;
-    bf16_t* hb = xh + r0 * ldh;
+    const bf16_t* hb = xh + r0 * ldh;
+    bf16_t* hbo = xh_out + r0 * ldh;  // (== hb in the inference engine; the training forward keeps the old hi: a saved activation)
     uint4 yq[NS], hq[NS];
     uint2 lq[NS];
     // slot s: row R0 for the lanes below BL, row R0 + 1 from BL on (BL >= 64: one row); the batch's last slot ends at lane VL
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(256, SWIFTK_MNPK_OCC) void modnorm_pair_packed_kern
             ol[e2 >> 1] = lo8_insert(xn[2 * e2], __uint_as_float(ph << 16), (ph >> 7) & 0xFFu, (2 * e2) & 3, ol[e2 >> 1]);
             ol[e2 >> 1] = lo8_insert(xn[2 * e2 + 1], __uint_as_float(ph & 0xffff0000u), (ph >> 23) & 0xFFu, (2 * e2 + 1) & 3, ol[e2 >> 1]);
         }
-        *reinterpret_cast<uint4*>(hb + hoff) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+        *reinterpret_cast<uint4*>(hbo + hoff) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
         if (lo_nt) {
             typedef __attribute__((ext_vector_type(2))) uint32_t u2;
             __builtin_nontemporal_store(u2{ol[0], ol[1]}, reinterpret_cast<u2*>(lb + 8 * (64 * s + lane)));
@@ -1031,7 +1032,7 @@ inline int grid_for(int64_t work_items, int per_block = 256, int cap = 256 * 16)
 // y_slab == 0: y is bf16 [M, ldy]; y_slab > 0: y is the sum of two fp32 slabs [M, ldy] that many elements apart
 static int modnorm_pair_impl(const void* y, int64_t ldy, int64_t y_slab, void* x_hi, int64_t ldh, void* x_lo, int64_t ldl,
                              int lo_bits, const float* gamma, const float* beta, const float* mod, int64_t ldmod, int64_t M, int d,
-                             int64_t rows_per_sample, float eps, void* stream) {
+                             int64_t rows_per_sample, float eps, void* stream, void* x_hi_out = nullptr) {
     if (!y || !x_hi || !x_lo || !gamma || !beta || !mod || M <= 0 || d <= 0 || rows_per_sample <= 0) return SWIFTK_EINVAL;
     if (lo_bits != 16 && lo_bits != 8) return SWIFTK_EINVAL;
     if (d % 8 || d > 2048 || rows_per_sample % MN_ROWS) return SWIFTK_ESHAPE;
@@ -1043,18 +1044,23 @@ static int modnorm_pair_impl(const void* y, int64_t ldy, int64_t y_slab, void* x
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int cgrid = (int)((M + MN_ROWS - 1) / MN_ROWS);
     // row widths of 132 / 160 chunks (d = 1056 / 1280) with the 8-bit low part and contiguous y / lo rows: the packed form
-    if (!y_slab && lo_bits == 8 && ldy == d && ldl == d && M % MN_ROWS == 0 && (g_modnorm_nt & 4) == 0 && (d == 1056 || d == 1280)) {
+    const bool separate_out = x_hi_out && x_hi_out != x_hi;
+    if (separate_out && (((uintptr_t)x_hi_out & 15))) return SWIFTK_EALIGN;
+    if (!y_slab && lo_bits == 8 && ldy == d && ldl == d && M % MN_ROWS == 0 && ((g_modnorm_nt & 4) == 0 || separate_out) &&
+        (d == 1056 || d == 1280)) {
+        bf16_t* ho = static_cast<bf16_t*>(separate_out ? x_hi_out : x_hi);
         if (d == 1056)
             hipLaunchKernelGGL((modnorm_pair_packed_kernel<132>), dim3(cgrid), dim3(256), 0, st, static_cast<const bf16_t*>(y),
-                               static_cast<bf16_t*>(x_hi), ldh, static_cast<uint8_t*>(x_lo), gamma, beta, mod, ldmod, M,
+                               static_cast<const bf16_t*>(x_hi), ho, ldh, static_cast<uint8_t*>(x_lo), gamma, beta, mod, ldmod, M,
                                rows_per_sample, eps, g_modnorm_nt);
         else
             hipLaunchKernelGGL((modnorm_pair_packed_kernel<160>), dim3(cgrid), dim3(256), 0, st, static_cast<const bf16_t*>(y),
-                               static_cast<bf16_t*>(x_hi), ldh, static_cast<uint8_t*>(x_lo), gamma, beta, mod, ldmod, M,
+                               static_cast<const bf16_t*>(x_hi), ho, ldh, static_cast<uint8_t*>(x_lo), gamma, beta, mod, ldmod, M,
                                rows_per_sample, eps, g_modnorm_nt);
         SWIFTK_CHECK_LAUNCH();
         return 0;
     }
+    if (separate_out) return SWIFTK_ESHAPE;  // the out-of-place hi exists in the packed kernel only (d = 1056 / 1280, 8-bit low part)
 #define SWIFTK_MNP(SL, L8, YF)                                                                                                  \
     hipLaunchKernelGGL((modnorm_pair_kernel<SL, L8, YF>), dim3(cgrid), dim3(256), 0, st, y, ldy, y_slab,                          \
                        static_cast<bf16_t*>(x_hi), ldh, x_lo, ldl, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps, g_modnorm_nt)
@@ -1108,6 +1114,14 @@ extern "C" int swiftk_modnorm_residual_pair(const void* y, int64_t ldy, void* x_
                                             int lo_bits, const float* gamma, const float* beta, const float* mod, int64_t ldmod,
                                             int64_t M, int d, int64_t rows_per_sample, float eps, void* stream) {
     return modnorm_pair_impl(y, ldy, 0, x_hi, ldh, x_lo, ldl, lo_bits, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps, stream);
+}
+
+extern "C" int swiftk_modnorm_residual_pair_to(const void* y, int64_t ldy, const void* x_hi_in, void* x_hi_out, int64_t ldh, void* x_lo,
+                                               int64_t ldl, int lo_bits, const float* gamma, const float* beta, const float* mod,
+                                               int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps, void* stream) {
+    if (!x_hi_out) return SWIFTK_EINVAL;
+    return modnorm_pair_impl(y, ldy, 0, const_cast<void*>(x_hi_in), ldh, x_lo, ldl, lo_bits, gamma, beta, mod, ldmod, M, d,
+                             rows_per_sample, eps, stream, x_hi_out);
 }
 
 extern "C" int swiftk_modnorm_residual_pair_slabs(const float* y_slabs, int64_t ldy, int64_t slab_stride, void* x_hi, int64_t ldh,

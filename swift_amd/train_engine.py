@@ -15,6 +15,7 @@ variants of experiment/era5-swinv2-1.4-scm.yaml:21-36).
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -241,8 +242,27 @@ class SwinTrainEngine:
         x = torch.empty(M, d, dtype=torch.float32, device=dev)
         _gemm(ape, self.pe, x, EPI_BIAS_POS, m.patch_embed.emb.bias.detach().float().contiguous(),
               m.pos_embed.detach().reshape(ntok, d).float().contiguous(), ntok)
-        xT = ops.pad_cols(x, self.kd, _BF)
+        # residual stream as in the inference engine (round 4): hi = bf16(x) IS the GEMM operand -- one saved activation per
+        # branch -- plus an 8-bit low part updated in place; 8 instead of 12 bytes per element and launch.  Row widths the packed
+        # kernel is not built for keep the fp32 stream + operand copy.
+        pair = d in (1056, 1280) and ntok % 16 == 0 and not os.environ.get("SWIFTK_TRAIN_FP32_STREAM")
+        if pair:
+            xT, xlo = ops.split_pair(x, self.kd, 8)
+        else:
+            xT = ops.pad_cols(x, self.kd, _BF)
         ctx["ape"] = ape
+
+        def norm_res(yb, g, bta, msl, hi_in):
+            """x += ModulatedNorm(yb); returns the new GEMM operand."""
+            hi_out = _padded(M, self.kd, d)
+            if pair:
+                check(lib().swiftk_modnorm_residual_pair_to(yb.data_ptr(), yb.stride(0), hi_in.data_ptr(), hi_out.data_ptr(), self.kd,
+                                                            xlo.data_ptr(), d, 8, g.data_ptr(), bta.data_ptr(), msl.data_ptr(),
+                                                            msl.stride(0), M, d, ntok, 1e-6, _s()), "swiftk_modnorm_residual_pair_to")
+            else:
+                ops.modnorm_residual(yb, x, g, bta, msl, ntok, xcopy=hi_out)
+            return hi_out
+
         do_shift = any(m.shift_size)
         for i, (att, ff) in enumerate(m.transformer.layers):
             W = self.L[i]
@@ -255,10 +275,8 @@ class SwinTrainEngine:
                                  flags=ATTN_PRENORM)
             y1 = torch.empty(M, d, dtype=_BF, device=dev)
             _gemm(a, W["wo"], y1)
-            xT_mid = _padded(M, self.kd, d)
             msl1 = mod[:, (2 * i) * 2 * d:(2 * i + 1) * 2 * d]
-            ops.modnorm_residual(y1, x, att.norm.norm.weight.detach().float(), att.norm.norm.bias.detach().float(), msl1, ntok,
-                                 xcopy=xT_mid)
+            xT_mid = norm_res(y1, att.norm.norm.weight.detach().float(), att.norm.norm.bias.detach().float(), msl1, xT)
             h = torch.empty(M, 2 * mlp, dtype=_BF, device=dev)
             hmid = _padded(M, self.kmlp, mlp)
             if mlp % 8 == 0:  # h (kept for the backward pass) and silu(gate) * up out of one GEMM epilogue
@@ -269,10 +287,8 @@ class SwinTrainEngine:
                       "swiftk_swiglu_fwd")
             y2 = torch.empty(M, d, dtype=_BF, device=dev)
             _gemm(hmid, W["w2"], y2)
-            xT_out = _padded(M, self.kd, d)
             msl2 = mod[:, (2 * i + 1) * 2 * d:(2 * i + 2) * 2 * d]
-            ops.modnorm_residual(y2, x, ff.norm.norm.weight.detach().float(), ff.norm.norm.bias.detach().float(), msl2, ntok,
-                                 xcopy=xT_out)
+            xT_out = norm_res(y2, ff.norm.norm.weight.detach().float(), ff.norm.norm.bias.detach().float(), msl2, xT_mid)
             ctx["layers"].append(dict(xT_in=xT, qkvh=qkvh, rn=rn, att=a, y1=y1, xT_mid=xT_mid, h=h, hmid=hmid, y2=y2, shift=sh))
             xT = xT_out
         ctx["xT_final"] = xT
