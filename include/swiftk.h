@@ -374,6 +374,12 @@ int swiftk_window_attention_jvp(const void* qkv, const void* dqkv, int64_t ldq, 
 int swiftk_modnorm_jvp(const void* y, const void* dy, int64_t ldy, float* x, float* dx, void* xT, void* dxT, int64_t ldxT,
                        const float* gamma, const float* beta, const float* mod, const float* dmod, int64_t ldmod, int64_t M,
                        int d, int64_t rows_per_sample, float eps, int dtype, void* stream);
+/* The same on the PAIR form of the stream and its tangent (bf16 operands; round 4): x and dx live as (bf16 hi, 8-bit lo) pairs,
+ * hi being the GEMM operands xT / dxT -- 16 bytes per element instead of 24.  hi is read from (xT_in, dxT_in) and written to
+ * (xT, dxT), which may be the same buffers; x_lo / dx_lo [M, d] bytes, updated in place (swiftk_split_pair creates them). */
+int swiftk_modnorm_jvp_pair(const void* y, const void* dy, int64_t ldy, const void* xT_in, const void* dxT_in, void* xT, void* dxT,
+                            int64_t ldxT, void* x_lo, void* dx_lo, const float* gamma, const float* beta, const float* mod,
+                            const float* dmod, int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps, void* stream);
 /* SwiGLU and its tangent on interleaved (gate_j, up_j) columns (swinv2.py:99-100). */
 int swiftk_swiglu_jvp(const void* h, const void* dh, int64_t ldh, void* out, void* dout, int64_t ldo, int64_t M, int mlp,
                       int dtype, void* stream);

@@ -145,6 +145,17 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
         make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
 }
 
+// 8-bit low part of the pair form: x = hi + (b - 128) * ulp(hi) / 256 with the byte b = round((x - hi) * 256 / ulp(hi)) + 128
+// in [0, 255] (|x - hi| <= ulp / 2), ulp(hi) = 2^(E - 134) for hi's biased exponent E: x is held to ulp / 512 = 2^-17 relative,
+// the bf16 low part's accuracy, in one byte.  Written for the VALU budget -- at 8 bytes per element the kernel would otherwise be
+// instruction-bound (0.5 T elements/s x ~40 operations against 33 T lane-operations/s): the scale factors are exponent
+// arithmetic (v_bfe_u32 + v_ldexp_f32, no table, no division), the byte leaves through v_cvt_pk_u8_f32 (saturating convert
+// AND insert) and arrives through v_cvt_f32_ubyteN.  |hi| < 2^-111 (E < 16): the low part under- / overflows harmlessly.
+__device__ __forceinline__ uint32_t lo8_insert(float x, float h, uint32_t E, uint32_t byte_idx, uint32_t acc) {
+    return __builtin_amdgcn_cvt_pk_u8_f32(ldexpf(x - h, 142 - (int)E) + 128.0f, byte_idx, acc);  // (the convert rounds to nearest)
+}
+__device__ __forceinline__ float lo8_value(float byte_as_float, uint32_t E) { return ldexpf(byte_as_float - 128.0f, (int)E - 142); }
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // attention_pipe.hip: persistent, LDS-DMA-pipelined window attention on pre-normalised bf16 q/k (head_dim 88)

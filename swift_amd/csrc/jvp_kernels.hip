@@ -258,6 +258,116 @@ __global__ __launch_bounds__(256) void modnorm_jvp_kernel(const T* __restrict__ 
     }
 }
 
+// Pair form (bf16 operands): the residual stream and its tangent are held as (bf16 hi, 8-bit lo) pairs -- hi is the GEMM operand
+// (xT / dxT), lo one byte in units of ulp(hi) / 256 (common.h) -- instead of fp32 x, dx plus operand copies: 16 bytes per element
+// (y, dy 4; hi 4 + lo 2 in; hi 4 + lo 2 out) where the fp32 form moves 24.  hi is read from (xT_in, dxT_in) and written to
+// (xT, dxT): the same buffers when the pass keeps nothing, the previous layer's saved operand otherwise.
+__global__ __launch_bounds__(256) void modnorm_jvp_pair_kernel(const bf16_t* __restrict__ y, const bf16_t* __restrict__ dy, int64_t ldy,
+                                                               const bf16_t* xT_in, const bf16_t* dxT_in, bf16_t* xT, bf16_t* dxT,
+                                                               int64_t ldxT, uint8_t* __restrict__ xlo, uint8_t* __restrict__ dxlo,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ mod, const float* __restrict__ dmod,
+                                                               int64_t ldmod, int64_t M, int d, int64_t rps, float eps) {
+    constexpr int SLOTS = 3;  // d <= 1536
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t b = row / rps;
+    const int nc = d >> 3;
+    float yv[SLOTS][8], dv[SLOTS][8];
+    uint4 hx[SLOTS], hd[SLOTS];
+    uint2 lx[SLOTS], ld_[SLOTS];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            load8<bf16_t>(y + row * ldy + 8 * c, yv[i]);
+            load8<bf16_t>(dy + row * ldy + 8 * c, dv[i]);
+            hx[i] = *reinterpret_cast<const uint4*>(xT_in + row * ldxT + 8 * c);
+            hd[i] = *reinterpret_cast<const uint4*>(dxT_in + row * ldxT + 8 * c);
+            lx[i] = *reinterpret_cast<const uint2*>(xlo + row * d + 8 * c);
+            ld_[i] = *reinterpret_cast<const uint2*>(dxlo + row * d + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s0 += yv[i][e];
+                s1 += dv[i][e];
+            }
+        }
+    }
+    const float inv_d = 1.0f / (float)d;
+    const float mu = wave_sum(s0) * inv_d, mdy = wave_sum(s1) * inv_d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i)
+        if (lane + 64 * i < nc) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                yv[i][e] -= mu;
+                s2 += yv[i][e] * yv[i][e];
+            }
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) * inv_d + eps);
+    float s3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i)
+        if (lane + 64 * i < nc) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                yv[i][e] *= rstd;  // n
+                s3 += yv[i][e] * dv[i][e];
+            }
+        }
+    const float mndy = wave_sum(s3) * inv_d;
+    const float* mrow = mod + b * ldmod;
+    const float* dmrow = dmod + b * ldmod;
+    auto value = [](const uint4& h, const uint2& l, float (&v)[8]) {  // the eight fp32 values a (hi, lo) slot stands for
+        const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[2] = {l.x, l.y};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float hf = (e & 1) ? __uint_as_float(hw[e >> 1] & 0xffff0000u) : __uint_as_float(hw[e >> 1] << 16);
+            const uint32_t E = (hw[e >> 1] >> ((e & 1) ? 23 : 7)) & 0xFFu;
+            v[e] = hf + lo8_value((float)((lw[e >> 2] >> (8 * (e & 3))) & 0xFFu), E);
+        }
+    };
+    auto store_pair = [](const float (&v)[8], bf16_t* hp, uint8_t* lp) {
+        uint32_t oh[4], ol[2] = {0u, 0u};
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const uint32_t ph = pack_bf16(v[2 * e2], v[2 * e2 + 1]);
+            oh[e2] = ph;
+            ol[e2 >> 1] = lo8_insert(v[2 * e2], __uint_as_float(ph << 16), (ph >> 7) & 0xFFu, (2 * e2) & 3, ol[e2 >> 1]);
+            ol[e2 >> 1] = lo8_insert(v[2 * e2 + 1], __uint_as_float(ph & 0xffff0000u), (ph >> 23) & 0xFFu, (2 * e2 + 1) & 3, ol[e2 >> 1]);
+        }
+        *reinterpret_cast<uint4*>(hp) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+        *reinterpret_cast<uint2*>(lp) = make_uint2(ol[0], ol[1]);
+    };
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            float ga[8], be[8], sc[8], sh[8], dsc[8], dsh[8], xr[8], dxr[8];
+            load8<float>(gamma + 8 * c, ga);
+            load8<float>(beta + 8 * c, be);
+            load8<float>(mrow + 8 * c, sc);
+            load8<float>(mrow + d + 8 * c, sh);
+            load8<float>(dmrow + 8 * c, dsc);
+            load8<float>(dmrow + d + 8 * c, dsh);
+            value(hx[i], lx[i], xr);
+            value(hd[i], ld_[i], dxr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float n = yv[i][e], dn = (dv[i][e] - mdy - n * mndy) * rstd;
+                const float ln = n * ga[e] + be[e];
+                xr[e] += ln * (1.0f + sc[e]) + sh[e];
+                dxr[e] += ga[e] * dn * (1.0f + sc[e]) + ln * dsc[e] + dsh[e];
+            }
+            store_pair(xr, xT + row * ldxT + 8 * c, xlo + row * d + 8 * c);
+            store_pair(dxr, dxT + row * ldxT + 8 * c, dxlo + row * d + 8 * c);
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------- windowed softmax attention tangent
 // Per (sample, window, head), q_hat/k_hat pre-normalised (qknorm_jvp), softmax scale 1 (swinv2.py:129-133):
 //   S = Q K^T,  P = softmax(S),  O = P V
@@ -727,6 +837,27 @@ extern "C" int swiftk_modnorm_jvp(const void* y, const void* dy, int64_t ldy, fl
                                  ldxT, gamma, beta, mod, dmod, ldmod, M, d, rows_per_sample, eps))
     if (vec) { SWIFTK_MNJ(modnorm_jvp_kernel); } else { SWIFTK_MNJ(modnorm_jvp_scalar_kernel); }
 #undef SWIFTK_MNJ
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int swiftk_modnorm_jvp_pair(const void* y, const void* dy, int64_t ldy, const void* xT_in, const void* dxT_in, void* xT,
+                                       void* dxT, int64_t ldxT, void* x_lo, void* dx_lo, const float* gamma, const float* beta,
+                                       const float* mod, const float* dmod, int64_t ldmod, int64_t M, int d,
+                                       int64_t rows_per_sample, float eps, void* stream) {
+    if (!y || !dy || !xT_in || !dxT_in || !xT || !dxT || !x_lo || !dx_lo || !gamma || !beta || !mod || !dmod || M <= 0 ||
+        rows_per_sample <= 0)
+        return SWIFTK_EINVAL;
+    if (d > 1536 || (d & 7) || M % rows_per_sample || ldxT < d || ldy < d || (ldy & 7) || (ldxT & 7) || (ldmod & 3)) return SWIFTK_ESHAPE;
+    if (((uintptr_t)y | (uintptr_t)dy | (uintptr_t)xT | (uintptr_t)dxT | (uintptr_t)xT_in | (uintptr_t)dxT_in | (uintptr_t)gamma |
+         (uintptr_t)beta | (uintptr_t)mod | (uintptr_t)dmod) & 15)
+        return SWIFTK_EALIGN;
+    if (((uintptr_t)x_lo | (uintptr_t)dx_lo) & 7) return SWIFTK_EALIGN;
+    hipLaunchKernelGGL(modnorm_jvp_pair_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(y), static_cast<const bf16_t*>(dy), ldy, static_cast<const bf16_t*>(xT_in),
+                       static_cast<const bf16_t*>(dxT_in), static_cast<bf16_t*>(xT), static_cast<bf16_t*>(dxT), ldxT,
+                       static_cast<uint8_t*>(x_lo), static_cast<uint8_t*>(dx_lo), gamma, beta, mod, dmod, ldmod, M, d, rows_per_sample,
+                       eps);
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

@@ -18,6 +18,7 @@ the tangent (loss.py:238-240).
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -188,14 +189,28 @@ class SwinJvpEngine:
             return b
 
         XT_in = operand(self.kd, d)
-        check(L.swiftk_cast_pad(X.data_ptr(), d, XT_in.data_ptr(), self.kd, 2 * M, d, tc, _s()), "swiftk_cast_pad")
+        # bf16 operands: the stream and its tangent as (bf16 hi, 8-bit lo) pairs, hi = the operand rows of XT (16 instead of 24
+        # bytes per element in the norm kernel); fp32 operands keep the fp32 stream
+        pair = T == torch.bfloat16 and d % 8 == 0 and d <= 1536 and not os.environ.get("SWIFTK_TRAIN_FP32_STREAM")
+        if pair:
+            XLO = torch.empty(2 * M, d, dtype=torch.uint8, device=dev)
+            check(L.swiftk_split_pair(X.data_ptr(), d, XT_in.data_ptr(), self.kd, XLO.data_ptr(), d, 8, 2 * M, d, _s()), "swiftk_split_pair")
+        else:
+            check(L.swiftk_cast_pad(X.data_ptr(), d, XT_in.data_ptr(), self.kd, 2 * M, d, tc, _s()), "swiftk_cast_pad")
         # one buffer set reused by every layer -- or, when the primal rows are kept for a backward pass, one set per layer
         shared = None if save else dict(QKV=torch.empty(2 * M, 3 * d, dtype=T, device=dev), ATT=operand(self.kd, d),
                                         Y=torch.empty(2 * M, d, dtype=T, device=dev),
                                         H=torch.empty(2 * M, 2 * mlp, dtype=T, device=dev), HM=operand(self.kmlp, mlp))
 
-        def modnorm(i2, gamma, beta, Y, XT):
+        def modnorm(i2, gamma, beta, Y, XT, XT_prev):
             off = i2 * 2 * d * 4
+            if pair:
+                check(L.swiftk_modnorm_jvp_pair(Y.data_ptr(), Y.data_ptr() + M * d * es, d, XT_prev.data_ptr(),
+                                                XT_prev.data_ptr() + M * self.kd * es, XT.data_ptr(), XT.data_ptr() + M * self.kd * es,
+                                                self.kd, XLO.data_ptr(), XLO.data_ptr() + M * d, gamma.data_ptr(), beta.data_ptr(),
+                                                mod.data_ptr() + off, dmod.data_ptr() + off, ldmod, M, d, ntok, 1e-6, _s()),
+                      "swiftk_modnorm_jvp_pair")
+                return
             check(L.swiftk_modnorm_jvp(Y.data_ptr(), Y.data_ptr() + M * d * es, d, x.data_ptr(), dx.data_ptr(), XT.data_ptr(),
                                        XT.data_ptr() + M * self.kd * es, self.kd, gamma.data_ptr(), beta.data_ptr(),
                                        mod.data_ptr() + off, dmod.data_ptr() + off, ldmod, M, d, ntok, 1e-6, tc, _s()),
@@ -218,7 +233,7 @@ class SwinJvpEngine:
             Y1 = shared["Y"] if shared else torch.empty(2 * M, d, dtype=T, device=dev)
             _gemm(ATT, W["wo"], Y1)
             XT_mid = XT_in if shared else operand(self.kd, d)
-            modnorm(2 * i, W["g1"], W["b1"], Y1, XT_mid)
+            modnorm(2 * i, W["g1"], W["b1"], Y1, XT_mid, XT_in)
             H = shared["H"] if shared else torch.empty(2 * M, 2 * mlp, dtype=T, device=dev)
             _gemm(XT_mid, W["w1"], H)
             HM = shared["HM"] if shared else operand(self.kmlp, mlp)
@@ -227,7 +242,7 @@ class SwinJvpEngine:
             Y2 = shared["Y"] if shared else torch.empty(2 * M, d, dtype=T, device=dev)
             _gemm(HM, W["w2"], Y2)
             XT_out = XT_mid if shared else operand(self.kd, d)
-            modnorm(2 * i + 1, W["g2"], W["b2"], Y2, XT_out)
+            modnorm(2 * i + 1, W["g2"], W["b2"], Y2, XT_out, XT_mid)
             if save:
                 layers.append(dict(xT_in=XT_in[:M], qkvh=QKV[:M], rn=rn, att=ATT[:M], y1=Y1[:M], xT_mid=XT_mid[:M], h=H[:M],
                                    hmid=HM[:M], y2=Y2[:M], shift=sh))
