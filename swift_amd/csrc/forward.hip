@@ -6,7 +6,7 @@
 int g_fwd_tiled = 1;  // tuning key 5 (A/B only): 0 keeps q/k/v row-major between to_qkv and attention
 int g_x3_exact = 17;  // tuning key 11: the DEFAULT mask a host binding copies into swiftk_model.x3_exact when it packs the weights
                       // (the forward reads the model's own field, never this global: ADVICE r3)
-int g_fwd_pair = 2;   // tuning key 12: bf16 engine's residual stream: 2 = (bf16 hi, int8 lo) pair, 1 = (bf16 hi, bf16 lo), 0 = fp32 + copy
+int g_fwd_pair = 2;   // tuning key 12: bf16 engine's residual stream: 2 = (bf16 hi, 8-bit lo) pair, 1 = (bf16 hi, bf16 lo), 0 = fp32 + copy
 int g_f32_chunk_k = 256;  // tuning key 13: fp32-operand GEMMs of the forward accumulate in chains of this many k (0 = one chain over K)
 int g_fwd_splitk = 1;  // tuning key 14: wo / w2 as two k-ranges into fp32 slabs when their tiles fill less than half the chip (one unit per step)
 int g_fwd_fused = 1;  // tuning key 8 (A/B only): 0 = to_qkv and window attention as two kernels (q/k/v window-tiled through HBM)
@@ -205,8 +205,8 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
                                         shifted ? m->sw : 0, dt, SWIFTK_ATTN_PRENORM | SWIFTK_ATTN_TILED, stream));
         } else {
-            // (SWIFTK_BF16X3 keeps to_qkv -- and the patch embedding -- on the exact-fp32 kernel by default: the cosine logits
-            // multiply q-hat . k-hat by up to 100, so the split product's 4.5e-6 would reach the softmax as 4.5e-4)
+            // (SWIFTK_BF16X3: the cosine logits multiply q-hat . k-hat by up to 100, so the split product's 4.5e-6 can reach the
+            // softmax as 4.5e-4 -- x3_exact bit 0 keeps the whole GEMM on the exact-fp32 kernel, bit 6 only the hot head pairs)
             RUN(G(xT, m->kd, ly.qkv_w, qkv, 3 * d, 3 * d, kdv, d, dt, fuse_norm ? SWIFTK_EPI_QKNORM : SWIFTK_EPI_NONE,
                   fuse_norm ? ly.scale : nullptr, nullptr, fuse_norm ? hd : 0, (x3_exact & 1) != 0));
             if (x3 && (x3_exact & 64) && !(x3_exact & 1) && fuse_norm && hd == 88 && ly.qkv_w_f32) {
@@ -229,13 +229,13 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             RUN(swiftk_modnorm_residual_pair_slabs(yslab, d, M * d, xT, m->kd, xlo, d, lo_bits, ly.ln1_g, ly.ln1_b,
                                                    mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
         } else {
-        RUN(G(att, m->kd, ly.wo_w, y, d, d, kdv, d, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (x3_exact & 2) != 0));
-        if (pair)
-            RUN(swiftk_modnorm_residual_pair(y, d, xT, m->kd, xlo, d, lo_bits, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M,
-                                             d, ntok, 1e-6f, stream));
-        else
-            RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok,
-                                        1e-6f, dt, stream));
+            RUN(G(att, m->kd, ly.wo_w, y, d, d, kdv, d, dt, SWIFTK_EPI_NONE, nullptr, nullptr, 0, (x3_exact & 2) != 0));
+            if (pair)
+                RUN(swiftk_modnorm_residual_pair(y, d, xT, m->kd, xlo, d, lo_bits, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d,
+                                                 ldmod, M, d, ntok, 1e-6f, stream));
+            else
+                RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok,
+                                            1e-6f, dt, stream));
         }
         RUN(G(xT, m->kd, ly.w1_w, hmid, m->kmlp, 2 * m->mlp, kdv, d, dt, SWIFTK_EPI_SWIGLU, nullptr, nullptr, 0, (x3_exact & 4) != 0));
         if (splitk) {
