@@ -91,7 +91,7 @@ int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
  * swiftk_gemm for fp32 operands with TWO-LEVEL accumulation: the MFMA chain restarts every `chunk_k` k (a multiple of 32)
  * and the partial sums meet in fp32 through `scratch` (caller-owned, >= swiftk_gemm_chunk_scratch_bytes(), 16-B aligned;
  * a workgroup-private slab that stays cache-resident).  One chain over K = 1056 .. 2816 ends 1.8 x further from the fp64
- * product than ATen's blocked CPU sgemm (tools/fp32_bisect.py); chains of 256 bring the exact-fp32 engine to the reference's
+ * product than ATen's blocked CPU sgemm (tests/fp32_bisect.py); chains of 256 bring the exact-fp32 engine to the reference's
  * own fp32 accuracy.  Same epilogues, same results up to summation order.  Replaces F.linear of
  * src/swift/models/swinv2.py:119,137,99-100,229,239 in the exact-fp32 engine.
  */

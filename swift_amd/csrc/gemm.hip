@@ -638,7 +638,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         par ^= 1;
         // Two-level accumulation (fp32 operands, g.kchunk > 0).  One MFMA chain over K = 1056 .. 2816 rounds 264 .. 704 times
         // at the growing partial sum's magnitude and ends 1.8 x further from the fp64 product than the CPU's blocked sgemm
-        // (tools/fp32_bisect.py: the GEMMs are the ONLY op family of the fp32 engine less accurate than ATen's).  Chains of
+        // (tests/fp32_bisect.py: the GEMMs are the ONLY op family of the fp32 engine less accurate than ATen's).  Chains of
         // `kchunk` k-tiles, summed through the workgroup's cache-resident scratch slab, bring that to the CPU's level; a
         // 256 x 352 fp32 tile takes ~300 us, parking 352 KB a few times per tile is not measurable.  Written like the ACCUM
         // epilogue (groups of four blocks, the next group's loads in flight) and placed behind the k-step's own wait, so the

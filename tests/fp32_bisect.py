@@ -7,7 +7,7 @@ kernel (fp32 operands), and every variant is measured against the oracle in fp64
   +attn      cosine window attention on swiftk_window_attention (fp32)
   +norm      ModulatedNorm on swiftk_modnorm_residual
   engine     the whole fp32 engine
-usage: fp32_bisect.py [depth]"""
+usage: python tests/fp32_bisect.py [depth]   (lives under tests/: it uses the oracle as its yardstick)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

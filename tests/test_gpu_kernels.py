@@ -116,7 +116,7 @@ def test_gemm_swiglu_backward_epilogue(dev, H):
 @pytest.mark.parametrize("K", [1056, 2816, 576])
 def test_gemm_fp32_two_level_accumulation(dev, K):
     """swiftk_gemm_chunked (round 4): fp32 operands, MFMA chains of 256 k met through a scratch slab.  The plain kernel's
-    single chain over K ends measurably further from the fp64 product than the chained form (tools/fp32_bisect.py traced the
+    single chain over K ends measurably further from the fp64 product than the chained form (tests/fp32_bisect.py traced the
     exact engine's 1.8 x excess over the CPU's fp32 error to it); both stay inside the per-op tolerance, the epilogues see
     the same accumulators."""
     from swift_amd import ops
