@@ -207,9 +207,9 @@ def main():
     if sdist.get_world_size() > 1 or os.environ.get("SWIFTK_RCCL_LOG"):
         # the first time N > 1 ranks meet, the record should show what RCCL built (ranks, channels, ring / tree orders)
         rccl_log = f"/tmp/swiftk_rccl.{os.getpid()}"
-        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ["NCCL_DEBUG"] = "INFO"  # (forced: the pool's environment presets NCCL_DEBUG=VERSION)
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
-        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log + ".%h.%p.log")
+        os.environ["NCCL_DEBUG_FILE"] = rccl_log + ".%h.%p.log"
     try:
         rank = sdist.setup_torch(single_rank_group=os.environ.get("SWIFTK_SINGLE_RANK_GROUP", "1") != "0")
     except Exception as e:  # noqa: BLE001
