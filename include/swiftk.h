@@ -58,6 +58,9 @@ extern "C" {
 #define SWIFTK_EPI_ACCUM 5     /* C += A W^T, fp32 C only: the backward pass adds a branch's input gradient onto the
                                   residual-stream gradient (autograd of x + f(x), swinv2.py:211-212) in the GEMM itself */
 
+#define SWIFTK_EPI_QKNORM_JVP 8 /* swiftk_gemm_jvp only: SWIFTK_EPI_QKNORM on the primal rows AND its tangent on the tangent rows */
+#define SWIFTK_EPI_SWIGLU_JVP 9 /* swiftk_gemm_jvp only: silu(gate) * up and its tangent (pre-activations optionally kept) */
+
 /* swiftk_window_attention flags */
 #define SWIFTK_ATTN_PRENORM 1  /* q, k in `qkv` are already normalised / scaled (SWIFTK_EPI_QKNORM); `scale` (optional) bounds
                                   |logit| <= exp(min(scale, ln 100)): where <= 48 softmax needs no row maximum */
@@ -380,6 +383,18 @@ int swiftk_modnorm_jvp(const void* y, const void* dy, int64_t ldy, float* x, flo
 int swiftk_modnorm_jvp_pair(const void* y, const void* dy, int64_t ldy, const void* xT_in, const void* dxT_in, void* xT, void* dxT,
                             int64_t ldxT, void* x_lo, void* dx_lo, const float* gamma, const float* beta, const float* mod,
                             const float* dmod, int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps, void* stream);
+/* A linear map of the tangent pass WITH the non-linear step behind it, in one launch (round 4): A [2 Mh, lda] bf16 holds the
+ * primal rows 0..Mh-1 and the tangent rows Mh..2Mh-1 (Mh % 128 == 0).  An output tile of the persistent GEMM takes 128 primal rows
+ * and THEIR 128 tangent rows, laid out so that a lane's accumulators hold a primal element and its tangent: the tangent rules
+ * below run on the fp32 accumulators, and neither the raw products nor their tangents reach memory.
+ *   SWIFTK_EPI_QKNORM_JVP  (to_qkv, swinv2.py:121-127): C [2 Mh, ldc] bf16 <- (q-hat | k-hat | v) and, in the tangent rows, their
+ *       tangents -- what swiftk_gemm + swiftk_qknorm_jvp leave; `scale` [heads]; `rn` (optional, [Mh, N / head_dim] fp32) as
+ *       swiftk_qknorm_jvp writes it; C2 unused.
+ *   SWIFTK_EPI_SWIGLU_JVP  (w1, swinv2.py:99-100; W rows interleaved gate / up): C2 [2 Mh, ldc2] bf16 <- silu(gate) * up in the primal
+ *       rows and its tangent in the tangent rows -- what swiftk_gemm + swiftk_swiglu_jvp leave; C (optional, [Mh, ldc] bf16) <- the
+ *       primal pre-activations (the saved activation of SWIFTK_EPI_SWIGLU_BWD). */
+int swiftk_gemm_jvp(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t Mh, int64_t N, int64_t K,
+                    int epilogue, const float* scale, float* rn, int head_dim, void* C2, int64_t ldc2, void* stream);
 /* SwiGLU and its tangent on interleaved (gate_j, up_j) columns (swinv2.py:99-100). */
 int swiftk_swiglu_jvp(const void* h, const void* dh, int64_t ldh, void* out, void* dout, int64_t ldo, int64_t M, int mlp,
                       int dtype, void* stream);

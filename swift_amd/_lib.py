@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("SWIFTK_LIB") or os.path.join(_HERE, "csrc", "libswift
 F32, BF16 = 0, 1
 BF16X3 = 2  # swiftk_model.dtype only: fp32 activations, every GEMM as three bf16 products (include/swiftk.h)
 EPI_NONE, EPI_BIAS_POS, EPI_SWIGLU, EPI_QKNORM, EPI_ACCUM, EPI_SWIGLU_BOTH, EPI_SWIGLU_BWD = 0, 1, 2, 3, 5, 6, 7
+EPI_QKNORM_JVP, EPI_SWIGLU_JVP = 8, 9  # swiftk_gemm_jvp only
 ATTN_PRENORM, ATTN_NO_PIPE, ATTN_TILED = 1, 2, 4
 PROF_ATTENTION = 100
 
@@ -90,6 +91,7 @@ _SIGS = {
     "swiftk_modnorm_jvp": ([_p, _p, _l, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l, _l, _i, _l, _f, _i, _p], _i),
     "swiftk_modnorm_jvp_pair": ([_p, _p, _l, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _l, _l, _i, _l, _f, _p], _i),
     "swiftk_swiglu_jvp": ([_p, _p, _l, _p, _p, _l, _l, _i, _i, _p], _i),
+    "swiftk_gemm_jvp": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _i, _p, _p, _i, _p, _l, _p], _i),
     "swiftk_ensemble_sums": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_rmse_sums": ([_p, _p, _l, _p, _p, _i, _i, _i, _i, _p], _i),
     "swiftk_scm_target": ([_p, _p, _p, _p, _p, _f, _f, _p, _p, _i, _l, _p], _i),

@@ -221,6 +221,60 @@ __device__ __forceinline__ void qknorm_tile(f32x4 (&acc)[MI][NI], int lane, int 
     }
 }
 
+// SWIFTK_EPI_QKNORM_JVP: the same prologue AND its tangent (swinv2.py:123-127 under torch.func.jvp) on a PAIRED wave tile --
+// accumulator rows i = 0, 1 are primal rows, i = 2, 3 the tangent rows of the same tokens (gemm_kernel_p, PAIRED), so a lane
+// holds v and dv of one element:  v-hat = tau v / n,  d v-hat = tau / n (dv - v (v . dv) / n^2),  n = max(|v|, 1e-12).
+// This half computes the row statistics: per row block i and head vector (A | B) the factors f = tau / n and f c = f (v . dv) / n^2,
+// so that v-hat = f v and d v-hat = f dv - (f c) v are formed where the tile is packed for its stores (formed here, the 88 scaled
+// quads sit in fresh registers until the store loop takes them and the k-loop's invariants spill).
+template <int NI>
+__device__ __forceinline__ void qknorm_jvp_stats(const f32x4 (&acc)[MI][NI], int lane, int c0, const float* __restrict__ scale,
+                                                 float* __restrict__ rn, int mrow0, int nvec, float (&qf)[MI / 2][4]) {
+    constexpr int HD = 8 * NI;
+    const int g4 = lane >> 4;
+    const int vA = c0 / HD, vB = vA + 1;
+    const int kA = vA % 3, kB = vB % 3;
+    const float tauA = kA == 0 ? expf(fminf(scale[vA / 3], 4.605170185988092f)) : 1.0f;
+    const float tauB = kB == 0 ? expf(fminf(scale[vB / 3], 4.605170185988092f)) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < MI / 2; ++i) {
+        float sa = 0.f, sb = 0.f, da = 0.f, db = 0.f;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const f32x4 v = acc[i][j], t = acc[i + 2][j];
+            if (16 * j + 12 < HD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sa = fmaf(v[e], v[e], sa); da = fmaf(v[e], t[e], da); }
+            } else if (16 * j >= HD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sb = fmaf(v[e], v[e], sb); db = fmaf(v[e], t[e], db); }
+            } else {  // (for HD = 88 the boundary runs through j = 5 between lane groups 1 and 2)
+                const bool first = 16 * j + 4 * g4 < HD;
+                float ss = 0.f, dd = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ss = fmaf(v[e], v[e], ss); dd = fmaf(v[e], t[e], dd); }
+                sa += first ? ss : 0.f; da += first ? dd : 0.f;
+                sb += first ? 0.f : ss; db += first ? 0.f : dd;
+            }
+        }
+        sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+        sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+        da += __shfl_xor(da, 16, 64); da += __shfl_xor(da, 32, 64);
+        db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
+        // one division per vector (1 / n), the rest are products of it
+        const float ra = kA == 2 ? 1.0f : 1.0f / fmaxf(sqrtf(sa), 1e-12f), rb = kB == 2 ? 1.0f : 1.0f / fmaxf(sqrtf(sb), 1e-12f);
+        qf[i][0] = kA == 2 ? 1.0f : tauA * ra;
+        qf[i][1] = kB == 2 ? 1.0f : tauB * rb;
+        qf[i][2] = kA == 2 ? 0.0f : qf[i][0] * da * ra * ra;
+        qf[i][3] = kB == 2 ? 0.0f : qf[i][1] * db * rb * rb;
+        if (rn && g4 == 0 && vB < nvec) {
+            const int m = mrow0 + i * 16 + (lane & 15);
+            rn[(int64_t)m * nvec + vA] = ra;
+            rn[(int64_t)m * nvec + vB] = rb;
+        }
+    }
+}
+
 template <typename T, typename OutT, int EPI>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
     // Two separate LDS objects (not one array carved in two): hipcc tags accesses to distinct LDS variables with
@@ -388,6 +442,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     constexpr int HD = 8 * NI;                  // QKNORM: head_dim (a wave tile = two head vectors)
     constexpr bool TOUCH = SWIFTK_X_TOUCH > 0 && NI <= 11 && sizeof(T) == 2;  // (384-wide tiles use all 160 KiB of LDS)
     constexpr bool HPF = SWIFTK_X_HPF > 0 && EPI == SWIFTK_EPI_SWIGLU_BWD && NI <= 11 && sizeof(T) == 2;
+    // PAIRED (swiftk_gemm_jvp): A holds primal rows 0..M/2-1 and tangent rows M/2..M-1; tile tm takes primal rows 128 tm .. + 127
+    // and their tangent rows, wave wm the 32 + 32 rows of tokens 128 tm + 32 wm .. + 31: accumulator row blocks i = 0, 1 are primal,
+    // i = 2, 3 the tangents of the same tokens -- the epilogue's tangent rules find both values of an element in one lane
+    constexpr bool PAIRED = EPI == SWIFTK_EPI_QKNORM_JVP || EPI == SWIFTK_EPI_SWIGLU_JVP;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (TOUCH || HPF ? 256 : 0)];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -439,6 +497,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             int rb = tm * BM + (wv * 4 + p) * 8;
+            if constexpr (PAIRED)  // piece (wv, p) = tile rows 64 (wv >> 1) + 32 (wv & 1) + 8 p ..: row block i = 2 (wv & 1) + (p >> 1)
+                rb = ((wv & 1) ? (g.M >> 1) : 0) + tm * (BM / 2) + (wv >> 1) * 32 + (p >> 1) * 16 + (p & 1) * 8;
             rb = rb < g.M ? rb : g.M - 8;
             abase[p] = g.A + (int64_t)rb * g.lda_b;
         }
@@ -724,7 +784,77 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             const int m0 = tm * BM, n0 = tn * BN;
             if constexpr (EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED)
                 qknorm_tile<NI>(acc, lane, n0 + wn * WT, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / HD);
+            float qf[MI / 2][4];  // QKNORM_JVP: (f_A, f_B, f c_A, f c_B) per primal row block
+            if constexpr (EPI == SWIFTK_EPI_QKNORM_JVP) {
+                int qlane = lane;  // (opaque copy: nothing of the tangent rule is hoisted above the k-loop)
+                asm volatile("" : "+v"(qlane));
+                qknorm_jvp_stats<NI>(acc, qlane, n0 + wn * WT, g.ep0, const_cast<float*>(g.ep1), tm * (BM / 2) + wm * 32, g.N / HD, qf);
+            }
             OutT* C = reinterpret_cast<OutT*>(g.C) + (int64_t)(tile % ksplit) * g.c_split;
+            if constexpr (EPI == SWIFTK_EPI_SWIGLU_JVP) {
+                // FeedForward gate and its tangent (swinv2.py:99-100 under jvp): per 16-token group the primal pre-activations
+                // (optional: the backward pass's saved activation), then silu(gate) * up and its tangent side by side in the
+                // wave's slab, rows leaving as whole 16-B chunks like every bf16 tile
+                constexpr int RS1 = WT * 2 + 16, RS2 = WT + 16;  // padded slab row strides (bytes): WT / WT/2 columns
+                constexpr int CP1 = WT / 8, CP2 = WT / 16;       // 16-B chunks per row
+                constexpr int SL = 16 * RS1 > 32 * RS2 ? 16 * RS1 : 32 * RS2;
+                __builtin_amdgcn_s_barrier();
+                char* slab = const_cast<char*>(s) + wv * SL;
+                int elane = lane;
+                asm volatile("" : "+v"(elane));
+                const int g4 = elane >> 4;
+                const int r16 = elane & 15;
+                bf16_t* C2 = reinterpret_cast<bf16_t*>(const_cast<float*>(g.ep1));
+                const int64_t ldc2 = g.pos_rows;
+                const int mh = g.M >> 1;
+#pragma unroll
+                for (int i = 0; i < MI / 2; ++i) {
+                    const int mrow0 = tm * (BM / 2) + wm * 32 + i * 16;
+                    if (g.C) {
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            const f32x4 v = acc[i][j];
+                            *reinterpret_cast<uint2*>(slab + r16 * RS1 + (j * 16 + 4 * g4) * 2) =
+                                make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+                        }
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int t = 0; t < (16 * CP1 + 63) / 64; ++t) {
+                            const int c = elane + 64 * t;
+                            const int row = c / CP1, cc = c - row * CP1;
+                            if (c < 16 * CP1) {
+                                const uint4 q = *reinterpret_cast<const uint4*>(slab + row * RS1 + cc * 16);
+                                const int n = n0 + wn * WT + cc * 8;
+                                if (n < g.N) *reinterpret_cast<uint4*>(C + (int64_t)(mrow0 + row) * g.ldc + n) = q;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const f32x4 v = acc[i][j], t = acc[i + 2][j];
+                        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc[i + 2][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const float s0 = __builtin_amdgcn_rcpf(1.0f + __expf(-v[0])), s1 = __builtin_amdgcn_rcpf(1.0f + __expf(-v[2]));
+                        const float a0 = v[0] * s0, a1 = v[2] * s1;  // silu(gate)
+                        *reinterpret_cast<uint32_t*>(slab + r16 * RS2 + (j * 8 + 2 * g4) * 2) = pack_bf16(a0 * v[1], a1 * v[3]);
+                        *reinterpret_cast<uint32_t*>(slab + (16 + r16) * RS2 + (j * 8 + 2 * g4) * 2) =
+                            pack_bf16((s0 + a0 * (1.0f - s0)) * t[0] * v[1] + a0 * t[1], (s1 + a1 * (1.0f - s1)) * t[2] * v[3] + a1 * t[3]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int t = 0; t < (32 * CP2 + 63) / 64; ++t) {
+                        const int c = elane + 64 * t;
+                        const int row = c / CP2, cc = c - row * CP2;  // rows 0..15: silu(gate) up, 16..31: its tangent
+                        if (c < 32 * CP2) {
+                            const uint4 q = *reinterpret_cast<const uint4*>(slab + row * RS2 + cc * 16);
+                            const int m = mrow0 + (row & 15) + (row >= 16 ? mh : 0), n = (n0 >> 1) + wn * (WT / 2) + cc * 8;
+                            if (n < (g.N >> 1)) *reinterpret_cast<uint4*>(C2 + (int64_t)m * ldc2 + n) = q;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else
             if constexpr (EPI == SWIFTK_EPI_SWIGLU_BWD) {
                 // backward of the FeedForward's gate: the accumulators are d(hidden)[m][j]; with the saved pre-activation
                 // (gate, up) = H[m][2j], H[m][2j+1] the tile leaves as d(pre-activation)[m][2j .. 2j+1] -- a lane's four
@@ -865,10 +995,24 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 const int ncol0 = (EPI == SWIFTK_EPI_SWIGLU ? (n0 >> 1) : n0) + wn * COLS;
                 const int nout = EPI == SWIFTK_EPI_SWIGLU ? (g.N >> 1) : g.N;
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
+                for (int ii = 0; ii < MI; ++ii) {
+                    // QKNORM_JVP: a tangent row block leaves before its primal block (2, 0, 3, 1) -- its rule reads the primal values
+                    const int i = EPI == SWIFTK_EPI_QKNORM_JVP ? ((ii & 1) ? ii >> 1 : 2 + (ii >> 1)) : ii;
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
-                        const f32x4 v = acc[i][j];
+                        f32x4 v = acc[i][j];
+                        if constexpr (EPI == SWIFTK_EPI_QKNORM_JVP) {
+                            const bool first = 16 * j + 12 < 8 * NI ? true : (16 * j >= 8 * NI ? false : 16 * j + 4 * g4 < 8 * NI);
+                            const float f = first ? qf[i & 1][0] : qf[i & 1][1];
+                            if (i >= 2) {
+                                const float fc = first ? qf[i & 1][2] : qf[i & 1][3];
+                                const f32x4 pv = acc[i & 1][j];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = fmaf(-fc, pv[e], f * v[e]);
+                            } else {
+                                v *= f;
+                            }
+                        }
                         acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                         if constexpr (EPI == SWIFTK_EPI_SWIGLU) {
                             // silu(g) * u with v_exp_f32 / v_rcp_f32 (1 ulp each; the libm forms cost ~30 VALU apiece)
@@ -881,7 +1025,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                         }
                     }
                     __builtin_amdgcn_wave_barrier();  // slab written (LDS ops of a wave execute in order)
-                    const int mrow0 = m0 + wm * 64 + i * 16;
+                    const int mrow0 = PAIRED ? (i >= 2 ? (g.M >> 1) : 0) + tm * (BM / 2) + wm * 32 + (i & 1) * 16 : m0 + wm * 64 + i * 16;
                     // Window-tiled destination (to_qkv for the streamed attention kernel): the 16 rows of a slab are 16
                     // consecutive tokens of one grid row (gw % 16 == 0), so sample / grid row / column base are
                     // wave-uniform per slab; a row's 88-wide q, k or v slice lands at [window][head][part][idx][0..87],
@@ -1050,6 +1194,21 @@ int launch(const GemmArgs& g, hipStream_t st) {
             hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
         }
     }
+    if (timed) swiftk_prof_end(st);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+// the paired-row epilogues exist in the persistent kernel only (bf16 in, bf16 out, whole tiles)
+template <int EPI>
+int launch_paired(const GemmArgs& g, hipStream_t st) {
+    const int ntm = g.M / BM;
+    const bool timed = swiftk_prof_begin(EPI, g.N, st);
+    const int ntiles = ntm * g.ntn;
+    const int grid = ntiles < g_persist_wgs ? ntiles : g_persist_wgs;
+    if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 10>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+    else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 12>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+    else hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 11>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
     if (timed) swiftk_prof_end(st);
     SWIFTK_CHECK_LAUNCH();
     return 0;
@@ -1259,6 +1418,61 @@ extern "C" int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ld
                            int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, const float* ep0, const float* ep1,
                            int64_t pos_rows, void* stream) {
     return gemm_impl(A, lda, W, ldw, C, ldc, M, N, K, dtype, out_dtype, epilogue, ep0, ep1, pos_rows, 1, 0, stream);
+}
+
+extern "C" int swiftk_gemm_jvp(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t Mh, int64_t N,
+                               int64_t K, int epilogue, const float* scale, float* rn, int head_dim, void* C2, int64_t ldc2,
+                               void* stream) {
+    if (!A || !W || Mh <= 0 || N <= 0 || K <= 0) return SWIFTK_EINVAL;
+    if (epilogue != SWIFTK_EPI_QKNORM_JVP && epilogue != SWIFTK_EPI_SWIGLU_JVP) return SWIFTK_EINVAL;
+    if (Mh % 128 || 2 * Mh > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SWIFTK_ESHAPE;
+    int khalf = 0;
+    if (K % 64 == 32 && lda >= K + 32 && ldw >= K + 32) {
+        khalf = 1;
+        K += 32;
+    }
+    if (K % 64 || lda < K || ldw < K) return SWIFTK_ESHAPE;
+    if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || (lda * 2) % 16 || (ldw * 2) % 16) return SWIFTK_EALIGN;
+    int ni = 11;
+    if (epilogue == SWIFTK_EPI_QKNORM_JVP) {
+        const int hd = head_dim > 0 ? head_dim : 88;
+        if (!C || !scale || (hd != 80 && hd != 88 && hd != 96) || N % (6 * hd) || ldc < N) return SWIFTK_ESHAPE;
+        if (((uintptr_t)C & 15) || ldc % 8) return SWIFTK_EALIGN;
+        ni = hd / 8;
+    } else {
+        if (!C2 || N % 16 || ldc2 < N / 2 || (C && ldc < N)) return SWIFTK_ESHAPE;
+        if (((uintptr_t)C2 & 15) || ldc2 % 8 || (C && (((uintptr_t)C & 15) || ldc % 8))) return SWIFTK_EALIGN;
+        if (N % 384 == 0 && N % 352) ni = 12;
+        else if (N % 320 == 0 && N % 352) ni = 10;
+    }
+    GemmArgs g;
+    g.A = static_cast<const char*>(A);
+    g.W = static_cast<const char*>(W);
+    g.C = static_cast<char*>(C);
+    g.lda_b = lda * 2;
+    g.ldw_b = ldw * 2;
+    g.ldc = ldc;
+    g.M = (int)(2 * Mh);
+    g.N = (int)N;
+    g.K = (int)K;
+    g.ep0 = scale;
+    g.ep1 = epilogue == SWIFTK_EPI_QKNORM_JVP ? rn : static_cast<const float*>(C2);
+    g.pos_rows = (int)ldc2;
+    g.ni = ni;
+    g.ntn = (int)((N + 32 * ni - 1) / (32 * ni));
+    g.dbg = g_dbg;
+    g.ksplit = 1;
+    g.c_split = 0;
+    g.batch_a = g.batch_w = g.batch_c = 0;
+    g.khalf = khalf;
+    g.touch = 0;
+    g.stagger = 0;
+    g.kscr = nullptr;
+    g.kchunk = 0;
+    g.t_gh = g.t_gw = g.t_sh = g.t_sw = g.t_heads = 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (epilogue == SWIFTK_EPI_QKNORM_JVP) return launch_paired<SWIFTK_EPI_QKNORM_JVP>(g, st);
+    return launch_paired<SWIFTK_EPI_SWIGLU_JVP>(g, st);
 }
 
 extern "C" int64_t swiftk_gemm_chunk_scratch_bytes(void) {

@@ -25,7 +25,7 @@ import torch
 
 from . import ops
 from .graphs import GraphCache
-from ._lib import EPI_BIAS_POS, EPI_NONE, SwiftkError, check, lib
+from ._lib import EPI_BIAS_POS, EPI_NONE, EPI_QKNORM_JVP, EPI_SWIGLU_JVP, SwiftkError, check, lib
 
 
 def _s():
@@ -197,10 +197,16 @@ class SwinJvpEngine:
             check(L.swiftk_split_pair(X.data_ptr(), d, XT_in.data_ptr(), self.kd, XLO.data_ptr(), d, 8, 2 * M, d, _s()), "swiftk_split_pair")
         else:
             check(L.swiftk_cast_pad(X.data_ptr(), d, XT_in.data_ptr(), self.kd, 2 * M, d, tc, _s()), "swiftk_cast_pad")
+        # to_qkv and w1 with the non-linear step behind them (QK normalisation, SwiGLU) and its tangent rule in the GEMM's epilogue:
+        # the persistent kernel pairs every primal row with its tangent row inside one lane (swiftk_gemm_jvp); the separate
+        # swiftk_qknorm_jvp / swiftk_swiglu_jvp passes (and the raw products they re-read) remain for fp32 operands
+        fused = (T == torch.bfloat16 and M % 128 == 0 and d % 64 in (0, 32) and self.hd in (80, 88, 96) and heads % 2 == 0
+                 and mlp % 8 == 0 and not os.environ.get("SWIFTK_JVP_UNFUSED"))
+        kk = d  # (d = 16.5 k-tiles: the kernel skips the zero half of the last one)
         # one buffer set reused by every layer -- or, when the primal rows are kept for a backward pass, one set per layer
         shared = None if save else dict(QKV=torch.empty(2 * M, 3 * d, dtype=T, device=dev), ATT=operand(self.kd, d),
                                         Y=torch.empty(2 * M, d, dtype=T, device=dev),
-                                        H=torch.empty(2 * M, 2 * mlp, dtype=T, device=dev), HM=operand(self.kmlp, mlp))
+                                        H=None if fused else torch.empty(2 * M, 2 * mlp, dtype=T, device=dev), HM=operand(self.kmlp, mlp))
 
         def modnorm(i2, gamma, beta, Y, XT, XT_prev):
             off = i2 * 2 * d * 4
@@ -222,10 +228,15 @@ class SwinJvpEngine:
             W = self.L[i]
             sh = tuple(m.shift_size) if (do_shift and i % 2) else (0, 0)
             QKV = shared["QKV"] if shared else torch.empty(2 * M, 3 * d, dtype=T, device=dev)
-            _gemm(XT_in, W["qkv"], QKV)
             rn = torch.empty(M, 3 * heads, dtype=torch.float32, device=dev) if save else None
-            check(L.swiftk_qknorm_jvp(QKV.data_ptr(), QKV.data_ptr() + M * 3 * d * es, 3 * d, W["scale"].data_ptr(),
-                                      None if rn is None else rn.data_ptr(), M, heads, self.hd, tc, _s()), "swiftk_qknorm_jvp")
+            if fused:  # to_qkv with the cosine-attention prologue and its tangent in the GEMM's epilogue (paired rows)
+                check(L.swiftk_gemm_jvp(XT_in.data_ptr(), XT_in.stride(0), W["qkv"].data_ptr(), W["qkv"].stride(0), QKV.data_ptr(), 3 * d,
+                                        M, 3 * d, kk, EPI_QKNORM_JVP, W["scale"].data_ptr(),
+                                        None if rn is None else rn.data_ptr(), self.hd, None, 0, _s()), "swiftk_gemm_jvp")
+            else:
+                _gemm(XT_in, W["qkv"], QKV)
+                check(L.swiftk_qknorm_jvp(QKV.data_ptr(), QKV.data_ptr() + M * 3 * d * es, 3 * d, W["scale"].data_ptr(),
+                                          None if rn is None else rn.data_ptr(), M, heads, self.hd, tc, _s()), "swiftk_qknorm_jvp")
             ATT = shared["ATT"] if shared else operand(self.kd, d)
             check(L.swiftk_window_attention_jvp(QKV.data_ptr(), QKV.data_ptr() + M * 3 * d * es, 3 * d, ATT.data_ptr(),
                                                 ATT.data_ptr() + M * self.kd * es, self.kd, B, gh, gw, heads, self.hd, sh[0], sh[1],
@@ -234,11 +245,17 @@ class SwinJvpEngine:
             _gemm(ATT, W["wo"], Y1)
             XT_mid = XT_in if shared else operand(self.kd, d)
             modnorm(2 * i, W["g1"], W["b1"], Y1, XT_mid, XT_in)
-            H = shared["H"] if shared else torch.empty(2 * M, 2 * mlp, dtype=T, device=dev)
-            _gemm(XT_mid, W["w1"], H)
             HM = shared["HM"] if shared else operand(self.kmlp, mlp)
-            check(L.swiftk_swiglu_jvp(H.data_ptr(), H.data_ptr() + M * 2 * mlp * es, 2 * mlp, HM.data_ptr(),
-                                      HM.data_ptr() + M * self.kmlp * es, self.kmlp, M, mlp, tc, _s()), "swiftk_swiglu_jvp")
+            if fused:  # w1 with the gate and its tangent in the epilogue; the primal pre-activations are kept only for a backward pass
+                H = torch.empty(M, 2 * mlp, dtype=T, device=dev) if save else None
+                check(L.swiftk_gemm_jvp(XT_mid.data_ptr(), XT_mid.stride(0), W["w1"].data_ptr(), W["w1"].stride(0),
+                                        None if H is None else H.data_ptr(), 2 * mlp, M, 2 * mlp, kk,
+                                        EPI_SWIGLU_JVP, None, None, 0, HM.data_ptr(), self.kmlp, _s()), "swiftk_gemm_jvp")
+            else:
+                H = shared["H"] if shared else torch.empty(2 * M, 2 * mlp, dtype=T, device=dev)
+                _gemm(XT_mid, W["w1"], H)
+                check(L.swiftk_swiglu_jvp(H.data_ptr(), H.data_ptr() + M * 2 * mlp * es, 2 * mlp, HM.data_ptr(),
+                                          HM.data_ptr() + M * self.kmlp * es, self.kmlp, M, mlp, tc, _s()), "swiftk_swiglu_jvp")
             Y2 = shared["Y"] if shared else torch.empty(2 * M, d, dtype=T, device=dev)
             _gemm(HM, W["w2"], Y2)
             XT_out = XT_mid if shared else operand(self.kd, d)

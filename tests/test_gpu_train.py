@@ -193,6 +193,78 @@ def test_qknorm_epilogue_rn_and_bwd(dev):
     assert float(dscale[3]) == 0.0 and float(dscale[8]) == 0.0  # heads clamped at ln(100): no gradient (swinv2.py:125)
 
 
+@pytest.mark.parametrize("Mh,dim,heads", [(256, 1056, 12), (1280, 1056, 12), (128, 1280, 16), (384, 1536, 16), (256, 176, 2)])
+def test_gemm_jvp_qknorm_paired_rows(dev, Mh, dim, heads):
+    """swiftk_gemm_jvp(SWIFTK_EPI_QKNORM_JVP): to_qkv on [primal rows; tangent rows] with the cosine-attention prologue and its
+    tangent in the epilogue (swinv2.py:121-127 under torch.func.jvp) -- against torch.func.jvp of the formula on the fp64 product,
+    and against the two-launch form it replaces (swiftk_gemm + swiftk_qknorm_jvp)."""
+    from swift_amd import _lib, ops
+    L = _lib.lib()
+    hd = dim // heads
+    N, K = 3 * dim, ops.k_pad(BF, dim)
+    a = torch.zeros(2 * Mh, K, dtype=BF, device=dev)
+    a[:, :dim] = rnd((2 * Mh, dim), 20).to(dev).to(BF)
+    w = torch.zeros(N, K, dtype=BF, device=dev)
+    w[:, :dim] = rnd((N, dim), 21, 0.03).to(dev).to(BF)
+    scale = (torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 10.0, 7.0, 2.0, 60.0, 40.0]))[:heads]).to(dev)
+    out = torch.full((2 * Mh, N), float("nan"), dtype=BF, device=dev)
+    rn = torch.full((Mh, 3 * heads), float("nan"), device=dev)
+    kk = dim if dim % 64 in (0, 32) else K
+    rc = L.swiftk_gemm_jvp(a.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, Mh, N, kk, _lib.EPI_QKNORM_JVP, scale.data_ptr(),
+                           rn.data_ptr(), hd, None, 0, s())
+    assert rc == 0
+    torch.cuda.synchronize()
+    raw = (a.float().cpu().double() @ w.float().cpu().double().t()).float()
+    f = lambda z: _prenorm(z.view(1, Mh, -1), scale.cpu(), heads, hd)[0]
+    ref, dref = torch.func.jvp(f, (raw[:Mh],), (raw[Mh:],))
+    assert not torch.isnan(out.float()).any()
+    e_p, e_t = rel_l2(out[:Mh].float().cpu(), ref), rel_l2(out[Mh:].float().cpu(), dref)
+    nr = raw[:Mh].view(Mh, heads, 3, hd).norm(dim=-1)
+    nr[:, :, 2] = 1.0
+    assert rel_l2(rn.cpu(), (1.0 / nr).reshape(Mh, -1)) < 1e-5
+    # the two-launch form on the same operands (it normalises the bf16-ROUNDED products: one rounding more)
+    two = torch.empty(2 * Mh, N, dtype=BF, device=dev)
+    assert L.swiftk_gemm(a.data_ptr(), K, w.data_ptr(), K, two.data_ptr(), N, 2 * Mh, N, K, _lib.BF16, _lib.BF16, _lib.EPI_NONE, None, None,
+                         0, s()) == 0
+    assert L.swiftk_qknorm_jvp(two.data_ptr(), two.data_ptr() + Mh * N * 2, N, scale.data_ptr(), None, Mh, heads, hd, _lib.BF16, s()) == 0
+    e_p2, e_t2 = rel_l2(two[:Mh].float().cpu(), ref), rel_l2(two[Mh:].float().cpu(), dref)
+    print(f"qknorm jvp epilogue Mh {Mh} dim {dim}: primal {e_p:.2e} tangent {e_t:.2e} (two launches: {e_p2:.2e} / {e_t2:.2e})")
+    assert e_p < 4e-3 and e_t < 4e-3            # one bf16 rounding of exact-to-fp32 values
+    assert e_p <= e_p2 * 1.05 and e_t <= e_t2 * 1.05
+
+
+@pytest.mark.parametrize("Mh,dim,mlp,keep", [(256, 1056, 2816, True), (1280, 1056, 2816, False), (128, 1280, 3416, True), (384, 1536, 4096, True)])
+def test_gemm_jvp_swiglu_paired_rows(dev, Mh, dim, mlp, keep):
+    """swiftk_gemm_jvp(SWIFTK_EPI_SWIGLU_JVP): w1 on [primal rows; tangent rows] with silu(gate) * up and its tangent in the epilogue
+    (swinv2.py:99-100 under torch.func.jvp), the primal pre-activations optionally kept for SWIFTK_EPI_SWIGLU_BWD."""
+    from swift_amd import _lib, ops
+    L = _lib.lib()
+    N, K, kmlp = 2 * mlp, ops.k_pad(BF, dim), ops.k_pad(BF, mlp)
+    a = torch.zeros(2 * Mh, K, dtype=BF, device=dev)
+    a[:, :dim] = rnd((2 * Mh, dim), 30).to(dev).to(BF)
+    w = torch.zeros(N, K, dtype=BF, device=dev)
+    w[:, :dim] = rnd((N, dim), 31, 0.05).to(dev).to(BF)  # rows interleaved (gate_j, up_j)
+    hm = torch.full((2 * Mh, kmlp), float("nan"), dtype=BF, device=dev)
+    hpre = torch.full((Mh, N), float("nan"), dtype=BF, device=dev) if keep else None
+    kk = dim if dim % 64 in (0, 32) else K
+    rc = L.swiftk_gemm_jvp(a.data_ptr(), K, w.data_ptr(), K, None if hpre is None else hpre.data_ptr(), N, Mh, N, kk, _lib.EPI_SWIGLU_JVP,
+                           None, None, 0, hm.data_ptr(), kmlp, s())
+    assert rc == 0
+    torch.cuda.synchronize()
+    raw = (a.float().cpu().double() @ w.float().cpu().double().t()).float()
+    f = lambda z: F.silu(z[:, 0::2]) * z[:, 1::2]
+    ref, dref = torch.func.jvp(f, (raw[:Mh],), (raw[Mh:],))
+    got = hm[:, :mlp].float().cpu()
+    assert not torch.isnan(got).any()
+    e_p, e_t = rel_l2(got[:Mh], ref), rel_l2(got[Mh:], dref)
+    print(f"swiglu jvp epilogue Mh {Mh} dim {dim} mlp {mlp}: primal {e_p:.2e} tangent {e_t:.2e}")
+    assert e_p < 4e-3 and e_t < 4e-3
+    if mlp < kmlp:  # the operand's k-padding columns are the caller's (zeroed once); the kernel leaves them alone
+        assert torch.isnan(hm[:, mlp:].float()).all()
+    if keep:
+        assert rel_l2(hpre.float().cpu(), raw[:Mh]) < 4e-3
+
+
 @pytest.mark.parametrize("B", [2, 16])  # 16: 768 items on 256 persistent workgroups (buffer rotation, cross-item prefetch)
 @pytest.mark.parametrize("shift", [(0, 0), (8, 8)])
 def test_window_attention_bwd(dev, shift, B):
