@@ -257,7 +257,8 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * key 12 = residual stream of the bf16 forward: 2 = (bf16 hi, 8-bit lo) pair (default), 1 = (bf16 hi, bf16 lo) pair, 0 = fp32
  * stream + bf16 operand copy,
  * key 13 = chain length (in k) of the fp32-operand GEMMs' two-level accumulation in swiftk_swinv2_forward (256; 0 = off),
- * key 14 = split-K wo / w2 at one unit per step (1). */
+ * key 14 = split-K wo / w2 at one unit per step (1), key 15 = swiftk_window_attention_bwd_qknorm applies the QK-norm backward
+ * inside the persistent attention backward (1; 0 = second pass). */
 int swiftk_set_tuning(int key, int value);
 /* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
  * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default
@@ -332,6 +333,13 @@ int swiftk_modnorm_bwd(const void* y, int64_t ldy, const float* g, void* dy, int
  * v's gradient passes through unchanged, so only the q-hat / k-hat vectors are read and rewritten (2/3 of the vectors). */
 int swiftk_qknorm_bwd(const void* qkvh, const void* dqkvh, int64_t ld, const float* rn, void* dqkv, int64_t ldo,
                       const float* scale, float* dscale, int64_t M, int heads, int head_dim, int dtype, void* stream);
+/* Both in one call (round 4): dqkv [tokens, ldd] <- the gradient w.r.t. the RAW to_qkv output (the operand of the to_qkv data- and
+ * weight-gradient GEMMs), dscale [heads] += d(logit scale).  Where the pipelined attention backward runs (head_dim 88) the
+ * QK-norm backward is applied to the fp32 accumulators on their way out -- d(q-hat) / d(k-hat) never reach memory; elsewhere the
+ * call is swiftk_window_attention_bwd_scaled followed by swiftk_qknorm_bwd in place. */
+int swiftk_window_attention_bwd_qknorm(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo, void* dqkv,
+                                       int64_t ldd, const float* scale, const float* rn, float* dscale, int B, int gh, int gw,
+                                       int heads, int head_dim, int shift_h, int shift_w, int dtype, void* stream);
 
 /* Backward of the attention core (bf16, head_dim 88, PRENORM layout): dqkvh = d(q-hat | k-hat | v). */
 int swiftk_window_attention_bwd(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo, void* dqkvh, int B,

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
 // with the 1/l factor -- a per-lane scalar, a lane owns one query column -- applied to dq once at the end.
 constexpr int ROW88 = 176, TILE88 = 256 * ROW88;
 constexpr int OSLAB88 = 16 * ROW88;   // wave-private output staging: 16 rows per round
-constexpr int BWD_LDS = 3 * TILE88 + 64 + 3 * 1024 + 8 * OSLAB88;   // 160,832 B
+constexpr int BWD_LDS = 3 * TILE88 + 64 + 3 * 1024 + 8 * OSLAB88 + 64;   // 160,896 B (the last 64: per-head logit-scale gradient sums)
 
 __device__ __forceinline__ uint4 tr_frag88(const char* img, int base_row, int db, int vbase) {
     const char* p = img + base_row * ROW88 + vbase + db * 64;
@@ -301,8 +301,57 @@ struct BwdPArgs {
     BwdArgs a;
     const float* scale;  // per-head logit scale parameter (bounds |logit|); null = unknown (always take the maximum)
     int nitems;
+    // QK-norm backward folded into the stores (swiftk_window_attention_bwd_qknorm): rn [tokens, 3 heads] = 1 / max(|.|, 1e-12) of the raw
+    // q / k vectors, dscale [heads] accumulates d(logit scale); null = the gradients of q-hat / k-hat leave as they are
+    const float* rn;
+    float* dscale;
     int dbg;  // timing experiments (tuning key 4, bits 16..): 1 no pass-A sweeps, 2 no pass-B loop, 4 no output stores, 8 no max sweep
 };
+
+// Backward of the cosine-attention prologue (SWIFTK_EPI_QKNORM: x-hat = tau x / n) on a transposed accumulator set, in place:
+// acc[db][4 g + e] = d(x-hat)[d][row] with d = 32 db + 8 g + 4 hh + e and the row on the lane.  The row's x-hat values are at
+// hand as the MFMA B-operand fragments f[ks] = 16-B chunk 2 ks + hh of the row; the accumulator layout wants elements
+// 4 hh .. 4 hh + 3 of chunk 4 db + g, i.e. for even g the low (hh = 0) or high (hh = 1) half of the chunk the hh = 0 lane holds
+// and for odd g the same of the hh = 1 lane's chunk: one exchange of two dwords per k-step with lane ^ 32.
+//   dx = rn (tau d(x-hat) - x-hat (x-hat . d(x-hat)) / tau);   returns x-hat . d(x-hat) (= tau x d(tau)'s share of this row)
+__device__ __forceinline__ float qknorm_bwd_acc(f32x16 (&acc)[DB], const uint4 (&f)[6], int hh, float tau, float rn) {
+    uint32_t up[DB][4][2];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const int db = ks >> 1, ge = 2 * (ks & 1);
+        const uint32_t r0 = __shfl_xor(hh ? f[ks].x : f[ks].z, 32, 64), r1 = __shfl_xor(hh ? f[ks].y : f[ks].w, 32, 64);
+        up[db][ge][0] = hh ? r0 : f[ks].x;
+        up[db][ge][1] = hh ? r1 : f[ks].y;
+        up[db][ge + 1][0] = hh ? f[ks].z : r0;
+        up[db][ge + 1][1] = hh ? f[ks].w : r1;
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (db * 32 + g * 8 >= 88) continue;  // (rows d >= 88 of the accumulators are never stored; their contents are arbitrary)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t w = up[db][g][e >> 1];
+                dot = fmaf(acc[db][4 * g + e], __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16)), dot);
+            }
+        }
+    dot += __shfl_xor(dot, 32, 64);
+    const float ca = rn * tau, cb = -rn * dot / tau;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (db * 32 + g * 8 >= 88) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t w = up[db][g][e >> 1];
+                acc[db][4 * g + e] = fmaf(cb, __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16)), ca * acc[db][4 * g + e]);
+            }
+        }
+    return dot;
+}
 
 __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
     constexpr int HD = 88, KS = 6, CPR = 11, NPQ = TILE88 / 1024;  // 44 pieces per image
@@ -311,6 +360,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
     float* st_m = reinterpret_cast<float*>(smem + 3 * TILE88 + 64);
     float* st_il = st_m + 256;
     float* st_dl = st_m + 512;
+    float* st_ds = reinterpret_cast<float*>(smem + BWD_LDS - 64);  // [16] d(logit scale) sums of this workgroup (zeroed with the rest)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c32 = lane & 31, hh = lane >> 5, i16 = lane & 15;
@@ -421,9 +471,13 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
         // one item ahead, in front of the previous item's dk / dv stores, with a counted wait here was measured slower:
         // 571 against 481 us per launch -- 48 more live registers across the item boundary, spills inside the loops.)
         uint4 qf[KS], dof[KS];
-        float delta;
+        float delta, rnq = 0.f, rnk = 0.f;
         {
             const int64_t t0 = tok0 + wtoken(a, w, wv * 32 + c32);
+            if (pa.rn) {  // (window row wv * 32 + c32 is this lane's QUERY in pass A and its KEY in pass B: one token)
+                rnq = pa.rn[t0 * (3 * a.heads) + 3 * h];
+                rnk = pa.rn[t0 * (3 * a.heads) + 3 * h + 1];
+            }
             row_frags<HD, KS>(a.qkvh + t0 * a.ldq + h * 3 * HD, hh, qf);
             row_frags<HD, KS>(a.d_o + t0 * a.ldo + h * HD, hh, dof);
             uint4 of[KS];
@@ -517,6 +571,13 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
         }
         __builtin_amdgcn_s_barrier();  // every wave is done with the K and V images; the row statistics are written
         dma_img(bK, do_base(b, h), w, ldo_b);
+        if (pa.rn) {
+            // d(q-hat) -> dq, and this item's share of d(logit scale) = sum over the window's queries of q-hat . d(q-hat)
+            // (every row is counted by both lane halves; no gradient where the clamp at ln 100 is active, swinv2.py:125)
+            const float dot = qknorm_bwd_acc(dq, qf, hh, expf(fminf(pa.scale[h], 4.605170185988092f)), rnq);
+            const float tot = 0.5f * wave_sum(dot);
+            if (lane == 0 && pa.scale[h] < 4.605170185988092f) atomicAdd(st_ds + h, tot);
+        }
         if (!(pa.dbg & 4)) store_rows(dq, w, tok0, h * 3 * HD);  // (the dO image lands under the dq stores)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // Q (requested a pass ago) and dO images complete
@@ -567,6 +628,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next K image (it had the whole pass) ...
         __builtin_amdgcn_s_barrier();  // ... every wave's; and every wave is done with the Q and dO images
         if (has_next) dma_img(bF, qkv_base(nb, nh, 2), nwn, ldq_b);  // next V over the dead Q image: lands under the stores below
+        if (pa.rn) qknorm_bwd_acc(dk, kf, hh, 1.0f, rnk);    // d(k-hat) -> dk
         if (!(pa.dbg & 4)) {                                 // and under the next item's maximum sweep
             store_rows(dk, w, tok0, h * 3 * HD + HD);
             store_rows(dv, w, tok0, h * 3 * HD + 2 * HD);
@@ -579,10 +641,15 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
         b = nb; w = nwn; h = nh;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (pa.dscale) {
+        __syncthreads();
+        if (tid < a.heads && st_ds[tid] != 0.f) atomicAdd(pa.dscale + tid, st_ds[tid]);
+    }
 }
 
 }  // namespace
 
+int g_attn_bwd_fuse = 1;                   // tuning key 15 (A/B): 0 = the QK-norm backward stays a second pass
 int g_attn_bwd_pipe = 1;                   // tuning key 9 (A/B): 0 = one workgroup per item (the round-1 kernel)
 static bool ntok_bytes_ok(const BwdArgs& a) {    // per-lane 32-bit source offsets inside one sample
     return (int64_t)a.gh * a.gw * a.ldq * 2 < (1ll << 32) && (int64_t)a.gh * a.gw * a.ldo * 2 < (1ll << 32);
@@ -595,9 +662,11 @@ extern "C" int swiftk_window_attention_bwd(const void* qkvh, int64_t ldq, const 
                                               dtype, stream);
 }
 
-extern "C" int swiftk_window_attention_bwd_scaled(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo,
-                                                  void* dqkvh, int64_t ldd, const float* scale, int B, int gh, int gw, int heads,
-                                                  int head_dim, int shift_h, int shift_w, int dtype, void* stream) {
+// rn != null: the QK-norm backward rides in the stores where the pipelined kernel runs (*fused = 1), else the caller follows up
+static int attn_bwd_impl(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo, void* dqkvh, int64_t ldd,
+                         const float* scale, const float* rn, float* dscale, int* fused, int B, int gh, int gw, int heads,
+                         int head_dim, int shift_h, int shift_w, int dtype, void* stream) {
+    if (fused) *fused = 0;
     if (!qkvh || !o || !d_o || !dqkvh || B <= 0 || heads <= 0) return SWIFTK_EINVAL;
     if (dtype != SWIFTK_BF16) return SWIFTK_ESHAPE;  // training runs under bf16 autocast (trainer.py:191)
     if (head_dim != 80 && head_dim != 88 && head_dim != 96) return SWIFTK_ESHAPE;
@@ -629,6 +698,13 @@ extern "C" int swiftk_window_attention_bwd_scaled(const void* qkvh, int64_t ldq,
         pa.a = a;
         pa.scale = scale;
         pa.nitems = B * a.nw * heads;
+        pa.rn = nullptr;
+        pa.dscale = nullptr;
+        if (rn && dscale && scale && heads <= 16 && g_attn_bwd_fuse) {
+            pa.rn = rn;
+            pa.dscale = dscale;
+            *fused = 1;
+        }
         pa.dbg = g_attn_dbg >> 16;
         int pgrid = 256;
         if (pa.nitems < pgrid) pgrid = pa.nitems >= 8 ? (pa.nitems & ~7) : pa.nitems;
@@ -641,4 +717,24 @@ extern "C" int swiftk_window_attention_bwd_scaled(const void* qkvh, int64_t ldq,
     else hipLaunchKernelGGL(attn_bwd_kernel<88>, grid, dim3(NT), 0, st, a);
     SWIFTK_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int swiftk_window_attention_bwd_scaled(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo,
+                                                  void* dqkvh, int64_t ldd, const float* scale, int B, int gh, int gw, int heads,
+                                                  int head_dim, int shift_h, int shift_w, int dtype, void* stream) {
+    return attn_bwd_impl(qkvh, ldq, o, d_o, ldo, dqkvh, ldd, scale, nullptr, nullptr, nullptr, B, gh, gw, heads, head_dim, shift_h,
+                         shift_w, dtype, stream);
+}
+
+extern "C" int swiftk_window_attention_bwd_qknorm(const void* qkvh, int64_t ldq, const void* o, const void* d_o, int64_t ldo,
+                                                  void* dqkv, int64_t ldd, const float* scale, const float* rn, float* dscale, int B,
+                                                  int gh, int gw, int heads, int head_dim, int shift_h, int shift_w, int dtype,
+                                                  void* stream) {
+    if (!scale || !rn || !dscale) return SWIFTK_EINVAL;
+    int fused = 0;
+    const int rc = attn_bwd_impl(qkvh, ldq, o, d_o, ldo, dqkv, ldd, scale, rn, dscale, &fused, B, gh, gw, heads, head_dim, shift_h,
+                                 shift_w, dtype, stream);
+    if (rc != 0 || fused) return rc;
+    // head_dim 80 / 96, or the one-workgroup-per-item kernel: the gradients of q-hat / k-hat are rewritten in place by a second pass
+    return swiftk_qknorm_bwd(qkvh, dqkv, ldq, rn, dqkv, ldd, scale, dscale, (int64_t)B * gh * gw, heads, head_dim, dtype, stream);
 }

@@ -1270,6 +1270,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 12: g_fwd_pair = value; return 0;
         case 13: g_f32_chunk_k = value; return 0;
         case 14: g_fwd_splitk = value; return 0;
+        case 15: g_attn_bwd_fuse = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -1290,6 +1291,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 12: return g_fwd_pair;
         case 13: return g_f32_chunk_k;
         case 14: return g_fwd_splitk;
+        case 15: return g_attn_bwd_fuse;
     }
     return SWIFTK_EINVAL;
 }

@@ -385,17 +385,17 @@ class SwinTrainEngine:
             datt = torch.empty(M, self.kd, dtype=_BF, device=dev)
             _gemm(dy1, W["wo_t"], datt)  # N = d columns written, row stride kd
             self._wgrad(dy1, A["att"], d, d, G(att.wo.weight))
-            # d(q-hat | k-hat | v) lands in the to_qkv data-gradient GEMM's operand buffer (row stride kqkv); the QK-norm backward
-            # then rewrites the q-hat / k-hat vectors in place -- v's gradient is already final
+            # d(q | k | v) lands in the to_qkv data-gradient GEMM's operand buffer (row stride kqkv): the attention backward applies
+            # the QK-norm backward to its accumulators on their way out (head_dim 88; elsewhere a second pass rewrites the q-hat / k-hat
+            # vectors in place -- v's gradient is already final)
             dqkv = _padded(M, self.kqkv, 3 * d)
             sh = A["shift"]
-            check(L.swiftk_window_attention_bwd_scaled(A["qkvh"].data_ptr(), 3 * d, A["att"].data_ptr(), datt.data_ptr(), self.kd,
-                                                       dqkv.data_ptr(), self.kqkv, W["scale"].data_ptr(), B, gh, gw, heads, self.hd,
-                                                       sh[0], sh[1], BF16, _s()), "swiftk_window_attention_bwd")
             gscale = G(att.scale)  # [heads, 1, 1] fp32, contiguous: the kernel accumulates (atomicAdd) straight into it
             assert gscale.is_contiguous() and gscale.numel() == heads
-            check(L.swiftk_qknorm_bwd(A["qkvh"].data_ptr(), dqkv.data_ptr(), 3 * d, A["rn"].data_ptr(), dqkv.data_ptr(), self.kqkv,
-                                      W["scale"].data_ptr(), gscale.data_ptr(), M, heads, self.hd, BF16, _s()), "swiftk_qknorm_bwd")
+            check(L.swiftk_window_attention_bwd_qknorm(A["qkvh"].data_ptr(), 3 * d, A["att"].data_ptr(), datt.data_ptr(), self.kd,
+                                                       dqkv.data_ptr(), self.kqkv, W["scale"].data_ptr(), A["rn"].data_ptr(),
+                                                       gscale.data_ptr(), B, gh, gw, heads, self.hd, sh[0], sh[1], BF16, _s()),
+                  "swiftk_window_attention_bwd_qknorm")
             _gemm(dqkv, W["qkv_t"], dx, EPI_ACCUM)
             self._wgrad(dqkv, A["xT_in"], 3 * d, d, G(att.to_qkv.weight))
             if grads_final is not None:  # everything of layer i except its modulation Linears (those follow in _embed_bwd)

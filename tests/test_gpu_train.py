@@ -328,6 +328,53 @@ def test_window_attention_bwd(dev, shift, B):
     assert torch.allclose(ds_a, ds_b, rtol=1e-4, atol=1e-4 * float(ds_a.abs().max()))
     for part, name in enumerate("qkv"):
         assert rel_l2(d_s.float().cpu().view(B, n, heads, 3, hd)[..., part, :], gr[..., part, :]) < 2.5e-2, name
+    # both in one launch (swiftk_window_attention_bwd_qknorm: the QK-norm backward applied to the fp32 accumulators on their way
+    # out) == the two-launch sequence up to the bf16 rounding of d(q-hat) / d(k-hat) it no longer performs; with one head's scale
+    # above the clamp (no d(scale) there), and against the chain rule in fp32 autograd
+    sc2 = sc.clone()
+    sc2[3] = math.log(150.0)
+    pre2 = _prenorm(rnd((B, n, 3 * heads * hd), 13), sc2.cpu(), heads, hd).to(dev).to(BF)
+    o2 = ops.window_attention(pre2, None, grid, heads, shift, flags=_lib.ATTN_PRENORM)
+    two = torch.full((B, n, 3200), 7.0, dtype=torch.bfloat16, device=dev)
+    ds_two, ds_one = torch.zeros(heads, device=dev), torch.zeros(heads, device=dev)
+    assert L.swiftk_window_attention_bwd_scaled(pre2.data_ptr(), 3168, o2.data_ptr(), do.data_ptr(), 1056, two.data_ptr(), 3200,
+                                                sc2.data_ptr(), B, grid[0], grid[1], heads, hd, shift[0], shift[1], _lib.BF16, s()) == 0
+    assert L.swiftk_qknorm_bwd(pre2.data_ptr(), two.data_ptr(), 3168, rn.data_ptr(), two.data_ptr(), 3200, sc2.data_ptr(),
+                               ds_two.data_ptr(), B * n, heads, hd, _lib.BF16, s()) == 0
+    one = torch.full((B, n, 3200), 7.0, dtype=torch.bfloat16, device=dev)
+    assert L.swiftk_window_attention_bwd_qknorm(pre2.data_ptr(), 3168, o2.data_ptr(), do.data_ptr(), 1056, one.data_ptr(), 3200,
+                                                sc2.data_ptr(), rn.data_ptr(), ds_one.data_ptr(), B, grid[0], grid[1], heads, hd,
+                                                shift[0], shift[1], _lib.BF16, s()) == 0
+    torch.cuda.synchronize()
+    assert bool((one[..., 3168:] == 7.0).all())
+    e12 = rel_l2(one[..., :3168].float().cpu(), two[..., :3168].float().cpu())
+    eds = float((ds_one - ds_two).abs().max() / ds_two.abs().max())
+    print(f"attention bwd + QK-norm bwd in one launch vs two: dqkv rel-L2 {e12:.3e}, dscale {eds:.3e}")
+    assert e12 < 1e-2 and eds < 1e-2
+    assert float(ds_one[3]) == 0.0 and float(ds_two[3]) == 0.0
+    # fp32 chain rule: raw -> (x-hat = tau x rn, with the GIVEN rn treated as the forward's 1 / |x|) is what both kernels implement:
+    #   dx = rn (tau d(x-hat) - x-hat (x-hat . d(x-hat)) / tau), with d(x-hat) from autograd of the attention core on pre2
+    pc2 = pre2.float().cpu().requires_grad_(True)
+    src2 = pc2[:, idx.reshape(-1)].reshape(B * idx.shape[0], 256, heads, 3, hd).permute(0, 2, 1, 3, 4)
+    ow2 = (src2[..., 0, :] @ src2[..., 1, :].transpose(-2, -1)).softmax(-1) @ src2[..., 2, :]
+    torch.zeros(B, n, heads * hd).index_add(1, idx.reshape(-1), ow2.permute(0, 2, 1, 3).reshape(B, n, -1)).backward(do.float().cpu())
+    gh_ = pc2.grad.view(B, n, heads, 3, hd)
+    xh = pc2.detach().view(B, n, heads, 3, hd)
+    tau = torch.clamp(sc2.cpu(), max=math.log(100.0)).exp().view(1, 1, heads, 1)
+    rnc = rn.cpu().view(B, n, heads, 3)
+    want = gh_.clone()
+    dotq = (xh[..., 0, :] * gh_[..., 0, :]).sum(-1, keepdim=True)
+    want[..., 0, :] = rnc[..., 0:1] * (tau * gh_[..., 0, :] - xh[..., 0, :] * dotq / tau)
+    dotk = (xh[..., 1, :] * gh_[..., 1, :]).sum(-1, keepdim=True)
+    want[..., 1, :] = rnc[..., 1:2] * (gh_[..., 1, :] - xh[..., 1, :] * dotk)
+    got = one[..., :3168].float().cpu().view(B, n, heads, 3, hd)
+    for part, name in enumerate("qkv"):
+        e1, e2 = rel_l2(got[..., part, :], want[..., part, :]), rel_l2(two[..., :3168].float().cpu().view(B, n, heads, 3, hd)[..., part, :], want[..., part, :])
+        print(f"  d{name} vs fp32 chain rule: one launch {e1:.3e}, two launches {e2:.3e}")
+        assert e1 < 2.5e-2 and e1 <= e2 * 1.1, name
+    ds_want = dotq.sum(dim=(0, 1)).view(-1) * (sc2.cpu() < math.log(100.0))
+    # (a sum of cancelling terms over 2k tokens; the sharp heads' d(q-hat) carry the attention kernel's bf16 roundings of P and dS)
+    assert rel_l2(ds_one.cpu(), ds_want) < 5e-2 and rel_l2(ds_one.cpu(), ds_want) <= 1.2 * rel_l2(ds_two.cpu(), ds_want) + 1e-3
 
 
 def test_loss_kernels(dev):
