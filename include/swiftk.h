@@ -258,7 +258,8 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * stream + bf16 operand copy,
  * key 13 = chain length (in k) of the fp32-operand GEMMs' two-level accumulation in swiftk_swinv2_forward (256; 0 = off),
  * key 14 = split-K wo / w2 at one unit per step (1), key 15 = swiftk_window_attention_bwd_qknorm applies the QK-norm backward
- * inside the persistent attention backward (1; 0 = second pass). */
+ * inside the persistent attention backward (1; 0 = second pass), key 16 = swiftk_modnorm_bwd as one kernel (1; 0 = row pass +
+ * column pass; n > 1 = 64 n rows per block). */
 int swiftk_set_tuning(int key, int value);
 /* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
  * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default
@@ -321,7 +322,8 @@ int swiftk_swiglu_bwd(const void* h, int64_t ldh, const void* dout, int64_t ldo,
 
 /* Backward of swiftk_modnorm_residual's norm branch: g = dL/d(out) fp32 [M, d] -> dy (dtype), and fp32 atomic sums
  * dgamma[d], dbeta[d], dmod[B, lddmod] (scale grads at [0,d), shift grads at [d,2d)); the residual branch is identity.
- * row_stats: caller-provided scratch of 2*M floats (per-row mean and 1/std, handed from the row pass to the column pass). */
+ * row_stats: caller-provided scratch of 2*M floats (per-row mean and 1/std, handed from the row pass to the column pass; the
+ * one-kernel form -- rows_per_sample a multiple of 64 and >= d -- keeps its per-sample column sums [2][B][d] there instead). */
 int swiftk_modnorm_bwd(const void* y, int64_t ldy, const float* g, void* dy, int64_t lddy, const float* gamma,
                        const float* beta, const float* mod, int64_t ldmod, float* dgamma, float* dbeta, float* dmod,
                        int64_t lddmod, float* row_stats, int64_t M, int d, int64_t rows_per_sample, float eps, int dtype,

@@ -1271,6 +1271,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 13: g_f32_chunk_k = value; return 0;
         case 14: g_fwd_splitk = value; return 0;
         case 15: g_attn_bwd_fuse = value; return 0;
+        case 16: g_modnorm_bwd_fused = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -1292,6 +1293,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 13: return g_f32_chunk_k;
         case 14: return g_fwd_splitk;
         case 15: return g_attn_bwd_fuse;
+        case 16: return g_modnorm_bwd_fused;
     }
     return SWIFTK_EINVAL;
 }

@@ -215,6 +215,168 @@ __global__ __launch_bounds__(256) void modnorm_bwd_rows_kernel(const T* __restri
     }
 }
 
+// Both passes in one (round 4): a block owns `rows_per_block` consecutive rows of ONE sample, its four waves take every fourth row.
+// The column sums need only two running sums per column,
+//     P1 = sum_rows g n,   P2 = sum_rows g:    dgamma += (1+sc) P1,  dbeta += (1+sc) P2,  dsc_b += gamma P1 + beta P2,  dsh_b += P2,
+// held per lane for its columns (2 x 4 x SLOTS registers) next to the row constant w = (1+sc) gamma the row pass multiplies by;
+// y and g are read once (8 instead of 14 bytes per element over the two kernels above), the four waves' sums meet in LDS and leave
+// as one atomic per column and output.
+template <typename T>
+struct Raw4;  // four consecutive elements as loaded
+template <>
+struct Raw4<float> {
+    typedef float4 type;
+    __device__ static void cvt(const float4& r, float (&v)[4]) { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+};
+template <>
+struct Raw4<bf16_t> {
+    typedef uint2 type;
+    __device__ static void cvt(const uint2& r, float (&v)[4]) {
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    }
+};
+
+template <typename T, int SLOTS>
+__global__ __launch_bounds__(256) void modnorm_bwd_fused_kernel(const T* __restrict__ y, int64_t ldy, const float* __restrict__ g,
+                                                                T* __restrict__ dy, int64_t lddy, const float* __restrict__ gamma,
+                                                                const float* __restrict__ mod, int64_t ldmod, float* __restrict__ psum,
+                                                                int64_t M, int d, int64_t rps, float eps, int rows_per_block) {
+    typedef typename Raw4<T>::type raw_t;
+    constexpr int dpad = SLOTS * 256;
+    __shared__ __attribute__((aligned(16))) float red[8 * dpad];  // [wave][P1 | P2][column]
+    __shared__ __attribute__((aligned(16))) float wl[dpad];       // the row constant w = (1 + sc) gamma
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(r0 + rows_per_block, M);
+    const int64_t b = r0 / rps;
+    const int nc = d >> 2;
+    const float* mrow = mod + b * ldmod;
+    for (int col = threadIdx.x; col < dpad; col += 256) wl[col] = col < d ? (1.0f + mrow[col]) * gamma[col] : 0.f;
+    float p1[SLOTS][4], p2[SLOTS][4];
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p1[i][e] = p2[i][e] = 0.f;
+    __syncthreads();
+    const float inv_d = 1.0f / (float)d;
+    // the next row's loads are in flight while this row is reduced and stored (a lone wave took 3.6 us per row without)
+    raw_t ry[SLOTS];
+    float4 rg[SLOTS];
+    auto fetch = [&](int64_t row) {
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                ry[i] = *reinterpret_cast<const raw_t*>(y + row * ldy + 4 * c);
+                rg[i] = *reinterpret_cast<const float4*>(g + row * d + 4 * c);
+            }
+        }
+    };
+    if (r0 + wv < r1) fetch(r0 + wv);
+    for (int64_t row = r0 + wv; row < r1; row += 4) {
+        float v[SLOTS][4], gg[SLOTS][4];
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            if (lane + 64 * i < nc) {
+                Raw4<T>::cvt(ry[i], v[i]);
+                gg[i][0] = rg[i].x; gg[i][1] = rg[i].y; gg[i][2] = rg[i].z; gg[i][3] = rg[i].w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] = gg[i][e] = 0.f;
+            }
+        }
+        if (row + 4 < r1) fetch(row + 4);
+        // ONE round of wave reductions per row: with t = y - y0 (y0 = the row's first element: a shift that keeps the one-pass
+        // variance well conditioned) the four sums  sum t, sum t^2, sum dn, sum dn t  give mean, rstd and both means the row's dy
+        // needs (mean(dn), mean(dn n) = rstd (sum dn t - mean_t sum dn) / d) -- not four dependent reductions
+        const float y0 = __shfl(v[0][0], 0, 64);
+        float q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const float4 w4 = *reinterpret_cast<const float4*>(&wl[4 * (lane + 64 * i)]);
+            const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = (lane + 64 * i < nc) ? v[i][e] - y0 : 0.f;
+                const float dn = gg[i][e] * ww[e];
+                v[i][e] = t;
+                q1 += t;
+                q2 = fmaf(t, t, q2);
+                q3 += dn;
+                q4 = fmaf(dn, t, q4);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            q1 += __shfl_xor(q1, o, 64);
+            q2 += __shfl_xor(q2, o, 64);
+            q3 += __shfl_xor(q3, o, 64);
+            q4 += __shfl_xor(q4, o, 64);
+        }
+        const float mt = q1 * inv_d;
+        const float rstd = rsqrtf(fmaxf(q2 * inv_d - mt * mt, 0.f) + eps);
+        const float s1 = q3 * inv_d, s2 = rstd * (q4 - mt * q3) * inv_d;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const float4 w4 = *reinterpret_cast<const float4*>(&wl[4 * (lane + 64 * i)]);
+            const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+            float o4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float n = (v[i][e] - mt) * rstd;  // (pad lanes: g = 0, nothing is added or stored)
+                p1[i][e] = fmaf(gg[i][e], n, p1[i][e]);
+                p2[i][e] += gg[i][e];
+                o4[e] = rstd * (gg[i][e] * ww[e] - s1 - n * s2);
+            }
+            const int c = lane + 64 * i;
+            if (c < nc) st4<T>(dy + row * lddy + 4 * c, o4[0], o4[1], o4[2], o4[3]);
+        }
+    }
+    // the four waves' sums meet in LDS indexed by COLUMN, so that the atomics below run over consecutive addresses (whole lines
+    // per instruction; issued in the accumulators' own layout -- a lane's four columns 16 B apart -- they were a quarter-line each
+    // and cost more than the pass they replaced)
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            *reinterpret_cast<float4*>(&red[(wv * 2 + 0) * dpad + 4 * c]) = make_float4(p1[i][0], p1[i][1], p1[i][2], p1[i][3]);
+            *reinterpret_cast<float4*>(&red[(wv * 2 + 1) * dpad + 4 * c]) = make_float4(p2[i][0], p2[i][1], p2[i][2], p2[i][3]);
+        }
+    }
+    __syncthreads();
+    // per SAMPLE sums first (psum [2][samples][d], zeroed by the launcher): every block of the launch adding into dgamma / dbeta
+    // directly put 1,024 atomics on each of their 2 x d addresses, which cost more than the pass this kernel removes
+    const int64_t nb = M / rps;
+    for (int col = threadIdx.x; col < d; col += 256) {
+        const float a1 = (red[0 * dpad + col] + red[2 * dpad + col]) + (red[4 * dpad + col] + red[6 * dpad + col]);
+        const float a2 = (red[1 * dpad + col] + red[3 * dpad + col]) + (red[5 * dpad + col] + red[7 * dpad + col]);
+        atomicAdd(psum + b * d + col, a1);
+        atomicAdd(psum + (nb + b) * d + col, a2);
+    }
+}
+
+// ... and the outputs from the per-sample sums: one thread per column
+__global__ __launch_bounds__(256) void modnorm_bwd_finish_kernel(const float* __restrict__ psum, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ mod,
+                                                                 int64_t ldmod, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 float* __restrict__ dmod, int64_t lddmod, int nb, int d) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= d) return;
+    const float ga = gamma[col], be = beta[col];
+    float dg = 0.f, db = 0.f;
+    for (int b = 0; b < nb; ++b) {
+        const float a1 = psum[(int64_t)b * d + col], a2 = psum[(int64_t)(nb + b) * d + col];
+        const float sc1 = 1.0f + mod[b * ldmod + col];
+        dg = fmaf(sc1, a1, dg);
+        db = fmaf(sc1, a2, db);
+        dmod[b * lddmod + col] += ga * a1 + be * a2;
+        dmod[b * lddmod + d + col] += a2;
+    }
+    dgamma[col] += dg;
+    dbeta[col] += db;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void modnorm_bwd_cols_kernel(const T* __restrict__ y, int64_t ldy, const float* __restrict__ g,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -632,6 +794,8 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(const swiftk_opt_chunk* 
 
 }  // namespace
 
+int g_modnorm_bwd_fused = 1;  // tuning key 16 (A/B): 0 = row pass and column pass as two kernels
+
 #define DT_SWITCH(dtype, CALL_BF16, CALL_F32) \
     if (dtype == SWIFTK_BF16) { CALL_BF16; } else if (dtype == SWIFTK_F32) { CALL_F32; } else return SWIFTK_EINVAL
 
@@ -700,6 +864,32 @@ extern "C" int swiftk_modnorm_bwd(const void* y, int64_t ldy, const float* g, vo
         return SWIFTK_EINVAL;
     if (d % 4 || d > 1536 || M % rows_per_sample) return SWIFTK_ESHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // one pass (rows and column sums together) when the row-statistics workspace [2 M] can hold the per-sample column sums [2][B][d]
+    int rpbf = 64 * g_modnorm_bwd_fused;  // key 16: 1 = the largest of 256 / 128 / 64 rows per block that still gives every CU a block
+    if (g_modnorm_bwd_fused == 1) {
+        rpbf = 256;
+        while (rpbf > 64 && (rows_per_sample % rpbf || M / rpbf < 256)) rpbf >>= 1;
+    }
+    if (g_modnorm_bwd_fused > 0 && rows_per_sample % rpbf == 0 && rows_per_sample >= d) {
+        const unsigned grid = (unsigned)(M / rpbf);
+        const int nb = (int)(M / rows_per_sample);
+        if (hipMemsetAsync(row_stats, 0, sizeof(float) * 2 * nb * d, st) != hipSuccess) return SWIFTK_EINVAL;
+#define SWIFTK_MNB(TT, SL)                                                                                                        \
+    hipLaunchKernelGGL((modnorm_bwd_fused_kernel<TT, SL>), dim3(grid), dim3(256), 0, st, static_cast<const TT*>(y), ldy, g,       \
+                       static_cast<TT*>(dy), lddy, gamma, mod, ldmod, row_stats, M, d, rows_per_sample, eps, rpbf)
+        if (dtype == SWIFTK_BF16) {
+            if (d <= 1280) SWIFTK_MNB(bf16_t, 5);
+            else SWIFTK_MNB(bf16_t, 6);
+        } else {
+            if (d <= 1280) SWIFTK_MNB(float, 5);
+            else SWIFTK_MNB(float, 6);
+        }
+#undef SWIFTK_MNB
+        hipLaunchKernelGGL(modnorm_bwd_finish_kernel, dim3((d + 255) / 256), dim3(256), 0, st, row_stats, gamma, beta, mod, ldmod, dgamma,
+                           dbeta, dmod, lddmod, nb, d);
+        SWIFTK_CHECK_LAUNCH();
+        return 0;
+    }
     const unsigned grid_rows = (unsigned)((M + 3) / 4);
     const int rpb = 256;
     const dim3 grid_cols((unsigned)(((d >> 2) + 63) / 64), (unsigned)((M / rows_per_sample) * ((rows_per_sample + rpb - 1) / rpb)));
