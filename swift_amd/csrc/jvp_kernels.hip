@@ -578,15 +578,22 @@ __global__ __launch_bounds__(512) void attn_jvp_kernel(AttnJvpArgs a) {
 // K / dK images (208-B rows) are resident together for the score products, then V / dV images (192-B rows) for the value
 // products; V^T fragments come from the row-major images through ds_read_b64_tr_b16, with the k-slots of a 32-key step
 // ordered to match the S^T accumulator registers of two 16-key blocks: slot (g, j) <-> key 16 (2p + j/4) + 4 g + j%4.
+// Round 4: the images are staged in HALVES of 128 keys (53 KB instead of 106: two workgroups per CU, one computing while the other
+// waits), and the next half's 16-B chunks are requested into registers before the current half is consumed -- the kernel used to
+// spend 32 us per workgroup on 2 us of matrix work, every image load exposed.  The two query halves of an item run on workgroups
+// 8 apart in the launch order, i.e. on the same XCD: the second one finds K, dK, V, dV in that XCD's L2.
 constexpr int JK = 208, JV = 192;
 
 template <int HD>
 __global__ __launch_bounds__(512) void attn_jvp_bf16_kernel(AttnJvpArgs a) {
-    __shared__ __attribute__((aligned(16))) char img[2 * 256 * JK];
+    __shared__ __attribute__((aligned(16))) char img[2 * 128 * JK];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qh = blockIdx.x & 1;
-    const int item = blockIdx.x >> 1;
+    int qh = blockIdx.x & 1, item = blockIdx.x >> 1;
+    if ((gridDim.x & 15) == 0) {  // (item, query half) = (16 j + i, h) for block 16 j + 8 h + i
+        qh = (blockIdx.x >> 3) & 1;
+        item = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+    }
     const int head = item % a.heads;
     const int w = (item / a.heads) % a.nw;
     const int b = item / (a.heads * a.nw);
@@ -595,21 +602,35 @@ __global__ __launch_bounds__(512) void attn_jvp_bf16_kernel(AttnJvpArgs a) {
     const bf16_t* dqkv = static_cast<const bf16_t*>(a.dqkv);
     const int l16 = lane & 15, g = lane >> 4;
 
-    // both images of `part` (1 = k, 2 = v): primal at img, tangent at img + 256 * stride; coalesced 16-B chunks
-    auto fill = [&](int part, int stride) {
-        for (int c = tid; c < 2 * 256 * 12; c += 512) {
-            const int tan = c >= 256 * 12;
-            const int cc0 = c - tan * 256 * 12;
+    // one half image pair of `part` (1 = k, 2 = v): 128 keys x 12 chunks, primal rows 0..127, tangent rows 128..255 of img;
+    // chunk c = tid + 512 k of [tangent][key][chunk]: six per thread
+    uint4 pre[6];
+    auto request = [&](int part, int half) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int c = tid + 512 * k;
+            const int tan = c >= 128 * 12;
+            const int cc0 = c - tan * 128 * 12;
             const int row = cc0 / 12, cc = cc0 - row * 12;
-            uint4 v = make_uint4(0, 0, 0, 0);
+            pre[k] = make_uint4(0, 0, 0, 0);
             if (cc < HD / 8) {
-                const bf16_t* src = (tan ? dqkv : qkv) + (tok0 + jvp_window_token(a, w, row)) * a.ldq + (head * 3 + part) * HD;
-                v = *reinterpret_cast<const uint4*>(src + 8 * cc);
+                const bf16_t* src = (tan ? dqkv : qkv) + (tok0 + jvp_window_token(a, w, half * 128 + row)) * a.ldq + (head * 3 + part) * HD;
+                pre[k] = *reinterpret_cast<const uint4*>(src + 8 * cc);
             }
-            *reinterpret_cast<uint4*>(img + (tan * 256 + row) * stride + cc * 16) = v;
+        }
+    };
+    auto deposit = [&](int stride) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int c = tid + 512 * k;
+            const int tan = c >= 128 * 12;
+            const int cc0 = c - tan * 128 * 12;
+            const int row = cc0 / 12, cc = cc0 - row * 12;
+            *reinterpret_cast<uint4*>(img + (tan * 128 + row) * stride + cc * 16) = pre[k];
         }
     };
 
+    request(1, 0);
     // q / dq fragments of query row qh*128 + wv*16 + l16: 8 bf16 at d = 32 ks + 8 g (zero beyond head_dim)
     uint4 qf[3], dqf[3];
     {
@@ -621,25 +642,34 @@ __global__ __launch_bounds__(512) void attn_jvp_bf16_kernel(AttnJvpArgs a) {
             dqf[ks] = d < HD ? *reinterpret_cast<const uint4*>(dqkv + r + d) : make_uint4(0, 0, 0, 0);
         }
     }
-    fill(1, JK);
+    deposit(JK);
     __syncthreads();
 
     f32x4 s[16], ds[16];
     const char* sK = img;
-    const char* sdK = img + 256 * JK;
+    const char* sdK = img + 128 * JK;
 #pragma unroll
-    for (int blk = 0; blk < 16; ++blk) {
-        s[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
-        ds[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int half = 0; half < 2; ++half) {
+        if (half == 0) request(1, 1);  // the other 128 keys' k / dk ...
+        else request(2, 0);            // ... then the first 128 keys' v / dv, in flight under the score products
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            const int off = (blk * 16 + l16) * JK + (32 * ks + 8 * g) * 2;
-            const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sK + off));
-            const bf16x8 dkf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sdK + off));
-            s[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, __builtin_bit_cast(bf16x8, qf[ks]), s[blk], 0, 0, 0);
-            ds[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, __builtin_bit_cast(bf16x8, dqf[ks]), ds[blk], 0, 0, 0);
-            ds[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dkf, __builtin_bit_cast(bf16x8, qf[ks]), ds[blk], 0, 0, 0);
+        for (int bl = 0; bl < 8; ++bl) {
+            const int blk = half * 8 + bl;
+            s[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ds[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const int off = (bl * 16 + l16) * JK + (32 * ks + 8 * g) * 2;
+                const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sK + off));
+                const bf16x8 dkf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sdK + off));
+                s[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, __builtin_bit_cast(bf16x8, qf[ks]), s[blk], 0, 0, 0);
+                ds[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, __builtin_bit_cast(bf16x8, dqf[ks]), ds[blk], 0, 0, 0);
+                ds[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dkf, __builtin_bit_cast(bf16x8, qf[ks]), ds[blk], 0, 0, 0);
+            }
         }
+        __syncthreads();  // every wave is done with this half's images
+        deposit(half == 0 ? JK : JV);
+        __syncthreads();
     }
 
     float mx = -INFINITY;
@@ -650,25 +680,25 @@ __global__ __launch_bounds__(512) void attn_jvp_bf16_kernel(AttnJvpArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float l = 0.f, rs = 0.f;
+    uint4 pfs[8], wfs[8];  // e and W = e o dS as the bf16 B operands of the value products
 #pragma unroll
-    for (int blk = 0; blk < 16; ++blk)
+    for (int p = 0; p < 8; ++p) {
+        float e[8], wg[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float e = __expf(s[blk][r] - mx);
-            const float wgt = e * ds[blk][r];
-            s[blk][r] = e;
-            ds[blk][r] = wgt;
-            l += e;
-            rs += wgt;
+        for (int r = 0; r < 8; ++r) {
+            e[r] = __expf(s[2 * p + (r >> 2)][r & 3] - mx);
+            wg[r] = e[r] * ds[2 * p + (r >> 2)][r & 3];
+            l += e[r];
+            rs += wg[r];
         }
+        pfs[p] = make_uint4(pack_bf16(e[0], e[1]), pack_bf16(e[2], e[3]), pack_bf16(e[4], e[5]), pack_bf16(e[6], e[7]));
+        wfs[p] = make_uint4(pack_bf16(wg[0], wg[1]), pack_bf16(wg[2], wg[3]), pack_bf16(wg[4], wg[5]), pack_bf16(wg[6], wg[7]));
+    }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     rs += __shfl_xor(rs, 16, 64);
     rs += __shfl_xor(rs, 32, 64);
 
-    __syncthreads();
-    fill(2, JV);
-    __syncthreads();
     f32x4 o[6], u[6], tt[6];
 #pragma unroll
     for (int db = 0; db < 6; ++db) {
@@ -677,33 +707,34 @@ __global__ __launch_bounds__(512) void attn_jvp_bf16_kernel(AttnJvpArgs a) {
         tt[db] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const char* sV = img;
-    const char* sdV = img + 256 * JV;
+    const char* sdV = img + 128 * JV;
     // transposed-read address of this lane inside a 4-row x 16-column block: row l16 >> 2, columns 4 (l16 & 3) ..
     const int troff = (4 * g + (l16 >> 2)) * JV + 4 * (l16 & 3) * 2;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        uint4 pf, wf;
-        pf.x = pack_bf16(s[2 * p][0], s[2 * p][1]);
-        pf.y = pack_bf16(s[2 * p][2], s[2 * p][3]);
-        pf.z = pack_bf16(s[2 * p + 1][0], s[2 * p + 1][1]);
-        pf.w = pack_bf16(s[2 * p + 1][2], s[2 * p + 1][3]);
-        wf.x = pack_bf16(ds[2 * p][0], ds[2 * p][1]);
-        wf.y = pack_bf16(ds[2 * p][2], ds[2 * p][3]);
-        wf.z = pack_bf16(ds[2 * p + 1][0], ds[2 * p + 1][1]);
-        wf.w = pack_bf16(ds[2 * p + 1][2], ds[2 * p + 1][3]);
-        const int rb = 32 * p * JV + troff;
+    for (int half = 0; half < 2; ++half) {
+        if (half == 0) request(2, 1);
 #pragma unroll
-        for (int db = 0; db < 6; ++db) {
-            typedef __attribute__((address_space(3))) s16x4* lds4;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(sV + rb + db * 32));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(sV + rb + 16 * JV + db * 32));
-            const s16x4 dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(sdV + rb + db * 32));
-            const s16x4 dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(sdV + rb + 16 * JV + db * 32));
-            const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            const bf16x8 dvf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(dlo, dhi, 0, 1, 2, 3, 4, 5, 6, 7));
-            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pf), o[db], 0, 0, 0);
-            u[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, wf), u[db], 0, 0, 0);
-            tt[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dvf, __builtin_bit_cast(bf16x8, pf), tt[db], 0, 0, 0);
+        for (int pl = 0; pl < 4; ++pl) {
+            const int p = half * 4 + pl;
+            const int rb = 32 * pl * JV + troff;
+#pragma unroll
+            for (int db = 0; db < 6; ++db) {
+                typedef __attribute__((address_space(3))) s16x4* lds4;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(sV + rb + db * 32));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(sV + rb + 16 * JV + db * 32));
+                const s16x4 dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(sdV + rb + db * 32));
+                const s16x4 dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(sdV + rb + 16 * JV + db * 32));
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                const bf16x8 dvf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(dlo, dhi, 0, 1, 2, 3, 4, 5, 6, 7));
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pfs[p]), o[db], 0, 0, 0);
+                u[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, wfs[p]), u[db], 0, 0, 0);
+                tt[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dvf, __builtin_bit_cast(bf16x8, pfs[p]), tt[db], 0, 0, 0);
+            }
+        }
+        if (half == 0) {
+            __syncthreads();
+            deposit(JV);
+            __syncthreads();
         }
     }
 
