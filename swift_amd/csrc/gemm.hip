@@ -1272,6 +1272,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 14: g_fwd_splitk = value; return 0;
         case 15: g_attn_bwd_fuse = value; return 0;
         case 16: g_modnorm_bwd_fused = value; return 0;
+        case 17: g_modnorm_jvp_rows = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -1294,6 +1295,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 14: return g_fwd_splitk;
         case 15: return g_attn_bwd_fuse;
         case 16: return g_modnorm_bwd_fused;
+        case 17: return g_modnorm_jvp_rows;
     }
     return SWIFTK_EINVAL;
 }

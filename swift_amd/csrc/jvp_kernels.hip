@@ -368,6 +368,160 @@ __global__ __launch_bounds__(256) void modnorm_jvp_pair_kernel(const bf16_t* __r
     }
 }
 
+// The same, a block walking `rows_per_block` rows of one sample (round 4): the six per-column constant vectors enter only through
+//     A = gamma (1+sc),  B = beta (1+sc) + sh,  C = gamma dsc,  D = beta dsc + dsh:   x += n A + B,   dx += dn A + n C + D,
+// formed once per block in LDS (the row-per-wave kernel above pulls 6 x 4 KB through L2 for every row, after its reductions); the
+// next row's loads are in flight while the current row is reduced and stored, and the row's four sums -- with t = y - y0:
+// sum t, sum t^2, sum dy, sum t dy, from which mean, rstd, mean(dy), mean(n dy) follow -- cross the wave in ONE round of adds
+// instead of three dependent ones.
+__global__ __launch_bounds__(256) void modnorm_jvp_pair_rows_kernel(const bf16_t* __restrict__ y, const bf16_t* __restrict__ dy, int64_t ldy,
+                                                                    const bf16_t* xT_in, const bf16_t* dxT_in, bf16_t* xT, bf16_t* dxT,
+                                                                    int64_t ldxT, uint8_t* xlo, uint8_t* dxlo,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    const float* __restrict__ mod, const float* __restrict__ dmod,
+                                                                    int64_t ldmod, int64_t M, int d, int64_t rps, float eps,
+                                                                    int rows_per_block) {
+    constexpr int SLOTS = 3, DP = SLOTS * 512;  // d <= 1536
+    __shared__ __attribute__((aligned(16))) float cst[4][DP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(r0 + rows_per_block, M);
+    const int64_t b = r0 / rps;
+    const int nc = d >> 3;
+    struct Raw {
+        uint4 y, dy, hx, hd;
+        uint2 lx, ld;
+    };
+    Raw nx[SLOTS];
+    auto fetch = [&](int64_t row) {
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                nx[i].y = *reinterpret_cast<const uint4*>(y + row * ldy + 8 * c);
+                nx[i].dy = *reinterpret_cast<const uint4*>(dy + row * ldy + 8 * c);
+                nx[i].hx = *reinterpret_cast<const uint4*>(xT_in + row * ldxT + 8 * c);
+                nx[i].hd = *reinterpret_cast<const uint4*>(dxT_in + row * ldxT + 8 * c);
+                nx[i].lx = *reinterpret_cast<const uint2*>(xlo + row * d + 8 * c);
+                nx[i].ld = *reinterpret_cast<const uint2*>(dxlo + row * d + 8 * c);
+            }
+        }
+    };
+    if (r0 + wv < r1) fetch(r0 + wv);
+    {
+        const float* mrow = mod + b * ldmod;
+        const float* dmrow = dmod + b * ldmod;
+        for (int col = threadIdx.x; col < DP; col += 256) {
+            float A = 0.f, Bc = 0.f, C = 0.f, D = 0.f;
+            if (col < d) {
+                const float ga = gamma[col], be = beta[col], sc1 = 1.0f + mrow[col], dsc = dmrow[col];
+                A = ga * sc1;
+                Bc = be * sc1 + mrow[d + col];
+                C = ga * dsc;
+                D = be * dsc + dmrow[d + col];
+            }
+            cst[0][col] = A; cst[1][col] = Bc; cst[2][col] = C; cst[3][col] = D;
+        }
+    }
+    __syncthreads();
+    auto unpack8 = [](const uint4& u, float (&v)[8]) {
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = __uint_as_float(w[e] << 16);
+            v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+        }
+    };
+    auto value = [](const uint4& h, const uint2& l, float (&v)[8]) {  // the eight fp32 values a (hi, lo) slot stands for
+        const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[2] = {l.x, l.y};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float hf = (e & 1) ? __uint_as_float(hw[e >> 1] & 0xffff0000u) : __uint_as_float(hw[e >> 1] << 16);
+            const uint32_t E = (hw[e >> 1] >> ((e & 1) ? 23 : 7)) & 0xFFu;
+            v[e] = hf + lo8_value((float)((lw[e >> 2] >> (8 * (e & 3))) & 0xFFu), E);
+        }
+    };
+    auto store_pair = [](const float (&v)[8], bf16_t* hp, uint8_t* lp) {
+        uint32_t oh[4], ol[2] = {0u, 0u};
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const uint32_t ph = pack_bf16(v[2 * e2], v[2 * e2 + 1]);
+            oh[e2] = ph;
+            ol[e2 >> 1] = lo8_insert(v[2 * e2], __uint_as_float(ph << 16), (ph >> 7) & 0xFFu, (2 * e2) & 3, ol[e2 >> 1]);
+            ol[e2 >> 1] = lo8_insert(v[2 * e2 + 1], __uint_as_float(ph & 0xffff0000u), (ph >> 23) & 0xFFu, (2 * e2 + 1) & 3, ol[e2 >> 1]);
+        }
+        *reinterpret_cast<uint4*>(hp) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+        *reinterpret_cast<uint2*>(lp) = make_uint2(ol[0], ol[1]);
+    };
+    const float inv_d = 1.0f / (float)d;
+    for (int64_t row = r0 + wv; row < r1; row += 4) {
+        Raw cur[SLOTS];
+        float yv[SLOTS][8], dv[SLOTS][8];
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            cur[i] = nx[i];
+            if (lane + 64 * i < nc) {
+                unpack8(cur[i].y, yv[i]);
+                unpack8(cur[i].dy, dv[i]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) yv[i][e] = dv[i][e] = 0.f;
+            }
+        }
+        if (row + 4 < r1) fetch(row + 4);
+        const float y0 = __shfl(yv[0][0], 0, 64);
+        float q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = (lane + 64 * i < nc) ? yv[i][e] - y0 : 0.f;
+                yv[i][e] = t;
+                q1 += t;
+                q2 = fmaf(t, t, q2);
+                q3 += dv[i][e];
+                q4 = fmaf(t, dv[i][e], q4);
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            q1 += __shfl_xor(q1, o, 64);
+            q2 += __shfl_xor(q2, o, 64);
+            q3 += __shfl_xor(q3, o, 64);
+            q4 += __shfl_xor(q4, o, 64);
+        }
+        const float mt = q1 * inv_d;
+        const float rstd = 1.0f / sqrtf(fmaxf(q2 * inv_d - mt * mt, 0.f) + eps);
+        const float mdy = q3 * inv_d, mndy = rstd * (q4 - mt * q3) * inv_d;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                float xr[8], dxr[8];
+                value(cur[i].hx, cur[i].lx, xr);
+                value(cur[i].hd, cur[i].ld, dxr);
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(&cst[0][8 * c + 4 * hq]);
+                    const float4 b4 = *reinterpret_cast<const float4*>(&cst[1][8 * c + 4 * hq]);
+                    const float4 c4 = *reinterpret_cast<const float4*>(&cst[2][8 * c + 4 * hq]);
+                    const float4 d4 = *reinterpret_cast<const float4*>(&cst[3][8 * c + 4 * hq]);
+                    const float aa[4] = {a4.x, a4.y, a4.z, a4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                    const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const int e = 4 * hq + e4;
+                        const float n = (yv[i][e] - mt) * rstd, dn = (dv[i][e] - mdy - n * mndy) * rstd;
+                        xr[e] += fmaf(n, aa[e4], bb[e4]);
+                        dxr[e] += fmaf(dn, aa[e4], fmaf(n, cc[e4], dd[e4]));
+                    }
+                }
+                store_pair(xr, xT + row * ldxT + 8 * c, xlo + row * d + 8 * c);
+                store_pair(dxr, dxT + row * ldxT + 8 * c, dxlo + row * d + 8 * c);
+            }
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------- windowed softmax attention tangent
 // Per (sample, window, head), q_hat/k_hat pre-normalised (qknorm_jvp), softmax scale 1 (swinv2.py:129-133):
 //   S = Q K^T,  P = softmax(S),  O = P V
@@ -786,6 +940,8 @@ __global__ __launch_bounds__(256) void scm_target_kernel(const float* __restrict
 
 }  // namespace
 
+int g_modnorm_jvp_rows = 1;  // tuning key 17: swiftk_modnorm_jvp_pair walks 32 n rows per block (0 = a row per wave)
+
 #define DT_SWITCH(dtype, CALL_BF16, CALL_F32) \
     if (dtype == SWIFTK_BF16) { CALL_BF16; } else if (dtype == SWIFTK_F32) { CALL_F32; } else return SWIFTK_EINVAL
 
@@ -884,6 +1040,16 @@ extern "C" int swiftk_modnorm_jvp_pair(const void* y, const void* dy, int64_t ld
          (uintptr_t)beta | (uintptr_t)mod | (uintptr_t)dmod) & 15)
         return SWIFTK_EALIGN;
     if (((uintptr_t)x_lo | (uintptr_t)dx_lo) & 7) return SWIFTK_EALIGN;
+    if (g_modnorm_jvp_rows > 0 && rows_per_sample % (32 * g_modnorm_jvp_rows) == 0) {
+        const int rpb = 32 * g_modnorm_jvp_rows;
+        hipLaunchKernelGGL(modnorm_jvp_pair_rows_kernel, dim3((unsigned)(M / rpb)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const bf16_t*>(y), static_cast<const bf16_t*>(dy), ldy, static_cast<const bf16_t*>(xT_in),
+                           static_cast<const bf16_t*>(dxT_in), static_cast<bf16_t*>(xT), static_cast<bf16_t*>(dxT), ldxT,
+                           static_cast<uint8_t*>(x_lo), static_cast<uint8_t*>(dx_lo), gamma, beta, mod, dmod, ldmod, M, d,
+                           rows_per_sample, eps, rpb);
+        SWIFTK_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(modnorm_jvp_pair_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const bf16_t*>(y), static_cast<const bf16_t*>(dy), ldy, static_cast<const bf16_t*>(xT_in),
                        static_cast<const bf16_t*>(dxT_in), static_cast<bf16_t*>(xT), static_cast<bf16_t*>(dxT), ldxT,
