@@ -58,6 +58,10 @@ extern "C" {
 #define SWIFTK_EPI_ACCUM 5     /* C += A W^T, fp32 C only: the backward pass adds a branch's input gradient onto the
                                   residual-stream gradient (autograd of x + f(x), swinv2.py:211-212) in the GEMM itself */
 
+#define SWIFTK_EPI_SWIGLU_SPLIT3 10 /* the split engine's w1 (bf16 operands = swiftk_split3 blocks, bf16 out): silu(gate) * up leaves as the
+                                  NEXT GEMM's operand blocks [hi | lo | hi], hi = bf16(h), lo = bf16(h - hi), block width (columns)
+                                  in `pos_rows` (>= N / 2, ldc >= 2 pos_rows + N / 2): what SWIFTK_EPI_SWIGLU with fp32 output +
+                                  swiftk_split3(order 0) leave, without h itself reaching memory */
 #define SWIFTK_EPI_QKNORM_JVP 8 /* swiftk_gemm_jvp only: SWIFTK_EPI_QKNORM on the primal rows AND its tangent on the tangent rows */
 #define SWIFTK_EPI_SWIGLU_JVP 9 /* swiftk_gemm_jvp only: silu(gate) * up and its tangent (pre-activations optionally kept) */
 
@@ -259,7 +263,8 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * key 13 = chain length (in k) of the fp32-operand GEMMs' two-level accumulation in swiftk_swinv2_forward (256; 0 = off),
  * key 14 = split-K wo / w2 at one unit per step (1), key 15 = swiftk_window_attention_bwd_qknorm applies the QK-norm backward
  * inside the persistent attention backward (1; 0 = second pass), key 16 = swiftk_modnorm_bwd as one kernel (1; 0 = row pass +
- * column pass; n > 1 = 64 n rows per block), key 17 = swiftk_modnorm_jvp_pair walks 32 n rows per block (1; 0 = a row per wave). */
+ * column pass; n > 1 = 64 n rows per block), key 17 = swiftk_modnorm_jvp_pair walks 32 n rows per block (1; 0 = a row per wave),
+ * key 18 = split engine: w1's epilogue writes w2's (hi, lo) operand blocks itself (1; 0 = fp32 h + swiftk_split3). */
 int swiftk_set_tuning(int key, int value);
 /* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
  * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default

@@ -18,6 +18,7 @@ F32, BF16 = 0, 1
 BF16X3 = 2  # swiftk_model.dtype only: fp32 activations, every GEMM as three bf16 products (include/swiftk.h)
 EPI_NONE, EPI_BIAS_POS, EPI_SWIGLU, EPI_QKNORM, EPI_ACCUM, EPI_SWIGLU_BOTH, EPI_SWIGLU_BWD = 0, 1, 2, 3, 5, 6, 7
 EPI_QKNORM_JVP, EPI_SWIGLU_JVP = 8, 9  # swiftk_gemm_jvp only
+EPI_SWIGLU_SPLIT3 = 10
 ATTN_PRENORM, ATTN_NO_PIPE, ATTN_TILED = 1, 2, 4
 PROF_ATTENTION = 100
 

@@ -8,7 +8,8 @@ int g_x3_exact = 17;  // tuning key 11: the DEFAULT mask a host binding copies i
                       // (the forward reads the model's own field, never this global: ADVICE r3)
 int g_fwd_pair = 2;   // tuning key 12: bf16 engine's residual stream: 2 = (bf16 hi, 8-bit lo) pair, 1 = (bf16 hi, bf16 lo), 0 = fp32 + copy
 int g_f32_chunk_k = 256;  // tuning key 13: fp32-operand GEMMs of the forward accumulate in chains of this many k (0 = one chain over K)
-int g_fwd_splitk = 1;  // tuning key 14: wo / w2 as two k-ranges into fp32 slabs when their tiles fill less than half the chip (one unit per step)
+int g_fwd_splitk = 1;
+int g_x3_ffsplit = 1;  // tuning key 18: split engine, w1 writes w2's operand blocks itself  // tuning key 14: wo / w2 as two k-ranges into fp32 slabs when their tiles fill less than half the chip (one unit per step)
 int g_fwd_fused = 1;  // tuning key 8 (A/B only): 0 = to_qkv and window attention as two kernels (q/k/v window-tiled through HBM)
 
 namespace {
@@ -23,7 +24,7 @@ __global__ __launch_bounds__(256) void zero_cols_kernel(char* p, int64_t ld_b, i
 }
 
 struct Layout {
-    int64_t emb, h1, lat, mod, ape, x, xt, xlo, qkv, att, y, yslab, hmid, tok, kscr, a3, total;
+    int64_t emb, h1, lat, mod, ape, x, xt, xlo, qkv, att, y, yslab, hmid, tok, kscr, a3, a3h, total;
 };
 
 inline int64_t al(int64_t v) { return (v + 255) & ~(int64_t)255; }
@@ -76,6 +77,8 @@ Layout make_layout(const swiftk_model* m, int B) {
         const int64_t kmax = kin > m->mlp ? (kin > d ? kin : d) : (m->mlp > d ? m->mlp : d);
         o += al(M * swiftk_gemm_k_pad(SWIFTK_BF16, 3 * ((kmax + 3) & ~(int64_t)3)) * 2);
     }
+    L.a3h = o;  // ... and the hidden activation's blocks, written by w1's epilogue while w1 still reads its own operand from a3
+    if (m->dtype == SWIFTK_BF16X3) o += al(M * swiftk_gemm_k_pad(SWIFTK_BF16, 3 * (((int64_t)m->mlp + 3) & ~(int64_t)3)) * 2);
     L.total = o;
     return L;
 }
@@ -123,6 +126,10 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     float* tok = reinterpret_cast<float*>(ws + L.tok);
     void *ape = ws + L.ape, *xT = ws + L.xt, *qkv = ws + L.qkv, *att = ws + L.att, *y = ws + L.y, *hmid = ws + L.hmid;
     void* a3 = ws + L.a3;
+    // split engine, FeedForward: w1's epilogue writes the hidden activation straight as w2's operand blocks (no fp32 h, no split pass)
+    const int64_t kvh = ((int64_t)m->mlp + 3) & ~(int64_t)3, ld3h = swiftk_gemm_k_pad(SWIFTK_BF16, 3 * kvh);
+    const bool ff_split = x3 && !(x3_exact & 12) && kvh == m->mlp && m->mlp % 8 == 0 && g_x3_ffsplit;
+    char* a3h = ws + L.a3h;
     // C = epilogue(A W^T) over the M token rows: `kpass` is the K handed to swiftk_gemm in the one-product engines (the padded
     // width, or the valid one when it ends half-way into the last k-tile), `kvalid` the number of meaningful columns of A
     auto G = [&](const void* A, int64_t lda, const void* Wm, void* Cm, int64_t ldc, int64_t N, int64_t kpass, int64_t kvalid,
@@ -174,6 +181,10 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     if (m->kd > d) {  // K-padding columns of the attention output must be finite (they meet zero weight columns)
         hipLaunchKernelGGL(zero_cols_kernel, dim3(1024), dim3(256), 0, st, static_cast<char*>(att), m->kd * es, d * es,
                            (m->kd - d) * es, M);
+        SWIFTK_CHECK_LAUNCH();
+    }
+    if (ff_split && ld3h > 3 * kvh) {  // k-padding behind the three blocks (the epilogue writes the blocks only)
+        hipLaunchKernelGGL(zero_cols_kernel, dim3(1024), dim3(256), 0, st, a3h, ld3h * 2, 3 * kvh * 2, (ld3h - 3 * kvh) * 2, M);
         SWIFTK_CHECK_LAUNCH();
     }
     if (m->kmlp > m->mlp) {
@@ -236,6 +247,18 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             else
                 RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok,
                                             1e-6f, dt, stream));
+        }
+        if (ff_split) {
+            const int64_t kv = (d + 3) & ~(int64_t)3, ld3 = swiftk_gemm_k_pad(SWIFTK_BF16, 3 * kv);
+            RUN(swiftk_split3(static_cast<const float*>(xT), m->kd, a3, ld3, M, kv, 0, stream));
+            const int64_t k3 = ((3 * kv) % 64 == 32 && ld3 >= 3 * kv + 32) ? 3 * kv : ld3;
+            RUN(swiftk_gemm(a3, ld3, ly.w1_w, ld3, a3h, ld3h, M, 2 * m->mlp, k3, SWIFTK_BF16, SWIFTK_BF16, SWIFTK_EPI_SWIGLU_SPLIT3, nullptr,
+                            nullptr, kvh, stream));
+            const int64_t k3h = ((3 * kvh) % 64 == 32 && ld3h >= 3 * kvh + 32) ? 3 * kvh : ld3h;
+            RUN(swiftk_gemm(a3h, ld3h, ly.w2_w, ld3h, y, d, M, d, k3h, SWIFTK_BF16, SWIFTK_F32, SWIFTK_EPI_NONE, nullptr, nullptr, 0, stream));
+            RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d, ntok, 1e-6f,
+                                        dt, stream));
+            continue;
         }
         RUN(G(xT, m->kd, ly.w1_w, hmid, m->kmlp, 2 * m->mlp, kdv, d, dt, SWIFTK_EPI_SWIGLU, nullptr, nullptr, 0, (x3_exact & 4) != 0));
         if (splitk) {

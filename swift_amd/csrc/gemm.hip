@@ -971,7 +971,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 // stores per wave -- the scattered form is store-issue bound (4.6 us per tile, 14.5 us with SwiGLU).
                 // The stage just consumed (`s`) is free: its refill is issued only after the next barrier, which no
                 // wave passes before every wave has finished this epilogue.  Slabs are wave-private: no barrier.
-                constexpr int COLS = (EPI == SWIFTK_EPI_SWIGLU) ? WT / 2 : WT;  // output columns of the wave tile
+                constexpr bool SPLIT3 = EPI == SWIFTK_EPI_SWIGLU_SPLIT3;
+                constexpr bool GLU = EPI == SWIFTK_EPI_SWIGLU || SPLIT3;
+                constexpr int COLS = GLU ? WT / 2 : WT;  // output columns of the wave tile
                 constexpr int CPR = COLS / 8;                                  // 16-B chunks per row
                 constexpr int RSTR = COLS * 2 + 16;                            // padded slab row stride (bytes)
                 // the slabs overlay operand bytes of the stage just consumed: every wave must be done READING that stage
@@ -992,8 +994,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 asm volatile("" : "+v"(elane));
                 const int g4 = elane >> 4;
                 const int r16 = elane & 15;
-                const int ncol0 = (EPI == SWIFTK_EPI_SWIGLU ? (n0 >> 1) : n0) + wn * COLS;
-                const int nout = EPI == SWIFTK_EPI_SWIGLU ? (g.N >> 1) : g.N;
+                const int ncol0 = (GLU ? (n0 >> 1) : n0) + wn * COLS;
+                const int nout = GLU ? (g.N >> 1) : g.N;
+                uint32_t lo_pk[SPLIT3 ? NI : 1];  // SPLIT3: the low halves of this row block's (hi, lo) pairs
 #pragma unroll
                 for (int ii = 0; ii < MI; ++ii) {
                     // QKNORM_JVP: a tangent row block leaves before its primal block (2, 0, 3, 1) -- its rule reads the primal values
@@ -1014,7 +1017,14 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                             }
                         }
                         acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if constexpr (EPI == SWIFTK_EPI_SWIGLU) {
+                        if constexpr (SPLIT3) {
+                            // the split engine's hidden activation leaves as the NEXT GEMM's operand blocks: hi = bf16(h),
+                            // lo = bf16(h - hi) (fp32-grade silu as in the fp32-output form; h itself never reaches memory)
+                            const float h0 = swiglu_out<float>(v[0], v[1]), h1 = swiglu_out<float>(v[2], v[3]);
+                            const uint32_t hp = pack_bf16(h0, h1);
+                            lo_pk[j] = pack_bf16(h0 - __uint_as_float(hp << 16), h1 - __uint_as_float(hp & 0xffff0000u));
+                            *reinterpret_cast<uint32_t*>(slab + r16 * RSTR + (j * 8 + 2 * g4) * 2) = hp;
+                        } else if constexpr (EPI == SWIFTK_EPI_SWIGLU) {
                             // silu(g) * u with v_exp_f32 / v_rcp_f32 (1 ulp each; the libm forms cost ~30 VALU apiece)
                             const float h0 = v[0] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[0])) * v[1];
                             const float h1 = v[2] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[2])) * v[3];
@@ -1062,9 +1072,28 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                                 }
                             }
                             if (m < g.M && n < nout) store16_out(C + dst, q);
+                            if constexpr (SPLIT3) {  // [hi | lo | hi]: the hi block twice (blocks g.pos_rows columns apart)
+                                if (m < g.M && n < nout) store16_out(C + dst + 2 * (int64_t)g.pos_rows, q);
+                            }
                         }
                     }
                     __builtin_amdgcn_wave_barrier();  // slab read before the next slab overwrites it
+                    if constexpr (SPLIT3) {
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) *reinterpret_cast<uint32_t*>(slab + r16 * RSTR + (j * 8 + 2 * g4) * 2) = lo_pk[j];
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int t = 0; t < (16 * CPR + 63) / 64; ++t) {
+                            const int c = elane + 64 * t;
+                            const int row = c / CPR, cc = c - row * CPR;
+                            if (c < 16 * CPR) {
+                                const uint4 q = *reinterpret_cast<const uint4*>(slab + row * RSTR + cc * 16);
+                                const int m = mrow0 + row, n = ncol0 + cc * 8;
+                                if (m < g.M && n < nout) store16_out(C + (int64_t)m * g.ldc + n + g.pos_rows, q);
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
             } else if constexpr (EPI == SWIFTK_EPI_ACCUM) {
                 // C += A W^T (fp32): the residual-stream gradient picks up a branch's input gradient in the GEMM that
@@ -1144,7 +1173,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         // stores, so leaving exactly those stores outstanding is enough (no store drain in front of a tile)
         if (interior) {
             // stores per wave of an interior tile: 4 slabs x ceil(16 rows x (COLS / 8) chunks / 64 lanes)
-            constexpr int NSTORE = 4 * ((16 * ((EPI == SWIFTK_EPI_SWIGLU ? WT / 2 : WT) / 8) + 63) / 64) +
+            constexpr int NSTORE = (EPI == SWIFTK_EPI_SWIGLU_SPLIT3 ? 12 : 4) *
+                                       ((16 * ((EPI == SWIFTK_EPI_SWIGLU || EPI == SWIFTK_EPI_SWIGLU_SPLIT3 ? WT / 2 : WT) / 8) + 63) / 64) +
                                    (EPI == SWIFTK_EPI_SWIGLU_BOTH ? 4 * ((16 * (WT / 16) + 63) / 64) : 0);
             if constexpr (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1202,7 +1232,7 @@ int launch(const GemmArgs& g, hipStream_t st) {
 // the paired-row epilogues exist in the persistent kernel only (bf16 in, bf16 out, whole tiles)
 template <int EPI>
 int launch_paired(const GemmArgs& g, hipStream_t st) {
-    const int ntm = g.M / BM;
+    const int ntm = (g.M + BM - 1) / BM;
     const bool timed = swiftk_prof_begin(EPI, g.N, st);
     const int ntiles = ntm * g.ntn;
     const int grid = ntiles < g_persist_wgs ? ntiles : g_persist_wgs;
@@ -1233,6 +1263,12 @@ int dispatch_epi(int epi, const GemmArgs& g, hipStream_t st) {
             if constexpr (sizeof(OutT) == 2)
                 if (g.t_gw) return launch<T, OutT, EPI_QKNORM_TILED>(g, st);
             return launch<T, OutT, SWIFTK_EPI_QKNORM>(g, st);
+        case SWIFTK_EPI_SWIGLU_SPLIT3:
+            if constexpr (sizeof(OutT) == 2 && sizeof(T) == 2) {
+                if ((g.M & 7) || (g.N & 15) || ((uintptr_t)g.C & 15) || (g.ldc & 7) || (g.pos_rows & 7)) return SWIFTK_ESHAPE;
+                return launch_paired<SWIFTK_EPI_SWIGLU_SPLIT3>(g, st);  // (persistent kernel only, like the paired-row epilogues)
+            }
+            return SWIFTK_EINVAL;
     }
     return SWIFTK_EINVAL;
 }
@@ -1273,6 +1309,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 15: g_attn_bwd_fuse = value; return 0;
         case 16: g_modnorm_bwd_fused = value; return 0;
         case 17: g_modnorm_jvp_rows = value; return 0;
+        case 18: g_x3_ffsplit = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -1296,6 +1333,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 15: return g_attn_bwd_fuse;
         case 16: return g_modnorm_bwd_fused;
         case 17: return g_modnorm_jvp_rows;
+        case 18: return g_x3_ffsplit;
     }
     return SWIFTK_EINVAL;
 }
@@ -1337,6 +1375,8 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     if (epilogue == SWIFTK_EPI_SWIGLU_BWD && (out_dtype != SWIFTK_BF16 || !ep1 || ((uintptr_t)ep1 & 15) || pos_rows < 2 * N || pos_rows % 8 ||
                                               ldc < 2 * N || ldc % 8 || ((uintptr_t)C & 15)))
         return SWIFTK_EINVAL;
+    if (epilogue == SWIFTK_EPI_SWIGLU_SPLIT3 && (dtype != SWIFTK_BF16 || out_dtype != SWIFTK_BF16 || pos_rows < N / 2 || ldc < 2 * pos_rows + N / 2))
+        return SWIFTK_EINVAL;
     if (epilogue == SWIFTK_EPI_SWIGLU_BOTH && (out_dtype != SWIFTK_BF16 || !ep1 || ((uintptr_t)ep1 & 15) || pos_rows < N / 2 || pos_rows % 8 || N % 16))
         return SWIFTK_EINVAL;
     if (dtype != SWIFTK_F32 && dtype != SWIFTK_BF16) return SWIFTK_EINVAL;
@@ -1353,7 +1393,7 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     if (K % tile_k != 0 || N % 4 != 0) return SWIFTK_ESHAPE;
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SWIFTK_ESHAPE;
     if (lda < K || ldw < K) return SWIFTK_ESHAPE;
-    const int ovec = (epilogue == SWIFTK_EPI_SWIGLU ? 2 : 4) * os;
+    const int ovec = (epilogue == SWIFTK_EPI_SWIGLU || epilogue == SWIFTK_EPI_SWIGLU_SPLIT3 ? 2 : 4) * os;
     if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || (lda * es) % 16 || (ldw * es) % 16) return SWIFTK_EALIGN;
     if (((uintptr_t)C % ovec) || (ldc * os) % ovec) return SWIFTK_EALIGN;
     // QKNORM: whole heads of 3 x head_dim columns, a wave tile = two head vectors -> tile width 4 x head_dim; head_dim

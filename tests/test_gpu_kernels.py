@@ -655,3 +655,27 @@ def test_split3_and_three_product_gemm(dev, K):
     e1 = float(((hi.double() @ whi.double().t()) - ref).norm() / ref.norm())
     print(f"K = {K}: three-product GEMM rel-L2 {e3:.2e} against fp64 (one bf16 product: {e1:.2e})")
     assert e3 < 1e-5 and e1 > 1e-3
+
+
+@pytest.mark.parametrize("M,K,mlp", [(512, 1056, 2816), (1032, 564, 704), (256, 1280, 3416)])
+def test_swiglu_split3_epilogue(dev, M, K, mlp):
+    """SWIFTK_EPI_SWIGLU_SPLIT3: the split engine's w1 leaves silu(gate) * up as w2's operand blocks [hi | lo | hi] -- bit for bit
+    what the fp32-output SwiGLU epilogue followed by swiftk_split3 leaves (same accumulators, same fp32-grade silu), pad columns
+    behind the blocks untouched."""
+    from swift_amd import _lib, ops
+    L = _lib.lib()
+    a, w = rnd((M, K), 80), rnd((2 * mlp, K), 81, 0.05)
+    a3, w3 = ops.split3(a.to(dev), 0), ops.split3(w.to(dev), 1)
+    h = ops.gemm(a3, w3, out_dtype=torch.float32, epilogue=_lib.EPI_SWIGLU)
+    want = ops.split3(h, 0)
+    ld = want.shape[1]
+    got = torch.full((M, ld), 3.0, dtype=torch.bfloat16, device=dev)
+    rc = L.swiftk_gemm(a3.data_ptr(), a3.stride(0), w3.data_ptr(), w3.stride(0), got.data_ptr(), ld, M, 2 * mlp, a3.shape[1], _lib.BF16,
+                       _lib.BF16, _lib.EPI_SWIGLU_SPLIT3, None, None, mlp, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(got[:, :3 * mlp], want[:, :3 * mlp])
+    assert ld == 3 * mlp or bool((got[:, 3 * mlp:] == 3.0).all())
+    ref = torch.nn.functional.silu(a.double() @ w.double().t()[:, 0::2]) * (a.double() @ w.double().t()[:, 1::2])
+    val = got[:, :mlp].float().cpu().double() + got[:, mlp:2 * mlp].float().cpu().double()
+    assert float((val - ref).norm() / ref.norm()) < 2e-5
