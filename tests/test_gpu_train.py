@@ -381,6 +381,39 @@ def test_window_attention_bwd(dev, shift, B):
     assert rel_l2(ds_one.cpu(), ds_want) < 5e-2 and rel_l2(ds_one.cpu(), ds_want) <= 1.2 * rel_l2(ds_two.cpu(), ds_want) + 1e-3
 
 
+@pytest.mark.parametrize("shift", [(0, 0), (8, 8)])
+@pytest.mark.parametrize("heads,hd", [(12, 88), (4, 80), (4, 96)])
+def test_window_attention_jvp_kernel(dev, shift, heads, hd):
+    """swiftk_window_attention_jvp (bf16 operands: the trainer's autocast) against torch.func.jvp of the explicit windowed
+    softmax(q k^T) v (swinv2.py:129-133 with jvp=True) on the same bf16-rounded inputs."""
+    from oracle.swinv2 import window_token_index
+    from swift_amd import _lib
+    L = _lib.lib()
+    B, grid = 2, (32, 32)
+    n, dq = grid[0] * grid[1], 3 * heads * hd
+    scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 60.0, 1.0, 10.0, 50.0, 20.0, 15.0, 5.0, 20.0, 10.0]))[:heads]
+    pre = _prenorm(rnd((B, n, dq), 40), scale, heads, hd).to(dev).to(BF)
+    dpre = (0.3 * rnd((B, n, dq), 41)).to(dev).to(BF)
+    both = torch.cat([pre, dpre]).contiguous()  # primal rows, then tangent rows (the engine's layout)
+    out = torch.full((2 * B, n, heads * hd), float("nan"), dtype=BF, device=dev)
+    rc = L.swiftk_window_attention_jvp(both.data_ptr(), both.data_ptr() + B * n * dq * 2, dq, out.data_ptr(),
+                                       out.data_ptr() + B * n * heads * hd * 2, heads * hd, B, grid[0], grid[1], heads, hd, shift[0],
+                                       shift[1], _lib.BF16, s())
+    assert rc == 0
+    torch.cuda.synchronize()
+    idx = window_token_index(grid, (16, 16), shift)
+
+    def attn(z):
+        src = z[:, idx.reshape(-1)].reshape(B * idx.shape[0], 256, heads, 3, hd).permute(0, 2, 1, 3, 4)
+        ow = (src[..., 0, :] @ src[..., 1, :].transpose(-2, -1)).softmax(-1) @ src[..., 2, :]
+        return torch.zeros(B, n, heads * hd).index_add(1, idx.reshape(-1), ow.permute(0, 2, 1, 3).reshape(B, n, -1))
+
+    ref, dref = torch.func.jvp(attn, (pre.float().cpu(),), (dpre.float().cpu(),))
+    e_o, e_d = rel_l2(out[:B].float().cpu(), ref), rel_l2(out[B:].float().cpu(), dref)
+    print(f"attention tangent kernel heads {heads} hd {hd} shift {shift}: out {e_o:.3e}, tangent {e_d:.3e}")
+    assert e_o < 1e-2 and e_d < 2e-2
+
+
 def test_loss_kernels(dev):
     from oracle import loss as oloss
     from swift_amd import _lib
