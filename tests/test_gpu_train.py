@@ -267,6 +267,16 @@ def test_gemm_jvp_swiglu_paired_rows(dev, Mh, dim, mlp, keep):
         assert torch.isnan(hm[:, mlp:].float()).all()
     if keep:
         assert rel_l2(hpre.float().cpu(), raw[:Mh]) < 4e-3
+    # the two-launch form it replaces (plain GEMM on 2 Mh rows, then swiftk_swiglu_jvp on the bf16-rounded products)
+    two = torch.empty(2 * Mh, N, dtype=BF, device=dev)
+    hm2 = torch.zeros(2 * Mh, kmlp, dtype=BF, device=dev)
+    assert L.swiftk_gemm(a.data_ptr(), K, w.data_ptr(), K, two.data_ptr(), N, 2 * Mh, N, K, _lib.BF16, _lib.BF16, _lib.EPI_NONE, None, None,
+                         0, s()) == 0
+    assert L.swiftk_swiglu_jvp(two.data_ptr(), two.data_ptr() + Mh * N * 2, N, hm2.data_ptr(), hm2.data_ptr() + Mh * kmlp * 2, kmlp, Mh, mlp,
+                               _lib.BF16, s()) == 0
+    e_p2, e_t2 = rel_l2(hm2[:Mh, :mlp].float().cpu(), ref), rel_l2(hm2[Mh:, :mlp].float().cpu(), dref)
+    print(f"  two launches: primal {e_p2:.2e} tangent {e_t2:.2e}")
+    assert e_p <= e_p2 * 1.05 and e_t <= e_t2 * 1.05 and e_p2 < 1e-2 and e_t2 < 1e-2
 
 
 @pytest.mark.parametrize("B", [2, 16])  # 16: 768 items on 256 persistent workgroups (buffer rotation, cross-item prefetch)
