@@ -106,6 +106,17 @@ def _gemm_stack(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, n: int, k: 
     return out
 
 
+def _fro_norm(X: torch.Tensor) -> torch.Tensor:
+    """Frobenius norm per matrix of a bf16 stack [L, m, n] -> [L, 1, 1] bf16, summed in fp32 and rounded once like ATen's bf16
+    norm -- but in two stages over 1,024 slices per matrix: ATen reduces each matrix with ONE workgroup (870 us for the twelve
+    1056 x 5632 matrices of w1, 30 us this way; tools/norm_probe.py)."""
+    L, m, n = X.shape
+    if (m * n) % 1024 or not X.is_contiguous():
+        return X.norm(dim=(-2, -1), keepdim=True)
+    part = torch.linalg.vector_norm(X.view(L, 1024, -1), dim=2, dtype=torch.float32)
+    return torch.linalg.vector_norm(part, dim=1).to(X.dtype).view(L, 1, 1)
+
+
 def zeropower_stack(G: torch.Tensor, steps: int = 5) -> torch.Tensor:
     """``zeropower_via_newtonschulz5`` for a stack [L, rows, cols] of same-shape matrices at once (the reference's routine
     takes batches as well, muon.py:13-35): per iteration three batched GEMM launches, L transposes and four element-wise
@@ -113,26 +124,45 @@ def zeropower_stack(G: torch.Tensor, steps: int = 5) -> torch.Tensor:
     assert G.ndim == 3 and G.is_cuda
     a, b, c = NS_COEFFS
     tall = G.shape[1] > G.shape[2]
-    X = G.to(_BF).mT if tall else G.to(_BF)
-    X = X / (X.norm(dim=(-2, -1), keepdim=True) + 1e-7)
+    X = G.to(_BF)
+    X = X / (_fro_norm(X) + 1e-7)  # (the norm of a matrix is that of its transpose: taken on the contiguous form)
+    if tall:
+        X = X.mT
     L, m, n = X.shape
     assert m % 4 == 0 and n % 4 == 0 and m >= 16
     km, kn = ops.k_pad(_BF, m), ops.k_pad(_BF, n)
     dev = G.device
-    Xb = torch.zeros(L, m, kn, dtype=_BF, device=dev)
+    # the stack with every matrix's rows padded to km (zero rows): transposing it as ONE [L km, n] matrix then yields, side by
+    # side in [n, L km], the k-padded operand forms X_l^T of all matrices -- one launch per iteration instead of L
+    Xp = torch.zeros(L, km, kn, dtype=_BF, device=dev)
+    Xb = Xp[:, :m, :]
     Xb[:, :, :n] = X
-    XT = torch.zeros(L, n, km, dtype=_BF, device=dev)
+    XTall = torch.empty(n, L * km, dtype=_BF, device=dev)
+    XT = XTall.view(n, L, km).permute(1, 0, 2)       # [L, n, km]: matrix l at column offset l km, row stride L km
     A, A2 = torch.zeros(L, m, km, dtype=_BF, device=dev), torch.zeros(L, m, km, dtype=_BF, device=dev)
     BX = torch.zeros(L, m, kn, dtype=_BF, device=dev)
     for _ in range(steps):
         _gemm_stack(Xb, Xb, A, m, kn)                # A = X X^T
         _gemm_stack(A, A, A2, m, km)                 # A A   (A symmetric)
-        B = b * A + c * A2
-        for l in range(L):
-            _transpose_into(Xb[l], m, n, XT[l])      # operand form of X for B X
+        B = A2.mul_(c).add_(A.mul_(b))               # b A + c A^2 with the reference's three bf16 roundings, in place (A is rebuilt next trip)
+        _transpose_into(Xp.view(L * km, kn), L * km, n, XTall)  # operand forms of X for B X
         _gemm_stack(B, XT, BX, n, km)                # B X
-        Xb = a * Xb + BX
+        Xb.mul_(a).add_(BX)
     X = Xb[:, :, :n]
+    return X.mT if tall else X
+
+
+def zeropower_stack_small(G: torch.Tensor, steps: int = 5) -> torch.Tensor:
+    """The same iteration for a stack [L, rows, cols] of matrices below the GEMM's shape granularity (the twelve layers'
+    [1, heads, 1, 1] logit scales viewed as 1 x heads, which the reference's rule also sends through Muon): batched library
+    matmuls on the whole stack -- a few dozen launches instead of ~100 per matrix."""
+    a, b, c = NS_COEFFS
+    tall = G.shape[1] > G.shape[2]
+    X = G.to(_BF).mT if tall else G.to(_BF)
+    X = X / (X.norm(dim=(-2, -1), keepdim=True) + 1e-7)
+    for _ in range(steps):
+        gram = X @ X.mT
+        X = a * X + (b * gram + c * (gram @ gram)) @ X
     return X.mT if tall else X
 
 
@@ -215,8 +245,9 @@ class MuonWithAuxAdam(torch.optim.Optimizer):
             classes.setdefault(tuple(p.shape), []).append(p)
         for shape, ps in classes.items():
             rows, cols = shape[0], max(1, math.prod(shape[1:])) if len(shape) == 4 else (shape[-1] if len(shape) > 1 else 1)
-            if len(ps) < 2 or len(shape) not in (2, 4) or rows % 4 or cols % 4 or min(rows, cols) < 16:
-                for p in ps:  # lone or degenerate shapes (the [1, heads, 1, 1] logit scales): matrix by matrix
+            small = rows % 4 != 0 or cols % 4 != 0 or min(rows, cols) < 16  # below the GEMM's granularity: library matmuls
+            if len(ps) < 2 or len(shape) not in (2, 4):
+                for p in ps:  # lone shapes: matrix by matrix
                     step = muon_update(p.grad, self.state[p]["momentum_buffer"], beta=beta)
                     p.mul_(decay).add_(step.reshape(p.shape).to(p.dtype), alpha=-lr)
                 continue
@@ -225,10 +256,42 @@ class MuonWithAuxAdam(torch.optim.Optimizer):
             torch._foreach_add_(bufs, grads, alpha=1.0 - beta)
             torch._foreach_mul_(grads, 1.0 - beta)                # ... and the Nesterov look-ahead, written into the gradients
             torch._foreach_add_(grads, bufs, alpha=beta)
-            ortho = zeropower_stack(torch.stack([g.reshape(rows, cols) for g in grads]))
+            stack = torch.stack([g.reshape(rows, cols) for g in grads])
+            ortho = zeropower_stack_small(stack) if small else zeropower_stack(stack)
             scaled = (ortho * math.sqrt(max(1.0, shape[-2] / shape[-1]))).float()
             torch._foreach_mul_(ps, decay)
             torch._foreach_add_(ps, [u.reshape(shape) for u in scaled.unbind(0)], alpha=-lr)
+
+    def _adam_group_foreach(self, group) -> None:
+        """`_adam_group` with multi-tensor launches (one rank, parameters on the GPU): the same arithmetic in the same order per
+        element -- ~10 launches for the group instead of ~10 per parameter (82 parameters at Swift-B)."""
+        decay = 1.0 - group["lr"] * group["weight_decay"]
+        b1, b2 = group["betas"]
+        ps = list(group["params"])
+        for p in ps:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            st = self.state[p]
+            if not st:
+                st["exp_avg"], st["exp_avg_sq"], st["step"] = torch.zeros_like(p), torch.zeros_like(p), 0
+            st["step"] += 1
+        by_step = {}
+        for p in ps:
+            by_step.setdefault(self.state[p]["step"], []).append(p)
+        for step, qs in by_step.items():
+            grads = [p.grad for p in qs]
+            m1, m2 = [self.state[p]["exp_avg"] for p in qs], [self.state[p]["exp_avg_sq"] for p in qs]
+            torch._foreach_mul_(m1, b1)
+            torch._foreach_add_(m1, grads, alpha=1.0 - b1)
+            torch._foreach_mul_(m2, b2)
+            torch._foreach_addcmul_(m2, grads, grads, value=1.0 - b2)
+            den = torch._foreach_div(m2, 1.0 - b2 ** step)
+            torch._foreach_sqrt_(den)
+            torch._foreach_add_(den, group["eps"])
+            upd = torch._foreach_div(m1, 1.0 - b1 ** step)
+            torch._foreach_div_(upd, den)
+            torch._foreach_mul_(qs, decay)
+            torch._foreach_add_(qs, upd, alpha=-group["lr"])
 
     def _adam_group(self, group) -> None:
         decay = 1.0 - group["lr"] * group["weight_decay"]
@@ -255,6 +318,8 @@ class MuonWithAuxAdam(torch.optim.Optimizer):
                 self._muon_group_stacked(group)  # nothing to exchange: same-shape matrices orthogonalised together
             elif group["use_muon"]:
                 self._muon_group(group, world, rank, multi)
+            elif world == 1 and all(p.is_cuda for p in group["params"]):
+                self._adam_group_foreach(group)
             else:
                 self._adam_group(group)
         return loss
