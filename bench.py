@@ -458,8 +458,8 @@ def main():
 def training_leg():
     """The training step that produces the forecast path's weights, measured by
     tools/train_bench.py in child processes (fresh allocator; they plan their resident activations around what this
-    process still holds): one multistep-CRPS finetune iteration (BASELINE configs[4] per GPU) and one sCM pre-training
-    iteration, Swift-B, local batch 8.  A reported extra, not the metric; a failure is recorded, not raised."""
+    process still holds): one multistep-CRPS finetune iteration (BASELINE configs[4] per GPU), one sCM pre-training
+    iteration and one TrigFlow iteration, Swift-B, local batch 8.  A reported extra, not the metric; a failure is recorded, not raised."""
     import subprocess
 
     import torch
@@ -469,6 +469,7 @@ def training_leg():
     tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "train_bench.py")
     # (six timed iterations each: with three, the first replays after the capture weighed 0.75-0.92 s on the CRPS figure)
     for name, args in (("crps_finetune_steps4", ["--loss", "crps", "--iters", "6"]), ("scm_pretrain", ["--loss", "scm", "--iters", "6"]),
+                       ("trigflow", ["--loss", "trigflow", "--iters", "6"]),
                        ("scm_pretrain_muon", ["--loss", "scm", "--opt", "muon", "--iters", "6"])):  # the experiment's own optimiser
         try:
             p = subprocess.run([sys.executable, tool] + args, capture_output=True, text=True, timeout=600)

@@ -7,14 +7,14 @@ import torch
 from swift_amd.data.era5 import SyntheticERA5Dataset
 from swift_amd.models.precond import PassPrecond
 from swift_amd.train import adamw_param_groups
-from swift_amd.training.loss import CRPSLoss, SCMLoss
+from swift_amd.training.loss import CRPSLoss, SCMLoss, TrigFlowLoss
 from swift_amd.training.trainer import Trainer
 from swift_amd.utils.detinit import swinv2_state
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8); ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--iters", type=int, default=6); ap.add_argument("--depth", type=int, default=12)
-ap.add_argument("--loss", default="crps", choices=["crps", "scm"])
+ap.add_argument("--loss", default="crps", choices=["crps", "scm", "trigflow"])
 ap.add_argument("--opt", default="adamw", choices=["adamw", "muon"])
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -36,8 +36,9 @@ if a.opt == "muon":  # the sCM experiment's optimiser (train.py:286-309 paramete
                            dict(params=ap_, use_muon=False, lr=3e-4, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-10)])
 else:
     opt = torch.optim.AdamW(adamw_param_groups(net, 1e-5), lr=1e-5, betas=(0.9, 0.95), eps=1e-6)
-loss_fn = (CRPSLoss(ds, 1.0, 2, 1.0) if a.loss == "crps" else
-           SCMLoss(ds, dict(dist="loguniform", sigma_min=0.02, sigma_max=200.0), 1.0, tangent_warmup_kimg=1)).to(dev)
+noise = dict(dist="loguniform", sigma_min=0.02, sigma_max=200.0)
+loss_fn = (CRPSLoss(ds, 1.0, 2, 1.0) if a.loss == "crps" else TrigFlowLoss(ds, noise, 1.0) if a.loss == "trigflow" else
+           SCMLoss(ds, noise, 1.0, tangent_warmup_kimg=1)).to(dev)
 tr = Trainer(net, opt, loss_fn, total_kimg=1, lr_rampup_kimg=0, lr_min_factor=1.0, device=dev,
              checkpoint_ticks=None)
 tr.global_batch_size = a.batch
@@ -87,6 +88,15 @@ print("host issue time per iteration (ms):", " ".join(f"{h:.0f}" for h in host_m
 print("loss per iteration (warm-up included):", " ".join(f"{float(l):.4f}" for l in losses), file=sys.stderr)
 PEAK = 2.5e15  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 fused = bool(getattr(tr, "_fused", None))
+if a.loss == "trigflow":  # TrigFlowLoss (loss.py:117-160): one forward, one backward (2x) per sample
+    fl = 3 * a.batch * 2.7535e12 * a.depth / 12
+    print(json.dumps({"metric": "TrigFlow training iteration (Swift-B, local batch %d, optimizer %s)" % (a.batch, a.opt), "value": dt, "unit": "s/iteration",
+                      "samples_per_s": a.batch / dt, "flop_per_iteration": fl, "what": "3 forward-equivalents per sample (forward 1, backward 2)",
+                      "roofline": {"bound": "mfma", "achieved": fl / dt / 1e12, "peak": PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / dt / PEAK, "traffic": None},
+                      "fused_optimizer_step": fused, "peak_mem_gib": torch.cuda.max_memory_allocated() / 2**30}))
+    print(f"TrigFlow training: batch {a.batch}, depth {a.depth}: {dt:.3f} s/iteration, loss {float(loss):.4f}; {a.batch / dt:.2f} samples/s; "
+          f"{fl / dt / 1e12:.0f} TFLOP/s; peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    sys.exit(0)
 if a.loss == "scm":
     # tangent pass = every GEMM on 2M rows (2 fwd) + backward (2); the reference's schedule adds a grad-enabled forward (1), which
     # the one-pass form does not execute (the tangent pass's primal rows are the saved activations)
