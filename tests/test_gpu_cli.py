@@ -174,7 +174,7 @@ def test_bench_contract_line(tmp_path):
     assert "error" not in sp and sp["value"] > pe["value"] and 0 < sp["rel_l2_vs_exact_engine_after_1_step"] < 1e-4
     assert d["config"]["noise"].startswith("swiftk_unit_noise") and d["attention_roofline"]["mfma_pipe_busy"]["kernel"] > 0.5
     # the training step behind the path's weights, measured in child processes (reported extra)
-    for leg, lo, hi in (("crps_finetune_steps4", 0.4, 2.0), ("scm_pretrain", 0.05, 0.5)):
+    for leg, lo, hi in (("crps_finetune_steps4", 0.4, 2.0), ("scm_pretrain", 0.05, 0.5), ("trigflow", 0.04, 0.4)):
         t = d["training"][leg]
         assert "error" not in t, t
         assert t["unit"] == "s/iteration" and lo < t["value"] < hi and 0.1 < t["roofline"]["frac"] < 0.6
