@@ -806,6 +806,52 @@ __global__ __launch_bounds__(256) void linear_small_lds_kernel(const float* __re
             *reinterpret_cast<float4*>(xs + j * K + 4 * c) = *reinterpret_cast<const float4*>(x + (int64_t)(b0 + j) * ldx + 4 * c);
         }
         __syncthreads();
+        if (k4 <= 5 * 64) {
+            // a weight row is at most five 16-B loads per lane: the NEXT row's loads are issued before this row's cross-lane sums,
+            // and only the live batch rows are summed (one unit per step: seven of eight reductions were of zeros -- the kernel
+            // walked the 214-MB modulation matrix at 2.7 TB/s)
+            const int n0 = blockIdx.x * 4 + wv, dn = gridDim.x * 4;
+            float4 w[5];
+            auto fetch = [&](int n, float4 (&r)[5]) {
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int c = lane + 64 * u;
+                    r[u] = (n < N && c < k4) ? *reinterpret_cast<const float4*>(W + (int64_t)n * ldw + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            };
+            fetch(n0, w);
+            for (int n = n0; n < N; n += dn) {
+                float acc[BB];
+#pragma unroll
+                for (int j = 0; j < BB; ++j) acc[j] = 0.f;
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int c = lane + 64 * u;
+                    if (c < k4) {
+#pragma unroll
+                        for (int j = 0; j < BB; ++j) {
+                            if (j < nb) {
+                                const float4 xv = *reinterpret_cast<const float4*>(xs + j * K + 4 * c);
+                                acc[j] += (w[u].x * xv.x + w[u].y * xv.y) + (w[u].z * xv.z + w[u].w * xv.w);
+                            }
+                        }
+                    }
+                }
+                fetch(n + dn, w);
+#pragma unroll
+                for (int j = 0; j < BB; ++j) {
+                    if (j < nb) {  // (block-uniform)
+                        const float s = wave_sum(acc[j]);
+                        if (lane == 0) {
+                            float v = s + (bias ? bias[n] : 0.f);
+                            if (act == 1) v = v / (1.0f + expf(-v));
+                            out[(int64_t)(b0 + j) * ldo + n] = v;
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         for (int n = blockIdx.x * 4 + wv; n < N; n += gridDim.x * 4) {
             float acc[BB];
 #pragma unroll

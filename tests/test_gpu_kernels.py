@@ -410,6 +410,12 @@ def test_timestep_embed_and_small_linear(dev):
     assert rel_l2(o.cpu(), torch.nn.functional.silu(x.double() @ w.double().T + b.double())) < 2e-6
     o = ops.linear_small(x.to(dev), w.to(dev), None, act=0)
     assert rel_l2(o.cpu(), x.double() @ w.double().T) < 2e-6
+    # wide outputs (the 24 modulation Linears as one matrix): x staged in LDS, the next weight row prefetched (K <= 1280) or
+    # the general walk (K = 1408); one unit, a ragged batch, and more than one LDS batch of 8
+    for K, Bn in ((1056, 1), (1056, 5), (1056, 11), (1408, 3)):
+        w, b, x = rnd((8448 + 4, K), 32, 0.03), rnd((8448 + 4,), 33), rnd((Bn, K), 34)
+        o = ops.linear_small(x.to(dev), w.to(dev), b.to(dev), act=0)
+        assert rel_l2(o.cpu(), x.double() @ w.double().T + b.double()) < 2e-6, (K, Bn)
 
 
 def test_rollout_update_and_axpby(dev):
