@@ -578,8 +578,14 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
             const float tot = 0.5f * wave_sum(dot);
             if (lane == 0 && pa.scale[h] < 4.605170185988092f) atomicAdd(st_ds + h, tot);
         }
-        if (!(pa.dbg & 4)) store_rows(dq, w, tok0, h * 3 * HD);  // (the dO image lands under the dq stores)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(pa.dbg & 4)) {
+            store_rows(dq, w, tok0, h * 3 * HD);  // (the dO image lands under the dq stores)
+            // VMEM retires in issue order and the dO pieces are older than the six row stores: leaving exactly those outstanding
+            // is enough for the image -- the stores drain under pass B instead of in front of it
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();  // Q (requested a pass ago) and dO images complete
         if (has_next) {                // the next item's K image lands under pass B
             dma_img(bV, qkv_base(nb, nh, 1), nwn, ldq_b);
