@@ -32,8 +32,12 @@ def _s():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _gemm(a, w, out, epi=EPI_NONE, ep0=None, ep1=None, pos_rows=0):
+def _gemm(a, w, out, epi=EPI_NONE, ep0=None, ep1=None, pos_rows=0, k=None):
     M, K = a.shape
+    # `k`: the operand's valid width when it ends half-way into the last 64-deep k-tile (d = 1056 = 16.5 tiles): the kernel then
+    # skips the zero half (both operands' rows extend to the end of the tile)
+    if k is not None and k % 64 == 32 and K >= k + 32 and w.stride(0) >= k + 32:
+        K = k
     check(lib().swiftk_gemm(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, w.shape[0],
                             K, ops.dtype_code(a.dtype), ops.dtype_code(out.dtype), epi, None if ep0 is None else ep0.data_ptr(),
                             None if ep1 is None else ep1.data_ptr(), pos_rows, _s()), "swiftk_gemm")
@@ -234,7 +238,7 @@ class SwinJvpEngine:
                                         M, 3 * d, kk, EPI_QKNORM_JVP, W["scale"].data_ptr(),
                                         None if rn is None else rn.data_ptr(), self.hd, None, 0, _s()), "swiftk_gemm_jvp")
             else:
-                _gemm(XT_in, W["qkv"], QKV)
+                _gemm(XT_in, W["qkv"], QKV, k=d)
                 check(L.swiftk_qknorm_jvp(QKV.data_ptr(), QKV.data_ptr() + M * 3 * d * es, 3 * d, W["scale"].data_ptr(),
                                           None if rn is None else rn.data_ptr(), M, heads, self.hd, tc, _s()), "swiftk_qknorm_jvp")
             ATT = shared["ATT"] if shared else operand(self.kd, d)
@@ -242,7 +246,7 @@ class SwinJvpEngine:
                                                 ATT.data_ptr() + M * self.kd * es, self.kd, B, gh, gw, heads, self.hd, sh[0], sh[1],
                                                 tc, _s()), "swiftk_window_attention_jvp")
             Y1 = shared["Y"] if shared else torch.empty(2 * M, d, dtype=T, device=dev)
-            _gemm(ATT, W["wo"], Y1)
+            _gemm(ATT, W["wo"], Y1, k=d)
             XT_mid = XT_in if shared else operand(self.kd, d)
             modnorm(2 * i, W["g1"], W["b1"], Y1, XT_mid, XT_in)
             HM = shared["HM"] if shared else operand(self.kmlp, mlp)
@@ -253,7 +257,7 @@ class SwinJvpEngine:
                                         EPI_SWIGLU_JVP, None, None, 0, HM.data_ptr(), self.kmlp, _s()), "swiftk_gemm_jvp")
             else:
                 H = shared["H"] if shared else torch.empty(2 * M, 2 * mlp, dtype=T, device=dev)
-                _gemm(XT_mid, W["w1"], H)
+                _gemm(XT_mid, W["w1"], H, k=d)
                 check(L.swiftk_swiglu_jvp(H.data_ptr(), H.data_ptr() + M * 2 * mlp * es, 2 * mlp, HM.data_ptr(),
                                           HM.data_ptr() + M * self.kmlp * es, self.kmlp, M, mlp, tc, _s()), "swiftk_swiglu_jvp")
             Y2 = shared["Y"] if shared else torch.empty(2 * M, d, dtype=T, device=dev)
@@ -268,10 +272,10 @@ class SwinJvpEngine:
         shape = (B, m.out_channels, *m.image_size)
         if not save:
             tok = torch.empty(M, po4, dtype=torch.float32, device=dev)
-            _gemm(XT_in[M:], self.head, tok)
+            _gemm(XT_in[M:], self.head, tok, k=d)
             return ops.unpatchify_affine(tok.view(B, ntok, po4), shape, m.patch_size)
         tok = torch.empty(2 * M, po4, dtype=torch.float32, device=dev)
-        _gemm(XT_in, self.head, tok)
+        _gemm(XT_in, self.head, tok, k=d)
         F = ops.unpatchify_affine(tok[:M].view(B, ntok, po4), shape, m.patch_size)
         dF = ops.unpatchify_affine(tok[M:].view(B, ntok, po4), shape, m.patch_size)
         logvar = None

@@ -31,9 +31,13 @@ def _s():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _gemm(a, w, out, epi=EPI_NONE, ep0=None, ep1=None, pos_rows=0):
+def _gemm(a, w, out, epi=EPI_NONE, ep0=None, ep1=None, pos_rows=0, k=None):
     """out[M,N] = a[M,K] @ w[N,K]^T (row-major 2-D tensors, explicit strides)."""
     M, K = a.shape
+    # `k`: the operand's valid width when it ends half-way into the last 64-deep k-tile (d = 1056 = 16.5 tiles): the kernel then
+    # skips the zero half (both operands' rows extend to the end of the tile)
+    if k is not None and k % 64 == 32 and K >= k + 32 and w.stride(0) >= k + 32:
+        K = k
     check(lib().swiftk_gemm(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, w.shape[0],
                             K, ops.dtype_code(a.dtype), ops.dtype_code(out.dtype), epi, None if ep0 is None else ep0.data_ptr(),
                             None if ep1 is None else ep1.data_ptr(), pos_rows, _s()), "swiftk_gemm")
@@ -269,20 +273,20 @@ class SwinTrainEngine:
             sh = tuple(m.shift_size) if (do_shift and i % 2) else (0, 0)
             qkvh = torch.empty(M, 3 * d, dtype=_BF, device=dev)
             rn = torch.empty(M, 3 * heads, dtype=torch.float32, device=dev)
-            _gemm(xT, W["qkv"], qkvh, EPI_QKNORM, W["scale"], rn, pos_rows=self.hd)  # (QKNORM: head_dim rides in pos_rows)
+            _gemm(xT, W["qkv"], qkvh, EPI_QKNORM, W["scale"], rn, pos_rows=self.hd, k=d)  # (QKNORM: head_dim rides in pos_rows)
             a = _padded(M, self.kd, d)
             ops.window_attention(qkvh.view(B, ntok, 3 * d), None, (gh, gw), heads, sh, out=a.view(B, ntok, self.kd),
                                  flags=ATTN_PRENORM)
             y1 = torch.empty(M, d, dtype=_BF, device=dev)
-            _gemm(a, W["wo"], y1)
+            _gemm(a, W["wo"], y1, k=d)
             msl1 = mod[:, (2 * i) * 2 * d:(2 * i + 1) * 2 * d]
             xT_mid = norm_res(y1, att.norm.norm.weight.detach().float(), att.norm.norm.bias.detach().float(), msl1, xT)
             h = torch.empty(M, 2 * mlp, dtype=_BF, device=dev)
             hmid = _padded(M, self.kmlp, mlp)
             if mlp % 8 == 0:  # h (kept for the backward pass) and silu(gate) * up out of one GEMM epilogue
-                _gemm(xT_mid, W["w1"], h, EPI_SWIGLU_BOTH, None, hmid, pos_rows=hmid.stride(0))
+                _gemm(xT_mid, W["w1"], h, EPI_SWIGLU_BOTH, None, hmid, pos_rows=hmid.stride(0), k=d)
             else:
-                _gemm(xT_mid, W["w1"], h)
+                _gemm(xT_mid, W["w1"], h, k=d)
                 check(lib().swiftk_swiglu_fwd(h.data_ptr(), h.stride(0), hmid.data_ptr(), hmid.stride(0), M, mlp, BF16, _s()),
                       "swiftk_swiglu_fwd")
             y2 = torch.empty(M, d, dtype=_BF, device=dev)
@@ -295,7 +299,7 @@ class SwinTrainEngine:
         po = m.out_channels * m.patch_size[0] * m.patch_size[1]
         po4 = self.head.shape[0]
         tok = torch.empty(M, po4, dtype=torch.float32, device=dev)
-        _gemm(xT, self.head, tok)
+        _gemm(xT, self.head, tok, k=d)
         out = ops.unpatchify_affine(tok.view(B, ntok, po4), (B, m.out_channels, *m.image_size), m.patch_size)
         return (out, logvar, ctx) if want_logvar else (out, ctx)
 
@@ -362,10 +366,10 @@ class SwinTrainEngine:
                               dmod[:, (2 * i + 1) * 2 * d:(2 * i + 2) * 2 * d], M, d, ntok)
             dh = _padded(M, max(self.kh, 2 * mlp), 2 * mlp)
             if mlp % 8 == 0:  # d(hidden) = dy2 @ w2 and the step back through silu(gate) * up in one launch
-                _gemm(dy2, W["w2_t"], dh, EPI_SWIGLU_BWD, None, A["h"], pos_rows=A["h"].stride(0))
+                _gemm(dy2, W["w2_t"], dh, EPI_SWIGLU_BWD, None, A["h"], pos_rows=A["h"].stride(0), k=d)
             else:
                 dhmid = torch.empty(M, mlp, dtype=_BF, device=dev)
-                _gemm(dy2, W["w2_t"], dhmid)
+                _gemm(dy2, W["w2_t"], dhmid, k=d)
                 check(L.swiftk_swiglu_bwd(A["h"].data_ptr(), A["h"].stride(0), dhmid.data_ptr(), dhmid.stride(0), dh.data_ptr(),
                                           dh.stride(0), M, mlp, BF16, _s()), "swiftk_swiglu_bwd")
             if mlp == mlp0:
@@ -383,7 +387,7 @@ class SwinTrainEngine:
             self._modnorm_bwd(A["y1"], dx, dy1, att.norm.norm, mod[:, (2 * i) * 2 * d:(2 * i + 1) * 2 * d],
                               dmod[:, (2 * i) * 2 * d:(2 * i + 1) * 2 * d], M, d, ntok)
             datt = torch.empty(M, self.kd, dtype=_BF, device=dev)
-            _gemm(dy1, W["wo_t"], datt)  # N = d columns written, row stride kd
+            _gemm(dy1, W["wo_t"], datt, k=d)  # N = d columns written, row stride kd
             self._wgrad(dy1, A["att"], d, d, G(att.wo.weight))
             # d(q | k | v) lands in the to_qkv data-gradient GEMM's operand buffer (row stride kqkv): the attention backward applies
             # the QK-norm backward to its accumulators on their way out (head_dim 88; elsewhere a second pass rewrites the q-hat / k-hat
@@ -396,7 +400,7 @@ class SwinTrainEngine:
                                                        dqkv.data_ptr(), self.kqkv, W["scale"].data_ptr(), A["rn"].data_ptr(),
                                                        gscale.data_ptr(), B, gh, gw, heads, self.hd, sh[0], sh[1], BF16, _s()),
                   "swiftk_window_attention_bwd_qknorm")
-            _gemm(dqkv, W["qkv_t"], dx, EPI_ACCUM)
+            _gemm(dqkv, W["qkv_t"], dx, EPI_ACCUM, k=3 * d)
             self._wgrad(dqkv, A["xT_in"], 3 * d, d, G(att.to_qkv.weight))
             if grads_final is not None:  # everything of layer i except its modulation Linears (those follow in _embed_bwd)
                 grads_final([p for n, p in m.transformer.layers[i].named_parameters() if "modulation" not in n])
