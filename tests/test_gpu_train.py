@@ -1124,3 +1124,16 @@ def test_graph_pools_survive_growing_rollouts_and_moved_gradients(dev, monkeypat
         for k, ((l0, g0), (l1, g1)) in enumerate(zip(ref, got)):
             assert l1 == pytest.approx(l0, rel=1e-5), (set_to_none, k)
             assert rel_l2(g1, g0) < 1e-4, (set_to_none, k, rel_l2(g1, g0))
+
+
+def test_repeat_screen_of_hand_synchronised_training_kernels(dev):
+    """The paired-row GEMM epilogues, the split-output SwiGLU epilogue, the staged attention tangent kernel and the attention
+    backward with its counted store wait: launched dozens of times on the same inputs, every output bit-equal to the first
+    launch's (tools/repeat_screen.py, tools/attn_bwd_repeat.py; the forecast kernels' screen is tools/stress.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "repeat_screen.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "REPEAT SCREEN: CLEAN" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_bwd_repeat.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "mismatching outputs: 0" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
