@@ -165,6 +165,11 @@ int swiftk_modnorm_residual_pair_slabs(const float* y_slabs, int64_t ldy, int64_
  * (bf16 or uint8 by lo_bits, ldl in elements). */
 int swiftk_split_pair(const float* src, int64_t lds, void* hi, int64_t ldh, void* lo, int64_t ldl, int lo_bits, int64_t rows,
                       int64_t cols, void* stream);
+/* The patch embedding straight into the pair form (round 4): what swiftk_gemm(..., SWIFTK_EPI_BIAS_POS, bias, pos, pos_rows) with fp32
+ * output followed by swiftk_split_pair(..., lo_bits 8) leaves -- hi [M, ldh] bf16 (columns [0, N); its k-padding is the caller's),
+ * lo [M, ldl] bytes -- without the fp32 stream in between.  bf16 operands, M % 8 == 0, N % 16 == 0, K % 64 == 0. */
+int swiftk_gemm_bias_pos_pair(const void* A, int64_t lda, const void* W, int64_t ldw, void* hi, int64_t ldh, void* lo, int64_t ldl,
+                              int64_t M, int64_t N, int64_t K, const float* bias, const float* pos, int64_t pos_rows, void* stream);
 
 /*
  * Channel-concat + patchify of up to three NCHW fp32 sources into the GEMM
@@ -264,7 +269,8 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * key 14 = split-K wo / w2 at one unit per step (1), key 15 = swiftk_window_attention_bwd_qknorm applies the QK-norm backward
  * inside the persistent attention backward (1; 0 = second pass), key 16 = swiftk_modnorm_bwd as one kernel (1; 0 = row pass +
  * column pass; n > 1 = 64 n rows per block), key 17 = swiftk_modnorm_jvp_pair walks 32 n rows per block (1; 0 = a row per wave),
- * key 18 = split engine: w1's epilogue writes w2's (hi, lo) operand blocks itself (1; 0 = fp32 h + swiftk_split3). */
+ * key 18 = split engine: w1's epilogue writes w2's (hi, lo) operand blocks itself (1; 0 = fp32 h + swiftk_split3),
+ * key 19 = bf16 engine: the patch embedding's epilogue writes the pair form itself (1; 0 = fp32 stream + swiftk_split_pair). */
 int swiftk_set_tuning(int key, int value);
 /* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
  * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default

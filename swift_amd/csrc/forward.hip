@@ -9,6 +9,7 @@ int g_x3_exact = 17;  // tuning key 11: the DEFAULT mask a host binding copies i
 int g_fwd_pair = 2;   // tuning key 12: bf16 engine's residual stream: 2 = (bf16 hi, 8-bit lo) pair, 1 = (bf16 hi, bf16 lo), 0 = fp32 + copy
 int g_f32_chunk_k = 256;  // tuning key 13: fp32-operand GEMMs of the forward accumulate in chains of this many k (0 = one chain over K)
 int g_fwd_splitk = 1;
+int g_fwd_pepair = 1;  // tuning key 19: the patch embedding's epilogue writes the pair form itself
 int g_x3_ffsplit = 1;  // tuning key 18: split engine, w1 writes w2's operand blocks itself  // tuning key 14: wo / w2 as two k-ranges into fp32 slabs when their tiles fill less than half the chip (one unit per step)
 int g_fwd_fused = 1;  // tuning key 8 (A/B only): 0 = to_qkv and window attention as two kernels (q/k/v window-tiled through HBM)
 
@@ -168,16 +169,27 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
 
     // patch embedding (+bias +pos_embed) into the fp32 residual stream, plus its GEMM-operand copy
     RUN(swiftk_patchify(src0, c0, s0, src1, c1, s1, src2, c2, s2, ape, m->kpe, B, m->H, m->W, m->p1, m->p2, dt, stream));
-    RUN(G(ape, m->kpe, m->pe_w, x, d, d, m->kpe, (int64_t)m->in_ch * m->p1 * m->p2, SWIFTK_F32, SWIFTK_EPI_BIAS_POS, m->pe_b, m->pos,
-          ntok, (x3_exact & 16) != 0));
-    // bf16 engine: from here on the residual stream is the pair (xT = hi, xlo = lo); the fp32 x is not touched again
+    // bf16 engine: the residual stream is the pair (xT = hi, xlo = lo) from the patch embedding on; the fp32 x is never formed when
+    // the embedding's epilogue can write the pair itself (8-bit low parts, whole 16-column groups), else x is split once here
     const bool pair = dt == SWIFTK_BF16 && g_fwd_pair && ntok % 16 == 0 && d % 8 == 0 && d <= 2048;
     void* xlo = ws + L.xlo;
     const int lo_bits = g_fwd_pair == 1 ? 16 : 8;
     const bool splitk = pair && small_m_splitk(m, M);
     float* yslab = reinterpret_cast<float*>(ws + L.yslab);
-    if (pair) RUN(swiftk_split_pair(x, d, xT, m->kd, xlo, d, lo_bits, M, d, stream));
-    else RUN(swiftk_cast_pad(x, d, xT, m->kd, M, d, dt, stream));
+    const bool pe_pair = pair && lo_bits == 8 && d % 16 == 0 && m->kpe % 64 == 0 && g_fwd_pepair;
+    if (pe_pair) {
+        if (m->kd > d) {  // (hi is a GEMM operand: its k-padding columns are zeroed once per evaluation)
+            hipLaunchKernelGGL(zero_cols_kernel, dim3(1024), dim3(256), 0, st, static_cast<char*>(xT), m->kd * 2, (int64_t)d * 2,
+                               (m->kd - d) * 2, M);
+            SWIFTK_CHECK_LAUNCH();
+        }
+        RUN(swiftk_gemm_bias_pos_pair(ape, m->kpe, m->pe_w, m->kpe, xT, m->kd, xlo, d, M, d, m->kpe, m->pe_b, m->pos, ntok, stream));
+    } else {
+        RUN(G(ape, m->kpe, m->pe_w, x, d, d, m->kpe, (int64_t)m->in_ch * m->p1 * m->p2, SWIFTK_F32, SWIFTK_EPI_BIAS_POS, m->pe_b, m->pos,
+              ntok, (x3_exact & 16) != 0));
+        if (pair) RUN(swiftk_split_pair(x, d, xT, m->kd, xlo, d, lo_bits, M, d, stream));
+        else RUN(swiftk_cast_pad(x, d, xT, m->kd, M, d, dt, stream));
+    }
     if (m->kd > d) {  // K-padding columns of the attention output must be finite (they meet zero weight columns)
         hipLaunchKernelGGL(zero_cols_kernel, dim3(1024), dim3(256), 0, st, static_cast<char*>(att), m->kd * es, d * es,
                            (m->kd - d) * es, M);

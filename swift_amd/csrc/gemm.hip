@@ -46,6 +46,7 @@ constexpr int MI = 4, NI = 11;  // NI: W-side MFMA tiles per wave of the 256 x 3
                                 // as a template parameter: 10 / 11 / 12 -> 320 / 352 / 384 columns per tile
 
 constexpr int EPI_QKNORM_TILED = 4;  // internal: SWIFTK_EPI_QKNORM with the window-tiled store (swiftk_gemm_qkv_tiled)
+constexpr int EPI_BIAS_POS_PAIR = 11;  // internal: SWIFTK_EPI_BIAS_POS leaving as the (bf16 hi, 8-bit lo) pair (swiftk_gemm_bias_pos_pair)
 
 // Build-time switches.  SWIFTK_GEMM_INSTR = 1 compiles the timing experiments (tuning key 3: ablation bits, s_memtime
 // timeline) into the persistent kernel -- `make variant EXTRA=-DSWIFTK_GEMM_INSTR=1`, never into libswiftk.so.
@@ -972,6 +973,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 // The stage just consumed (`s`) is free: its refill is issued only after the next barrier, which no
                 // wave passes before every wave has finished this epilogue.  Slabs are wave-private: no barrier.
                 constexpr bool SPLIT3 = EPI == SWIFTK_EPI_SWIGLU_SPLIT3;
+                constexpr bool PAIROUT = EPI == EPI_BIAS_POS_PAIR;
                 constexpr bool GLU = EPI == SWIFTK_EPI_SWIGLU || SPLIT3;
                 constexpr int COLS = GLU ? WT / 2 : WT;  // output columns of the wave tile
                 constexpr int CPR = COLS / 8;                                  // 16-B chunks per row
@@ -996,7 +998,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 const int r16 = elane & 15;
                 const int ncol0 = (GLU ? (n0 >> 1) : n0) + wn * COLS;
                 const int nout = GLU ? (g.N >> 1) : g.N;
-                uint32_t lo_pk[SPLIT3 ? NI : 1];  // SPLIT3: the low halves of this row block's (hi, lo) pairs
+                uint32_t lo_pk[SPLIT3 || PAIROUT ? NI : 1];  // SPLIT3 / PAIROUT: the low parts of this row block's (hi, lo) pairs
 #pragma unroll
                 for (int ii = 0; ii < MI; ++ii) {
                     // QKNORM_JVP: a tangent row block leaves before its primal block (2, 0, 3, 1) -- its rule reads the primal values
@@ -1017,7 +1019,28 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                             }
                         }
                         acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if constexpr (SPLIT3) {
+                        if constexpr (PAIROUT) {
+                            // patch embedding straight into the pair form of the residual stream: x = acc + bias + pos in fp32 (the
+                            // fp32-output epilogue's order), hi = bf16(x) through the slab, the 8-bit low parts follow in a second pass
+                            const int nb = n0 + wn * WT + j * 16 + 4 * g4;
+                            const int m = m0 + wm * 64 + i * 16 + r16;
+                            if (m < g.M && nb < g.N) {
+                                const float4 b = *reinterpret_cast<const float4*>(g.ep0 + nb);
+                                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                                if (g.ep1) {
+                                    const float4 pp = *reinterpret_cast<const float4*>(g.ep1 + (int64_t)(m % g.pos_rows) * g.N + nb);
+                                    v[0] += pp.x; v[1] += pp.y; v[2] += pp.z; v[3] += pp.w;
+                                }
+                            }
+                            const uint32_t h0 = pack_bf16(v[0], v[1]), h1 = pack_bf16(v[2], v[3]);
+                            uint32_t lb = 0u;
+                            lb = lo8_insert(v[0], __uint_as_float(h0 << 16), (h0 >> 7) & 0xFFu, 0, lb);
+                            lb = lo8_insert(v[1], __uint_as_float(h0 & 0xffff0000u), (h0 >> 23) & 0xFFu, 1, lb);
+                            lb = lo8_insert(v[2], __uint_as_float(h1 << 16), (h1 >> 7) & 0xFFu, 2, lb);
+                            lb = lo8_insert(v[3], __uint_as_float(h1 & 0xffff0000u), (h1 >> 23) & 0xFFu, 3, lb);
+                            lo_pk[j] = lb;
+                            *reinterpret_cast<uint2*>(slab + r16 * RSTR + (j * 16 + 4 * g4) * 2) = make_uint2(h0, h1);
+                        } else if constexpr (SPLIT3) {
                             // the split engine's hidden activation leaves as the NEXT GEMM's operand blocks: hi = bf16(h),
                             // lo = bf16(h - hi) (fp32-grade silu as in the fp32-output form; h itself never reaches memory)
                             const float h0 = swiglu_out<float>(v[0], v[1]), h1 = swiglu_out<float>(v[2], v[3]);
@@ -1090,6 +1113,24 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                                 const uint4 q = *reinterpret_cast<const uint4*>(slab + row * RSTR + cc * 16);
                                 const int m = mrow0 + row, n = ncol0 + cc * 8;
                                 if (m < g.M && n < nout) store16_out(C + (int64_t)m * g.ldc + n + g.pos_rows, q);
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if constexpr (PAIROUT) {
+                        constexpr int RB = WT + 16, CB = WT / 16;  // byte rows of the low parts: WT bytes = CB 16-B chunks
+                        uint8_t* lo = reinterpret_cast<uint8_t*>(g.kscr);
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) *reinterpret_cast<uint32_t*>(slab + r16 * RB + j * 16 + 4 * g4) = lo_pk[j];
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int t = 0; t < (16 * CB + 63) / 64; ++t) {
+                            const int c = elane + 64 * t;
+                            const int row = c / CB, cc = c - row * CB;
+                            if (c < 16 * CB) {
+                                const uint4 q = *reinterpret_cast<const uint4*>(slab + row * RB + cc * 16);
+                                const int m = mrow0 + row, n = n0 + wn * WT + cc * 16;
+                                if (m < g.M && n < g.N) store16_out(lo + (int64_t)m * g.c_split + n, q);
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -1173,7 +1214,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         // stores, so leaving exactly those stores outstanding is enough (no store drain in front of a tile)
         if (interior) {
             // stores per wave of an interior tile: 4 slabs x ceil(16 rows x (COLS / 8) chunks / 64 lanes)
-            constexpr int NSTORE = (EPI == SWIFTK_EPI_SWIGLU_SPLIT3 ? 12 : 4) *
+            constexpr int NSTORE = (EPI == EPI_BIAS_POS_PAIR ? 4 * ((16 * (WT / 16) + 63) / 64) : 0) + (EPI == SWIFTK_EPI_SWIGLU_SPLIT3 ? 12 : 4) *
                                        ((16 * ((EPI == SWIFTK_EPI_SWIGLU || EPI == SWIFTK_EPI_SWIGLU_SPLIT3 ? WT / 2 : WT) / 8) + 63) / 64) +
                                    (EPI == SWIFTK_EPI_SWIGLU_BOTH ? 4 * ((16 * (WT / 16) + 63) / 64) : 0);
             if constexpr (sizeof(OutT) == 2 && EPI != SWIFTK_EPI_BIAS_POS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
@@ -1310,6 +1351,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 16: g_modnorm_bwd_fused = value; return 0;
         case 17: g_modnorm_jvp_rows = value; return 0;
         case 18: g_x3_ffsplit = value; return 0;
+        case 19: g_fwd_pepair = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -1334,6 +1376,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 16: return g_modnorm_bwd_fused;
         case 17: return g_modnorm_jvp_rows;
         case 18: return g_x3_ffsplit;
+        case 19: return g_fwd_pepair;
     }
     return SWIFTK_EINVAL;
 }
@@ -1519,6 +1562,47 @@ extern "C" int swiftk_gemm_jvp(const void* A, int64_t lda, const void* W, int64_
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (epilogue == SWIFTK_EPI_QKNORM_JVP) return launch_paired<SWIFTK_EPI_QKNORM_JVP>(g, st);
     return launch_paired<SWIFTK_EPI_SWIGLU_JVP>(g, st);
+}
+
+extern "C" int swiftk_gemm_bias_pos_pair(const void* A, int64_t lda, const void* W, int64_t ldw, void* hi, int64_t ldh, void* lo,
+                                         int64_t ldl, int64_t M, int64_t N, int64_t K, const float* bias, const float* pos,
+                                         int64_t pos_rows, void* stream) {
+    if (!A || !W || !hi || !lo || !bias || M <= 0 || N <= 0 || K <= 0 || (pos && pos_rows <= 0)) return SWIFTK_EINVAL;
+    if (M % 8 || N % 16 || K % 64 || lda < K || ldw < K || ldh < N || ldl < N || M > (1 << 30) || N > (1 << 30)) return SWIFTK_ESHAPE;
+    if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)hi & 15) || ((uintptr_t)lo & 15) || ((uintptr_t)bias & 15) ||
+        ((uintptr_t)pos & 15) || (lda * 2) % 16 || (ldw * 2) % 16 || ldh % 8 || ldl % 16)
+        return SWIFTK_EALIGN;
+    int ni = 11;
+    if (N % 352) {
+        if (N % 384 == 0) ni = 12;
+        else if (N % 320 == 0) ni = 10;
+    }
+    GemmArgs g;
+    g.A = static_cast<const char*>(A);
+    g.W = static_cast<const char*>(W);
+    g.C = static_cast<char*>(hi);
+    g.lda_b = lda * 2;
+    g.ldw_b = ldw * 2;
+    g.ldc = ldh;
+    g.M = (int)M;
+    g.N = (int)N;
+    g.K = (int)K;
+    g.ep0 = bias;
+    g.ep1 = pos;
+    g.pos_rows = (int)pos_rows;
+    g.ni = ni;
+    g.ntn = (int)((N + 32 * ni - 1) / (32 * ni));
+    g.dbg = g_dbg;
+    g.ksplit = 1;
+    g.c_split = ldl;  // (row stride of the low parts, bytes)
+    g.batch_a = g.batch_w = g.batch_c = 0;
+    g.khalf = 0;
+    g.touch = 0;
+    g.stagger = 0;
+    g.kscr = static_cast<float*>(lo);
+    g.kchunk = 0;
+    g.t_gh = g.t_gw = g.t_sh = g.t_sw = g.t_heads = 0;
+    return launch_paired<EPI_BIAS_POS_PAIR>(g, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t swiftk_gemm_chunk_scratch_bytes(void) {

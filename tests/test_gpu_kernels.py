@@ -685,3 +685,31 @@ def test_swiglu_split3_epilogue(dev, M, K, mlp):
     ref = torch.nn.functional.silu(a.double() @ w.double().t()[:, 0::2]) * (a.double() @ w.double().t()[:, 1::2])
     val = got[:, :mlp].float().cpu().double() + got[:, mlp:2 * mlp].float().cpu().double()
     assert float((val - ref).norm() / ref.norm()) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,pos_rows", [(2048, 1056, 576, 512), (1032, 1280, 192, 0), (512, 1536, 576, 256)])
+def test_gemm_bias_pos_pair_epilogue(dev, M, N, K, pos_rows):
+    """swiftk_gemm_bias_pos_pair: the patch embedding (+ bias + pos_embed) leaves as the (bf16 hi, 8-bit lo) pair -- bit for bit what
+    the fp32-output SWIFTK_EPI_BIAS_POS GEMM followed by swiftk_split_pair leaves; hi's k-padding columns are not touched."""
+    from swift_amd import _lib, ops
+    L = _lib.lib()
+    BF = torch.bfloat16
+    a, w = rnd((M, K), 90).to(dev).to(BF), rnd((N, K), 91, 0.05).to(dev).to(BF)
+    bias = rnd((N,), 92).to(dev)
+    pos = rnd((pos_rows, N), 93).to(dev) if pos_rows else None
+    x = ops.gemm(a, w, out_dtype=torch.float32, epilogue=_lib.EPI_BIAS_POS, bias=bias, pos=pos)
+    ldh = ops.k_pad(BF, N) + (64 if N % 64 == 0 else 0)
+    hi_ref, lo_ref = ops.split_pair(x, ldh, lo_bits=8)
+    hi = torch.full((M, ldh), 5.0, dtype=BF, device=dev)
+    lo = torch.zeros(M, N, dtype=torch.uint8, device=dev)
+    rc = L.swiftk_gemm_bias_pos_pair(a.data_ptr(), K, w.data_ptr(), K, hi.data_ptr(), ldh, lo.data_ptr(), N, M, N, K, bias.data_ptr(),
+                                     None if pos is None else pos.data_ptr(), pos_rows, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(hi[:, :N], hi_ref[:, :N]) and torch.equal(lo, lo_ref)
+    assert bool((hi[:, N:] == 5.0).all())
+    ref = a.float().cpu().double() @ w.float().cpu().double().t() + bias.cpu().double()
+    if pos is not None:
+        ref = ref + pos.cpu().double().repeat(M // pos_rows, 1)
+    val = ops.pair_value(hi, lo, N).cpu().double()
+    assert float((val - ref).norm() / ref.norm()) < 2e-5
