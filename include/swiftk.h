@@ -161,6 +161,10 @@ int swiftk_modnorm_residual_pair_to(const void* y, int64_t ldy, const void* x_hi
 int swiftk_modnorm_residual_pair_slabs(const float* y_slabs, int64_t ldy, int64_t slab_stride, void* x_hi, int64_t ldh, void* x_lo,
                                        int64_t ldl, int lo_bits, const float* gamma, const float* beta, const float* mod,
                                        int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps, void* stream);
+/* The same with bf16 slabs (swiftk_gemm_splitk_bf16): 10 instead of 14 bytes per element; slab_stride in elements, % 8 == 0. */
+int swiftk_modnorm_residual_pair_slabs_bf16(const void* y_slabs, int64_t ldy, int64_t slab_stride, void* x_hi, int64_t ldh, void* x_lo,
+                                            int64_t ldl, int lo_bits, const float* gamma, const float* beta, const float* mod,
+                                            int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps, void* stream);
 /* fp32 [rows, lds] -> the pair form: hi [rows, ldh] bf16 with columns [cols, ldh) zeroed (GEMM k-padding), lo [rows, ldl]
  * (bf16 or uint8 by lo_bits, ldl in elements). */
 int swiftk_split_pair(const float* src, int64_t lds, void* hi, int64_t ldh, void* lo, int64_t ldl, int lo_bits, int64_t rows,
@@ -266,7 +270,7 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * key 12 = residual stream of the bf16 forward: 2 = (bf16 hi, 8-bit lo) pair (default), 1 = (bf16 hi, bf16 lo) pair, 0 = fp32
  * stream + bf16 operand copy,
  * key 13 = chain length (in k) of the fp32-operand GEMMs' two-level accumulation in swiftk_swinv2_forward (256; 0 = off),
- * key 14 = split-K wo / w2 at one unit per step (1), key 15 = swiftk_window_attention_bwd_qknorm applies the QK-norm backward
+ * key 14 = split-K wo / w2 at one unit per step (2 = bf16 slabs, 1 = fp32 slabs, 0 = off), key 15 = swiftk_window_attention_bwd_qknorm applies the QK-norm backward
  * inside the persistent attention backward (1; 0 = second pass), key 16 = swiftk_modnorm_bwd as one kernel (1; 0 = row pass +
  * column pass; n > 1 = 64 n rows per block), key 17 = swiftk_modnorm_jvp_pair walks 32 n rows per block (1; 0 = a row per wave),
  * key 18 = split engine: w1's epilogue writes w2's (hi, lo) operand blocks itself (1; 0 = fp32 h + swiftk_split3),
@@ -310,6 +314,10 @@ int swiftk_gemm_batched(const void* A, int64_t lda, int64_t stride_a, const void
  * slabs + s*slab_stride.  Same operand rules as swiftk_gemm; M % 8 == 0, N % 8 == 0. */
 int swiftk_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, float* slabs, int64_t ldc, int64_t slab_stride,
                        int64_t M, int64_t N, int64_t K, int dtype, int ksplit, void* stream);
+/* Split-K with bf16 slabs (bf16 operands; M, N % 8 == 0): slab s = bf16(A[:, k-range s] W[:, k-range s]^T), each partial product
+ * rounded once as a plain bf16 GEMM rounds its output.  The forecast path's wo / w2 at one unit per step. */
+int swiftk_gemm_splitk_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* slabs, int64_t ldc, int64_t slab_stride,
+                            int64_t M, int64_t N, int64_t K, int ksplit, void* stream);
 /* The same weight gradient without the transposed copies (TN form; autograd of the Linears at swinv2.py:96-98,112-113,134):
  *   slabs[s][N1, ldc] (fp32) = sum over the s-th of `ksplit` ranges of the K token rows of P[m, 0..N1)^T * Q[m, 0..N2)
  * P = dY [K, ldp], Q = X [K, ldq], bf16, token-major as the forward / backward passes leave them.  K % 64 == 0,

@@ -238,12 +238,14 @@ __device__ __forceinline__ void store_q_nt(bf16_t* p, const uint4& q) {
 
 // YF32: y arrives as TWO fp32 slabs (y and y + yslab, row stride ldy) whose sum is the branch output -- the split-K form of wo / w2
 // at one or two units per step, where 96 output tiles cannot fill 256 CUs (forward.hip)
-template <int SLOTS, bool LO8, bool YF32>
-__global__ __launch_bounds__(256, (SLOTS == 3 && !YF32) ? SWIFTK_MNP_OCC : ((SLOTS == 4 && YF32) ? 1 : 2)) void modnorm_pair_kernel(const void* __restrict__ y_, int64_t ldy, int64_t yslab,
+// YM = 2: the two slabs are bf16 (one unit per step: 10 instead of 14 bytes per element; each partial sum is rounded like y itself)
+template <int SLOTS, bool LO8, int YM>
+__global__ __launch_bounds__(256, (SLOTS == 3 && YM == 0) ? SWIFTK_MNP_OCC : ((SLOTS == 4 && YM != 0) ? 1 : 2)) void modnorm_pair_kernel(const void* __restrict__ y_, int64_t ldy, int64_t yslab,
                                                             bf16_t* __restrict__ xh, int64_t ldh, void* __restrict__ xl_,
                                                             int64_t ldl, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ mod,
                                                             int64_t ldmod, int64_t M, int d, int64_t rps, float eps, int nt) {
+    constexpr bool YF32 = YM != 0;  // (the row's y is held as eight summed floats per slot)
     const bool NT = nt & 1;
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -284,7 +286,16 @@ __global__ __launch_bounds__(256, (SLOTS == 3 && !YF32) ? SWIFTK_MNP_OCC : ((SLO
         for (int i = 0; i < SLOTS; ++i) {
             const int c = lane + 64 * i;
             if (c < nc) {
-                if constexpr (YF32) {
+                if constexpr (YM == 2) {
+                    raw8<bf16_t> t0, t1;
+                    t0.q = load_q(y + row * ldy + 8 * c);
+                    t1.q = load_q(y + yslab + row * ldy + 8 * c);
+                    float f0[8], f1[8];
+                    unpack_raw(t0, f0);
+                    unpack_raw(t1, f1);
+                    r.y[i].a = make_float4(f0[0] + f1[0], f0[1] + f1[1], f0[2] + f1[2], f0[3] + f1[3]);
+                    r.y[i].b = make_float4(f0[4] + f1[4], f0[5] + f1[5], f0[6] + f1[6], f0[7] + f1[7]);
+                } else if constexpr (YF32) {
                     raw8<float> s0, s1;
                     load_raw(yf + row * ldy + 8 * c, s0);
                     load_raw(yf + yslab + row * ldy + 8 * c, s1);
@@ -1067,12 +1078,12 @@ inline int grid_for(int64_t work_items, int per_block = 256, int cap = 256 * 16)
 // y_slab == 0: y is bf16 [M, ldy]; y_slab > 0: y is the sum of two fp32 slabs [M, ldy] that many elements apart
 static int modnorm_pair_impl(const void* y, int64_t ldy, int64_t y_slab, void* x_hi, int64_t ldh, void* x_lo, int64_t ldl,
                              int lo_bits, const float* gamma, const float* beta, const float* mod, int64_t ldmod, int64_t M, int d,
-                             int64_t rows_per_sample, float eps, void* stream, void* x_hi_out = nullptr) {
+                             int64_t rows_per_sample, float eps, void* stream, void* x_hi_out = nullptr, bool slab_bf16 = false) {
     if (!y || !x_hi || !x_lo || !gamma || !beta || !mod || M <= 0 || d <= 0 || rows_per_sample <= 0) return SWIFTK_EINVAL;
     if (lo_bits != 16 && lo_bits != 8) return SWIFTK_EINVAL;
     if (d % 8 || d > 2048 || rows_per_sample % MN_ROWS) return SWIFTK_ESHAPE;
     if (ldy < d || ldh < d || ldl < d) return SWIFTK_ESHAPE;
-    const int lb = lo_bits / 8, ys = y_slab ? 4 : 2;
+    const int lb = lo_bits / 8, ys = (y_slab && !slab_bf16) ? 4 : 2;
     if (((uintptr_t)y & 15) || (ldy * ys) % 16 || ((uintptr_t)x_hi & 15) || (ldh * 2) % 16 || ((uintptr_t)x_lo & (8 * lb - 1)) ||
         (ldl * lb) % (8 * lb) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)mod & 15) || (ldmod % 4))
         return SWIFTK_EALIGN;
@@ -1101,8 +1112,9 @@ static int modnorm_pair_impl(const void* y, int64_t ldy, int64_t y_slab, void* x
                        static_cast<bf16_t*>(x_hi), ldh, x_lo, ldl, gamma, beta, mod, ldmod, M, d, rows_per_sample, eps, g_modnorm_nt)
 #define SWIFTK_MNP2(SL)                                                                   \
     do {                                                                                   \
-        if (y_slab) { if (lo_bits == 8) SWIFTK_MNP(SL, true, true); else SWIFTK_MNP(SL, false, true); }   \
-        else { if (lo_bits == 8) SWIFTK_MNP(SL, true, false); else SWIFTK_MNP(SL, false, false); }        \
+        if (y_slab && slab_bf16) { if (lo_bits == 8) SWIFTK_MNP(SL, true, 2); else SWIFTK_MNP(SL, false, 2); }   \
+        else if (y_slab) { if (lo_bits == 8) SWIFTK_MNP(SL, true, 1); else SWIFTK_MNP(SL, false, 1); }   \
+        else { if (lo_bits == 8) SWIFTK_MNP(SL, true, 0); else SWIFTK_MNP(SL, false, 0); }        \
     } while (0)
     if (d <= 3 * 512) SWIFTK_MNP2(3); else SWIFTK_MNP2(4);
 #undef SWIFTK_MNP2
@@ -1166,6 +1178,15 @@ extern "C" int swiftk_modnorm_residual_pair_slabs(const float* y_slabs, int64_t 
     if (slab_stride <= 0 || slab_stride % 4) return SWIFTK_EINVAL;
     return modnorm_pair_impl(y_slabs, ldy, slab_stride, x_hi, ldh, x_lo, ldl, lo_bits, gamma, beta, mod, ldmod, M, d,
                              rows_per_sample, eps, stream);
+}
+
+extern "C" int swiftk_modnorm_residual_pair_slabs_bf16(const void* y_slabs, int64_t ldy, int64_t slab_stride, void* x_hi, int64_t ldh,
+                                                       void* x_lo, int64_t ldl, int lo_bits, const float* gamma, const float* beta,
+                                                       const float* mod, int64_t ldmod, int64_t M, int d, int64_t rows_per_sample,
+                                                       float eps, void* stream) {
+    if (slab_stride <= 0 || slab_stride % 8) return SWIFTK_EINVAL;
+    return modnorm_pair_impl(y_slabs, ldy, slab_stride, x_hi, ldh, x_lo, ldl, lo_bits, gamma, beta, mod, ldmod, M, d,
+                             rows_per_sample, eps, stream, nullptr, true);
 }
 
 extern "C" int swiftk_split_pair(const float* src, int64_t lds, void* hi, int64_t ldh, void* lo, int64_t ldl, int lo_bits,

@@ -8,7 +8,7 @@ int g_x3_exact = 17;  // tuning key 11: the DEFAULT mask a host binding copies i
                       // (the forward reads the model's own field, never this global: ADVICE r3)
 int g_fwd_pair = 2;   // tuning key 12: bf16 engine's residual stream: 2 = (bf16 hi, 8-bit lo) pair, 1 = (bf16 hi, bf16 lo), 0 = fp32 + copy
 int g_f32_chunk_k = 256;  // tuning key 13: fp32-operand GEMMs of the forward accumulate in chains of this many k (0 = one chain over K)
-int g_fwd_splitk = 1;
+int g_fwd_splitk = 2;  // tuning key 14: 2 = bf16 slabs, 1 = fp32 slabs
 int g_fwd_pepair = 1;  // tuning key 19: the patch embedding's epilogue writes the pair form itself
 int g_x3_ffsplit = 1;  // tuning key 18: split engine, w1 writes w2's operand blocks itself  // tuning key 14: wo / w2 as two k-ranges into fp32 slabs when their tiles fill less than half the chip (one unit per step)
 int g_fwd_fused = 1;  // tuning key 8 (A/B only): 0 = to_qkv and window attention as two kernels (q/k/v window-tiled through HBM)
@@ -247,7 +247,11 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
                                         shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
         }
-        if (splitk) {
+        if (splitk && g_fwd_splitk == 2) {
+            RUN(swiftk_gemm_splitk_bf16(att, m->kd, ly.wo_w, m->kd, yslab, d, M * d, M, d, kdv, 2, stream));
+            RUN(swiftk_modnorm_residual_pair_slabs_bf16(yslab, d, M * d, xT, m->kd, xlo, d, lo_bits, ly.ln1_g, ly.ln1_b,
+                                                        mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
+        } else if (splitk) {
             RUN(swiftk_gemm_splitk(att, m->kd, ly.wo_w, m->kd, yslab, d, M * d, M, d, kdv, SWIFTK_BF16, 2, stream));
             RUN(swiftk_modnorm_residual_pair_slabs(yslab, d, M * d, xT, m->kd, xlo, d, lo_bits, ly.ln1_g, ly.ln1_b,
                                                    mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
@@ -273,6 +277,12 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             continue;
         }
         RUN(G(xT, m->kd, ly.w1_w, hmid, m->kmlp, 2 * m->mlp, kdv, d, dt, SWIFTK_EPI_SWIGLU, nullptr, nullptr, 0, (x3_exact & 4) != 0));
+        if (splitk && g_fwd_splitk == 2) {
+            RUN(swiftk_gemm_splitk_bf16(hmid, m->kmlp, ly.w2_w, m->kmlp, yslab, d, M * d, M, d, m->kmlp, 2, stream));
+            RUN(swiftk_modnorm_residual_pair_slabs_bf16(yslab, d, M * d, xT, m->kd, xlo, d, lo_bits, ly.ln2_g, ly.ln2_b,
+                                                        mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
+            continue;
+        }
         if (splitk) {
             RUN(swiftk_gemm_splitk(hmid, m->kmlp, ly.w2_w, m->kmlp, yslab, d, M * d, M, d, m->kmlp, SWIFTK_BF16, 2, stream));
             RUN(swiftk_modnorm_residual_pair_slabs(yslab, d, M * d, xT, m->kd, xlo, d, lo_bits, ly.ln2_g, ly.ln2_b,

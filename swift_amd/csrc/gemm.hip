@@ -1413,7 +1413,8 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
                      int ksplit, int64_t c_split, void* stream, const int* tiling = nullptr, float* kscr = nullptr,
                      int kchunk = 0) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || ksplit < 1) return SWIFTK_EINVAL;
-    if (ksplit > 1 && (out_dtype != SWIFTK_F32 || epilogue != SWIFTK_EPI_NONE || c_split < M * ldc)) return SWIFTK_EINVAL;
+    if (ksplit > 1 && ((out_dtype != SWIFTK_F32 && !(out_dtype == SWIFTK_BF16 && dtype == SWIFTK_BF16)) || epilogue != SWIFTK_EPI_NONE || c_split < M * ldc))
+        return SWIFTK_EINVAL;
     if (epilogue == SWIFTK_EPI_ACCUM && out_dtype != SWIFTK_F32) return SWIFTK_EINVAL;
     if (epilogue == SWIFTK_EPI_SWIGLU_BWD && (out_dtype != SWIFTK_BF16 || !ep1 || ((uintptr_t)ep1 & 15) || pos_rows < 2 * N || pos_rows % 8 ||
                                               ldc < 2 * N || ldc % 8 || ((uintptr_t)C & 15)))
@@ -1680,6 +1681,15 @@ extern "C" int swiftk_gemm_qkv_tiled(const void* A, int64_t lda, const void* W, 
     const int64_t M = (int64_t)B * gh * gw, N = 3 * (int64_t)heads * head_dim;
     return gemm_impl(A, lda, W, ldw, qkv_tiled, N, M, N, K, SWIFTK_BF16, SWIFTK_BF16, SWIFTK_EPI_QKNORM, scale, nullptr,
                      head_dim, 1, 0, stream, tiling);
+}
+
+// the same with bf16 slabs (each partial product rounded once, as a plain bf16 GEMM rounds its output): the one-unit-per-step form
+// of wo / w2, whose consumer (swiftk_modnorm_residual_pair_slabs_bf16) then reads 4 instead of 8 bytes per element of y
+extern "C" int swiftk_gemm_splitk_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* slabs, int64_t ldc,
+                                       int64_t slab_stride, int64_t M, int64_t N, int64_t K, int ksplit, void* stream) {
+    if ((M & 7) || (N & 7) || ((uintptr_t)slabs & 15) || (ldc & 7) || (slab_stride & 7)) return SWIFTK_ESHAPE;  // persistent kernel only
+    return gemm_impl(A, lda, W, ldw, slabs, ldc, M, N, K, SWIFTK_BF16, SWIFTK_BF16, SWIFTK_EPI_NONE, nullptr, nullptr, 0, ksplit,
+                     slab_stride, stream);
 }
 
 extern "C" int swiftk_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, float* slabs, int64_t ldc,

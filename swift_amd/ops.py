@@ -305,11 +305,12 @@ def modnorm_residual_pair(y: torch.Tensor, x_hi: torch.Tensor, x_lo: torch.Tenso
 def modnorm_residual_pair_slabs(y_slabs: torch.Tensor, x_hi: torch.Tensor, x_lo: torch.Tensor, gamma, beta, mod: torch.Tensor,
                                 rows_per_sample: int, d: int, eps: float = 1e-6) -> None:
     """``modnorm_residual_pair`` with the branch output as the sum of the two fp32 slabs y_slabs[0] + y_slabs[1] ([2, M, d]):
-    what a split-K wo / w2 leaves at one unit per step."""
+    what a split-K wo / w2 leaves at one unit per step (bf16 slabs: ``swiftk_gemm_splitk_bf16``)."""
     _dev(y_slabs, x_hi, x_lo, gamma, beta, mod)
-    assert y_slabs.dtype == torch.float32 and y_slabs.dim() == 3 and y_slabs.shape[0] == 2 and y_slabs.is_contiguous()
+    assert y_slabs.dtype in (torch.float32, torch.bfloat16) and y_slabs.dim() == 3 and y_slabs.shape[0] == 2 and y_slabs.is_contiguous()
     M = y_slabs.shape[1]
-    check(lib().swiftk_modnorm_residual_pair_slabs(y_slabs.data_ptr(), y_slabs.stride(1), y_slabs.stride(0), x_hi.data_ptr(),
+    fn = lib().swiftk_modnorm_residual_pair_slabs if y_slabs.dtype == torch.float32 else lib().swiftk_modnorm_residual_pair_slabs_bf16
+    check(fn(y_slabs.data_ptr(), y_slabs.stride(1), y_slabs.stride(0), x_hi.data_ptr(),
                                                    x_hi.stride(0), x_lo.data_ptr(), x_lo.stride(0),
                                                    16 if x_lo.dtype == torch.bfloat16 else 8, gamma.data_ptr(), beta.data_ptr(),
                                                    mod.data_ptr(), mod.stride(0), M, d, rows_per_sample, float(eps), _stream()),

@@ -363,7 +363,19 @@ def test_modnorm_residual_pair_from_splitk_slabs(dev, lo_bits):
     assert e < 1e-5
     hi2, lo2 = ops.split_pair(x.to(dev), ld, lo_bits)
     ops.modnorm_residual_pair(ops.gemm(ad, wd), hi2, lo2, p["n.norm.weight"].to(dev), p["n.norm.bias"].to(dev), mod, rps, d)
-    assert rel_l2(ops.pair_value(hi2, lo2, d).cpu(), got) < 3e-3  # (y rounded to bf16 on that path)
+    e_one = rel_l2(ops.pair_value(hi2, lo2, d).cpu(), got)
+    assert e_one < 3e-3  # (y rounded to bf16 on that path)
+    # bf16 slabs (the forecast path's default at one unit per step): every slab is the bf16 rounding of the fp32 slab, and the result
+    # is as far from the exact one as the one-launch path's (each rounds the branch output at bf16 precision)
+    sb = torch.full((2, M, d), float("nan"), dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.lib().swiftk_gemm_splitk_bf16(ad.data_ptr(), K, wd.data_ptr(), K, sb.data_ptr(), d, M * d, M, d, K, 2,
+                                                  torch.cuda.current_stream().cuda_stream), "swiftk_gemm_splitk_bf16")
+    assert torch.equal(sb, slabs.to(torch.bfloat16))
+    hi3, lo3 = ops.split_pair(x.to(dev), ld, lo_bits)
+    ops.modnorm_residual_pair_slabs(sb, hi3, lo3, p["n.norm.weight"].to(dev), p["n.norm.bias"].to(dev), mod, rps, d)
+    e_bf = rel_l2(ops.pair_value(hi3, lo3, d).cpu(), got)
+    print(f"  bf16 slabs vs fp32 slabs {e_bf:.2e} (one launch, bf16 y: {e_one:.2e})")
+    assert e_bf < 3e-3 and e_bf < 2.0 * e_one
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
