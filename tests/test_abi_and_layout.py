@@ -37,6 +37,14 @@ def test_host_side_argument_validation_needs_no_gpu():
     assert L.swiftk_gemm(8, 64, 16, 64, 16, 4, 4, 4, 64, _lib.BF16, _lib.BF16, 0, None, None, 0, None) == -3  # alignment
     assert L.swiftk_window_attention(16, 3168, 16, 1056, 16, 1, 24, 16, 12, 88, 0, 0, 0, 0, None) == -2
     assert L.swiftk_workspace_bytes(None, 1) == 0
+    # round-4 entry points: the paired-row tangent GEMM wants whole 128-row groups, the pair-output patch embedding whole k-tiles,
+    # the fused attention backward all three of scale / rn / dscale
+    assert L.swiftk_gemm_jvp(16, 64, 16, 64, 16, 528, 100, 528, 64, _lib.EPI_QKNORM_JVP, 16, None, 88, None, 0, None) == -2
+    assert L.swiftk_gemm_jvp(16, 64, 16, 64, 16, 528, 128, 528, 64, 0, 16, None, 88, None, 0, None) == -1
+    assert L.swiftk_gemm_bias_pos_pair(16, 64, 16, 64, 16, 1056, 16, 1056, 256, 1056, 40, 16, None, 0, None) == -2
+    assert L.swiftk_gemm_bias_pos_pair(16, 64, 16, 64, 16, 1056, 16, 1056, 256, 1056, 64, None, None, 0, None) == -1
+    assert L.swiftk_window_attention_bwd_qknorm(16, 3168, 16, 16, 1056, 16, 3168, None, 16, 16, 1, 16, 16, 12, 88, 0, 0, _lib.BF16, None) == -1
+    assert L.swiftk_gemm_splitk_bf16(16, 64, 16, 64, 16, 4, 16, 4, 4, 64, 2, None) == -2
 
 
 def test_product_never_imports_the_oracle():
