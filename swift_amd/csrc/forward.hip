@@ -43,12 +43,21 @@ bool model_ok(const swiftk_model* m) {
 
 // bf16 engine, pair-form stream: wo / w2 have (M / 256) x (d / 352) output tiles -- 96 per unit for 256 CUs, so one unit fills
 // 37 % of a round of the persistent grid.  While two k-ranges per tile still fit ONE round the two GEMMs run as split-K into two
-// fp32 slabs which the norm kernel sums on its way: B = 1 235 -> 250 sample-steps/s (255 replayed as a graph).  Not beyond one
-// round: at three units (288 tiles, 56 % of two rounds) the split fills 75 % of three, but the norm kernel's 8 instead of 2 bytes
-// of y per element cost more than the rounds save (306 -> 272, measured).
+// slabs which the norm kernel sums on its way: B = 1 235 -> 250 sample-steps/s with fp32 slabs (255 replayed as a graph), 259 -> 277
+// with bf16 slabs (key 14 = 2, the default).  Not beyond one round: at three units (288 tiles, 56 % of two rounds) the split fills
+// 75 % of three, but it loses with either slab type (fp32: 306 -> 272; bf16: 324 -> 310, measured).
 inline bool small_m_splitk(const swiftk_model* m, int64_t M) {
     const int64_t tiles = ((M + 255) / 256) * ((m->dim + 351) / 352);
-    return m->dtype == SWIFTK_BF16 && g_fwd_splitk && g_fwd_pair && m->dim % 8 == 0 && 2 * tiles <= 256;
+    if (!(m->dtype == SWIFTK_BF16 && g_fwd_splitk && g_fwd_pair && m->dim % 8 == 0)) return false;
+    if (2 * tiles <= 256) return true;
+    // (experiment, key 14 = 3: with bf16 slabs also where two half-depth items per tile fill their rounds >= 1.25 x better --
+    // measured at three / four units per step: 324 -> 310 / 356 -> 332 sample-steps/s: the half-depth k-loops pay two epilogues)
+    if (g_fwd_splitk == 3 && tiles <= 1024) {
+        const double plain = (double)tiles / (double)(((tiles + 255) / 256) * 256);
+        const double split = (double)(2 * tiles) / (double)(((2 * tiles + 255) / 256) * 256);
+        return split >= 1.25 * plain;
+    }
+    return false;
 }
 
 Layout make_layout(const swiftk_model* m, int B) {
@@ -247,7 +256,7 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
                                         shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
         }
-        if (splitk && g_fwd_splitk == 2) {
+        if (splitk && g_fwd_splitk >= 2) {
             RUN(swiftk_gemm_splitk_bf16(att, m->kd, ly.wo_w, m->kd, yslab, d, M * d, M, d, kdv, 2, stream));
             RUN(swiftk_modnorm_residual_pair_slabs_bf16(yslab, d, M * d, xT, m->kd, xlo, d, lo_bits, ly.ln1_g, ly.ln1_b,
                                                         mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
@@ -277,7 +286,7 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             continue;
         }
         RUN(G(xT, m->kd, ly.w1_w, hmid, m->kmlp, 2 * m->mlp, kdv, d, dt, SWIFTK_EPI_SWIGLU, nullptr, nullptr, 0, (x3_exact & 4) != 0));
-        if (splitk && g_fwd_splitk == 2) {
+        if (splitk && g_fwd_splitk >= 2) {
             RUN(swiftk_gemm_splitk_bf16(hmid, m->kmlp, ly.w2_w, m->kmlp, yslab, d, M * d, M, d, m->kmlp, 2, stream));
             RUN(swiftk_modnorm_residual_pair_slabs_bf16(yslab, d, M * d, xT, m->kd, xlo, d, lo_bits, ly.ln2_g, ly.ln2_b,
                                                         mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
