@@ -270,7 +270,7 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * key 12 = residual stream of the bf16 forward: 2 = (bf16 hi, 8-bit lo) pair (default), 1 = (bf16 hi, bf16 lo) pair, 0 = fp32
  * stream + bf16 operand copy,
  * key 13 = chain length (in k) of the fp32-operand GEMMs' two-level accumulation in swiftk_swinv2_forward (256; 0 = off),
- * key 14 = split-K wo / w2 at one unit per step (2 = bf16 slabs, 1 = fp32 slabs, 0 = off), key 15 = swiftk_window_attention_bwd_qknorm applies the QK-norm backward
+ * key 14 = split-K wo / w2 at one unit per step (2 = bf16 slabs, 1 = fp32 slabs, 0 = off; 3 = bf16 slabs beyond one round of the grid as well, an experiment that loses), key 15 = swiftk_window_attention_bwd_qknorm applies the QK-norm backward
  * inside the persistent attention backward (1; 0 = second pass), key 16 = swiftk_modnorm_bwd as one kernel (1; 0 = row pass +
  * column pass; n > 1 = 64 n rows per block), key 17 = swiftk_modnorm_jvp_pair walks 32 n rows per block (1; 0 = a row per wave),
  * key 18 = split engine: w1's epilogue writes w2's (hi, lo) operand blocks itself (1; 0 = fp32 h + swiftk_split3),
