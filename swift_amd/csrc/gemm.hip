@@ -90,6 +90,25 @@ constexpr int EPI_BIAS_POS_PAIR = 11;  // internal: SWIFTK_EPI_BIAS_POS leaving 
 #ifndef SWIFTK_X_TOUCH
 #define SWIFTK_X_TOUCH 0
 #endif
+// Ping-pong k-loop (cdna_hip_programming.md section 5, "8-phase" schedule, on this kernel's 256 x 352 geometry): a k-tile is
+// four phases (k-half x column half of the wave tile); in every phase a wave first requests the phase's fragments from LDS
+// and issues its share of the next stage's DMA pieces (MEM), then -- behind a workgroup barrier -- runs the phase's 20-24 MFMAs
+// back to back (COMPUTE), then a second barrier.  Waves 4-7 (the SIMD partners of waves 0-3) run one barrier behind, so on every
+// SIMD one wave is in COMPUTE while its partner is in MEM: fragment-read latency and DMA issue never sit between a wave's own
+// MFMAs.  1 = per-k-tile drain of the DMA (placed in the last MEM phase); 2 = counted: the W pieces of the second column
+// half stay in flight across the k-tile boundary and are waited for in the next k-tile's first MEM phase.
+#ifndef SWIFTK_X_PP
+#define SWIFTK_X_PP 0
+#endif
+#ifndef SWIFTK_X_PP_PRIO
+#define SWIFTK_X_PP_PRIO 1
+#endif
+// diagnostic build of the ping-pong loop (never in libswiftk.so): tuning key 3 bits 1 / 4 / 8 as in SWIFTK_GEMM_INSTR (no DMA, no
+// epilogue, every stage re-reads k-tile 0), bit 64 = s_memtime stamps of waves 0 and 4 of every 32nd workgroup around every
+// barrier of the workgroup's second tile, into the buffer passed as ep1 (EPI_NONE): [wg / 32][wave group][k-tile][16] uint64
+#ifndef SWIFTK_PP_STAMP
+#define SWIFTK_PP_STAMP 0
+#endif
 
 struct GemmArgs {
     const char* A;
@@ -447,6 +466,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     // and their tangent rows, wave wm the 32 + 32 rows of tokens 128 tm + 32 wm .. + 31: accumulator row blocks i = 0, 1 are primal,
     // i = 2, 3 the tangents of the same tokens -- the epilogue's tangent rules find both values of an element in one lane
     constexpr bool PAIRED = EPI == SWIFTK_EPI_QKNORM_JVP || EPI == SWIFTK_EPI_SWIGLU_JVP;
+    constexpr bool PP = SWIFTK_X_PP > 0 && sizeof(T) == 2 && !TOUCH && !HPF && !SWIFTK_GEMM_INSTR;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (TOUCH || HPF ? 256 : 0)];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -575,9 +595,20 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 #if SWIFTK_X_PRIO
     // the second-dispatched half of the workgroup loses every issue arbitration against its SIMD partner; one static
     // priority for that half, no per-segment flips (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-    if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+    if (!PP && wv >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int grp = wv >> 2;  // ping-pong: waves wv and wv + 4 share a SIMD; group 1 runs one barrier behind group 0
+    bool first_kt = true;     // ping-pong: this trip is the first k-tile of an output tile (all waves aligned at its top)
+#if SWIFTK_PP_STAMP
+    unsigned long long* plog = nullptr;
+    int pl_tile = 0, pl_kt = 0, pl_i = 0;
+    if ((g.dbg & 64) && (wv & 3) == 0 && lane == 0 && (blockIdx.x & 31) == 0)
+        plog = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.ep1)) + ((blockIdx.x >> 5) * 2 + (wv >> 2)) * 20 * 16;
+#define PP_STAMP() do { if (plog && pl_tile == 1 && pl_i < 16) plog[pl_kt * 16 + pl_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PP_STAMP() do {} while (0)
+#endif
     for (;;) {
         // (waited at the bottom of the previous trip) own DMA of the stage about to be read has landed; after the
         // barrier every wave's has, and every wave is done reading the other stage (its fragment reads were consumed
@@ -603,7 +634,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         }
         first_k = false;
 #else
-        __builtin_amdgcn_s_barrier();
+        if constexpr (PP) {
+            // only a tile's first k-tile meets all waves aligned (the stage about to be read was waited for by every wave in front
+            // of this barrier); inside a tile the phase barriers hand the stages over.  Group 1 then drops one barrier behind.
+            if (first_kt) {
+                __builtin_amdgcn_s_barrier();
+                if (grp) __builtin_amdgcn_s_barrier();
+            }
+        } else {
+            __builtin_amdgcn_s_barrier();
+        }
 #endif
         const char* s = smem + par * STAGE;
         const uint32_t fill = lds0 + (par ^ 1) * STAGE;
@@ -634,7 +674,80 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         // k-tiles: the last k-tile of the K range carries data in its first half only; its second half meets zero pad
         // columns, so those 44 MFMAs are skipped -- 3 % of the GEMM).  Branches between the MFMA groups make hipcc
         // shuffle and spill accumulators (297 v_mov + 27 spilled dwords per k-tile in the SwiGLU build).
-        {
+        if constexpr (PP) {
+            // Ping-pong form of the same k-tile: phases (k-half, column half) = (0, lo) (0, hi) (1, lo) (1, hi); the wave tile's NI
+            // column blocks split JA | NI - JA.  All ten DMA pieces of the next stage leave in the first two MEM phases (five
+            // each) so that they have the rest of the k-tile to land; the drain sits in the last MEM phase, i.e. under the SIMD
+            // partner's MFMAs.  A tile's last k-tile does not wait at all: its pieces feed the next tile and are waited for behind
+            // the epilogue (counted against the epilogue's stores, below).
+            constexpr int JA = (NI + 1) / 2, JB = NI - JA;
+            uint4 xf[MI], wf[JA];
+#if SWIFTK_PP_STAMP
+            pl_i = 0;
+            if (g.dbg & 8) koff = 0;
+#endif
+            auto bar = [&] {
+                __builtin_amdgcn_sched_barrier(0);
+                PP_STAMP();
+                __builtin_amdgcn_s_barrier();
+                PP_STAMP();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto mem = [&](const int ch, const int j0, const int nj, const bool newx, const int p0, const int p1) {
+                if (newx) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch);
+                }
+#pragma unroll
+                for (int jj = 0; jj < JA; ++jj)
+                    if (jj < nj) wf[jj] = *reinterpret_cast<const uint4*>(s + woff + (j0 + jj) * 16 * ROWB + ch);
+#pragma unroll
+                for (int pc = 0; pc < 10; ++pc) {
+#if SWIFTK_PP_STAMP
+                    if (g.dbg & 1) continue;
+#endif
+                    if (pc >= p0 && pc < p1) issue_piece(fill, koff, pc);
+                }
+            };
+            auto comp = [&](const int j0, const int nj) {
+#if SWIFTK_X_PP_PRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+                for (int jj = 0; jj < JA; ++jj) {
+                    if (jj < nj) {
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) mma_chunk<T>(acc[i][j0 + jj], wf[jj], xf[i]);
+                    }
+                }
+#if SWIFTK_X_PP_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            };
+            mem(ch0, 0, JA, true, 0, 5);
+            bar();
+            comp(0, JA);
+            bar();
+            mem(ch0, JA, JB, false, 5, 10);
+            // (the stage's last fragment reads when the k-tile is a half one: nothing may still be reading when the partner group,
+            // a barrier later, lets the next DMA into this stage)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bar();
+            comp(JA, JB);
+            bar();
+            if (!half) {
+                mem(ch1, 0, JA, true, 0, 0);
+                bar();
+                comp(0, JA);
+                bar();
+                mem(ch1, JA, JB, false, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (!last_k) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bar();
+                comp(JA, JB);
+                bar();
+            }
+        } else {
             uint4 xf[MI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch0);
@@ -743,11 +856,25 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         if constexpr (sizeof(T) == 4) chain_end = last_k || (g.kchunk > 0 && (kt + 1 - k_begin(tile)) % g.kchunk == 0);
         if (!chain_end) {
             ++kt;
+            first_kt = false;
+#if SWIFTK_PP_STAMP
+            ++pl_kt;
+#endif
             // (a k-tile that is not its tile's last is never the half one: both k-halves ran, so with the look-ahead on its two
             // requests are this wave's youngest VMEM operations and stay in flight)
-            if constexpr (TOUCH) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if constexpr (PP) {}  // (waited in the k-tile's last MEM phase)
+            else if constexpr (TOUCH) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             continue;
+        }
+        if constexpr (PP) {
+            // group 0 finished its MFMAs one barrier ahead of group 1: meet it, every wave is aligned again for the epilogue
+            if (!grp) __builtin_amdgcn_s_barrier();
+            first_kt = true;
+#if SWIFTK_PP_STAMP
+            ++pl_tile;
+            pl_kt = 0;
+#endif
         }
         if constexpr (sizeof(T) == 4) {
             // end of a chain that is not the tile's last: park the partial sum (added to what is parked already);
@@ -766,9 +893,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         }
         bool interior = false;
         // ---- epilogue of `tile`: lane holds C[m][nb .. nb+3] for m = ..+r16, nb = ..+4*(lane>>4) ----
+#if SWIFTK_GEMM_INSTR || SWIFTK_PP_STAMP
 #if SWIFTK_GEMM_INSTR
         if (tlog) tlog[tl_i * 8 + 1] = __builtin_amdgcn_s_memtime();
         first_k = true;
+#endif
         if (g.dbg & 4) {  // tuning experiment: drop the epilogue (keeps the accumulators live through a fake use)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
