@@ -109,6 +109,12 @@ constexpr int EPI_BIAS_POS_PAIR = 11;  // internal: SWIFTK_EPI_BIAS_POS leaving 
 #ifndef SWIFTK_PP_STAMP
 #define SWIFTK_PP_STAMP 0
 #endif
+// phase order of the ping-pong loop: 2 = column-half major (W0 region refilled two k-tiles ahead, activation fragments read in
+// every phase: 38 fragment reads per k-tile), 3 = k-half major (30 reads; every piece one k-tile ahead, the W1 pieces -- needed
+// from the next k-tile's second phase on -- issued last and waited for in the next k-tile's first MEM phase)
+#ifndef SWIFTK_PP_ORDER
+#define SWIFTK_PP_ORDER 3
+#endif
 
 struct GemmArgs {
     const char* A;
@@ -451,7 +457,7 @@ struct TileIter {
     }
 };
 
-template <typename T, typename OutT, int EPI, int NI>
+template <typename T, typename OutT, int EPI, int NI, bool PPK>
 __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm) {
     // geometry of this instantiation: 8 waves as 4 (M) x 2 (N), each 64 x 16 NI
     constexpr int WT = 16 * NI;                 // columns of a wave tile (160 / 176 / 192)
@@ -466,7 +472,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     // and their tangent rows, wave wm the 32 + 32 rows of tokens 128 tm + 32 wm .. + 31: accumulator row blocks i = 0, 1 are primal,
     // i = 2, 3 the tangents of the same tokens -- the epilogue's tangent rules find both values of an element in one lane
     constexpr bool PAIRED = EPI == SWIFTK_EPI_QKNORM_JVP || EPI == SWIFTK_EPI_SWIGLU_JVP;
-    constexpr bool PP = SWIFTK_X_PP > 0 && sizeof(T) == 2 && !TOUCH && !HPF && !SWIFTK_GEMM_INSTR;
+    // PPK: the ping-pong k-loop (needs at least three k-tiles per work item; the launcher checks)
+    constexpr bool PP = PPK && sizeof(T) == 2 && !TOUCH && !HPF && !SWIFTK_GEMM_INSTR;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (TOUCH || HPF ? 256 : 0)];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -530,6 +537,56 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             wbase[i] = g.W + (int64_t)rb * g.ldw_b;
         }
     };
+    // Ping-pong loop: the W rows of a stage form two regions with lives of their own -- W0 = the first JA column blocks of both
+    // wave-tile halves (read in a k-tile's first two phases), W1 = the other JB (last two phases).  W0 pieces n = wv + 8 i < 4 JA,
+    // W1 pieces n = wv + 8 i < 4 JB; piece n of a region: half h = n / (2 J), rows h WT + [JA 16 +] 8 (n - 2 J h) .. + 7 of the
+    // tile (2 J and WT / 8 are even: the swizzle parity of a piece is wv & 1, so `vb` serves every W piece here too).
+#ifndef SWIFTK_PP_JA_HI
+#define SWIFTK_PP_JA_HI (SWIFTK_PP_ORDER == 2)
+#endif
+    // (k-half major order: the LOW column half is the smaller one -- its MEM phase carries the four activation fragments too and
+    // runs beside the partner's MFMAs of the high half, so the longer MEM phase meets the longer COMPUTE phase)
+    constexpr int JA = SWIFTK_PP_JA_HI ? (NI + 1) / 2 : NI / 2, JB = NI - JA, JM = JA > JB ? JA : JB;
+    const char* w0base[3];
+    const char* w1base[3];
+    auto w0row = [&](int i) { const int n = wv + 8 * i, h = n >= 2 * JA; return h * WT + (n - 2 * JA * h) * 8; };
+    auto w1row = [&](int i) { const int n = wv + 8 * i, h = n >= 2 * JB; return h * WT + JA * 16 + (n - 2 * JB * h) * 8; };
+    auto set_sources_aw1 = [&](int t) {
+        int tm, tn;
+        it.coords(t / ksplit, tm, tn);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int rb = tm * BM + (wv * 4 + p) * 8;
+            if constexpr (PAIRED) rb = ((wv & 1) ? (g.M >> 1) : 0) + tm * (BM / 2) + (wv >> 1) * 32 + (p >> 1) * 16 + (p & 1) * 8;
+            rb = rb < g.M ? rb : g.M - 8;
+            abase[p] = g.A + (int64_t)rb * g.lda_b;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int rb = tn * BN + w1row(i);
+            rb = rb < g.N ? rb : g.N - 8;
+            w1base[i] = g.W + (int64_t)rb * g.ldw_b;
+        }
+    };
+    auto set_sources_w0 = [&](int t) {
+        int tm, tn;
+        it.coords(t / ksplit, tm, tn);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int rb = tn * BN + w0row(i);
+            rb = rb < g.N ? rb : g.N - 8;
+            w0base[i] = g.W + (int64_t)rb * g.ldw_b;
+        }
+    };
+    auto pp_a = [&](uint32_t sa, uint32_t koff, int p) {
+        dma_piece_fast(sa + (wv * 4 + p) * 1024, abase[p], ((p & 1) ? va_odd : va_even) + koff);
+    };
+    auto pp_w0 = [&](uint32_t sa, uint32_t koff, int i) {
+        if (wv + 8 * i < 4 * JA) dma_piece_fast(sa + A_BYTES + w0row(i) * ROWB, w0base[i], vb + koff);
+    };
+    auto pp_w1 = [&](uint32_t sa, uint32_t koff, int i) {
+        if (wv + 8 * i < 4 * JB) dma_piece_fast(sa + A_BYTES + w1row(i) * ROWB, w1base[i], vb + koff);
+    };
     // piece p of the stage at LDS byte address `sa`: pieces 0-3 = A rows, 4-9 = W rows (1 KiB = 8 rows x 128 B);
     // `koff` = byte offset of the k-tile inside a row, carried in the per-lane offset
     auto issue_piece = [&](uint32_t sa, uint32_t koff, int p) {
@@ -562,10 +619,21 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 
     // Flattened (tile, k-tile) walk.  Each step computes from one stage while the DMA of the following step fills
     // the other; past the very last step the "following step" is a harmless re-load of this tile's first k-tile.
-    set_sources(tile);
     int nk = k_end(tile);
+    if constexpr (PP) {
+        set_sources_aw1(tile);
+        set_sources_w0(tile);
 #pragma unroll
-    for (int p = 0; p < 10; ++p) issue_piece(lds0, (uint32_t)kt * ROWB, p);
+        for (int p = 0; p < 4; ++p) pp_a(lds0, (uint32_t)kt * ROWB, p);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pp_w0(lds0, (uint32_t)kt * ROWB, i);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pp_w1(lds0, (uint32_t)kt * ROWB, i);
+    } else {
+        set_sources(tile);
+#pragma unroll
+        for (int p = 0; p < 10; ++p) issue_piece(lds0, (uint32_t)kt * ROWB, p);
+    }
     int par = 0;
     bool have_part = false;  // (fp32 operands, kchunk > 0) this tile has a partial sum parked in the workgroup's scratch slab
     // dbg bit 32 (timing experiment, EPI_NONE only): wave 0 of every 32nd workgroup logs s_memtime at five points of each tile
@@ -663,6 +731,19 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 hpf_base = reinterpret_cast<const char*>(g.ep1) + ((int64_t)rb * g.pos_rows + 2 * t_n0) * 2;
             }
         }
+        uint32_t koff2 = (uint32_t)(kt + 2) * ROWB;  // ping-pong: k offset of the W0 pieces (they run two k-tiles ahead)
+        if constexpr (PP) {
+            const int ntile = tile + stride < ntiles ? tile + stride : tile;  // (past the last item: harmless re-loads)
+            if (last_k) {
+                set_sources_aw1(ntile);
+                if (SWIFTK_PP_ORDER == 3) set_sources_w0(ntile);
+                koff = (uint32_t)k_begin(ntile) * ROWB;
+            }
+            if (SWIFTK_PP_ORDER == 2 && kt + 2 == nk) {  // the W0 pieces of this k-tile feed the next item's first k-tile
+                set_sources_w0(ntile);
+                koff2 = (uint32_t)k_begin(ntile) * ROWB;
+            }
+        } else
         if (last_k) {
             const int ntile = tile + stride;
             if (ntile < ntiles) set_sources(ntile);
@@ -675,46 +756,54 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         // columns, so those 44 MFMAs are skipped -- 3 % of the GEMM).  Branches between the MFMA groups make hipcc
         // shuffle and spill accumulators (297 v_mov + 27 spilled dwords per k-tile in the SwiGLU build).
         if constexpr (PP) {
-            // Ping-pong form of the same k-tile: phases (k-half, column half) = (0, lo) (0, hi) (1, lo) (1, hi); the wave tile's NI
-            // column blocks split JA | NI - JA.  All ten DMA pieces of the next stage leave in the first two MEM phases (five
-            // each) so that they have the rest of the k-tile to land; the drain sits in the last MEM phase, i.e. under the SIMD
-            // partner's MFMAs.  A tile's last k-tile does not wait at all: its pieces feed the next tile and are waited for behind
-            // the epilogue (counted against the epilogue's stores, below).
-            constexpr int JA = (NI + 1) / 2, JB = NI - JA;
-            uint4 xf[MI], wf[JA];
+            // Ping-pong form of the same k-tile.  Phases (column half, k-half) = (lo, 0) (lo, 1) (hi, 0) (hi, 1): the W0 region is dead
+            // after the second phase and is refilled two k-tiles ahead from the third phase on, so DMA stays in flight across the
+            // k-tile boundary under counted waits (VMEM retires in issue order).  Issue order of a wave per k-tile:
+            //   MEM 0: A0 A1 | MEM 1: A2 A3 W1a, wait W1(this k-tile) | MEM 2: W1b W1c W0a | MEM 3: W0b W0c, wait A(next k-tile)
+            // (A, W1 -> the other stage, one k-tile ahead; W0 -> this stage, two ahead).  W1(t) needs all but the C0 + 5 youngest
+            // requests retired, A(t + 1) [and with it the older W0(t + 1)] all but the C1 + C0 youngest.  A tile's first k-tile
+            // also issues W0 of its second one (the previous tile's last k-tile must not: that stage is the epilogue's scratch)
+            // and skips the first wait (everything older than the epilogue's stores was waited for behind the epilogue); a tile's
+            // last k-tile issues no W0 and skips the second wait.  Every MEM phase ends with lgkmcnt(0) in front of its barrier:
+            // the fragments are in registers when the MFMAs start, and no read is pending when the partner group, one barrier
+            // later, lets DMA into a region.
+            constexpr int C0L = 3, C0H = 4 * JA >= 24 ? 3 : 2, C1L = 3, C1H = 4 * JB >= 24 ? 3 : 2;
+            uint4 xf[MI], wf[JM];
 #if SWIFTK_PP_STAMP
             pl_i = 0;
-            if (g.dbg & 8) koff = 0;
+            if (g.dbg & 8) koff = koff2 = 0;
+#define PP_DMA(x) do { if (!(g.dbg & 1)) { x; } } while (0)
+#else
+#define PP_DMA(x) do { x; } while (0)
 #endif
             auto bar = [&] {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 PP_STAMP();
                 __builtin_amdgcn_s_barrier();
                 PP_STAMP();
                 __builtin_amdgcn_sched_barrier(0);
             };
-            auto mem = [&](const int ch, const int j0, const int nj, const bool newx, const int p0, const int p1) {
-                if (newx) {
+            auto bar2 = [&] {
+                __builtin_amdgcn_sched_barrier(0);
+                PP_STAMP();
+                __builtin_amdgcn_s_barrier();
+                PP_STAMP();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto rd = [&](const int ch, const int j0, const int nj) {
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch);
-                }
+                for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch);
 #pragma unroll
-                for (int jj = 0; jj < JA; ++jj)
+                for (int jj = 0; jj < JM; ++jj)
                     if (jj < nj) wf[jj] = *reinterpret_cast<const uint4*>(s + woff + (j0 + jj) * 16 * ROWB + ch);
-#pragma unroll
-                for (int pc = 0; pc < 10; ++pc) {
-#if SWIFTK_PP_STAMP
-                    if (g.dbg & 1) continue;
-#endif
-                    if (pc >= p0 && pc < p1) issue_piece(fill, koff, pc);
-                }
             };
             auto comp = [&](const int j0, const int nj) {
 #if SWIFTK_X_PP_PRIO
                 __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-                for (int jj = 0; jj < JA; ++jj) {
+                for (int jj = 0; jj < JM; ++jj) {
                     if (jj < nj) {
 #pragma unroll
                         for (int i = 0; i < MI; ++i) mma_chunk<T>(acc[i][j0 + jj], wf[jj], xf[i]);
@@ -724,29 +813,128 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 __builtin_amdgcn_s_setprio(0);
 #endif
             };
-            mem(ch0, 0, JA, true, 0, 5);
-            bar();
-            comp(0, JA);
-            bar();
-            mem(ch0, JA, JB, false, 5, 10);
-            // (the stage's last fragment reads when the k-tile is a half one: nothing may still be reading when the partner group,
-            // a barrier later, lets the next DMA into this stage)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            bar();
-            comp(JA, JB);
-            bar();
-            if (!half) {
-                mem(ch1, 0, JA, true, 0, 0);
+            auto wait_w1 = [&] {
+                if (wv < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C0L + 5) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C0H + 5) : "memory");
+            };
+            auto wait_a = [&] {
+                if (wv < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1L + C0L) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1H + C0H) : "memory");
+            };
+            if constexpr (SWIFTK_PP_ORDER == 3) {
+                // k-half major: (0, lo) (0, hi) (1, lo) (1, hi); activation fragments are read once per k-half.  Issue order of a
+                // wave per k-tile, everything into the other stage:  MEM 0: A0 A1 A2, wait W1(this k-tile) | MEM 1: A3 W0a W0b |
+                // MEM 2: W0c W1a | MEM 3: W1b W1c, wait A, W0(next k-tile).  The second wait leaves the C1 youngest requests (W1)
+                // in flight across the k-tile boundary; the first one -- three requests later -- retires them.
+                auto rdx = [&](const int ch) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch);
+                };
+                auto rdw = [&](const int ch, const int j0, const int nj) {
+#pragma unroll
+                    for (int jj = 0; jj < JM; ++jj)
+                        if (jj < nj) wf[jj] = *reinterpret_cast<const uint4*>(s + woff + (j0 + jj) * 16 * ROWB + ch);
+                };
+                // ---- (0, lo)
+                rdx(ch0);
+                rdw(ch0, 0, JA);
+                PP_DMA(pp_a(fill, koff, 0));
+                PP_DMA(pp_a(fill, koff, 1));
+                PP_DMA(pp_a(fill, koff, 2));
+                if (!first_kt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                bar2();
+                comp(0, JA);
+                bar2();
+                // ---- (0, hi)
+                rdw(ch0, JA, JB);
+                PP_DMA(pp_a(fill, koff, 3));
+                PP_DMA(pp_w0(fill, koff, 0));
+                PP_DMA(pp_w0(fill, koff, 1));
+                if (half) {  // the k-tile ends here: the rest of its requests, and its last fragment reads
+                    PP_DMA(pp_w0(fill, koff, 2));
+                    PP_DMA(pp_w1(fill, koff, 0));
+                    PP_DMA(pp_w1(fill, koff, 1));
+                    PP_DMA(pp_w1(fill, koff, 2));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                bar2();
+                comp(JA, JB);
+                bar2();
+                if (!half) {
+                    // ---- (1, lo)
+                    rdx(ch1);
+                    rdw(ch1, 0, JA);
+                    PP_DMA(pp_w0(fill, koff, 2));
+                    PP_DMA(pp_w1(fill, koff, 0));
+                    bar2();
+                    comp(0, JA);
+                    bar2();
+                    // ---- (1, hi)
+                    rdw(ch1, JA, JB);
+                    PP_DMA(pp_w1(fill, koff, 1));
+                    PP_DMA(pp_w1(fill, koff, 2));
+                    if (!last_k) {
+                        if (wv < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1L) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1H) : "memory");
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    bar2();
+                    comp(JA, JB);
+                    bar2();
+                }
+            } else {
+                const uint32_t cur = lds0 + par * STAGE;
+                // ---- (lo, 0)
+                rd(ch0, 0, JA);
+                if (first_kt) {
+                    PP_DMA(pp_w0(fill, koff, 0));
+                    PP_DMA(pp_w0(fill, koff, 1));
+                    PP_DMA(pp_w0(fill, koff, 2));
+                }
+                PP_DMA(pp_a(fill, koff, 0));
+                PP_DMA(pp_a(fill, koff, 1));
+                if (half) {
+                    PP_DMA(pp_a(fill, koff, 2));
+                    PP_DMA(pp_a(fill, koff, 3));
+                    PP_DMA(pp_w1(fill, koff, 0));
+                    wait_w1();
+                }
                 bar();
                 comp(0, JA);
-                bar();
-                mem(ch1, JA, JB, false, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (!last_k) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bar2();
+                if (!half) {
+                    // ---- (lo, 1)
+                    rd(ch1, 0, JA);
+                    PP_DMA(pp_a(fill, koff, 2));
+                    PP_DMA(pp_a(fill, koff, 3));
+                    PP_DMA(pp_w1(fill, koff, 0));
+                    if (!first_kt) wait_w1();
+                    bar();
+                    comp(0, JA);
+                    bar2();
+                }
+                // ---- (hi, 0)
+                rd(ch0, JA, JB);
+                PP_DMA(pp_w1(fill, koff, 1));
+                PP_DMA(pp_w1(fill, koff, 2));
+                if (!last_k) PP_DMA(pp_w0(cur, koff2, 0));
                 bar();
                 comp(JA, JB);
-                bar();
+                bar2();
+                if (!half) {
+                    // ---- (hi, 1)
+                    rd(ch1, JA, JB);
+                    if (!last_k) {
+                        PP_DMA(pp_w0(cur, koff2, 1));
+                        PP_DMA(pp_w0(cur, koff2, 2));
+                        wait_a();
+                    }
+                    bar();
+                    comp(JA, JB);
+                    bar2();
+                }
             }
+#undef PP_DMA
         } else {
             uint4 xf[MI];
 #pragma unroll
@@ -1361,6 +1549,10 @@ int g_group_m = 8;   // tile rows per group in the persistent order
 int g_persist_wgs = 256;
 int g_dbg = 0;
 int g_stagger_permille = 0;  // tuning key 7: start-up phase step as a fraction (in 1/1000) of an eighth of the estimated tile time
+int g_pp = SWIFTK_X_PP;      // tuning key 20: ping-pong k-loop of the persistent kernel (bf16 operands)
+
+// the ping-pong loop prefetches W0 two k-tiles ahead: every work item needs at least three k-tiles
+inline bool pp_ok(const GemmArgs& g) { return g_pp > 0 && !SWIFTK_GEMM_INSTR && (g.K / 64) / g.ksplit >= 3; }
 
 struct Prof {
     int epilogue = -1, N = 0;
@@ -1387,11 +1579,17 @@ int launch(const GemmArgs& g, hipStream_t st) {
         const int ntiles = ntm * g.ntn * g.ksplit;
         const int grid = ntiles < g_persist_wgs ? ntiles : g_persist_wgs;
         if constexpr (sizeof(T) == 2) {  // bf16 operands: all three tile widths (head_dim 80 / 88 / 96 families)
-            if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 10>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
-            else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 12>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
-            else hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+            if (pp_ok(g)) {
+                if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 10, true>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+                else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 12, true>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+                else hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11, true>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+            } else {
+                if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 10, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+                else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 12, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+                else hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+            }
         } else {
-            hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+            hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
         }
     }
     if (timed) swiftk_prof_end(st);
@@ -1406,9 +1604,15 @@ int launch_paired(const GemmArgs& g, hipStream_t st) {
     const bool timed = swiftk_prof_begin(EPI, g.N, st);
     const int ntiles = ntm * g.ntn;
     const int grid = ntiles < g_persist_wgs ? ntiles : g_persist_wgs;
-    if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 10>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
-    else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 12>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
-    else hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 11>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+    if (pp_ok(g)) {
+        if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 10, true>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+        else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 12, true>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+        else hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 11, true>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+    } else {
+        if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 10, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+        else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 12, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+        else hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 11, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+    }
     if (timed) swiftk_prof_end(st);
     SWIFTK_CHECK_LAUNCH();
     return 0;
@@ -1481,6 +1685,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 17: g_modnorm_jvp_rows = value; return 0;
         case 18: g_x3_ffsplit = value; return 0;
         case 19: g_fwd_pepair = value; return 0;
+        case 20: g_pp = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -1506,6 +1711,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 17: return g_modnorm_jvp_rows;
         case 18: return g_x3_ffsplit;
         case 19: return g_fwd_pepair;
+        case 20: return g_pp;
     }
     return SWIFTK_EINVAL;
 }

@@ -21,16 +21,19 @@ want = sys.argv[3:]
 paths = {"product": os.path.join(ROOT, "swift_amd", "csrc", "libswiftk.so")}
 for p in sorted(glob.glob(os.path.join(ROOT, "swift_amd", "csrc", "variants", "libswiftk_*.so"))):
     paths[os.path.basename(p)[len("libswiftk_"):-3]] = p
-if want:  # "name", "name@V" (swiftk_set_tuning(0, V): kernel variant) or "name+sP" (tuning key 7: start-up stagger, P permille)
-    paths = {k: paths[k.partition("@")[0].partition("+")[0]] for k in want}
-libs, variant, stagger = {}, {}, {}
+if want:  # "name", "name@V" (swiftk_set_tuning(0, V): kernel variant), "name+sP" (tuning key 7: start-up stagger, P permille),
+    # "name~P" (tuning key 20: ping-pong k-loop on / off)
+    paths = {k: paths[k.partition("~")[0].partition("@")[0].partition("+")[0]] for k in want}
+libs, variant, stagger, pp = {}, {}, {}, {}
 for name, p in paths.items():
     h = C.CDLL(p)
     for fn in ("swiftk_gemm", "swiftk_gemm_qkv_tiled", "swiftk_set_tuning"):
         getattr(h, fn).argtypes, getattr(h, fn).restype = _lib._SIGS[fn]
     libs[name] = h
-    variant[name] = int(name.partition("@")[2].partition("+")[0] or 1)
-    stagger[name] = int(name.partition("+s")[2] or 0)
+    pp[name] = name.partition("~")[2]
+    name_ = name.partition("~")[0]
+    variant[name] = int(name_.partition("@")[2].partition("+")[0] or 1)
+    stagger[name] = int(name_.partition("+s")[2] or 0)
 names = list(libs)
 dev = torch.device("cuda")
 M = B * 8192
@@ -56,6 +59,8 @@ for sname, N, K, Kalg, epi in shapes:
         h, o = libs[n], outs[n]
         h.swiftk_set_tuning(0, variant[n])
         h.swiftk_set_tuning(7, stagger[n])
+        if pp[n] != "":
+            h.swiftk_set_tuning(20, int(pp[n]))
         if epi == "tiled":
             rc = h.swiftk_gemm_qkv_tiled(a.data_ptr(), K, w.data_ptr(), K, o.data_ptr(), Kalg, scale.data_ptr(), B, 64, 128, 12,
                                          88, 8, 8, st())
