@@ -98,7 +98,7 @@ constexpr int EPI_BIAS_POS_PAIR = 11;  // internal: SWIFTK_EPI_BIAS_POS leaving 
 // MFMAs.  1 = per-k-tile drain of the DMA (placed in the last MEM phase); 2 = counted: the W pieces of the second column
 // half stay in flight across the k-tile boundary and are waited for in the next k-tile's first MEM phase.
 #ifndef SWIFTK_X_PP
-#define SWIFTK_X_PP 0
+#define SWIFTK_X_PP 1
 #endif
 #ifndef SWIFTK_X_PP_PRIO
 #define SWIFTK_X_PP_PRIO 1
