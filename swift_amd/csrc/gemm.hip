@@ -109,6 +109,10 @@ constexpr int EPI_BIAS_POS_PAIR = 11;  // internal: SWIFTK_EPI_BIAS_POS leaving 
 #ifndef SWIFTK_PP_STAMP
 #define SWIFTK_PP_STAMP 0
 #endif
+// bf16 epilogue: request all of a 16-row slab's row chunks from LDS before the first store (1) or chunk by chunk (0)
+#ifndef SWIFTK_X_EPIBATCH
+#define SWIFTK_X_EPIBATCH 0
+#endif
 // phase order of the ping-pong loop: 2 = column-half major (W0 region refilled two k-tiles ahead, activation fragments read in
 // every phase: 38 fragment reads per k-tile), 3 = k-half major (30 reads; every piece one k-tile ahead, the W1 pieces -- needed
 // from the next k-tile's second phase on -- issued last and waited for in the next k-tile's first MEM phase)
@@ -1392,12 +1396,26 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                             twin0 = tb * ((g.t_gh >> 4) * (g.t_gw >> 4)) + (try_ >> 4) * (g.t_gw >> 4);
                         }
                     }
+                    constexpr int NCH = (16 * CPR + 63) / 64;
+#if SWIFTK_X_EPIBATCH
+                    uint4 qs[NCH];
 #pragma unroll
-                    for (int t = 0; t < (16 * CPR + 63) / 64; ++t) {
+                    for (int t = 0; t < NCH; ++t) {
+                        const int c = min(elane + 64 * t, 16 * CPR - 1);
+                        const int row = c / CPR, cc = c - row * CPR;
+                        qs[t] = *reinterpret_cast<const uint4*>(slab + row * RSTR + cc * 16);
+                    }
+#endif
+#pragma unroll
+                    for (int t = 0; t < NCH; ++t) {
                         const int c = elane + 64 * t;
                         const int row = c / CPR, cc = c - row * CPR;
                         if (c < 16 * CPR) {
+#if SWIFTK_X_EPIBATCH
+                            const uint4 q = qs[t];
+#else
                             const uint4 q = *reinterpret_cast<const uint4*>(slab + row * RSTR + cc * 16);
+#endif
                             const int m = mrow0 + row, n = ncol0 + cc * 8;
                             int64_t dst = (int64_t)m * g.ldc + n;
                             if constexpr (EPI == EPI_QKNORM_TILED) {
