@@ -70,7 +70,7 @@ struct FusedArgs {
     int64_t ldx_b, ldw_b, ldo;
     int B, gh, gw, heads, sh, sw;
     int nk, khalf;      // k-tiles, and whether the last one is half full
-    int dbg;            // timing experiments: 1 = skip the attention core
+    int dbg;            // timing experiments: 1 = skip the attention core, 2 = every item reads head 0's weights
 };
 
 __device__ __forceinline__ int win_token(int wy, int wx, int j, int gh, int gw, int sh, int sw) {
@@ -159,7 +159,9 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
     auto set_item = [&](int b, int w, int h) {
         if (w != cur_w) set_window(w);
         xbase = pin(a.x + (int64_t)b * ntok * a.ldx_b);
-        wbase = pin(a.w + (int64_t)h * (3 * HD) * a.ldw_b);
+        // (dbg bit 2, timing experiment with WRONG results: every item reads head 0's weight slab -- 557 KB that stay in every
+        // XCD's L2 -- to price the twelve slabs' streaming from the Infinity Cache: profiles/r05i_qkv_attn_w0.txt)
+        wbase = pin(a.w + (int64_t)((a.dbg & 2) ? 0 : h) * (3 * HD) * a.ldw_b);
     };
     // piece p of a stage (0-3 token rows, 4-8 weight rows) for k-tile byte offset koff
     auto issue_piece = [&](uint32_t stage, uint32_t koff, int p) {

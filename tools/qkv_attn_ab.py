@@ -27,11 +27,16 @@ def fused():
     ops.qkv_attention_fused(a, w, scale, B, grid, heads, (8, 8), out=of, k=d)
 def fused_noattn():
     L.swiftk_set_tuning(4, 1 << 8); fused(); L.swiftk_set_tuning(4, 0)
+def fused_w0():
+    L.swiftk_set_tuning(4, 2 << 8); fused(); L.swiftk_set_tuning(4, 0)
+def fused_w0_noattn():
+    L.swiftk_set_tuning(4, 3 << 8); fused(); L.swiftk_set_tuning(4, 0)
 def stag(n):
     def f():
         L.swiftk_set_tuning(4, (n << 2) << 8); fused(); L.swiftk_set_tuning(4, 0)
     return f
-fns = {"two kernels": two, "fused, waves 4-7 +192 cyc": stag(2), "  (to_qkv GEMM alone)": gemm_only, "fused": fused, "  (fused, attention core skipped)": fused_noattn}
+fns = {"two kernels": two, "fused, waves 4-7 +192 cyc": stag(2), "  (to_qkv GEMM alone)": gemm_only, "fused": fused, "  (fused, attention core skipped)": fused_noattn,
+       "  (fused, every item reads head 0's weights: WRONG results)": fused_w0, "  (the same, attention core skipped)": fused_w0_noattn}
 res = {k: [] for k in fns}
 for rnd in range(R):
     for k in (list(fns) if rnd % 2 == 0 else list(fns)[::-1]):
@@ -45,5 +50,5 @@ rel = float((of[..., :d].float() - o2[..., :d].float()).norm() / o2[..., :d].flo
 flop = 2.0 * M * 3 * d * d + B * 8.858e9
 for k in fns:
     t = sorted(res[k]); med = t[len(t) // 2]
-    print(f"{k:34s} median {med*1e3:8.1f} us  min {t[0]*1e3:8.1f} us   {flop/med/1e9:7.1f} TFLOP/s (qkv + attention FLOPs)", flush=True)
+    print(f"{k:60s} median {med*1e3:8.1f} us  min {t[0]*1e3:8.1f} us   {flop/med/1e9:7.1f} TFLOP/s (qkv + attention FLOPs)", flush=True)
 print(f"fused vs two-kernel output: rel-L2 {rel:.2e}")
