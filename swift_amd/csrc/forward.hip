@@ -80,7 +80,9 @@ Layout make_layout(const swiftk_model* m, int B) {
     L.hmid = o; o += al(M * m->kmlp * es);
     L.tok = o; o += al(M * (int64_t)((m->out_ch * m->p1 * m->p2 + 3) & ~3) * 4);
     L.kscr = o;
-    if (m->dtype != SWIFTK_BF16) o += al(swiftk_gemm_chunk_scratch_bytes());  // parked accumulators of the fp32-operand GEMMs
+    // parked accumulators of the two-level fp32 GEMMs: the exact engine only (the split engine's exact-kernel GEMMs run one
+    // chain; sized whatever tuning key 13 says now, since the key may change after the workspace was sized)
+    if (m->dtype == SWIFTK_F32) o += al(swiftk_gemm_chunk_scratch_bytes());
     L.a3 = o;
     if (m->dtype == SWIFTK_BF16X3) {  // the split GEMM operand [M, k_pad(3 K)] bf16 of the widest GEMM input
         const int64_t kin = (int64_t)m->in_ch * m->p1 * m->p2;
@@ -241,7 +243,11 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             // softmax as 4.5e-4 -- x3_exact bit 0 keeps the whole GEMM on the exact-fp32 kernel, bit 6 only the hot head pairs)
             RUN(G(xT, m->kd, ly.qkv_w, qkv, 3 * d, 3 * d, kdv, d, dt, fuse_norm ? SWIFTK_EPI_QKNORM : SWIFTK_EPI_NONE,
                   fuse_norm ? ly.scale : nullptr, nullptr, fuse_norm ? hd : 0, (x3_exact & 1) != 0));
-            if (x3 && (x3_exact & 64) && !(x3_exact & 1) && fuse_norm && hd == 88 && ly.qkv_w_f32) {
+            // (bit 6 without bit 0 promises the hot-pair recompute: a model it cannot serve -- another head_dim, or hot pairs
+            // without their fp32 weights -- is refused rather than run fully split)
+            if (x3 && (x3_exact & 64) && !(x3_exact & 1) && (!fuse_norm || hd != 88 || (ly.qk_exact_pairs && !ly.qkv_w_f32)))
+                return SWIFTK_EINVAL;
+            if (x3 && (x3_exact & 64) && !(x3_exact & 1) && ly.qkv_w_f32) {
                 // adaptive to_qkv of the split engine: the head pairs whose logit scale is large enough for the split product's
                 // 4.5e-6 to matter in front of the softmax are recomputed on the exact-fp32 kernel -- 528 output columns each,
                 // written over the split result (same QK-norm epilogue, the pair's two logit scales)

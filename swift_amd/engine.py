@@ -59,6 +59,10 @@ class SwinEngine:
         exact_mask = int(os.environ.get("SWIFTK_X3_EXACT", "80"))  # travels in the model descriptor (mo.x3_exact), per engine
         tau_max = float(os.environ.get("SWIFTK_X3_TAU", "25"))
         adaptive = x3 and bool(exact_mask & 64) and not (exact_mask & 1) and m.heads % 2 == 0 and (m.dim // m.heads) == 88
+        if x3 and (exact_mask & 64) and not adaptive:
+            # the hot-pair recompute exists for head_dim 88 and an even head count only: any other shape keeps to_qkv on the exact
+            # kernel (bit 0, the round-3 default) instead of running it fully split with no recompute (2.8e-4 on Swift-B)
+            exact_mask = (exact_mask & ~64) | 1
         dt = torch.float32 if x3 else self.dtype  # activations, k-paddings and every non-GEMM kernel
         d, heads, depth, mlp = m.dim, m.heads, m.depth, m.mlp_dim
         p1, p2 = m.patch_size
@@ -119,7 +123,7 @@ class SwinEngine:
         mo.sh, mo.sw = m.shift_size
         mo.aux_dim = m.auxiliary_dim
         mo.has_logvar = int(m.logvar_embed is not None)
-        mo.x3_exact = (exact_mask if adaptive else exact_mask & ~64) if x3 else 0
+        mo.x3_exact = exact_mask if x3 else 0
         mo.timestep_weight = float(m.timestep_weight)
         mo.kd, mo.kmlp, mo.kpe = kd, kmlp, kpe
         mo.pe_w = gemm_w(m.patch_embed.emb.weight, kpe, exact=bool(exact_mask & 16))

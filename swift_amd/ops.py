@@ -103,9 +103,12 @@ def gemm_chunked(a: torch.Tensor, w: torch.Tensor, *, chunk_k: int = 256, out_dt
     N = w.shape[0]
     assert a.dtype == w.dtype == torch.float32 and w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
     need = int(lib().swiftk_gemm_chunk_scratch_bytes())
-    scr = _chunk_scratch.get(a.device)
+    # (the kernel parks partial accumulators in the slab by blockIdx / wave: one slab per stream, so that two calls in flight on
+    # different streams never share it)
+    key = (a.device, _stream())
+    scr = _chunk_scratch.get(key)
     if scr is None or scr.numel() < need:
-        scr = _chunk_scratch[a.device] = torch.empty(need, dtype=torch.uint8, device=a.device)
+        scr = _chunk_scratch[key] = torch.empty(need, dtype=torch.uint8, device=a.device)
     out = torch.empty(M, N // 2 if epilogue == EPI_SWIGLU else N, dtype=out_dtype or torch.float32, device=a.device)
     check(lib().swiftk_gemm_chunked(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K,
                                     dtype_code(a.dtype), dtype_code(out.dtype), epilogue, _ptr(bias), _ptr(pos),

@@ -85,6 +85,7 @@ class RolloutEngine:
         if "randn_like" not in kw:
             kw["randn_like"] = self._randn_like
         self.sampler = sampler_factory(solver, net, denoise_dtype=denoise_dtype, **kw)
+        self.renoises = solver == "scm" and int(kw["num_steps"]) > 1  # (diffusion.py:452-455: draws between network calls)
         self.residual = getattr(dataset, "residual", False)  # generate.py:76
         self._stats = None
 
@@ -130,6 +131,11 @@ class RolloutEngine:
         draw = seeds is not None
         if draw and step is None:
             raise ValueError("capture_step(seeds=...) needs the device step counter as well")
+        if draw and self.renoises:
+            # only the latent draw lives on the counter stream: a multi-step sampler's re-noising would come from the default
+            # generator inside the graph (replay-order dependent, unlike run()'s (seed, step + (k << 40)) draws)
+            raise ValueError("capture_step(seeds=...) supports one-step samplers only: a multi-step sampler re-noises between its "
+                             "evaluations, and those draws are not on the device counter stream")
 
         def body():
             if draw:
