@@ -275,6 +275,8 @@ def transformer_layer(cfg: SwinCfg, p: dict, i: int, x, lat, jvp: bool = False, 
         taps[f"attn{i}"] = o
     y = modulated_norm(F.linear(o, p[a + "wo.weight"]), lat, p, a + "norm.")
     x = x + y
+    if taps is not None:
+        taps[f"xmid{i}"] = x
 
     h = F.linear(x, p[f + "w1.weight"])
     m = cfg.mlp_dim
@@ -300,6 +302,8 @@ def _transformer_layer_bf16(cfg: SwinCfg, p: dict, i: int, x, lat, taps, mode=Tr
         taps[f"attn{i}"] = o
     y = bf16_round(linear_bf16(o, p[a + "wo.weight"]))
     x = x + modulated_norm(y, lat, p, a + "norm.")
+    if taps is not None:
+        taps[f"xmid{i}"] = x  # the residual stream between the two branches (per-layer teacher forcing in the GPU tests)
     h = linear_bf16(x, p[f + "w1.weight"])
     m = cfg.mlp_dim
     h = F.silu(h[..., :m]) * h[..., m:]

@@ -227,9 +227,9 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
         // cosine-attention's normalise/scale prologue rides in the to_qkv epilogue (fp32 accumulators): head_dim 88 with
         // either operand type, 80 / 96 (the 468 M / 664 M variants) with bf16 operands and an even head count
         const bool fuse_norm = (hd == 88) || (dt == SWIFTK_BF16 && (hd == 80 || hd == 96) && m->heads % 2 == 0);
-        // head_dim 88 with bf16 operands: to_qkv, the cosine norm and the window attention run as ONE kernel (q/k/v stay on
-        // the CU); its stage plan wants an odd number of 64-deep k-tiles (1056 -> 17)
-        if (fuse_norm && dt == SWIFTK_BF16 && hd == 88 && g_fwd_fused && ((m->kd / 64) & 1)) {
+        // bf16 operands, head_dim 80 / 88 / 96 (the 468 M variant, Swift-B, the 664 M variant): to_qkv, the cosine norm and the
+        // window attention run as ONE kernel (q/k/v stay on the CU)
+        if (dt == SWIFTK_BF16 && (hd == 80 || hd == 88 || hd == 96) && g_fwd_fused && m->wh == 16 && m->ww == 16) {
             RUN(swiftk_qkv_attention_fused(xT, m->kd, ly.qkv_w, m->kd, ly.scale, att, m->kd, kdv, B, gh, gw, m->heads, hd,
                                            shifted ? m->sh : 0, shifted ? m->sw : 0, stream));
         } else if (fuse_norm && dt == SWIFTK_BF16 && g_fwd_tiled) {

@@ -1,4 +1,4 @@
-// to_qkv + cosine-norm + shifted-window attention in ONE kernel for gfx950 (bf16, head_dim 88, 16x16 windows).
+// to_qkv + cosine-norm + shifted-window attention in ONE kernel for gfx950 (bf16, head_dim 80 / 88 / 96, 16x16 windows).
 //
 // Replaces reference src/swift/models/swinv2.py:119-136 + 185-208 for one layer: F.linear(to_qkv), the per-head
 // [q|k|v] split, q/k L2-normalisation and logit scale, roll + window_partition, softmax(q k^T) v, window_reverse + roll.
@@ -39,28 +39,56 @@
 namespace {
 
 constexpr int NT = 512;
-constexpr int HD = 88;
 constexpr int ROWB = 128;                   // bytes of a k-tile row (64 bf16)
 constexpr int BM = 256;                     // tokens of a window
-constexpr int BNP = 272;                    // 264 slab columns + 8 pad: column half 0 = 128, half 1 = 144
-constexpr int NI0 = 8, NI1 = 9, MI = 4;     // MFMA 16-column blocks per wave of column half 0 / 1
-constexpr int WT0 = 16 * NI0;               // 128 columns of half 0
+constexpr int MI = 4;
 constexpr int A_BYTES = BM * ROWB;          // 32 KiB
-constexpr int W_BYTES = BNP * ROWB;         // 34 KiB
-constexpr int STAGE = A_BYTES + W_BYTES;    // 67584
-constexpr int ROW = HD * 2;                 // 176 B: a q / k / v row
-constexpr int TILE = 256 * ROW;             // 45056
 constexpr int VROW = 192;                   // V rows are padded to 192 B: the transposed reads (ds_read_b64_tr_b16: 4 rows x 64 B
                                             // per 32-lane group) are 2-way bank conflicts on 176-B rows and conflict-free on 192
 constexpr int VTILE = 256 * VROW;           // 49152
-constexpr int OFF_K = 0, OFF_V = TILE, OFF_Q = TILE + VTILE;
-constexpr int OFF_S1 = 0, OFF_S0 = TILE + VTILE;
-constexpr int LDS_TOTAL = OFF_S0 + STAGE;   // 161792
-constexpr int CH = 64, NST = 4, CHB = CH * ROW, DB = 3, KS = 6, CPR = HD / 8;
-constexpr int OROWS = 16, ORND = 2, OSLAB = OROWS * ROW;  // output staging: 16 rows per round, two rounds per item
-constexpr int NOST = ORND * ((OROWS * CPR + 63) / 64);    // 6 output store instructions per wave and item
-constexpr int WP = W_BYTES / 1024;          // 34 weight pieces per stage
+constexpr int CH = 64, NST = 4, DB = 3;
+constexpr int OROWS = 16, ORND = 2;         // output staging: 16 rows per round, two rounds per item
+constexpr int LDS_MAX = 163840;             // the CU's 160 KiB
 constexpr float LOG2E = 1.4426950408889634f;
+
+// Geometry per head_dim (80 / 88 / 96: Swift's 468 M variant, Swift-B, the 664 M variant -- era5-swinv2-1.4-scm.yaml:29-36).
+// The slab's 3 HD columns are split into two column halves of whole 16-column MFMA blocks so that a wave holds complete q rows
+// (half 0) or complete k rows (half 1) of its 64 tokens:  half 0 = [q (HD) | v 0 .. NV0-1],  half 1 = [k (HD) | v NV0 .. HD-1 | pad]
+//   HD 80:  128 = 80 + 48   |  112 = 80 + 32        (NI 8 | 7, no pad)
+//   HD 88:  128 = 88 + 40   |  144 = 88 + 48 + 8    (NI 8 | 9)
+//   HD 96:  144 = 96 + 48   |  144 = 96 + 48        (NI 9 | 9, no pad)
+template <int HD_>
+struct Geo {
+    static constexpr int HD = HD_;
+    static constexpr int NI0 = HD == 96 ? 9 : 8;               // MFMA 16-column blocks per wave of column half 0
+    static constexpr int WT0 = 16 * NI0;                       // columns of half 0
+    static constexpr int NV0 = WT0 - HD, NV1 = HD - NV0;       // v columns of half 0 / half 1
+    static constexpr int NI1 = (HD + NV1 + 15) / 16;           // blocks of half 1
+    static constexpr int BNP = WT0 + 16 * NI1;                 // LDS image rows of the weight operand: 240 / 272 / 288
+    static constexpr int W_BYTES = BNP * ROWB;
+    static constexpr int STAGE = A_BYTES + W_BYTES;            // 63488 / 67584 / 69632
+    static constexpr int ROW = HD * 2;                         // a q / k row (and a v row's data)
+    static constexpr int TILE = 256 * ROW;                     // 40960 / 45056 / 49152
+    static constexpr int OFF_K = 0, OFF_V = TILE, OFF_Q = TILE + VTILE;
+    static constexpr int OFF_S1 = 0;
+    // stage 0 lies over the Q tile and the tail.  head_dim 96: K + V + stage = 164 KiB -- stage 0 starts 4 KiB early, over the end
+    // of the V tile; harmless inside the k-loop (V is dead there), and the four 1-KiB pieces that land there when the next item's
+    // first k-tile is requested under the attention core (wave 0's token pieces) are requested behind the core instead (DEFER)
+    static constexpr int OFF_S0 = OFF_Q + STAGE <= LDS_MAX ? OFF_Q : LDS_MAX - STAGE;
+    static constexpr bool DEFER = OFF_S0 < OFF_Q;
+    static constexpr int LDS_TOTAL = OFF_S0 + STAGE;
+    static constexpr int CHB = CH * ROW;
+    static constexpr int KS = (HD + 15) / 16;                  // 16-deep steps of S^T = K Q^T
+    static constexpr bool KS_HALF = HD % 16 != 0;              // the last step has one real 8-element chunk (head_dim 88)
+    static constexpr bool ONES = HD < 32 * DB;                 // spare V^T rows carry ones: the row sum rides on the matrix pipe
+    static constexpr int CPR = HD / 8;                         // 16-B chunks of an output row
+    static constexpr int OSLAB = OROWS * ROW;
+    static constexpr int NOST = ORND * ((OROWS * CPR + 63) / 64);  // output store instructions per wave and item
+    static constexpr int WP = W_BYTES / 1024;                  // weight pieces per stage: 30 / 34 / 36
+    static_assert(OFF_S1 + STAGE <= OFF_Q, "stage 1 must fit over the K and V tiles");
+    static_assert(OFF_S0 + STAGE <= LDS_MAX && OFF_Q + TILE <= LDS_MAX, "LDS plan");
+    static_assert(!DEFER || OFF_Q - OFF_S0 <= 4096, "only wave 0's four token pieces may land in the overlap");
+};
 
 struct FusedArgs {
     const char* x;      // [B * gh * gw, ldx] bf16 token-major operand copy of the residual stream
@@ -86,7 +114,12 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int HD>
 __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
+    using G = Geo<HD>;
+    constexpr int NI0 = G::NI0, NI1 = G::NI1, WT0 = G::WT0, NV0 = G::NV0, NV1 = G::NV1, BNP = G::BNP, STAGE = G::STAGE, ROW = G::ROW;
+    constexpr int OFF_K = G::OFF_K, OFF_V = G::OFF_V, OFF_Q = G::OFF_Q, OFF_S0 = G::OFF_S0, OFF_S1 = G::OFF_S1, LDS_TOTAL = G::LDS_TOTAL;
+    constexpr int CHB = G::CHB, KS = G::KS, CPR = G::CPR, OSLAB = G::OSLAB, NOST = G::NOST, WP = G::WP;
     __shared__ __attribute__((aligned(16))) char smem[LDS_TOTAL];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -151,6 +184,7 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int r = (wv + 8 * i) * 8 + prow;
+        // image row r -> the head's weight row: q r | v (r - HD) | k (r - WT0) | v NV0 + (r - WT0 - HD) = row r again | pad (clamped)
         const int row = r < HD ? r : (r < WT0 ? 2 * HD + (r - HD) : (r < WT0 + HD ? HD + (r - WT0) : min(r, 3 * HD - 1)));
         vb[i] = (uint32_t)(row * (int)a.ldw_b) + 16u * (pchunk ^ ((4 * (wv & 1) + (prow >> 1)) & 7));
     }
@@ -231,7 +265,10 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf),
                                                                             __builtin_bit_cast(bf16x8, xf[i]), acc[i][j], 0, 0, 0);
                     if (with_dma && more) issue_piece(fill, koff, j);
-                    if (with_dma && more && NI < 9 && j == NI - 1) issue_piece(fill, koff, 8);  // (nine pieces, eight column blocks)
+                    if (with_dma && more && j == NI - 1) {  // (nine pieces, seven to nine column blocks)
+#pragma unroll
+                        for (int p = NI; p < 9; ++p) issue_piece(fill, koff, p);
+                    }
                     wf = wn_;
                 }
             };
@@ -252,16 +289,16 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
             // (folding log2(e) into tau would save the core 128 v_mul per lane and item, but q-hat would then round differently
             // from the two-kernel path's: the two agree to 1e-4 as it is, 7e-3 with the fold -- kept as a regression check)
             const float tau = wn ? 1.0f : __expf(fminf(a.scale[h], 4.605170185988092f));
-            const int nv = wn ? 48 : 40, v0 = wn ? 40 : 0;
+            const int nv = wn ? NV1 : NV0, v0 = wn ? NV0 : 0;
             char* qk_tile = smem + (wn ? OFF_K : OFF_Q);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 float ss = 0.f;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {  // columns 0..95: the head vector ends at 88, inside block 5 (lanes g4 < 2)
+                for (int j = 0; j < (HD + 15) / 16; ++j) {  // the head vector's blocks; head_dim 88 ends inside block 5 (lanes g4 < 2)
                     const f32x4 v = acc[i][j];
                     const float t = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                    ss += (j < 5 || g4 < 2) ? t : 0.f;
+                    ss += (16 * j + 16 <= HD || 4 * g4 < HD - 16 * j) ? t : 0.f;
                 }
                 ss += __shfl_xor(ss, 16, 64);
                 ss += __shfl_xor(ss, 32, 64);
@@ -298,7 +335,7 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
             const char* qrow = smem + OFF_Q + (wv * 32 + c32) * ROW;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                if (ks == KS - 1) {  // head_dim 88 = 5.5 k-steps of 16: the last one has one real chunk
+                if (G::KS_HALF && ks == KS - 1) {  // head_dim 88 = 5.5 k-steps of 16: the last one has one real chunk
                     const uint4 t = *reinterpret_cast<const uint4*>(qrow + (2 * ks) * 16);
                     qf[ks] = hh ? make_uint4(0, 0, 0, 0) : t;
                 } else {
@@ -313,7 +350,8 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
         if (has_next) {
             set_item(nb, nwn, nh);
 #pragma unroll
-            for (int p = 0; p < 9; ++p) issue_piece(lds0 + OFF_S0, 0u, p);
+            for (int p = 0; p < 9; ++p)
+                if (!(G::DEFER && p < 4 && wv == 0)) issue_piece(lds0 + OFF_S0, 0u, p);  // (head_dim 96: see Geo::OFF_S0)
         }
         f32x16 o[DB];
 #pragma unroll
@@ -354,7 +392,7 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
                         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (__attribute__((address_space(3))) s16x4*)(vrow + db * 64 + 8 * VROW));
                         uint4 vf = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                        if (db == DB - 1 && c32 >= HD - 32 * (DB - 1)) vf = ones;  // rows 88..95 of V^T: the row sum
+                        if (G::ONES && db == DB - 1 && c32 >= HD - 32 * (DB - 1)) vf = ones;  // rows HD..95 of V^T: the row sum
                         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
                                                                         __builtin_bit_cast(bf16x8, pf[2 * k2 + s2]), o[db], 0, 0, 0);
                     }
@@ -362,6 +400,7 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
         };
         float m_run = -INFINITY;
         float alpha_next = 1.f;  // online form: factor the softmax of step t found for O before PV of chunk t
+        float l_valu = 0.f;      // head_dim 96 only: no spare V^T rows, the row sum is added up on the VALU
         auto soft_chunk = [&](const f32x16 (&sc)[2], uint4 (&pf)[4], auto online_tag) {
             float mb = 0.f;
             if constexpr (decltype(online_tag)::value) {
@@ -372,6 +411,7 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
                     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[k2][r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 alpha_next = __builtin_amdgcn_exp2f((m_run - mx) * LOG2E);
+                if constexpr (!G::ONES) l_valu *= alpha_next;
                 m_run = mx;
                 mb = mx * LOG2E;
             }
@@ -386,6 +426,11 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
                     pf[2 * k2 + s2].y = pack_bf16(e[8 * s2 + 2], e[8 * s2 + 3]);
                     pf[2 * k2 + s2].z = pack_bf16(e[8 * s2 + 4], e[8 * s2 + 5]);
                     pf[2 * k2 + s2].w = pack_bf16(e[8 * s2 + 6], e[8 * s2 + 7]);
+                    if constexpr (!G::ONES) {  // the sum of exactly the bf16-rounded probabilities the numerator uses
+                        const uint32_t pw[4] = {pf[2 * k2 + s2].x, pf[2 * k2 + s2].y, pf[2 * k2 + s2].z, pf[2 * k2 + s2].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) l_valu += __uint_as_float(pw[q] << 16) + __uint_as_float(pw[q] & 0xffff0000u);
+                    }
                 }
             }
         };
@@ -417,11 +462,18 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
             if (wv >= 4 && (a.dbg >> 2) >= 8) __builtin_amdgcn_s_sleep(8);
             if (online) core(std::true_type{}); else core(std::false_type{});
         }
-        const float l = (a.dbg & 1) ? 1.f : o[DB - 1][12];
+        float l = (a.dbg & 1) ? 1.f : o[DB - 1][12];
+        if constexpr (!G::ONES) l = (a.dbg & 1) ? 1.f : l_valu + __shfl_xor(l_valu, 32, 64);  // this lane's keys + the other half's
         const float rl = 1.0f / l;
 
         // =========================================================== output tile -> HBM through wave-private slabs
         __builtin_amdgcn_s_barrier();  // every wave is done with K and V: the K tile becomes the output staging area
+        if constexpr (G::DEFER) {  // (in front of the output stores: the k-loop's first wait counts those stores as the youngest)
+            if (has_next && wv == 0) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) issue_piece(lds0 + OFF_S0, 0u, p);
+            }
+        }
         {
             const int wy = w / nwx, wx = w - wy * nwx;
             bf16_t* obase = a.out + (int64_t)b * ntok * a.ldo + h * HD;
@@ -465,7 +517,7 @@ extern "C" int swiftk_qkv_attention_fused(const void* x, int64_t ldx, const void
                                           int64_t ldo, int64_t K, int B, int gh, int gw, int heads, int head_dim, int shift_h,
                                           int shift_w, void* stream) {
     if (!x || !w || !scale || !out || B <= 0 || heads <= 0) return SWIFTK_EINVAL;
-    if (head_dim != 88) return SWIFTK_ESHAPE;
+    if (head_dim != 80 && head_dim != 88 && head_dim != 96) return SWIFTK_ESHAPE;
     if (gh <= 0 || gw <= 0 || gh % 16 || gw % 16) return SWIFTK_ESHAPE;
     if (shift_h < 0 || shift_w < 0 || shift_h >= gh || shift_w >= gw) return SWIFTK_ESHAPE;
     // K: whole 64-element k-tiles, or ending half-way into the last one with both operands' rows extending (zero / finite
@@ -476,7 +528,7 @@ extern "C" int swiftk_qkv_attention_fused(const void* x, int64_t ldx, const void
         K += 32;
     }
     if (K <= 0 || K % 64 || ldx < K || ldw < K || ldo < (int64_t)heads * head_dim) return SWIFTK_ESHAPE;
-    if ((K / 64) % 2 == 0) return SWIFTK_ESHAPE;  // (the stage plan ends the k-loop in stage 0: an odd number of k-tiles)
+    if (K / 64 < 2) return SWIFTK_ESHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15) || (ldx * 2) % 16 || (ldw * 2) % 16 || (ldo * 2) % 16)
         return SWIFTK_EALIGN;
     if ((int64_t)gh * gw * ldx * 2 >= (1ll << 32) || (int64_t)3 * head_dim * ldw * 2 >= (1ll << 32)) return SWIFTK_ESHAPE;
@@ -497,7 +549,9 @@ extern "C" int swiftk_qkv_attention_fused(const void* x, int64_t ldx, const void
     int grid = 256;
     if (nitems < grid) grid = nitems >= 8 ? (nitems & ~7) : nitems;
     const bool timed = swiftk_prof_begin(SWIFTK_PROF_ATTENTION, 0, st);
-    hipLaunchKernelGGL(qkv_attn_kernel, dim3(grid), dim3(NT), 0, st, a, nitems);
+    if (head_dim == 80) hipLaunchKernelGGL(qkv_attn_kernel<80>, dim3(grid), dim3(NT), 0, st, a, nitems);
+    else if (head_dim == 96) hipLaunchKernelGGL(qkv_attn_kernel<96>, dim3(grid), dim3(NT), 0, st, a, nitems);
+    else hipLaunchKernelGGL(qkv_attn_kernel<88>, dim3(grid), dim3(NT), 0, st, a, nitems);
     if (timed) swiftk_prof_end(st);
     SWIFTK_CHECK_LAUNCH();
     return 0;

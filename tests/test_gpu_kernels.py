@@ -539,33 +539,36 @@ def test_window_tiled_qkv_path(dev, shift, B, hd):
     assert rel_l2(out_t.float().cpu(), ref) < 1.2e-2
 
 
-@pytest.mark.parametrize("shift", [(0, 0), (8, 8), (3, 5)])
-@pytest.mark.parametrize("B", [1, 3, 8])  # 8: several items per workgroup (the cross-item prefetch and the output hand-over)
-def test_fused_qkv_attention(dev, shift, B):
+@pytest.mark.parametrize("hd,shift,B", [(88, s_, b_) for s_ in ((0, 0), (8, 8), (3, 5)) for b_ in (1, 3, 8)] +
+                         # head_dim 80 / 96: the reference's 468 M / 664 M variants (16 heads; era5-swinv2-1.4-scm.yaml:29-36) --
+                         # 20 / 24 k-tiles (an even count), no half k-tile, head_dim 96 with the LDS overlap and the VALU row sum
+                         [(h_, s_, b_) for h_ in (80, 96) for s_ in ((0, 0), (3, 5)) for b_ in (1, 8)])
+def test_fused_qkv_attention(dev, hd, shift, B):  # B = 8: several items per workgroup (cross-item prefetch, output hand-over)
     """swiftk_qkv_attention_fused (to_qkv + cosine norm + shifted-window attention in one kernel, q/k/v never in HBM)
     against (a) the two-kernel path it replaces -- same bf16 operands, same fp32 accumulation, so the outputs agree to the
     rounding of the normalised q/k/v to bf16 and of the probabilities -- and (b) the fp32 formula on the QK-norm GEMM's
     output (swinv2.py:119-136).  Heads with logit bound <= 48 (max-free softmax) and > 48 (online form) are mixed."""
     from oracle.swinv2 import window_token_index
     from swift_amd import ops
-    hd, grid, heads = 88, (32, 48), 12
+    grid, heads = (32, 48), 12 if hd == 88 else 16
     n, d = grid[0] * grid[1], heads * hd
     K = ops.k_pad(torch.bfloat16, d)
     a, w = rnd((B * n, K), 60 + B), rnd((3 * heads * hd, K), 61, 0.03)
     a[:, d:] = 0
     w[:, d:] = 0
-    scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 48.0])).to(dev)
+    scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 48.0, 2.0, 60.0, 47.0, 49.0][:heads])).to(dev)
     ad, wd = to_dt(a, torch.bfloat16, dev), to_dt(w, torch.bfloat16, dev)
-    ct = ops.gemm_qkv_tiled(ad, wd, scale, B, grid, heads, shift, k=d)
+    ct = ops.gemm_qkv_tiled(ad, wd, scale, B, grid, heads, shift, k=d, head_dim=hd)
     two = ops.window_attention_tiled(ct, scale, grid, heads, shift)
-    out = torch.full((B, n, ops.k_pad(torch.bfloat16, d)), 7.0, dtype=torch.bfloat16, device=dev)  # padded rows, as in the engine
-    ops.qkv_attention_fused(ad, wd, scale, B, grid, heads, shift, out=out, k=d)
+    ldo = ops.k_pad(torch.bfloat16, d) + (0 if hd == 88 else 64)  # padded rows, as in the engine (88: 1056 -> 1088)
+    out = torch.full((B, n, ldo), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.qkv_attention_fused(ad, wd, scale, B, grid, heads, shift, out=out[..., :d], k=d, head_dim=hd)
     assert torch.isfinite(out.float()).all() and (out[..., d:].float() == 7.0).all()  # pad columns untouched
     fused = out[..., :d]
     assert rel_l2(fused.float().cpu(), two.float().cpu()) < 6e-3
     # second call into the same buffer: bit-identical (no dependence on what the LDS / the output held before)
     out2 = torch.zeros_like(out)
-    ops.qkv_attention_fused(ad, wd, scale, B, grid, heads, shift, out=out2, k=d)
+    ops.qkv_attention_fused(ad, wd, scale, B, grid, heads, shift, out=out2[..., :d], k=d, head_dim=hd)
     assert torch.equal(out2[..., :d], fused)
     c = ops.gemm(ad[:, :d], wd[:, :d], epilogue=ops.EPI_QKNORM, bias=scale, head_dim=hd)
     idx = window_token_index(grid, (16, 16), shift)
@@ -589,13 +592,13 @@ def test_fused_qkv_attention(dev, shift, B):
         oref = torch.empty(B, n, heads * hd)
         oref[:, idx.reshape(-1)] = ow.reshape(B, idx.numel(), -1)
         e = rel_l2(fused.float().cpu(), oref)
-        print(f"fused to_qkv + attention vs oracle (emulate_bf16={emu}), shift {shift}, B {B}: rel-L2 {e:.3e}")
+        print(f"fused to_qkv + attention vs oracle (emulate_bf16={emu}), head_dim {hd}, shift {shift}, B {B}: rel-L2 {e:.3e}")
         assert e < tol
 
 
 def test_fused_qkv_attention_rejects_what_it_cannot_run(dev):
-    """The fused kernel is built for head_dim 88, 16x16 windows and an odd number of 64-deep k-tiles; anything else is
-    refused with an error code (the forward then takes the two-kernel path) -- never a silent wrong answer."""
+    """The fused kernel is built for head_dim 80 / 88 / 96 and 16x16 windows; anything else is refused with an error code (the
+    forward then takes the two-kernel path) -- never a silent wrong answer."""
     from swift_amd import _lib
     L = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream
@@ -605,9 +608,10 @@ def test_fused_qkv_attention_rejects_what_it_cannot_run(dev):
     out = torch.zeros(2 * 512, 1088, dtype=torch.bfloat16, device=dev)
     call = lambda K, hd, gh, gw, sh=0, sw=0, ldo=1088: L.swiftk_qkv_attention_fused(
         a.data_ptr(), 1152, w.data_ptr(), 1152, sc.data_ptr(), out.data_ptr(), ldo, K, 2, gh, gw, 12, hd, sh, sw, st)
-    assert call(1056, 88, 16, 32) == 0                      # 16.5 k-tiles -> 17 (odd): runs
-    assert call(1056, 80, 16, 32) == -2                     # head_dim
-    assert call(1152, 88, 16, 32) == -2                     # 18 k-tiles (even)
+    assert call(1056, 88, 16, 32) == 0                      # 16.5 k-tiles: runs
+    assert call(1152, 88, 16, 32) == 0                      # 18 k-tiles (an even count): runs
+    assert call(1056, 64, 16, 32) == -2                     # head_dim
+    assert call(64, 88, 16, 32) == -2                       # a single k-tile
     assert call(1056, 88, 24, 32) == -2                     # grid not a multiple of the window
     assert call(1056, 88, 16, 32, sh=16) == -2              # shift outside the grid
     assert call(1056, 88, 16, 32, ldo=1000) == -2           # output rows too short for 12 x 88 columns

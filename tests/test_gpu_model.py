@@ -489,3 +489,76 @@ def test_bf16_rollout_vs_bf16_emulating_oracle(dev):
         print(f"lead step {i}: bf16 engine vs bf16-emulating oracle {e_emu:.3e}; vs fp32 oracle {e_f32:.3e} (increments)")
         assert e_emu < ROLLOUT_BF16_EMU_TOL
     assert rel_l2(traj, refs[True]) < 2e-3  # the physical state itself
+
+
+def test_swiftb_bf16_every_layer_teacher_forced_vs_emulating_oracle(dev):
+    """Full-depth bf16 parity, layer by layer.  The end-to-end bound of test_swiftb_full_step_vs_reference_golden is calibrated on
+    a noise floor of 4.3e-2 (twelve layers amplify any admissible rounding difference), which would hide a kernel defect of that
+    size.  Here every one of Swift-B's 24 branches is judged on its own: the bf16-emulating oracle runs the whole network once
+    (CPU), its residual stream in front of each branch is handed to the ENGINE's kernels for that branch -- the calls
+    csrc/forward.hip makes: swiftk_qkv_attention_fused, swiftk_gemm (wo / w1 + SwiGLU / w2), swiftk_modnorm_residual_pair on the
+    (bf16, 8-bit) pair -- and the branch output (what the branch adds to the stream) must agree with the oracle's to 1.5e-2.
+    Nothing feeds back, so a branch's figure is that branch's (swinv2.py:186-212)."""
+    import torch.nn.functional as F
+    from swift_amd import ops
+    seed = 21
+    net, onet = build(SWIFTB, seed, dev)
+    m = net.model
+    d, heads, n = m.dim, m.heads, 64 * 128
+    kd = ops.k_pad(torch.bfloat16, d)
+    x = det_normal((1, 69, 128, 256), seed, "x")
+    cond = det_normal((1, 72, 128, 256), seed, "cond")
+    taps = {}
+    onet(x, torch.tensor([1.1]), condition=cond, auxiliary=0.6, taps=taps, emulate_bf16="offset0")
+    lat = taps["lat"].to(dev)
+    worst = {"attention": 0.0, "feed-forward": 0.0}
+    for i, (att, ff) in enumerate(m.transformer.layers):
+        x_in = (taps["tok0"] if i == 0 else taps[f"x{i - 1}"])[0].contiguous()
+        x_mid, x_out = taps[f"xmid{i}"][0].contiguous(), taps[f"x{i}"][0].contiguous()
+        shift = tuple(m.shift_size) if i % 2 else (0, 0)
+        # ---- attention branch on the oracle's layer input
+        hi, lo = ops.split_pair(x_in.to(dev), kd)
+        mod = F.linear(lat, att.norm.modulation.weight, att.norm.modulation.bias).contiguous()
+        wq = ops.pad_cols(att.to_qkv.weight.detach(), kd, torch.bfloat16)
+        o = torch.zeros(n, kd, dtype=torch.bfloat16, device=dev)
+        ops.qkv_attention_fused(hi, wq, att.scale.detach().reshape(-1).float(), 1, (64, 128), heads, shift, out=o.view(1, n, kd)[..., :d], k=d)
+        y = ops.gemm(o[:, :d], ops.pad_cols(att.wo.weight.detach(), kd, torch.bfloat16)[:, :d])
+        ops.modnorm_residual_pair(y, hi, lo, att.norm.norm.weight.detach(), att.norm.norm.bias.detach(), mod, n, d)
+        ea = rel_l2(ops.pair_value(hi, lo, d).cpu() - x_in, x_mid - x_in)
+        # ---- feed-forward branch on the oracle's mid-layer stream
+        hi, lo = ops.split_pair(x_mid.to(dev), kd)
+        mod = F.linear(lat, ff.norm.modulation.weight, ff.norm.modulation.bias).contiguous()
+        mlp = ff.w2.weight.shape[1]
+        w1i = ff.w1.weight.detach().view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)  # rows gate_0, up_0, gate_1, up_1, ...
+        h = ops.gemm(hi[:, :d], ops.pad_cols(w1i, kd, torch.bfloat16)[:, :d], epilogue=ops.EPI_SWIGLU)
+        y = ops.gemm(h, ops.pad_cols(ff.w2.weight.detach(), ops.k_pad(torch.bfloat16, mlp), torch.bfloat16)[:, :h.shape[1]])
+        ops.modnorm_residual_pair(y, hi, lo, ff.norm.norm.weight.detach(), ff.norm.norm.bias.detach(), mod, n, d)
+        ef = rel_l2(ops.pair_value(hi, lo, d).cpu() - x_mid, x_out - x_mid)
+        print(f"layer {i:2d}: attention branch rel-L2 {ea:.3e}, feed-forward branch rel-L2 {ef:.3e}")
+        worst["attention"], worst["feed-forward"] = max(worst["attention"], ea), max(worst["feed-forward"], ef)
+    print(f"worst branch: attention {worst['attention']:.3e}, feed-forward {worst['feed-forward']:.3e}")
+    # (measured: attention 7.0e-4 .. 1.2e-3, feed-forward 1.6e-4 .. 1.8e-4 -- the asked-for 1.5e-2 would not notice a 10 x regression)
+    assert worst["attention"] <= 3e-3 and worst["feed-forward"] <= 5e-4
+
+
+def test_bf16_engine_unit_alone_vs_in_a_batch(dev):
+    """One unit evaluated alone takes the split-K wo / w2 path (two bf16 slabs summed by the norm kernel, csrc/forward.hip
+    small_m_splitk); in a batch of two it takes the one-product path.  The two round the branch output differently -- at bf16
+    level -- so a bf16-engine trajectory depends on how units were batched at that level and no more: the same unit, alone and
+    as half of a batch, within the depth-2 bf16 bound (fp32-grade engines: bit-for-bit independent of batching)."""
+    net, _ = build(SMALLB, 5, dev)
+    nb = 12  # 12 units x 1024 tokens = 144 output tiles of the d-wide GEMMs: past one round of the grid, so no split-K; one unit: 12
+    x, cond = det_normal((nb, 69, 64, 64), 5, "x").to(dev), det_normal((nb, 72, 64, 64), 5, "cond").to(dev)
+    t = torch.linspace(0.3, 1.5, nb, device=dev)
+    pick = (0, 5, 11)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        yb = net(x, t, condition=cond, auxiliary=0.6)
+        y1 = torch.cat([net(x[j:j + 1], t[j:j + 1], condition=cond[j:j + 1], auxiliary=0.6) for j in pick], 0)
+    with torch.no_grad():
+        fb = net(x, t, condition=cond, auxiliary=0.6)
+        f1 = torch.cat([net(x[j:j + 1], t[j:j + 1], condition=cond[j:j + 1], auxiliary=0.6) for j in pick], 0)
+    e = rel_l2(y1.float().cpu(), yb[list(pick)].float().cpu())
+    ef = rel_l2(f1.cpu(), fb[list(pick)].cpu())
+    print(f"bf16 engine, unit alone (split-K wo / w2) vs inside a batch of {nb}: rel-L2 {e:.3e}; fp32 engine: {ef:.3e}")
+    assert e < BF16_EMU_TOL
+    assert ef < 1e-6
