@@ -315,18 +315,32 @@ def main():
     ck_steps = torch.zeros(W + K + 4, dtype=torch.float64, device=dev)  # per step: sum over all units of the job
     step_no = [0]
 
+    # per-rank split of the timed region (HIP events on the launch stream): step start -> in front of the output collective ->
+    # behind it.  Summed per rank after the loop: compute_ms / collective_ms; barrier_wait_ms = the rank's idle time at the closing
+    # barrier.  What a first multi-GPU run is read by; three event records per step.
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+    timed = [False]
+
     def collect():
         """Output collection of one step: per-unit checksums of the physical state, gathered from every rank."""
         ops.unit_checksum(phys, out=ck)
+        k = step_no[0] - W
+        mark = timed[0] and 0 <= k < K
+        if mark:
+            ev[k][1].record()
         if grouped:
             dist.all_gather_into_tensor(ck_all, ck)
         else:
             ck_all.copy_(ck)
+        if mark:
+            ev[k][2].record()
         ck_steps[step_no[0]] = ck_all.sum()
         step_no[0] += 1
 
     def step():
         i = step_no[0]
+        if timed[0] and 0 <= i - W < K:
+            ev[i - W][0].record()
         ops.unit_noise(z, seeds, 0, step_dev=lead)
         ops.counter_add(lead, 1)
         Y = eng.sampler((X, forc_all[i % n_slabs]), latents=z)
@@ -338,6 +352,8 @@ def main():
         graph = eng.capture_step(X, fslab, z, phys, seeds=seeds, step=lead)
 
         def step():  # noqa: F811
+            if timed[0] and 0 <= step_no[0] - W < K:
+                ev[step_no[0] - W][0].record()
             fslab.copy_(forc_all[step_no[0] % n_slabs])
             graph.replay()
             collect()
@@ -348,11 +364,18 @@ def main():
     if not a.graph:  # the per-launch event pairs of the roofline leg cannot be recorded inside a replayed graph
         lib.swiftk_profile_gemm(_lib.EPI_SWIGLU, mlp2)
     sync()
+    timed[0] = True
     t0 = time.perf_counter()
     for _ in range(K):
         step()
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0  # this rank's own work is done; what follows is waiting for the slowest rank
     sync()
     dt = time.perf_counter() - t0
+    timed[0] = False
+    per_rank = sdist.gather_rank_times({
+        "compute_ms": sum(e[0].elapsed_time(e[1]) for e in ev), "collective_ms": sum(e[1].elapsed_time(e[2]) for e in ev),
+        "barrier_wait_ms": 1e3 * (dt - t_local), "timed_region_s": dt}, device=dev)
     tot_ms, n_launch = ctypes.c_double(0), ctypes.c_int64(0)
     lib.swiftk_profile_collect(ctypes.byref(tot_ms), ctypes.byref(n_launch))
     lib.swiftk_profile_gemm(-1, 0)
@@ -375,6 +398,19 @@ def main():
     if grouped:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+
+    strong = None
+    strong_spec = os.environ.get("SWIFTK_BENCH_STRONG", "12x64x60")  # (tests shrink the job; the key carries the spec)
+    if world > 1 and (not a.no_extras or "SWIFTK_BENCH_STRONG" in os.environ) and a.solver == "scm" and nsteps == 1:
+        # BASELINE configs[3] itself -- 12 members x 64 ICs x 60 steps, a FIXED job split over the ranks (strong scaling) -- beside
+        # the weak-scaling headline, so that one driver invocation per N yields both curves
+        import copy
+        a3 = copy.copy(a)
+        a3.rollout = strong_spec
+        try:
+            strong = rollout_mode(a3, eng, dev, rank, world, B, dtype, rccl, sync)
+        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline
+            strong = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         # per-launch fabric traffic of the two roofline kernels from the committed PMC passes (valid for the profiled workload)
@@ -414,7 +450,12 @@ def main():
                        "noise": "swiftk_unit_noise: Philox4x32-10 + Box-Muller keyed by (member, IC, lead step), one launch per step",
                        "forcings": f"{n_slabs} pre-staged slabs [B, 3, 128, 256], one per lead step",
                        "parallelism": f"units sharded over {world} GPU(s), no data-path collective on the state"},
+            f"rollout_{strong_spec}": ({k: strong[k] for k in ("value", "unit", "scaling", "timed_region_s", "per_rank", "config", "checksum") if k in strong}
+                                 if strong and "error" not in strong else strong),
             "rccl": rccl,
+            "per_rank": dict(per_rank, what="per rank, over the timed region: compute_ms = step start to the output collective (HIP "
+                             "events on the launch stream), collective_ms = the all-gather of per-unit checksums, barrier_wait_ms = idle "
+                             "at the closing barrier (the slowest rank shows ~0)"),
             "checksum": {"what": "fixed-order fp64 sum of each unit's physical state [69,128,256], all-gathered every step",
                          "units_collected": int(ck_host.numel()),
                          "last_step_rank0_units_sum": float(ck_host[:B].sum()),
@@ -474,6 +515,7 @@ def main():
             for key, leg in (("batch_sweep", lambda: batch_sweep_leg(eng.net, ds, dev, X0, forc, units, dtype)),
                              ("config3_2s", lambda: config3_leg(eng.net, ds, dev, X0, forc, units, dtype)),
                              ("rollout_12x8x60", lambda: rollout_leg(a, eng, dev, B, sync)),
+                             ("variants", lambda: variants_leg(dev, dtype)),
                              ("parity_engine", lambda: parity_engine_leg(eng.net, ds, dev, lib, X0, forc, units)),
                              ("bf16_vs_fp32", lambda: drift_leg(eng.net, ds, dev, X0, forc, units))):
                 try:
@@ -517,7 +559,7 @@ def training_leg():
         try:
             p = subprocess.run([sys.executable, tool] + args, capture_output=True, text=True, timeout=600)
             rec = json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{")))
-            out[name] = {k: rec[k] for k in ("metric", "value", "unit", "samples_per_s", "what", "roofline", "peak_mem_gib") if k in rec}
+            out[name] = {k: rec[k] for k in ("metric", "value", "unit", "samples_per_s", "what", "roofline", "peak_mem_gib", "allreduce") if k in rec}
         except Exception as e:  # noqa: BLE001 -- the forecast metric above must still be printed
             out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
@@ -661,6 +703,54 @@ def batch_sweep_leg(net, ds, dev, X0, forc, units, dtype, sizes=(1, 4, 8, 16, 32
     return out
 
 
+def variants_leg(dev, dtype, units: int = 32, steps: int = 4):
+    """the reference's larger Swift variants (era5-swinv2-1.4-scm.yaml:29-36 -- dim 1280 / 1536, 16
+    heads -> head_dim 80 / 96, depth 16) at FULL size on the same kernels: sCM 1-step sampler, `units` units per step, seeded
+    random weights.  Both take the fused to_qkv + window attention kernel (qkv_attn_kernel<80> / <96>) since round 5."""
+    import torch
+
+    from swift_amd.generating.factory import sampler_factory
+    from swift_amd.models.precond import PassPrecond
+    from swift_amd.utils.detinit import swinv2_state
+
+    def flops_per_eval(dim, depth):
+        ntok, mlp = 64 * 128, int(8 / 3 * dim)
+        layer = 2 * ntok * (dim * 3 * dim + dim * dim + dim * 2 * mlp + mlp * dim) + 4 * ntok * 256 * dim + 2 * 2 * dim * 2 * dim
+        return 2 * ntok * 564 * dim + depth * layer + 2 * ntok * dim * 276
+
+    out = {}
+    for name, dim, heads, depth in (("468M", 1280, 16, 16), ("664M", 1536, 16, 16)):
+        mcfg = dict(_target_="swift.models.swinv2.SwinV2", window_size=[16, 16], shift_size=[8, 8], patch_size=[2, 2], depth=depth,
+                    dim=dim, heads=heads)
+        net = PassPrecond(mcfg, img_resolution=list(IMG), img_channels=NV, condition_channels=NV + NF, auxiliary_dim=1)
+        net.load_state_dict(swinv2_state(grid=(64, 128), in_channels=2 * NV + NF, out_channels=NV, patch_size=(2, 2), depth=depth,
+                                         dim=dim, heads=heads, seed=7))
+        net = net.to(dev).eval()
+        sampler = sampler_factory("scm", net, denoise_dtype=dtype, num_steps=1, sigma_min=0.02, sigma_max=200.0, auxiliary=0.6)
+        g = torch.Generator(device=dev).manual_seed(0)
+        cond = torch.randn(units, NV + NF, *IMG, generator=g, device=dev)
+        with torch.no_grad():
+            for _ in range(2):
+                y = sampler(cond)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                y = sampler(cond)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        fl = flops_per_eval(dim, depth) * units
+        out[name] = {"dim": dim, "heads": heads, "head_dim": dim // heads, "depth": depth, "units_per_step": units,
+                     "sample_steps_per_s": units / dt, "ms_per_step": 1e3 * dt, "tflops": fl / dt / 1e12,
+                     "frac_of_dense_mfma_peak": fl / dt / PEAK_BF16, "finite": bool(torch.isfinite(y).all()),
+                     "fused_qkv_attention": True}
+        del net, sampler, cond, y
+        torch.cuda.empty_cache()
+    out["what"] = ("the reference's commented larger variants at full size (depth 16), bf16 engine, sampler + network per unit-step "
+                   "(no dataset / state update); parity: tests/test_gpu_model.py::test_forward_other_swift_variants_vs_oracle and "
+                   "tests/test_gpu_kernels.py::test_fused_qkv_attention[80 / 96]")
+    return out
+
+
 def config3_leg(net, ds, dev, X0, forc, units, dtype, sizes=(1, 8)):
     """BASELINE configs[2]: the multi-step ODE sampler (dpm_solver_2s, num_steps 20 = 39 network evaluations per sample-step)."""
     import torch
@@ -758,8 +848,11 @@ def rollout_mode(a, eng, dev, rank, world, B, dtype, rccl, sync):
         dist.all_gather_into_tensor(gathered, ck_sum)
     else:
         gathered = ck_sum
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
+    per_rank = sdist.gather_rank_times({"own_work_s": t_local, "barrier_wait_ms": 1e3 * (dt - t_local), "units": float(len(mine))}, device=dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if sdist.collectives_active():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -776,6 +869,7 @@ def rollout_mode(a, eng, dev, rank, world, B, dtype, rccl, sync):
                    "batch": B, "sample_steps": total, "params": 225980976,
                    "parallelism": f"IC-major units sharded over {world} GPU(s); per-rank ensemble checksums all-gathered"},
         "rccl": rccl,
+        "per_rank": dict(per_rank, what="per rank: seconds until its own units were done, idle milliseconds at the closing barrier, units it rolled out"),
         "checksum": {"what": "sum over all units of the fixed-order fp64 checksum of the final physical state",
                      "all_units_sum": float(gathered.sum())},
         "e2e": {"tflops": FLOP_PER_EVAL * value / 1e12, "frac_of_dense_mfma_peak": FLOP_PER_EVAL * value / (peak * world)},

@@ -191,3 +191,23 @@ def shard_units(n_units: int, rank: int, world: int):
     base, rem = divmod(n_units, world)
     start = rank * base + min(rank, rem)
     return range(start, start + base + (1 if rank < rem else 0))
+
+
+def gather_rank_times(local: dict, device=None) -> dict:
+    """Per-rank timing record of a measured region, for the first multi-GPU run to be read at a glance: every rank hands in
+    the same keys (milliseconds or seconds as named by the caller), rank order is preserved, and every rank gets
+    ``{key: [value of rank 0, value of rank 1, ...]}`` back (one all-gather of a float64 vector; a process without a group
+    gets one-element lists).  bench.py / generate use it for ``compute_ms``, ``collective_ms``, ``barrier_wait_ms``."""
+    import torch
+    keys = sorted(local)
+    if not collectives_active():
+        return {k: [float(local[k])] for k in keys}
+    import torch.distributed as tdist
+    world = tdist.get_world_size()
+    dev = device if device is not None else (get_torch_device() if tdist.get_backend() == "nccl" else torch.device("cpu"))
+    mine = torch.tensor([float(local[k]) for k in keys], dtype=torch.float64, device=dev)
+    out = torch.zeros(world * len(keys), dtype=torch.float64, device=dev)
+    tdist.all_gather_into_tensor(out, mine)
+    out = out.view(world, len(keys)).cpu()
+    return {k: [float(out[r, j]) for r in range(world)] for j, k in enumerate(keys)}
+

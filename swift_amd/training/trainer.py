@@ -33,6 +33,13 @@ class GradAllReduce(torch.nn.Module):
         self.module = module
         self._flat = None
         self._pending, self._ranges = [], []
+        # what the first multi-GPU run needs to be read at a glance (per rank): how long the iteration's collectives would take
+        # on their own (serial_ms, calibrate_serial), how long the compute stream actually waited for them in sync()
+        # (exposed_ms), and how many bytes were announced early by the backward pass
+        self._timing = []           # per sync(): (event before the waits, event behind them) or (t0, t1) host seconds on the CPU
+        self._announced_elems = 0   # elements handed to reduce_params in the current iteration
+        self._announced_hist = []
+        self.serial_ms = None
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
@@ -92,11 +99,62 @@ class GradAllReduce(torch.nn.Module):
             handle, scale = self._reduce(flat[lo:hi], async_op=True)
             self._pending.append((handle, lo, hi, scale))
             self._ranges.append((lo, hi))
+            self._announced_elems += hi - lo
+
+    def _mark(self, flat):
+        if flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        import time
+        return time.perf_counter()
+
+    def calibrate_serial(self, reps: int = 3) -> float:
+        """Milliseconds one blocking all-reduce of the whole flat gradient buffer takes (best of ``reps``): the yardstick the
+        exposed wait of an iteration is compared with (on a scratch buffer of the same size: the gradients are not touched)."""
+        flat = self.flatten_grads()
+        if not self._active():
+            self.serial_ms = 0.0
+            return 0.0
+        import time
+        best = None
+        probe = torch.zeros_like(flat)  # (a scratch copy of the same size: gloo's SUM would scale the gradients themselves)
+        for _ in range(reps):
+            if flat.is_cuda:
+                torch.cuda.synchronize(flat.device)
+            t0 = time.perf_counter()
+            self._reduce(probe)
+            if flat.is_cuda:
+                torch.cuda.synchronize(flat.device)
+            dt = (time.perf_counter() - t0) * 1e3
+            best = dt if best is None else min(best, dt)
+        self.serial_ms = best
+        return best
+
+    def allreduce_stats(self) -> dict:
+        """Per-rank record for the training JSON: bytes, the share the backward pass announced early, the serial time of the
+        collective (None until calibrate_serial ran), the mean exposed wait of the recorded iterations and the overlap fraction
+        1 - exposed / serial."""
+        flat = self._flat
+        if flat is None:
+            return {}
+        waits = []
+        for a, b in self._timing:
+            waits.append(a.elapsed_time(b) if hasattr(a, "elapsed_time") else (b - a) * 1e3)
+        exposed = sum(waits) / len(waits) if waits else None
+        ann = self._announced_hist
+        out = {"world": self._world(), "bytes": int(flat.numel()) * 4, "iterations_recorded": len(waits),
+               "announced_early_frac": (sum(ann) / len(ann) / flat.numel()) if ann else 0.0,
+               "serial_ms": self.serial_ms, "exposed_wait_ms": exposed,
+               "overlap_frac": (max(0.0, min(1.0, 1.0 - exposed / self.serial_ms))
+                                if exposed is not None and self.serial_ms else None)}
+        return out
 
     def sync(self):
         flat = self.flatten_grads()
         world = self._world()
         if self._active():
+            t_a = self._mark(flat)
             pending, self._pending = getattr(self, "_pending", []), []
             done = sorted(getattr(self, "_ranges", []))
             self._ranges = []
@@ -111,6 +169,10 @@ class GradAllReduce(torch.nn.Module):
                 handle.wait()
                 if scale:
                     flat[lo:hi].div_(world)
+            if len(self._timing) < 64:
+                self._timing.append((t_a, self._mark(flat)))
+                self._announced_hist.append(self._announced_elems)
+            self._announced_elems = 0
         return flat
 
 
@@ -331,6 +393,16 @@ class Trainer:
                        "train/kimg": int(global_nimg / 1e3), "train/dt/dt": now - t_start, "train/dt/tick": now - tick_t0,
                        "train/dt/kimg": 1e3 * (now - tick_t0) / max(global_nimg - tick_start_nimg, 1),
                        "train/lr": self.optimizer.param_groups[0]["lr"]}
+            if tdist.is_initialized():
+                # per-rank gradient all-reduce record of this tick (what a first multi-GPU run is read by): serial time of the
+                # collective (calibrated once, between iterations), mean exposed wait per iteration, overlap fraction
+                if self.ddp.serial_ms is None and self.ddp._flat is not None:
+                    self.ddp.calibrate_serial()
+                mine = self.ddp.allreduce_stats()
+                self.ddp._timing, self.ddp._announced_hist = [], []
+                per_rank = [None] * world
+                tdist.all_gather_object(per_rank, mine)
+                metrics["train/allreduce"] = per_rank
             dist.log0(json.dumps(metrics))
             if stats is not None:
                 stats.write(json.dumps(metrics) + "\n")

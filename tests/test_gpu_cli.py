@@ -200,7 +200,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    e = dict(os.environ, PYTHONPATH=ROOT, SWIFTK_ALLOW_SHARED_GPU="1", SWIFTK_DIST_BACKEND="gloo")
+    e = dict(os.environ, PYTHONPATH=ROOT, SWIFTK_ALLOW_SHARED_GPU="1", SWIFTK_DIST_BACKEND="gloo", SWIFTK_BENCH_STRONG="2x3x2")
     e.pop("WORLD_SIZE", None)
     common = ["--steps", "3", "--warmup", "1", "--batch", "4", "--no-extras"]
     out = {}
@@ -218,6 +218,15 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert d2["checksum"]["last_step_first_units"] == d1["checksum"]["last_step_first_units"]
     assert d2["checksum"]["last_step_all_units_sum"] != d1["checksum"]["last_step_all_units_sum"]
     assert d2["value"] == pytest.approx(2 * 4 * 3 / (d2["ms_per_step"] * 3 / 1e3), rel=1e-3)
+    # the per-rank split of the timed region and, for N > 1, the strong-scaling job (BASELINE configs[3]; shrunk here) in the same line
+    for d, n in ((d1, 1), (d2, 2)):
+        pr = d["per_rank"]
+        assert all(len(pr[k]) == n for k in ("compute_ms", "collective_ms", "barrier_wait_ms", "timed_region_s"))
+        assert all(v > 0 for v in pr["compute_ms"]) and all(v >= 0 for v in pr["collective_ms"]) and min(pr["barrier_wait_ms"]) < 50.0
+        assert max(c + x for c, x in zip(pr["compute_ms"], pr["collective_ms"])) <= 1e3 * max(pr["timed_region_s"]) * 1.05
+    st = d2["rollout_2x3x2"]
+    assert "rollout_2x3x2" not in d1 and st["scaling"] == "strong" and st["value"] > 0 and st["config"]["units"] == 6
+    assert st["per_rank"]["units"] == [3.0, 3.0] and len(st["per_rank"]["barrier_wait_ms"]) == 2
 
 
 @pytest.mark.timeout(900)

@@ -187,6 +187,16 @@ DDP_WORKER = textwrap.dedent("""
         except RuntimeError:
             pass
     flat = ddp.sync()                              # ... the rest reduced here
+    keep = flat.clone()
+    if dist.collectives_active():                  # the per-rank record a first multi-GPU run is read by
+        st = ddp.allreduce_stats()
+        assert st["world"] == world and st["bytes"] == flat.numel() * 4 and st["iterations_recorded"] == 1
+        assert 0.0 < st["announced_early_frac"] < 1.0 and st["serial_ms"] is None and st["exposed_wait_ms"] >= 0.0
+        assert ddp.calibrate_serial() >= 0.0 and torch.equal(flat, keep)   # calibration leaves the gradients alone
+        st = ddp.allreduce_stats()
+        assert st["serial_ms"] is not None and (st["overlap_frac"] is None or 0.0 <= st["overlap_frac"] <= 1.0)
+        per = dist.gather_rank_times({"compute_ms": 10.0 + rank, "collective_ms": 0.5, "barrier_wait_ms": float(world - 1 - rank)})
+        assert per["compute_ms"] == [10.0 + r for r in range(world)] and per["barrier_wait_ms"][-1] == 0.0 and len(per["collective_ms"]) == world
     if rank == 0:
         torch.save(flat.clone(), sys.argv[1])
     dist.barrier()

@@ -16,8 +16,21 @@ ap.add_argument("--batch", type=int, default=8); ap.add_argument("--steps", type
 ap.add_argument("--iters", type=int, default=6); ap.add_argument("--depth", type=int, default=12)
 ap.add_argument("--loss", default="crps", choices=["crps", "scm", "trigflow"])
 ap.add_argument("--opt", default="adamw", choices=["adamw", "muon"])
+ap.add_argument("--dist", type=int, default=1, help="1: run the gradient collectives for real (a one-rank RCCL group unless launched "
+                "under torchrun), so that the record carries the all-reduce's serial time, exposed wait and overlap fraction")
 a = ap.parse_args()
-dev = torch.device("cuda", 0)
+dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+torch.cuda.set_device(dev)
+if a.dist:
+    import socket
+    import torch.distributed as tdist
+    if "RANK" in os.environ:  # torchrun: one rank per GPU
+        tdist.init_process_group("nccl", device_id=dev)
+    else:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 names = ["2m_temperature", "10m_u_component_of_wind", "10m_v_component_of_wind", "mean_sea_level_pressure"]
 for v in ["geopotential", "u_component_of_wind", "v_component_of_wind", "temperature", "specific_humidity"]:
     names += [f"{v}_{l}" for l in [50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925, 1000]]
@@ -71,6 +84,7 @@ if os.environ.get("SWIFTK_SYNC_DEBUG"):  # list every call that makes the host w
     warnings.showwarning = _show
     warnings.simplefilter("always")
     torch.cuda.set_sync_debug_mode(1)
+tr.ddp._timing, tr.ddp._announced_hist = [], []  # (the warm-up iterations' waits are not the steady state's)
 t0 = time.perf_counter()
 host_ms = []
 for k in range(a.iters):
@@ -87,6 +101,15 @@ dt = (time.perf_counter() - t0) / a.iters
 print("host issue time per iteration (ms):", " ".join(f"{h:.0f}" for h in host_ms), file=sys.stderr)
 print("loss per iteration (warm-up included):", " ".join(f"{float(l):.4f}" for l in losses), file=sys.stderr)
 PEAK = 2.5e15  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+AR = {}
+if a.dist:
+    tr.ddp.calibrate_serial()
+    AR = tr.ddp.allreduce_stats()
+    AR["note"] = ("gradient all-reduce of this rank: serial_ms = one blocking all-reduce of the whole flat buffer, exposed_wait_ms = what the "
+                  "compute stream waited for the collectives in sync() per iteration, overlap_frac = 1 - exposed / serial; a one-rank group "
+                  "measures the call path, not xGMI")
+_dumps = json.dumps
+json.dumps = lambda rec, *aa, **kk: _dumps(dict(rec, allreduce=AR) if isinstance(rec, dict) and "metric" in rec else rec, *aa, **kk)
 fused = bool(getattr(tr, "_fused", None))
 if a.loss == "trigflow":  # TrigFlowLoss (loss.py:117-160): one forward, one backward (2x) per sample
     fl = 3 * a.batch * 2.7535e12 * a.depth / 12
