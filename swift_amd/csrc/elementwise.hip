@@ -964,6 +964,10 @@ __global__ __launch_bounds__(256) void rollout_update_kernel(float* __restrict__
         p.x = (xv.x * s + m) + yv.x * t; p.y = (xv.y * s + m) + yv.y * t;
         p.z = (xv.z * s + m) + yv.z * t; p.w = (xv.w * s + m) + yv.w * t;
         q.x = (p.x - m) / s; q.y = (p.y - m) / s; q.z = (p.z - m) / s; q.w = (p.w - m) / s;
+        // s == 0 marks a channel whose STANDARDISED value the dataset forces to zero (zero_field, data/era5.py:135-149:
+        // sea_surface_temperature): the old state contributes nothing (x * 0 + m with m = 0), the residual still lands in the
+        // physical output when its scale t is non-zero (--interval 24), and the next standardised state is 0
+        if (s == 0.f) q = make_float4(0.f, 0.f, 0.f, 0.f);
         if (phys) reinterpret_cast<float4*>(phys)[i] = p;
         reinterpret_cast<float4*>(xstd)[i] = q;
     }

@@ -207,6 +207,10 @@ class Trainer:
         self.net = net.to(self.device)
         if amp_type not in ("bfloat16", None):
             raise NotImplementedError("the gfx950 training kernels take bf16 GEMM operands (amp_type: bfloat16)")
+        # the reference's GradScaler is enabled for float16 only (trainer.py:72-75); with bf16 operands it is a disabled instance
+        # whose state_dict() -- {} -- is what the checkpoint's "scaler" entry holds.  Kept as a real object so that saving and
+        # resuming go through the same calls (a float16 run's scale found in a reference checkpoint is dropped, with a note).
+        self.scaler = torch.GradScaler(self.device.type, enabled=False)
         self.ddp = GradAllReduce(self.net)
         self.ema = copy.deepcopy(net).eval().requires_grad_(False)
         self.base_lr = [g["lr"] for g in optimizer.param_groups]
@@ -219,6 +223,9 @@ class Trainer:
                 optimizer.load_state_dict(state["optimizer"])
             except ValueError:
                 dist.log0("Could not load optimizer state, starting fresh.")
+            if state.get("scaler"):  # trainer.py:109 -- a float16 run's loss scale has no meaning for bf16 operands
+                dist.log0(f"checkpoint carries an enabled GradScaler state ({sorted(state['scaler'])}); bf16 training does not scale the loss")
+            self.scaler.load_state_dict(state.get("scaler", {}))
         else:
             self.resume_kimg = 0
         self.loss_fn, self.optimizer = loss_fn, optimizer
@@ -420,7 +427,7 @@ class Trainer:
     def _save_checkpoint(self, cur_nimg):
         """{"ema","net","optimizer","scaler"} -> checkpoints/checkpoint-{kimg:06d}.pt  (trainer.py:522-535)."""
         state = {"ema": self.ema.state_dict(), "net": self.net.state_dict(), "optimizer": self.optimizer.state_dict(),
-                 "scaler": {}}
+                 "scaler": self.scaler.state_dict()}
         path = os.path.join(os.getcwd(), "checkpoints")
         os.makedirs(path, exist_ok=True)
         torch.save(state, os.path.join(path, f"checkpoint-{cur_nimg // 1000:06d}.pt"))

@@ -443,6 +443,15 @@ def test_rollout_update_and_axpby(dev):
     assert rel_l2(xd.cpu(), (p - v(mx)) / v(sx)) < 1e-6
     o = ops.axpby(0.25, x.to(dev), -1.5, y.to(dev))
     assert rel_l2(o.cpu(), 0.25 * x - 1.5 * y) < 1e-7
+    # a channel the dataset forces to zero in standardised form (zero_field: sea_surface_temperature) travels as std_x = 0 --
+    # with --interval 24 its residual still reaches the physical output (data/era5.py:135-170, generate.py:120-131)
+    mx2, sx2 = mx.clone(), sx.clone()
+    mx2[3], sx2[3] = 0.0, 0.0
+    xd, phys = x.to(dev).clone(), torch.empty(B, C, H, W, device=dev)
+    ops.rollout_update(xd, y.to(dev), mx2.to(dev), sx2.to(dev), st.to(dev), phys=phys)
+    assert torch.equal(phys[:, 3].cpu(), y[:, 3] * st[3]) and float(xd[:, 3].abs().sum()) == 0.0
+    keep = [c for c in range(C) if c != 3]
+    assert rel_l2(phys[:, keep].cpu(), p[:, keep]) < 1e-7 and torch.isfinite(xd).all()
 
 
 def test_rejects_cpu_tensors_and_bad_shapes(dev):

@@ -77,7 +77,24 @@ def test_dataset_interface_matches_oracle_stats():
     ds2 = SyntheticERA5Dataset(["2m_temperature", "sea_surface_temperature"], [], img_resolution=(8, 16), random_stats=True)
     mx, sx, stt = ds2.rollout_stats(6, "cpu")
     assert (float(mx[1]), float(sx[1]), float(stt[1])) == (0.0, 1.0, 0.0)
-    assert float(ds2.rollout_stats(24, "cpu")[1][1]) != 1.0
+    mx24, sx24, st24 = ds2.rollout_stats(24, "cpu")
+    assert (float(mx24[1]), float(sx24[1])) == (0.0, 0.0) and float(st24[1]) == float(np.asarray(ds2.t_stds[24]).reshape(-1)[1]) != 0.0
+    # the flat statistics against the reference's own sequence (generate.py:120-131: unstandardize_x and standardize_x with the
+    # DEFAULT delta, unstandardize_t with delta = interval), with the update formula of swiftk_rollout_update restated in torch
+    g = torch.Generator().manual_seed(0)
+    for interval in (6, 24):
+        X, Y = torch.randn(2, 2, 8, 16, generator=g), torch.randn(2, 2, 8, 16, generator=g)
+        phys_ref = ds2.unstandardize_x(X.clone()) + ds2.unstandardize_t(Y.clone(), delta=interval)
+        next_ref = ds2.standardize_x(phys_ref.clone())
+        mx, sx, stt = (v.view(1, -1, 1, 1) for v in ds2.rollout_stats(interval, "cpu"))
+        if interval == 24:
+            assert float(phys_ref[:, 1].abs().sum()) > 0 and float(next_ref[:, 1].abs().sum()) == 0.0  # SST: residual kept, state zeroed
+        X0 = X.clone()
+        X0[:, 1] = 0  # SST's standardised value is what the dataset / the previous step hands on: zero
+        phys = (X0 * sx + mx) + Y * stt
+        nxt = torch.where(sx == 0, torch.zeros_like(phys), (phys - mx) / torch.where(sx == 0, torch.ones_like(sx), sx))
+        assert torch.allclose(phys[:, 0], phys_ref[:, 0], atol=1e-5) and torch.allclose(nxt[:, 0], next_ref[:, 0], atol=1e-5)
+        assert torch.allclose(phys[:, 1], phys_ref[:, 1], atol=1e-6) and torch.equal(nxt[:, 1], next_ref[:, 1])
 
 
 def test_shard_units_partition():
