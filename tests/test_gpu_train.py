@@ -1137,3 +1137,25 @@ def test_repeat_screen_of_hand_synchronised_training_kernels(dev):
     assert p.returncode == 0 and "REPEAT SCREEN: CLEAN" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_bwd_repeat.py")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "mismatching outputs: 0" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+@pytest.mark.timeout(600)
+def test_crps_finetune_memory_rule_at_the_664m_variant(dev):
+    """BASELINE configs[4]'s iteration at the reference's largest commented variant (dim 1536, 16 heads, depth 16;
+    era5-swinv2-1.4-scm.yaml:29-36), local batch 8: all eight rollout steps resident would need ~420 GiB, so the planner
+    (loss.py::_plan_once) must keep only what fits and recompute the rest -- like the reference's checkpoint_sequential --
+    instead of running out of memory.  Run as the tool the bench line uses, in a fresh process (its own allocator)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "train_bench.py"), "--loss", "crps", "--dim", "1536", "--heads", "16",
+                        "--depth", "16", "--iters", "2"], capture_output=True, text=True, timeout=560)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{")))
+    print(f"CRPS finetune at dim 1536 / depth 16: {rec['value']:.3f} s per iteration, {rec['kept_rollout_steps']} of 8 rollout steps resident, "
+          f"peak {rec['peak_mem_gib']:.0f} GiB, {rec['roofline']['frac']:.3f} of the dense bf16 peak")
+    assert 0 < rec["kept_rollout_steps"] < 8          # some steps resident, the rest recomputed
+    assert rec["peak_mem_gib"] < 0.9 * 288            # well inside the device
+    assert rec["roofline"]["frac"] > 0.25 and rec["allreduce"]["iterations_recorded"] == 2

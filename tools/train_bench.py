@@ -16,6 +16,7 @@ ap.add_argument("--batch", type=int, default=8); ap.add_argument("--steps", type
 ap.add_argument("--iters", type=int, default=6); ap.add_argument("--depth", type=int, default=12)
 ap.add_argument("--loss", default="crps", choices=["crps", "scm", "trigflow"])
 ap.add_argument("--opt", default="adamw", choices=["adamw", "muon"])
+ap.add_argument("--dim", type=int, default=1056); ap.add_argument("--heads", type=int, default=12)  # 1280 / 16, 1536 / 16: the larger variants
 ap.add_argument("--dist", type=int, default=1, help="1: run the gradient collectives for real (a one-rank RCCL group unless launched "
                 "under torchrun), so that the record carries the all-reduce's serial time, exposed wait and overlap fraction")
 a = ap.parse_args()
@@ -31,15 +32,17 @@ if a.dist:
             so.bind(("127.0.0.1", 0))
             port = so.getsockname()[1]
         tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    import atexit
+    atexit.register(lambda: tdist.is_initialized() and tdist.destroy_process_group())
 names = ["2m_temperature", "10m_u_component_of_wind", "10m_v_component_of_wind", "mean_sea_level_pressure"]
 for v in ["geopotential", "u_component_of_wind", "v_component_of_wind", "temperature", "specific_humidity"]:
     names += [f"{v}_{l}" for l in [50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925, 1000]]
 ds = SyntheticERA5Dataset(names, ["f0", "f1", "f2"], img_resolution=(128, 256), length=64, seed=1)
 mcfg = dict(_target_="swift.models.swinv2.SwinV2", window_size=[16, 16], shift_size=[8, 8], patch_size=[2, 2], depth=a.depth,
-            dim=1056, heads=12)
+            dim=a.dim, heads=a.heads)
 net = PassPrecond(mcfg, img_resolution=[128, 256], img_channels=69, condition_channels=72, auxiliary_dim=1)
-net.load_state_dict(swinv2_state(grid=(64, 128), in_channels=141, out_channels=69, patch_size=(2, 2), depth=a.depth, dim=1056,
-                                 heads=12, seed=1))
+net.load_state_dict(swinv2_state(grid=(64, 128), in_channels=141, out_channels=69, patch_size=(2, 2), depth=a.depth, dim=a.dim,
+                                 heads=a.heads, seed=1))
 net = net.to(dev).train().requires_grad_(True)
 if a.opt == "muon":  # the sCM experiment's optimiser (train.py:286-309 parameter split)
     from swift_amd.training.optimizers.muon import MuonWithAuxAdam
@@ -101,6 +104,11 @@ dt = (time.perf_counter() - t0) / a.iters
 print("host issue time per iteration (ms):", " ".join(f"{h:.0f}" for h in host_ms), file=sys.stderr)
 print("loss per iteration (warm-up included):", " ".join(f"{float(l):.4f}" for l in losses), file=sys.stderr)
 PEAK = 2.5e15  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+def _fwd_flop(dim, depth):  # one network evaluation of one sample (SURVEY.md section 8d's count, any width)
+    ntok, mlp = 64 * 128, int(8 / 3 * dim)
+    layer = 2 * ntok * (dim * 3 * dim + dim * dim + dim * 2 * mlp + mlp * dim) + 4 * ntok * 256 * dim + 2 * 2 * dim * 2 * dim
+    return 2 * ntok * 564 * dim + depth * layer + 2 * ntok * dim * 276
+FWD = _fwd_flop(a.dim, a.depth) if a.dim != 1056 else 2.7535e12 * a.depth / 12
 AR = {}
 if a.dist:
     tr.ddp.calibrate_serial()
@@ -112,7 +120,7 @@ _dumps = json.dumps
 json.dumps = lambda rec, *aa, **kk: _dumps(dict(rec, allreduce=AR) if isinstance(rec, dict) and "metric" in rec else rec, *aa, **kk)
 fused = bool(getattr(tr, "_fused", None))
 if a.loss == "trigflow":  # TrigFlowLoss (loss.py:117-160): one forward, one backward (2x) per sample
-    fl = 3 * a.batch * 2.7535e12 * a.depth / 12
+    fl = 3 * a.batch * FWD
     print(json.dumps({"metric": "TrigFlow training iteration (Swift-B, local batch %d, optimizer %s)" % (a.batch, a.opt), "value": dt, "unit": "s/iteration",
                       "samples_per_s": a.batch / dt, "flop_per_iteration": fl, "what": "3 forward-equivalents per sample (forward 1, backward 2)",
                       "roofline": {"bound": "mfma", "achieved": fl / dt / 1e12, "peak": PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / dt / PEAK, "traffic": None},
@@ -125,7 +133,7 @@ if a.loss == "scm":
     # the one-pass form does not execute (the tangent pass's primal rows are the saved activations)
     one_pass = bool(getattr(loss_fn, "last_one_pass", False))
     fwd_eq = 4 if one_pass else 5
-    fl = fwd_eq * a.batch * 2.7535e12 * a.depth / 12
+    fl = fwd_eq * a.batch * FWD
     print(json.dumps({"metric": "sCM pre-training iteration (Swift-B, local batch %d, optimizer %s)" % (a.batch, a.opt), "value": dt, "unit": "s/iteration",
                       "samples_per_s": a.batch / dt, "flop_per_iteration": fl,
                       "what": f"~{fwd_eq} forward-equivalents executed per sample (tangent pass 2, backward 2" + ("" if one_pass else ", forward 1") +
@@ -139,8 +147,8 @@ if a.loss == "scm":
 evals = 2 * a.steps
 n_keep = int(getattr(loss_fn, "last_n_keep", 0))  # rollout steps whose activations stayed in HBM: no recomputed forward for those
 fwd_eq = 4 * evals - n_keep  # EXECUTED work; the reference's schedule (checkpoint_sequential) is 4 * evals
-fl = fwd_eq * a.batch * 2.7535e12 * a.depth / 12
-print(json.dumps({"metric": "multistep-CRPS finetune iteration (Swift-B, steps %d, ensemble 2, local batch %d; BASELINE configs[4] per GPU)" % (a.steps, a.batch),
+fl = fwd_eq * a.batch * FWD
+print(json.dumps({"metric": "multistep-CRPS finetune iteration (%s, steps %d, ensemble 2, local batch %d; BASELINE configs[4] per GPU)" % ("Swift-B" if a.dim == 1056 else "dim %d / %d heads / depth %d" % (a.dim, a.heads, a.depth), a.steps, a.batch),
                   "value": dt, "unit": "s/iteration", "samples_per_s": a.batch / dt, "flop_per_iteration": fl,
                   "what": f"{evals} rollout forwards + {evals - n_keep} recomputed forwards + {evals} backwards (2x) = {fwd_eq} forward-equivalents executed per sample "
                           f"({n_keep} of {evals} rollout steps keep their activations; the reference's schedule recomputes all: {4 * evals})",
