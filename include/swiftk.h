@@ -274,7 +274,10 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * inside the persistent attention backward (1; 0 = second pass), key 16 = swiftk_modnorm_bwd as one kernel (1; 0 = row pass +
  * column pass; n > 1 = 64 n rows per block), key 17 = swiftk_modnorm_jvp_pair walks 32 n rows per block (1; 0 = a row per wave),
  * key 18 = split engine: w1's epilogue writes w2's (hi, lo) operand blocks itself (1; 0 = fp32 h + swiftk_split3),
- * key 19 = bf16 engine: the patch embedding's epilogue writes the pair form itself (1; 0 = fp32 stream + swiftk_split_pair). */
+ * key 19 = bf16 engine: the patch embedding's epilogue writes the pair form itself (1; 0 = fp32 stream + swiftk_split_pair),
+ * key 20 = k-loop of the persistent GEMM with bf16 operands: 1 = ping-pong phases (the SIMD partners alternate between
+ * fragment reads + DMA issue and back-to-back MFMAs, counted waits; needs >= 3 k-tiles per work item, else falls back), 0 = one
+ * barrier per k-tile (the round-1..4 loop).  Bit-equal results either way. */
 int swiftk_set_tuning(int key, int value);
 /* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
  * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default
@@ -468,13 +471,15 @@ int swiftk_cast_pad(const float* src, int64_t lds, void* dst, int64_t ldd, int64
                     void* stream);
 
 /*
- * to_qkv + cosine norm + shifted-window attention of one layer in one kernel (bf16, head_dim 88): the q / k / v slab of a
- * (sample, window, head) is produced, normalised and consumed on the CU; only the attention output reaches memory.
+ * to_qkv + cosine norm + shifted-window attention of one layer in one kernel (bf16; head_dim 80 / 88 / 96 = the 468 M variant,
+ * Swift-B, the 664 M variant of configs/experiment/era5-swinv2-1.4-scm.yaml:21-36; 16 x 16 windows; K >= 128): the q / k / v
+ * slab of a (sample, window, head) is produced, normalised and consumed on the CU; only the attention output reaches memory.
  * Replaces src/swift/models/swinv2.py:119-136 (to_qkv, split, normalise, scale, attention) and :185-208 (roll,
  * window_partition, window_reverse) -- i.e. swiftk_gemm_qkv_tiled + swiftk_window_attention.
  *   x    [B*gh*gw, ldx] bf16 token-major (K valid columns; K = 16.5 k-tiles style padding as in swiftk_gemm)
- *   w    [3*heads*88, ldw] bf16 (to_qkv.weight as stored: per-head [q|k|v] rows)
- *   out  [B*gh*gw, ldo] bf16, head h in columns [88 h, 88 h + 88), token order (un-rolled)
+ *   w    [3*heads*head_dim, ldw] bf16 (to_qkv.weight as stored: per-head [q|k|v] rows)
+ *   out  [B*gh*gw, ldo] bf16, head h in columns [head_dim h, head_dim (h + 1)), token order (un-rolled)
+ * SWIFTK_ESHAPE for any other head_dim, a grid that is not a multiple of the window, a shift outside the grid.
  */
 int swiftk_qkv_attention_fused(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* scale, void* out,
                                int64_t ldo, int64_t K, int B, int gh, int gw, int heads, int head_dim, int shift_h,
