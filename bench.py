@@ -450,8 +450,6 @@ def main():
                        "noise": "swiftk_unit_noise: Philox4x32-10 + Box-Muller keyed by (member, IC, lead step), one launch per step",
                        "forcings": f"{n_slabs} pre-staged slabs [B, 3, 128, 256], one per lead step",
                        "parallelism": f"units sharded over {world} GPU(s), no data-path collective on the state"},
-            f"rollout_{strong_spec}": ({k: strong[k] for k in ("value", "unit", "scaling", "timed_region_s", "per_rank", "config", "checksum") if k in strong}
-                                 if strong and "error" not in strong else strong),
             "rccl": rccl,
             "per_rank": dict(per_rank, what="per rank, over the timed region: compute_ms = step start to the output collective (HIP "
                              "events on the launch stream), collective_ms = the all-gather of per-unit checksums, barrier_wait_ms = idle "
@@ -471,6 +469,9 @@ def main():
                          "launches": int(n_launch.value), "avg_launch_ms": avg_s * 1e3,
                          "flop_per_launch": flop_launch},
         }
+        if strong is not None:  # (N > 1 only)
+            line[f"rollout_{strong_spec}"] = ({k: strong[k] for k in ("value", "unit", "scaling", "timed_region_s", "per_rank", "config", "checksum")
+                                              if k in strong} if "error" not in strong else strong)
         if att_n.value > 0:
             # The north star's named kernel.  Swift-B / bf16 runs to_qkv + cosine norm + shifted-window attention as ONE kernel
             # (swiftk_qkv_attention_fused: q, k, v never reach HBM), so it is judged against the MFMA roofline over the fused

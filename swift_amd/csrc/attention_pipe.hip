@@ -28,6 +28,7 @@
 #include "common.h"
 
 int g_attn_dbg = 0;
+int g_attn_pp = 0;  // tuning key 21 (qkv_attn.hip)
 
 namespace {
 

@@ -1704,6 +1704,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 18: g_x3_ffsplit = value; return 0;
         case 19: g_fwd_pepair = value; return 0;
         case 20: g_pp = value; return 0;
+        case 21: g_attn_pp = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -1730,6 +1731,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 18: return g_x3_ffsplit;
         case 19: return g_fwd_pepair;
         case 20: return g_pp;
+        case 21: return g_attn_pp;
     }
     return SWIFTK_EINVAL;
 }

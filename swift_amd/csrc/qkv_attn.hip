@@ -114,7 +114,7 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int HD>
+template <int HD, bool PP>
 __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
     using G = Geo<HD>;
     constexpr int NI0 = G::NI0, NI1 = G::NI1, WT0 = G::WT0, NV0 = G::NV0, NV1 = G::NV1, BNP = G::BNP, STAGE = G::STAGE, ROW = G::ROW;
@@ -188,6 +188,25 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
         const int row = r < HD ? r : (r < WT0 ? 2 * HD + (r - HD) : (r < WT0 + HD ? HD + (r - WT0) : min(r, 3 * HD - 1)));
         vb[i] = (uint32_t)(row * (int)a.ldw_b) + 16u * (pchunk ^ ((4 * (wv & 1) + (prow >> 1)) & 7));
     }
+    // Ping-pong k-loop (PP; the schedule of gemm.hip's persistent kernel): the weight image's rows form two regions -- LO = the
+    // first four column blocks of both column halves (rows [0, 64) and [WT0, WT0 + 64): read in a k-half's first phase), HI = the
+    // rest (second phase) -- and the weight pieces are dealt to the waves per region so that a wave can issue its HI pieces last
+    // and wait for them one phase later than for everything else.  LO piece n = wv + 8 i < 16, HI piece n = wv + 8 i < NHI; the
+    // piece's first image row is lo_row(i) / hi_row(i) (all region sizes are even piece counts: the swizzle parity stays wv & 1).
+    constexpr int JA = 4, NH0 = (WT0 - 64) / 8, NHI = (BNP - 128) / 8;
+    auto lo_row = [&](int i) { const int n = wv + 8 * i, hh_ = n >= 8; return hh_ * WT0 + (n - 8 * hh_) * 8; };
+    auto hi_row = [&](int i) { const int n = wv + 8 * i, hh_ = n >= NH0; return hh_ ? WT0 + 64 + (n - NH0) * 8 : 64 + n * 8; };
+    auto wrow = [&](int r) { return r < HD ? r : (r < WT0 ? 2 * HD + (r - HD) : (r < WT0 + HD ? HD + (r - WT0) : min(r, 3 * HD - 1))); };
+    uint32_t vlo[2], vhi[3];
+    if constexpr (PP) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            vlo[i] = (uint32_t)(wrow(lo_row(i) + prow) * (int)a.ldw_b) + 16u * (pchunk ^ ((4 * (wv & 1) + (prow >> 1)) & 7));
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            vhi[i] = (uint32_t)(wrow(min(hi_row(i), BNP - 8) + prow) * (int)a.ldw_b) + 16u * (pchunk ^ ((4 * (wv & 1) + (prow >> 1)) & 7));
+    }
+    const int c_hi = (wv < NHI - 16) ? 3 : ((wv + 8 < NHI) ? 2 : 1);  // HI pieces of this wave
     const char* xbase = nullptr;
     const char* wbase = nullptr;
     auto set_item = [&](int b, int w, int h) {
@@ -207,6 +226,29 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
         }
     };
 
+    auto pp_a = [&](uint32_t stage, uint32_t koff, int p_) { dma_piece_fast(stage + (wv * 4 + p_) * 1024, xbase, va[p_] + koff); };
+    auto pp_lo = [&](uint32_t stage, uint32_t koff, int i) { dma_piece_fast(stage + A_BYTES + lo_row(i) * ROWB, wbase, vlo[i] + koff); };
+    auto pp_hi = [&](uint32_t stage, uint32_t koff, int i) {
+        if (wv + 8 * i < NHI) dma_piece_fast(stage + A_BYTES + hi_row(i) * ROWB, wbase, vhi[i] + koff);
+    };
+    // every piece of one k-tile (an item's first k-tile: requested ahead of the item, waited for in front of its k-loop);
+    // `skip_a0`: head_dim 96 defers wave 0's token pieces behind the attention core (Geo::DEFER)
+    auto issue_all = [&](uint32_t stage, uint32_t koff, bool skip_a) {
+        if constexpr (PP) {
+#pragma unroll
+            for (int p_ = 0; p_ < 4; ++p_)
+                if (!skip_a) pp_a(stage, koff, p_);
+            pp_lo(stage, koff, 0);
+            pp_lo(stage, koff, 1);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pp_hi(stage, koff, i);
+        } else {
+#pragma unroll
+            for (int p_ = 0; p_ < 9; ++p_)
+                if (!(skip_a && p_ < 4)) issue_piece(stage, koff, p_);
+        }
+    };
+
     // ---- fragment read offsets of the k-loop
     const int wm = wv & 3, wn = wv >> 2;
     const int r16 = lane & 15, g4 = lane >> 4;
@@ -220,8 +262,7 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
     int b, w, h;
     decode(first, b, w, h);
     set_item(b, w, h);
-#pragma unroll
-    for (int p = 0; p < 9; ++p) issue_piece(lds0 + OFF_S0, 0u, p);
+    issue_all(lds0 + OFF_S0, 0u, false);
     bool have_prev = false;
 
     for (int item = first; item < last; item += istep) {
@@ -239,6 +280,100 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
             for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // the first k-tile was requested before the previous item's output stores (VMEM retires in issue order)
         if (have_prev) wait_vm<NOST>(); else wait_vm<0>();
+        if constexpr (PP) {
+            // Ping-pong form (see gemm.hip, SWIFTK_X_PP): phases (k-half, column part) = (0, lo) (0, hi) (1, lo) (1, hi); in each a
+            // wave first requests the phase's fragments and issues its share of the next stage's pieces (MEM), then -- behind a
+            // barrier -- runs the phase's MFMAs back to back (COMPUTE), then a second barrier.  Waves 4-7 (column half 1), the SIMD
+            // partners of waves 0-3, run one barrier behind.  Issue order per k-tile: A0 A1 A2 [wait HI of this k-tile] | A3 LO LO |
+            // HI HI | HI [wait A, LO of the next k-tile, the HI pieces stay in flight].
+            constexpr int JB = NI - JA;
+            const int grp = wv >> 2;
+            auto bar = [] {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            uint4 xf[MI], wf[JA > JB ? JA : JB];
+            __builtin_amdgcn_s_barrier();  // the first stage landed for every wave
+            if (grp) __builtin_amdgcn_s_barrier();
+            for (int kt = 0; kt < a.nk; ++kt) {
+                const char* s = smem + ((kt & 1) ? OFF_S1 : OFF_S0);
+                const uint32_t fill = lds0 + ((kt & 1) ? OFF_S0 : OFF_S1);
+                const bool more = kt + 1 < a.nk;
+                const uint32_t koff = (uint32_t)(kt + 1) * ROWB;
+                const bool half = a.khalf && !more;
+                auto rdx = [&](const int ch) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch);
+                };
+                auto rdw = [&](const int ch, const int j0, const int nj) {
+#pragma unroll
+                    for (int jj = 0; jj < (JA > JB ? JA : JB); ++jj)
+                        if (jj < nj) wf[jj] = *reinterpret_cast<const uint4*>(s + woff + (j0 + jj) * 16 * ROWB + ch);
+                };
+                auto comp = [&](const int j0, const int nj) {
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int jj = 0; jj < (JA > JB ? JA : JB); ++jj) {
+                        if (jj < nj) {
+#pragma unroll
+                            for (int i = 0; i < MI; ++i)
+                                acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[jj]),
+                                                                                         __builtin_bit_cast(bf16x8, xf[i]), acc[i][j0 + jj], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                };
+                // ---- (0, lo)
+                rdx(ch0);
+                rdw(ch0, 0, JA);
+                if (more) {
+                    pp_a(fill, koff, 0);
+                    pp_a(fill, koff, 1);
+                    pp_a(fill, koff, 2);
+                    if (kt > 0) wait_vm<3>();   // this k-tile's HI pieces (the previous k-tile's last requests)
+                } else if (kt > 0) {
+                    wait_vm<0>();
+                }
+                bar();
+                comp(0, JA);
+                bar();
+                // ---- (0, hi)
+                rdw(ch0, JA, JB);
+                if (more) {
+                    pp_a(fill, koff, 3);
+                    pp_lo(fill, koff, 0);
+                    pp_lo(fill, koff, 1);
+                }
+                if (half) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage's last fragment reads
+                bar();
+                comp(JA, JB);
+                bar();
+                if (!half) {
+                    // ---- (1, lo)
+                    rdx(ch1);
+                    rdw(ch1, 0, JA);
+                    if (more) {
+                        pp_hi(fill, koff, 0);
+                        pp_hi(fill, koff, 1);
+                    }
+                    bar();
+                    comp(0, JA);
+                    bar();
+                    // ---- (1, hi)
+                    rdw(ch1, JA, JB);
+                    if (more) {
+                        pp_hi(fill, koff, 2);
+                        if (c_hi == 3) wait_vm<3>(); else if (c_hi == 2) wait_vm<2>(); else wait_vm<1>();
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    bar();
+                    comp(JA, JB);
+                    bar();
+                }
+            }
+            if (!grp) __builtin_amdgcn_s_barrier();
+        } else
         for (int kt = 0; kt < a.nk; ++kt) {
             __builtin_amdgcn_s_barrier();  // stage of kt landed for every wave; every wave is done with the other stage
             const int so = (kt & 1) ? OFF_S1 : OFF_S0;
@@ -349,9 +484,7 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
         __builtin_amdgcn_s_barrier();
         if (has_next) {
             set_item(nb, nwn, nh);
-#pragma unroll
-            for (int p = 0; p < 9; ++p)
-                if (!(G::DEFER && p < 4 && wv == 0)) issue_piece(lds0 + OFF_S0, 0u, p);  // (head_dim 96: see Geo::OFF_S0)
+            issue_all(lds0 + OFF_S0, 0u, G::DEFER && wv == 0);  // (head_dim 96: see Geo::OFF_S0)
         }
         f32x16 o[DB];
 #pragma unroll
@@ -549,9 +682,15 @@ extern "C" int swiftk_qkv_attention_fused(const void* x, int64_t ldx, const void
     int grid = 256;
     if (nitems < grid) grid = nitems >= 8 ? (nitems & ~7) : nitems;
     const bool timed = swiftk_prof_begin(SWIFTK_PROF_ATTENTION, 0, st);
-    if (head_dim == 80) hipLaunchKernelGGL(qkv_attn_kernel<80>, dim3(grid), dim3(NT), 0, st, a, nitems);
-    else if (head_dim == 96) hipLaunchKernelGGL(qkv_attn_kernel<96>, dim3(grid), dim3(NT), 0, st, a, nitems);
-    else hipLaunchKernelGGL(qkv_attn_kernel<88>, dim3(grid), dim3(NT), 0, st, a, nitems);
+    if (g_attn_pp) {
+        if (head_dim == 80) hipLaunchKernelGGL((qkv_attn_kernel<80, true>), dim3(grid), dim3(NT), 0, st, a, nitems);
+        else if (head_dim == 96) hipLaunchKernelGGL((qkv_attn_kernel<96, true>), dim3(grid), dim3(NT), 0, st, a, nitems);
+        else hipLaunchKernelGGL((qkv_attn_kernel<88, true>), dim3(grid), dim3(NT), 0, st, a, nitems);
+    } else {
+        if (head_dim == 80) hipLaunchKernelGGL((qkv_attn_kernel<80, false>), dim3(grid), dim3(NT), 0, st, a, nitems);
+        else if (head_dim == 96) hipLaunchKernelGGL((qkv_attn_kernel<96, false>), dim3(grid), dim3(NT), 0, st, a, nitems);
+        else hipLaunchKernelGGL((qkv_attn_kernel<88, false>), dim3(grid), dim3(NT), 0, st, a, nitems);
+    }
     if (timed) swiftk_prof_end(st);
     SWIFTK_CHECK_LAUNCH();
     return 0;

@@ -31,11 +31,13 @@ def fused_w0():
     L.swiftk_set_tuning(4, 2 << 8); fused(); L.swiftk_set_tuning(4, 0)
 def fused_w0_noattn():
     L.swiftk_set_tuning(4, 3 << 8); fused(); L.swiftk_set_tuning(4, 0)
+def fused_pp():
+    L.swiftk_set_tuning(21, 1); fused(); L.swiftk_set_tuning(21, 0)
 def stag(n):
     def f():
         L.swiftk_set_tuning(4, (n << 2) << 8); fused(); L.swiftk_set_tuning(4, 0)
     return f
-fns = {"two kernels": two, "fused, waves 4-7 +192 cyc": stag(2), "  (to_qkv GEMM alone)": gemm_only, "fused": fused, "  (fused, attention core skipped)": fused_noattn,
+fns = {"two kernels": two, "fused, waves 4-7 +192 cyc": stag(2), "  (to_qkv GEMM alone)": gemm_only, "fused": fused, "fused, ping-pong k-loop (tuning key 21)": fused_pp, "  (fused, attention core skipped)": fused_noattn,
        "  (fused, every item reads head 0's weights: WRONG results)": fused_w0, "  (the same, attention core skipped)": fused_w0_noattn}
 res = {k: [] for k in fns}
 for rnd in range(R):
@@ -45,7 +47,10 @@ for rnd in range(R):
         e0.record()
         for _ in range(4): fns[k]()
         e1.record(); torch.cuda.synchronize(); res[k].append(e0.elapsed_time(e1) / 4)
+ofp = torch.zeros_like(of)
+L.swiftk_set_tuning(21, 1); ops.qkv_attention_fused(a, w, scale, B, grid, heads, (8, 8), out=ofp, k=d); L.swiftk_set_tuning(21, 0)
 two(); fused(); torch.cuda.synchronize()
+print("ping-pong k-loop output bit-equal to the one-barrier loop's:", bool(torch.equal(ofp, of)))
 rel = float((of[..., :d].float() - o2[..., :d].float()).norm() / o2[..., :d].float().norm())
 flop = 2.0 * M * 3 * d * d + B * 8.858e9
 for k in fns:
