@@ -277,7 +277,8 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * key 19 = bf16 engine: the patch embedding's epilogue writes the pair form itself (1; 0 = fp32 stream + swiftk_split_pair),
  * key 20 = k-loop of the persistent GEMM with bf16 operands: 1 = ping-pong phases (the SIMD partners alternate between
  * fragment reads + DMA issue and back-to-back MFMAs, counted waits; needs >= 3 k-tiles per work item, else falls back), 0 = one
- * barrier per k-tile (the round-1..4 loop).  Bit-equal results either way. */
+ * barrier per k-tile (the round-1..4 loop).  Bit-equal results either way.
+ * key 21 = the same choice for the k-loop inside swiftk_qkv_attention_fused (1 = ping-pong, 0 = one barrier per k-tile). */
 int swiftk_set_tuning(int key, int value);
 /* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
  * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default

@@ -28,7 +28,7 @@
 #include "common.h"
 
 int g_attn_dbg = 0;
-int g_attn_pp = 0;  // tuning key 21 (qkv_attn.hip)
+int g_attn_pp = 1;  // tuning key 21 (qkv_attn.hip): ping-pong k-loop of the fused to_qkv + attention kernel
 
 namespace {
 
