@@ -490,19 +490,20 @@ def main():
                     "avg_launch_ms": att_s * 1e3, "flop_per_launch": flop, "algorithmic_bytes_per_launch": bytes_,
                     "attention_core_flop_per_launch": B * 8.858e9,
                     "note": "frac = fused FLOPs / time / the 2.5 PF dense peak (a 2.4 GHz figure).  SQ counters of this kernel at 96 units "
-                            "(profiles/r04a_qkv_attn_sq_counters_report.txt): MFMA pipe busy 0.53 of the SIMD cycles at an effective "
-                            "clock of 1.92 GHz under this load (0.53 x 1.92 / 2.4 = 0.43); the attention core alone (fused minus a build "
-                            "with the core skipped, 0.73 ms of the 5.9) runs at 0.63 MFMA-busy with 4.5 VALU instructions per MFMA and "
-                            "no LDS bank conflicts, the to_qkv k-loop around it at 0.51 -- the plain to_qkv GEMM's 0.50.  The 6.5 x "
-                            "fabric traffic (traffic vs algorithmic_bytes_per_launch: weight slabs re-streamed per window) is not the "
-                            "limiter (head-grouped order: +2 % time, profiles/r03e_*_ab8.txt).  Replaces swiftk_gemm_qkv_tiled + "
-                            "swiftk_window_attention, which moved 10 GB of q/k/v per layer through HBM at 96 units",
-                    "sq_counters": "profiles/r04a_qkv_attn_sq_counters_report.txt (rocprofv3 --pmc at 96 units, bf16, default tuning; figures "
-                                   "of that run, not of this one)"}
+                            "(profiles/r05n_attn_counters_report.txt, round 5: ping-pong k-loop): MFMA pipe busy 0.60 of the SIMD cycles at an "
+                            "effective clock of 1.86 GHz under this load (0.60 x 1.86 / 2.4 = 0.46; round 4: 0.53 at 1.92 GHz -- the chip gives "
+                            "about half of a cycle saving back as clock); the attention core alone (fused minus a build with the core skipped, "
+                            "0.73 ms of the 5.4) runs at 0.65 MFMA-busy with 4.5 VALU instructions per MFMA and no LDS bank conflicts.  Reading "
+                            "head 0's weight slab in every item (L2-resident, wrong results) is 4.5 % faster: that is what the twelve slabs' "
+                            "streaming from the Infinity Cache costs (profiles/r05i_qkv_attn_w0.txt; the head-grouped order that would keep slabs "
+                            "in L2 measured +2 % time, profiles/r03e_*_ab8.txt).  Replaces swiftk_gemm_qkv_tiled + swiftk_window_attention, which "
+                            "moved 10 GB of q/k/v per layer through HBM at 96 units",
+                    "sq_counters": "profiles/r05n_attn_counters_report.txt (rocprofv3 --pmc at 96 units, bf16, default tuning; figures of that run, "
+                                   "not of this one)"}
                 if B == 96 and a.dtype == "bf16" and not os.environ.get("SWIFTK_TUNE"):  # the profiled configuration only
                     line["attention_roofline"]["mfma_pipe_busy"] = {
-                        "kernel": 0.532, "attention_core": 0.628, "to_qkv_k_loop": 0.512, "plain_to_qkv_gemm": 0.504,
-                        "effective_clock_ghz": 1.92, "source": "profiles/r04a_qkv_attn_sq_counters_report.txt (rocprofv3 --pmc, 96 units)"}
+                        "kernel": 0.599, "attention_core": 0.648, "to_qkv_k_loop": 0.590, "plain_to_qkv_gemm": 0.522,
+                        "effective_clock_ghz": 1.86, "source": "profiles/r05n_attn_counters_report.txt (rocprofv3 --pmc, 96 units)"}
             else:
                 att_bytes, att_flop = B * 8192 * 4 * 1056 * 2.0, B * 8.858e9
                 line["attention_roofline"] = {
