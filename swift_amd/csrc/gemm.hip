@@ -1705,6 +1705,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 19: g_fwd_pepair = value; return 0;
         case 20: g_pp = value; return 0;
         case 21: g_attn_pp = value; return 0;
+        case 22: g_tn_pp = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -1732,6 +1733,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 19: return g_fwd_pepair;
         case 20: return g_pp;
         case 21: return g_attn_pp;
+        case 22: return g_tn_pp;
     }
     return SWIFTK_EINVAL;
 }

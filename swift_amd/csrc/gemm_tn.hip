@@ -53,7 +53,13 @@ __device__ __forceinline__ uint4 tr_pair(const char* lo, const char* hi) {
     return __builtin_bit_cast(uint4, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int NI>
+// PP: ping-pong k-loop (the schedule of gemm.hip's persistent kernel, section "The k-loop" of DESIGN.md): a k-tile is 2 NP phases
+// (32-row k-step x a third / a half of the wave tile's column blocks); waves 4-7 run one barrier behind waves 0-3.  Here a k-tile's
+// rows split by WAVE: row group w (k rows 8 w .. 8 w + 7) is filled by wave w, so the first k-step reads what waves 0-3 requested
+// and the second what waves 4-7 requested -- waves 0-3 issue their pieces in the first phases and wait for them in the k-tile's
+// last MEM phase, waves 4-7 spread theirs over all phases, leave them in flight across the k-tile boundary and retire them
+// (counted) in front of the next k-tile's second k-step.
+template <int NI, bool PP>
 __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) {
     constexpr int WT = 16 * NI, BN = 2 * WT;
     constexpr int B_RG = NI * 512, B_BYTES = 8 * B_RG, STAGE = A_BYTES + B_BYTES;
@@ -157,11 +163,20 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
 #pragma unroll
     for (int p = 0; p < 10; ++p) issue_piece(lds0, 0u, 0u, p);
     int par = 0;
-    if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+    if (!PP && wv >= 4) __builtin_amdgcn_s_setprio(1);
     const uint32_t kstep_a = (uint32_t)(KT * g.ldp_b), kstep_q = (uint32_t)(KT * g.ldq_b);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int grp = wv >> 2;
+    bool first_kt = true;
     for (;;) {
-        __builtin_amdgcn_s_barrier();
+        if constexpr (PP) {
+            if (first_kt) {  // (inside an item the phase barriers hand the stages over)
+                __builtin_amdgcn_s_barrier();
+                if (grp) __builtin_amdgcn_s_barrier();
+            }
+        } else {
+            __builtin_amdgcn_s_barrier();
+        }
         const char* s = smem + par * STAGE;
         const uint32_t fill = lds0 + (par ^ 1) * STAGE;
         const bool last_k = (kt + 1 == nk);
@@ -171,7 +186,60 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
             set_sources(ntile < ntiles ? ntile : tile);
             koff_a = koff_q = 0;
         }
-        {
+        if constexpr (PP) {
+            constexpr int NP = NI == 12 ? 3 : 2, PS = (NI + NP - 1) / NP, NQ = 2 * NP;
+            uint4 xf[MI], wf[PS];
+            auto bar = [] {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int ks = q / NP, j0 = (q % NP) * PS, nj = NI - j0 < PS ? NI - j0 : PS;
+                if (q % NP == 0) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int o = 512 * (i >> 1) + ks * 4 * A_RG;
+                        xf[i] = tr_pair(s + vA[i & 1][0] + o, s + vA[i & 1][1] + o);
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < PS; ++jj) {
+                    if (jj < nj) {
+                        const int j = j0 + jj, o = 512 * (j >> 1) + ks * 4 * B_RG;
+                        wf[jj] = tr_pair(s + vW[j & 1][0] + o, s + vW[j & 1][1] + o);
+                    }
+                }
+                if (grp) {  // waves 4-7: ten pieces over all phases; the previous k-tile's pieces retire behind phase NP - 1
+#pragma unroll
+                    for (int pc = 0; pc < 10; ++pc)
+                        if (pc * NQ / 10 == q) issue_piece(fill, koff_a, koff_q, pc);
+                    // (pieces 0..4 -- the four P pieces and the first Q piece, real for every wave -- are this k-tile's requests so far)
+                    static_assert(4 * NQ / 10 == NP - 1 && 5 * NQ / 10 == NP, "phases 0 .. NP - 1 of waves 4-7 carry pieces 0 .. 4");
+                    if (q == NP - 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                } else {    // waves 0-3: everything in the first NQ - 1 phases, waited for in the last one
+#pragma unroll
+                    for (int pc = 0; pc < 10; ++pc)
+                        if (pc * (NQ - 1) / 10 == q) issue_piece(fill, koff_a, koff_q, pc);
+                    if (q == NQ - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (q == NQ - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                bar();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int jj = 0; jj < PS; ++jj) {
+                    if (jj < nj) {
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+                            acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[jj]),
+                                                                                     __builtin_bit_cast(bf16x8, xf[i]), acc[i][j0 + jj], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                bar();
+            }
+        } else {
             auto k_half = [&](const int ks, const bool with_dma) {
                 uint4 xf[MI];
 #pragma unroll
@@ -208,8 +276,13 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
         par ^= 1;
         if (!last_k) {
             ++kt;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            first_kt = false;
+            if constexpr (!PP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             continue;
+        }
+        if constexpr (PP) {
+            if (!grp) __builtin_amdgcn_s_barrier();  // waves 0-3 meet waves 4-7: every wave aligned again
+            first_kt = true;
         }
         // ---- store this item's slab: lane holds C[n1 = ..+r16][n2 = ..+4*(lane>>4) .. +3]
         {
@@ -242,6 +315,8 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
 }
 
 }  // namespace
+
+int g_tn_pp = 0;  // tuning key 22: ping-pong k-loop of the weight-gradient GEMM
 
 // slabs[s][N1][N2] (fp32, row stride ldc, slab stride `slab_stride`) = partial products over the s-th of `ksplit` ranges of
 // the K token rows.  P: [K, >= N1] bf16 with row stride ldp, Q: [K, >= N2] with ldq.  Shapes this kernel does not take
@@ -285,9 +360,15 @@ extern "C" int swiftk_gemm_tn_splitk(const void* P, int64_t ldp, const void* Q, 
     const int items = ntm * g.ntn * ksplit;
     const dim3 grid(items < 256 ? items : 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (ni == 10) hipLaunchKernelGGL(gemm_tn_kernel<10>, grid, dim3(NT), 0, st, g, ntm, 8);
-    else if (ni == 12) hipLaunchKernelGGL(gemm_tn_kernel<12>, grid, dim3(NT), 0, st, g, ntm, 8);
-    else hipLaunchKernelGGL(gemm_tn_kernel<11>, grid, dim3(NT), 0, st, g, ntm, 8);
+    if (g_tn_pp) {
+        if (ni == 10) hipLaunchKernelGGL((gemm_tn_kernel<10, true>), grid, dim3(NT), 0, st, g, ntm, 8);
+        else if (ni == 12) hipLaunchKernelGGL((gemm_tn_kernel<12, true>), grid, dim3(NT), 0, st, g, ntm, 8);
+        else hipLaunchKernelGGL((gemm_tn_kernel<11, true>), grid, dim3(NT), 0, st, g, ntm, 8);
+    } else {
+        if (ni == 10) hipLaunchKernelGGL((gemm_tn_kernel<10, false>), grid, dim3(NT), 0, st, g, ntm, 8);
+        else if (ni == 12) hipLaunchKernelGGL((gemm_tn_kernel<12, false>), grid, dim3(NT), 0, st, g, ntm, 8);
+        else hipLaunchKernelGGL((gemm_tn_kernel<11, false>), grid, dim3(NT), 0, st, g, ntm, 8);
+    }
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }
