@@ -113,11 +113,16 @@ constexpr int EPI_BIAS_POS_PAIR = 11;  // internal: SWIFTK_EPI_BIAS_POS leaving 
 #ifndef SWIFTK_X_EPIBATCH
 #define SWIFTK_X_EPIBATCH 0
 #endif
-// phase order of the ping-pong loop: 2 = column-half major (W0 region refilled two k-tiles ahead, activation fragments read in
-// every phase: 38 fragment reads per k-tile), 3 = k-half major (30 reads; every piece one k-tile ahead, the W1 pieces -- needed
-// from the next k-tile's second phase on -- issued last and waited for in the next k-tile's first MEM phase)
+// SwiGLU epilogue: two LDS slabs per wave used alternately (1) or one slab with a wave barrier behind its read-back (0)
+#ifndef SWIFTK_X_EPI2SLAB
+#define SWIFTK_X_EPI2SLAB 0
+#endif
+// schedule of the ping-pong loop: 3 = every piece one k-tile ahead, the high column part's W pieces issued last and retired in
+// the next k-tile's first MEM phase; 4 = "deep": both k-halves' activation fragments are held in registers (NI <= 11), so the A
+// rows and the low W rows of a stage are dead after the k-tile's second phase and are refilled TWO k-tiles ahead from its third
+// phase on, the high W rows one k-tile ahead from its first phase on -- every request has about a whole k-tile to land
 #ifndef SWIFTK_PP_ORDER
-#define SWIFTK_PP_ORDER 3
+#define SWIFTK_PP_ORDER 4
 #endif
 
 struct GemmArgs {
@@ -478,6 +483,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     constexpr bool PAIRED = EPI == SWIFTK_EPI_QKNORM_JVP || EPI == SWIFTK_EPI_SWIGLU_JVP;
     // PPK: the ping-pong k-loop (needs at least three k-tiles per work item; the launcher checks)
     constexpr bool PP = PPK && sizeof(T) == 2 && !TOUCH && !HPF && !SWIFTK_GEMM_INSTR;
+    // (NI = 12: 192 accumulators leave no room for the second fragment set; SWIGLU_BWD / BIAS_POS_PAIR at NI = 11: their epilogues'
+    // registers tip the deep form into scratch -- both keep order 3)
+    constexpr bool DEEP = SWIFTK_PP_ORDER == 4 && NI <= 11 && !(NI == 11 && (EPI == SWIFTK_EPI_SWIGLU_BWD || EPI == EPI_BIAS_POS_PAIR));
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (TOUCH || HPF ? 256 : 0)];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -555,7 +563,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     const char* w1base[3];
     auto w0row = [&](int i) { const int n = wv + 8 * i, h = n >= 2 * JA; return h * WT + (n - 2 * JA * h) * 8; };
     auto w1row = [&](int i) { const int n = wv + 8 * i, h = n >= 2 * JB; return h * WT + JA * 16 + (n - 2 * JB * h) * 8; };
-    auto set_sources_aw1 = [&](int t) {
+    auto set_sources_a = [&](int t) {
         int tm, tn;
         it.coords(t / ksplit, tm, tn);
 #pragma unroll
@@ -565,12 +573,20 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             rb = rb < g.M ? rb : g.M - 8;
             abase[p] = g.A + (int64_t)rb * g.lda_b;
         }
+    };
+    auto set_sources_w1 = [&](int t) {
+        int tm, tn;
+        it.coords(t / ksplit, tm, tn);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             int rb = tn * BN + w1row(i);
             rb = rb < g.N ? rb : g.N - 8;
             w1base[i] = g.W + (int64_t)rb * g.ldw_b;
         }
+    };
+    auto set_sources_aw1 = [&](int t) {
+        set_sources_a(t);
+        set_sources_w1(t);
     };
     auto set_sources_w0 = [&](int t) {
         int tm, tn;
@@ -738,14 +754,23 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         uint32_t koff2 = (uint32_t)(kt + 2) * ROWB;  // ping-pong: k offset of the W0 pieces (they run two k-tiles ahead)
         if constexpr (PP) {
             const int ntile = tile + stride < ntiles ? tile + stride : tile;  // (past the last item: harmless re-loads)
-            if (last_k) {
-                set_sources_aw1(ntile);
-                if (SWIFTK_PP_ORDER == 3) set_sources_w0(ntile);
-                koff = (uint32_t)k_begin(ntile) * ROWB;
-            }
-            if (SWIFTK_PP_ORDER == 2 && kt + 2 == nk) {  // the W0 pieces of this k-tile feed the next item's first k-tile
-                set_sources_w0(ntile);
-                koff2 = (uint32_t)k_begin(ntile) * ROWB;
+            if constexpr (DEEP) {
+                // koff / w1base: the high W rows, one k-tile ahead; koff2 / abase, w0base: the A rows and the low W rows, two ahead
+                if (last_k) {
+                    set_sources_w1(ntile);
+                    koff = (uint32_t)k_begin(ntile) * ROWB;
+                }
+                if (kt + 2 == nk) {
+                    set_sources_a(ntile);
+                    set_sources_w0(ntile);
+                    koff2 = (uint32_t)k_begin(ntile) * ROWB;
+                }
+            } else {
+                if (last_k) {
+                    set_sources_aw1(ntile);
+                    set_sources_w0(ntile);
+                    koff = (uint32_t)k_begin(ntile) * ROWB;
+                }
             }
         } else
         if (last_k) {
@@ -825,7 +850,102 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 if (wv < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1L + C0L) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1H + C0H) : "memory");
             };
-            if constexpr (SWIFTK_PP_ORDER == 3) {
+            if constexpr (DEEP) {
+                // Deep form.  Phases (column part, k-half) = (lo, 0) (lo, 1) (hi, 0) (hi, 1); both k-halves' activation fragments stay
+                // in registers, so after the second phase nothing reads this stage's A rows and low W rows any more.  Per k-tile t
+                // a wave issues, in this order:   MEM 0: W-hi(t+1) a b | MEM 1: W-hi(t+1) c, wait W-hi(t) | MEM 2: A(t+2) 0 1 2 |
+                // MEM 3: A(t+2) 3, W-lo(t+2) a b c, wait A, W-lo(t+1)   (W-hi -> the other stage, A / W-lo -> THIS stage).
+                // Both waits leave the N = 4 + c0 + c1 youngest requests in flight: every request has 8+ phases to land.
+                // A tile's first k-tile also issues A / W-lo of its second one (the previous tile's last k-tile must not: that
+                // stage is the epilogue's scratch) and skips the first wait; a tile's last k-tile issues no A / W-lo and skips
+                // the second wait (everything older than the epilogue's stores is waited for behind the epilogue).
+                uint4 xg[MI];  // the second k-half's activation fragments (xf holds the first's)
+                auto rdxr = [&](uint4 (&x)[MI], const int ch) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) x[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch);
+                };
+                auto rdw = [&](const int ch, const int j0, const int nj) {
+#pragma unroll
+                    for (int jj = 0; jj < JM; ++jj)
+                        if (jj < nj) wf[jj] = *reinterpret_cast<const uint4*>(s + woff + (j0 + jj) * 16 * ROWB + ch);
+                };
+                auto compx = [&](const uint4 (&x)[MI], const int j0, const int nj) {
+#if SWIFTK_X_PP_PRIO
+                    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+                    for (int jj = 0; jj < JM; ++jj) {
+                        if (jj < nj) {
+#pragma unroll
+                            for (int i = 0; i < MI; ++i) mma_chunk<T>(acc[i][j0 + jj], wf[jj], x[i]);
+                        }
+                    }
+#if SWIFTK_X_PP_PRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
+                };
+                auto wait_n = [&] {
+                    if (wv < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + C0L + C1L) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + C0H + C1H) : "memory");
+                };
+                const uint32_t cur = lds0 + par * STAGE;
+                // ---- (lo, 0)
+                rdxr(xf, ch0);
+                rdw(ch0, 0, JA);
+                if (first_kt) {  // A / W-lo of this tile's second k-tile (nothing older is in flight into that stage)
+#pragma unroll
+                    for (int pc = 0; pc < 4; ++pc) PP_DMA(pp_a(fill, (uint32_t)(kt + 1) * ROWB, pc));
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) PP_DMA(pp_w0(fill, (uint32_t)(kt + 1) * ROWB, pc));
+                }
+                PP_DMA(pp_w1(fill, koff, 0));
+                PP_DMA(pp_w1(fill, koff, 1));
+                if (half) {
+                    PP_DMA(pp_w1(fill, koff, 2));
+                    wait_n();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                bar2();
+                compx(xf, 0, JA);
+                bar2();
+                if (!half) {
+                    // ---- (lo, 1)
+                    rdxr(xg, ch1);
+                    rdw(ch1, 0, JA);
+                    PP_DMA(pp_w1(fill, koff, 2));
+                    if (!first_kt) wait_n();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last reads of the A rows and the low W rows
+                    bar2();
+                    compx(xg, 0, JA);
+                    bar2();
+                }
+                // ---- (hi, 0)
+                rdw(ch0, JA, JB);
+                if (!last_k) {
+                    PP_DMA(pp_a(cur, koff2, 0));
+                    PP_DMA(pp_a(cur, koff2, 1));
+                    PP_DMA(pp_a(cur, koff2, 2));
+                }
+                if (half) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                bar2();
+                compx(xf, JA, JB);
+                bar2();
+                if (!half) {
+                    // ---- (hi, 1)
+                    rdw(ch1, JA, JB);
+                    if (!last_k) {
+                        PP_DMA(pp_a(cur, koff2, 3));
+                        PP_DMA(pp_w0(cur, koff2, 0));
+                        PP_DMA(pp_w0(cur, koff2, 1));
+                        PP_DMA(pp_w0(cur, koff2, 2));
+                        wait_n();
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    bar2();
+                    compx(xg, JA, JB);
+                    bar2();
+                }
+            } else {
                 // k-half major: (0, lo) (0, hi) (1, lo) (1, hi); activation fragments are read once per k-half.  Issue order of a
                 // wave per k-tile, everything into the other stage:  MEM 0: A0 A1 A2, wait W1(this k-tile) | MEM 1: A3 W0a W0b |
                 // MEM 2: W0c W1a | MEM 3: W1b W1c, wait A, W0(next k-tile).  The second wait leaves the C1 youngest requests (W1)
@@ -883,57 +1003,6 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     bar2();
-                    comp(JA, JB);
-                    bar2();
-                }
-            } else {
-                const uint32_t cur = lds0 + par * STAGE;
-                // ---- (lo, 0)
-                rd(ch0, 0, JA);
-                if (first_kt) {
-                    PP_DMA(pp_w0(fill, koff, 0));
-                    PP_DMA(pp_w0(fill, koff, 1));
-                    PP_DMA(pp_w0(fill, koff, 2));
-                }
-                PP_DMA(pp_a(fill, koff, 0));
-                PP_DMA(pp_a(fill, koff, 1));
-                if (half) {
-                    PP_DMA(pp_a(fill, koff, 2));
-                    PP_DMA(pp_a(fill, koff, 3));
-                    PP_DMA(pp_w1(fill, koff, 0));
-                    wait_w1();
-                }
-                bar();
-                comp(0, JA);
-                bar2();
-                if (!half) {
-                    // ---- (lo, 1)
-                    rd(ch1, 0, JA);
-                    PP_DMA(pp_a(fill, koff, 2));
-                    PP_DMA(pp_a(fill, koff, 3));
-                    PP_DMA(pp_w1(fill, koff, 0));
-                    if (!first_kt) wait_w1();
-                    bar();
-                    comp(0, JA);
-                    bar2();
-                }
-                // ---- (hi, 0)
-                rd(ch0, JA, JB);
-                PP_DMA(pp_w1(fill, koff, 1));
-                PP_DMA(pp_w1(fill, koff, 2));
-                if (!last_k) PP_DMA(pp_w0(cur, koff2, 0));
-                bar();
-                comp(JA, JB);
-                bar2();
-                if (!half) {
-                    // ---- (hi, 1)
-                    rd(ch1, JA, JB);
-                    if (!last_k) {
-                        PP_DMA(pp_w0(cur, koff2, 1));
-                        PP_DMA(pp_w0(cur, koff2, 2));
-                        wait_a();
-                    }
-                    bar();
                     comp(JA, JB);
                     bar2();
                 }
@@ -1310,7 +1379,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 // SwiGLU) global stores after its last DMA piece -- the count the next loop trip leaves outstanding
                 interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
 #endif
-                char* slab = const_cast<char*>(s) + wv * (16 * RSTR);
+#if SWIFTK_X_EPI2SLAB
+                // two slabs per wave, used alternately: the next row block's arithmetic and slab writes need not wait for this
+                // one's row chunks to be read back (the GLU forms only: two plain slabs per wave do not fit the stage)
+                constexpr bool TWO = GLU && !SPLIT3;
+                char* slab0 = const_cast<char*>(s) + wv * ((TWO ? 2 : 1) * 16 * RSTR);
+#else
+                constexpr bool TWO = false;
+                char* slab0 = const_cast<char*>(s) + wv * (16 * RSTR);
+#endif
+                char* slab = slab0;
                 // lane-derived epilogue addresses are rebuilt from an opaque copy of the lane id: left visible, hipcc
                 // hoists ~40 loop-invariant epilogue VGPRs above the k-loop and spills them inside it
                 int elane = lane;
@@ -1324,6 +1402,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 for (int ii = 0; ii < MI; ++ii) {
                     // QKNORM_JVP: a tangent row block leaves before its primal block (2, 0, 3, 1) -- its rule reads the primal values
                     const int i = EPI == SWIFTK_EPI_QKNORM_JVP ? ((ii & 1) ? ii >> 1 : 2 + (ii >> 1)) : ii;
+                    if constexpr (TWO) slab = slab0 + (ii & 1) * (16 * RSTR);
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
                         f32x4 v = acc[i][j];
@@ -1435,7 +1514,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                             }
                         }
                     }
-                    __builtin_amdgcn_wave_barrier();  // slab read before the next slab overwrites it
+                    if constexpr (!TWO) __builtin_amdgcn_wave_barrier();  // slab read before the next slab overwrites it
                     if constexpr (SPLIT3) {
 #pragma unroll
                         for (int j = 0; j < NI; ++j) *reinterpret_cast<uint32_t*>(slab + r16 * RSTR + (j * 8 + 2 * g4) * 2) = lo_pk[j];
