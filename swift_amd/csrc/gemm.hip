@@ -113,17 +113,6 @@ constexpr int EPI_BIAS_POS_PAIR = 11;  // internal: SWIFTK_EPI_BIAS_POS leaving 
 #ifndef SWIFTK_X_EPIBATCH
 #define SWIFTK_X_EPIBATCH 0
 #endif
-// SwiGLU epilogue: two LDS slabs per wave used alternately (1) or one slab with a wave barrier behind its read-back (0)
-#ifndef SWIFTK_X_EPI2SLAB
-#define SWIFTK_X_EPI2SLAB 0
-#endif
-// schedule of the ping-pong loop: 3 = every piece one k-tile ahead, the high column part's W pieces issued last and retired in
-// the next k-tile's first MEM phase; 4 = "deep": both k-halves' activation fragments are held in registers (NI <= 11), so the A
-// rows and the low W rows of a stage are dead after the k-tile's second phase and are refilled TWO k-tiles ahead from its third
-// phase on, the high W rows one k-tile ahead from its first phase on -- every request has about a whole k-tile to land
-#ifndef SWIFTK_PP_ORDER
-#define SWIFTK_PP_ORDER 4
-#endif
 
 struct GemmArgs {
     const char* A;
@@ -483,9 +472,6 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     constexpr bool PAIRED = EPI == SWIFTK_EPI_QKNORM_JVP || EPI == SWIFTK_EPI_SWIGLU_JVP;
     // PPK: the ping-pong k-loop (needs at least three k-tiles per work item; the launcher checks)
     constexpr bool PP = PPK && sizeof(T) == 2 && !TOUCH && !HPF && !SWIFTK_GEMM_INSTR;
-    // (NI = 12: 192 accumulators leave no room for the second fragment set; SWIGLU_BWD / BIAS_POS_PAIR at NI = 11: their epilogues'
-    // registers tip the deep form into scratch -- both keep order 3)
-    constexpr bool DEEP = SWIFTK_PP_ORDER == 4 && NI <= 11 && !(NI == 11 && (EPI == SWIFTK_EPI_SWIGLU_BWD || EPI == EPI_BIAS_POS_PAIR));
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (TOUCH || HPF ? 256 : 0)];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -554,7 +540,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     // W1 pieces n = wv + 8 i < 4 JB; piece n of a region: half h = n / (2 J), rows h WT + [JA 16 +] 8 (n - 2 J h) .. + 7 of the
     // tile (2 J and WT / 8 are even: the swizzle parity of a piece is wv & 1, so `vb` serves every W piece here too).
 #ifndef SWIFTK_PP_JA_HI
-#define SWIFTK_PP_JA_HI (SWIFTK_PP_ORDER == 2)
+#define SWIFTK_PP_JA_HI 0
 #endif
     // (k-half major order: the LOW column half is the smaller one -- its MEM phase carries the four activation fragments too and
     // runs beside the partner's MFMAs of the high half, so the longer MEM phase meets the longer COMPUTE phase)
@@ -563,7 +549,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     const char* w1base[3];
     auto w0row = [&](int i) { const int n = wv + 8 * i, h = n >= 2 * JA; return h * WT + (n - 2 * JA * h) * 8; };
     auto w1row = [&](int i) { const int n = wv + 8 * i, h = n >= 2 * JB; return h * WT + JA * 16 + (n - 2 * JB * h) * 8; };
-    auto set_sources_a = [&](int t) {
+    auto set_sources_aw1 = [&](int t) {
         int tm, tn;
         it.coords(t / ksplit, tm, tn);
 #pragma unroll
@@ -573,20 +559,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             rb = rb < g.M ? rb : g.M - 8;
             abase[p] = g.A + (int64_t)rb * g.lda_b;
         }
-    };
-    auto set_sources_w1 = [&](int t) {
-        int tm, tn;
-        it.coords(t / ksplit, tm, tn);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             int rb = tn * BN + w1row(i);
             rb = rb < g.N ? rb : g.N - 8;
             w1base[i] = g.W + (int64_t)rb * g.ldw_b;
         }
-    };
-    auto set_sources_aw1 = [&](int t) {
-        set_sources_a(t);
-        set_sources_w1(t);
     };
     auto set_sources_w0 = [&](int t) {
         int tm, tn;
@@ -751,26 +729,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 hpf_base = reinterpret_cast<const char*>(g.ep1) + ((int64_t)rb * g.pos_rows + 2 * t_n0) * 2;
             }
         }
-        uint32_t koff2 = (uint32_t)(kt + 2) * ROWB;  // ping-pong: k offset of the W0 pieces (they run two k-tiles ahead)
         if constexpr (PP) {
             const int ntile = tile + stride < ntiles ? tile + stride : tile;  // (past the last item: harmless re-loads)
-            if constexpr (DEEP) {
-                // koff / w1base: the high W rows, one k-tile ahead; koff2 / abase, w0base: the A rows and the low W rows, two ahead
-                if (last_k) {
-                    set_sources_w1(ntile);
-                    koff = (uint32_t)k_begin(ntile) * ROWB;
-                }
-                if (kt + 2 == nk) {
-                    set_sources_a(ntile);
-                    set_sources_w0(ntile);
-                    koff2 = (uint32_t)k_begin(ntile) * ROWB;
-                }
-            } else {
-                if (last_k) {
-                    set_sources_aw1(ntile);
-                    set_sources_w0(ntile);
-                    koff = (uint32_t)k_begin(ntile) * ROWB;
-                }
+            if (last_k) {
+                set_sources_aw1(ntile);
+                set_sources_w0(ntile);
+                koff = (uint32_t)k_begin(ntile) * ROWB;
             }
         } else
         if (last_k) {
@@ -785,47 +749,24 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         // columns, so those 44 MFMAs are skipped -- 3 % of the GEMM).  Branches between the MFMA groups make hipcc
         // shuffle and spill accumulators (297 v_mov + 27 spilled dwords per k-tile in the SwiGLU build).
         if constexpr (PP) {
-            // Ping-pong form of the same k-tile.  Phases (column half, k-half) = (lo, 0) (lo, 1) (hi, 0) (hi, 1): the W0 region is dead
-            // after the second phase and is refilled two k-tiles ahead from the third phase on, so DMA stays in flight across the
-            // k-tile boundary under counted waits (VMEM retires in issue order).  Issue order of a wave per k-tile:
-            //   MEM 0: A0 A1 | MEM 1: A2 A3 W1a, wait W1(this k-tile) | MEM 2: W1b W1c W0a | MEM 3: W0b W0c, wait A(next k-tile)
-            // (A, W1 -> the other stage, one k-tile ahead; W0 -> this stage, two ahead).  W1(t) needs all but the C0 + 5 youngest
-            // requests retired, A(t + 1) [and with it the older W0(t + 1)] all but the C1 + C0 youngest.  A tile's first k-tile
-            // also issues W0 of its second one (the previous tile's last k-tile must not: that stage is the epilogue's scratch)
-            // and skips the first wait (everything older than the epilogue's stores was waited for behind the epilogue); a tile's
-            // last k-tile issues no W0 and skips the second wait.  Every MEM phase ends with lgkmcnt(0) in front of its barrier:
-            // the fragments are in registers when the MFMAs start, and no read is pending when the partner group, one barrier
-            // later, lets DMA into a region.
-            constexpr int C0L = 3, C0H = 4 * JA >= 24 ? 3 : 2, C1L = 3, C1H = 4 * JB >= 24 ? 3 : 2;
+            // Ping-pong form of the same k-tile ("The k-loop"): phases (k-half, column part) = (0, lo) (0, hi)
+            // (1, lo) (1, hi); the activation fragments are read once per k-half.  The last MEM phase ends with lgkmcnt(0) in front
+            // of its barrier: no fragment read is pending when the partner group, one barrier later, lets DMA into the stage.
+            constexpr int C1L = 3, C1H = 4 * JB >= 24 ? 3 : 2;  // W pieces of the high column part per wave (waves 0-3 | 4-7)
             uint4 xf[MI], wf[JM];
 #if SWIFTK_PP_STAMP
             pl_i = 0;
-            if (g.dbg & 8) koff = koff2 = 0;
+            if (g.dbg & 8) koff = 0;
 #define PP_DMA(x) do { if (!(g.dbg & 1)) { x; } } while (0)
 #else
 #define PP_DMA(x) do { x; } while (0)
 #endif
-            auto bar = [&] {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                PP_STAMP();
-                __builtin_amdgcn_s_barrier();
-                PP_STAMP();
-                __builtin_amdgcn_sched_barrier(0);
-            };
             auto bar2 = [&] {
                 __builtin_amdgcn_sched_barrier(0);
                 PP_STAMP();
                 __builtin_amdgcn_s_barrier();
                 PP_STAMP();
                 __builtin_amdgcn_sched_barrier(0);
-            };
-            auto rd = [&](const int ch, const int j0, const int nj) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch);
-#pragma unroll
-                for (int jj = 0; jj < JM; ++jj)
-                    if (jj < nj) wf[jj] = *reinterpret_cast<const uint4*>(s + woff + (j0 + jj) * 16 * ROWB + ch);
             };
             auto comp = [&](const int j0, const int nj) {
 #if SWIFTK_X_PP_PRIO
@@ -842,170 +783,65 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 __builtin_amdgcn_s_setprio(0);
 #endif
             };
-            auto wait_w1 = [&] {
-                if (wv < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C0L + 5) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C0H + 5) : "memory");
+            // k-half major: (0, lo) (0, hi) (1, lo) (1, hi); activation fragments are read once per k-half.  Issue order of a
+            // wave per k-tile, everything into the other stage:  MEM 0: A0 A1 A2, wait W1(this k-tile) | MEM 1: A3 W0a W0b |
+            // MEM 2: W0c W1a | MEM 3: W1b W1c, wait A, W0(next k-tile).  The second wait leaves the C1 youngest requests (W1)
+            // in flight across the k-tile boundary; the first one -- three requests later -- retires them.
+            auto rdx = [&](const int ch) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch);
             };
-            auto wait_a = [&] {
-                if (wv < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1L + C0L) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1H + C0H) : "memory");
+            auto rdw = [&](const int ch, const int j0, const int nj) {
+#pragma unroll
+                for (int jj = 0; jj < JM; ++jj)
+                    if (jj < nj) wf[jj] = *reinterpret_cast<const uint4*>(s + woff + (j0 + jj) * 16 * ROWB + ch);
             };
-            if constexpr (DEEP) {
-                // Deep form.  Phases (column part, k-half) = (lo, 0) (lo, 1) (hi, 0) (hi, 1); both k-halves' activation fragments stay
-                // in registers, so after the second phase nothing reads this stage's A rows and low W rows any more.  Per k-tile t
-                // a wave issues, in this order:   MEM 0: W-hi(t+1) a b | MEM 1: W-hi(t+1) c, wait W-hi(t) | MEM 2: A(t+2) 0 1 2 |
-                // MEM 3: A(t+2) 3, W-lo(t+2) a b c, wait A, W-lo(t+1)   (W-hi -> the other stage, A / W-lo -> THIS stage).
-                // Both waits leave the N = 4 + c0 + c1 youngest requests in flight: every request has 8+ phases to land.
-                // A tile's first k-tile also issues A / W-lo of its second one (the previous tile's last k-tile must not: that
-                // stage is the epilogue's scratch) and skips the first wait; a tile's last k-tile issues no A / W-lo and skips
-                // the second wait (everything older than the epilogue's stores is waited for behind the epilogue).
-                uint4 xg[MI];  // the second k-half's activation fragments (xf holds the first's)
-                auto rdxr = [&](uint4 (&x)[MI], const int ch) {
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) x[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch);
-                };
-                auto rdw = [&](const int ch, const int j0, const int nj) {
-#pragma unroll
-                    for (int jj = 0; jj < JM; ++jj)
-                        if (jj < nj) wf[jj] = *reinterpret_cast<const uint4*>(s + woff + (j0 + jj) * 16 * ROWB + ch);
-                };
-                auto compx = [&](const uint4 (&x)[MI], const int j0, const int nj) {
-#if SWIFTK_X_PP_PRIO
-                    __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-                    for (int jj = 0; jj < JM; ++jj) {
-                        if (jj < nj) {
-#pragma unroll
-                            for (int i = 0; i < MI; ++i) mma_chunk<T>(acc[i][j0 + jj], wf[jj], x[i]);
-                        }
-                    }
-#if SWIFTK_X_PP_PRIO
-                    __builtin_amdgcn_s_setprio(0);
-#endif
-                };
-                auto wait_n = [&] {
-                    if (wv < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + C0L + C1L) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + C0H + C1H) : "memory");
-                };
-                const uint32_t cur = lds0 + par * STAGE;
-                // ---- (lo, 0)
-                rdxr(xf, ch0);
-                rdw(ch0, 0, JA);
-                if (first_kt) {  // A / W-lo of this tile's second k-tile (nothing older is in flight into that stage)
-#pragma unroll
-                    for (int pc = 0; pc < 4; ++pc) PP_DMA(pp_a(fill, (uint32_t)(kt + 1) * ROWB, pc));
-#pragma unroll
-                    for (int pc = 0; pc < 3; ++pc) PP_DMA(pp_w0(fill, (uint32_t)(kt + 1) * ROWB, pc));
-                }
+            // ---- (0, lo)
+            rdx(ch0);
+            rdw(ch0, 0, JA);
+            PP_DMA(pp_a(fill, koff, 0));
+            PP_DMA(pp_a(fill, koff, 1));
+            PP_DMA(pp_a(fill, koff, 2));
+            if (!first_kt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            bar2();
+            comp(0, JA);
+            bar2();
+            // ---- (0, hi)
+            rdw(ch0, JA, JB);
+            PP_DMA(pp_a(fill, koff, 3));
+            PP_DMA(pp_w0(fill, koff, 0));
+            PP_DMA(pp_w0(fill, koff, 1));
+            if (half) {  // the k-tile ends here: the rest of its requests, and its last fragment reads
+                PP_DMA(pp_w0(fill, koff, 2));
                 PP_DMA(pp_w1(fill, koff, 0));
                 PP_DMA(pp_w1(fill, koff, 1));
-                if (half) {
-                    PP_DMA(pp_w1(fill, koff, 2));
-                    wait_n();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                bar2();
-                compx(xf, 0, JA);
-                bar2();
-                if (!half) {
-                    // ---- (lo, 1)
-                    rdxr(xg, ch1);
-                    rdw(ch1, 0, JA);
-                    PP_DMA(pp_w1(fill, koff, 2));
-                    if (!first_kt) wait_n();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last reads of the A rows and the low W rows
-                    bar2();
-                    compx(xg, 0, JA);
-                    bar2();
-                }
-                // ---- (hi, 0)
-                rdw(ch0, JA, JB);
-                if (!last_k) {
-                    PP_DMA(pp_a(cur, koff2, 0));
-                    PP_DMA(pp_a(cur, koff2, 1));
-                    PP_DMA(pp_a(cur, koff2, 2));
-                }
-                if (half) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                bar2();
-                compx(xf, JA, JB);
-                bar2();
-                if (!half) {
-                    // ---- (hi, 1)
-                    rdw(ch1, JA, JB);
-                    if (!last_k) {
-                        PP_DMA(pp_a(cur, koff2, 3));
-                        PP_DMA(pp_w0(cur, koff2, 0));
-                        PP_DMA(pp_w0(cur, koff2, 1));
-                        PP_DMA(pp_w0(cur, koff2, 2));
-                        wait_n();
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    bar2();
-                    compx(xg, JA, JB);
-                    bar2();
-                }
-            } else {
-                // k-half major: (0, lo) (0, hi) (1, lo) (1, hi); activation fragments are read once per k-half.  Issue order of a
-                // wave per k-tile, everything into the other stage:  MEM 0: A0 A1 A2, wait W1(this k-tile) | MEM 1: A3 W0a W0b |
-                // MEM 2: W0c W1a | MEM 3: W1b W1c, wait A, W0(next k-tile).  The second wait leaves the C1 youngest requests (W1)
-                // in flight across the k-tile boundary; the first one -- three requests later -- retires them.
-                auto rdx = [&](const int ch) {
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const uint4*>(s + xoff + i * 16 * ROWB + ch);
-                };
-                auto rdw = [&](const int ch, const int j0, const int nj) {
-#pragma unroll
-                    for (int jj = 0; jj < JM; ++jj)
-                        if (jj < nj) wf[jj] = *reinterpret_cast<const uint4*>(s + woff + (j0 + jj) * 16 * ROWB + ch);
-                };
-                // ---- (0, lo)
-                rdx(ch0);
-                rdw(ch0, 0, JA);
-                PP_DMA(pp_a(fill, koff, 0));
-                PP_DMA(pp_a(fill, koff, 1));
-                PP_DMA(pp_a(fill, koff, 2));
-                if (!first_kt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                PP_DMA(pp_w1(fill, koff, 2));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            bar2();
+            comp(JA, JB);
+            bar2();
+            if (!half) {
+                // ---- (1, lo)
+                rdx(ch1);
+                rdw(ch1, 0, JA);
+                PP_DMA(pp_w0(fill, koff, 2));
+                PP_DMA(pp_w1(fill, koff, 0));
                 bar2();
                 comp(0, JA);
                 bar2();
-                // ---- (0, hi)
-                rdw(ch0, JA, JB);
-                PP_DMA(pp_a(fill, koff, 3));
-                PP_DMA(pp_w0(fill, koff, 0));
-                PP_DMA(pp_w0(fill, koff, 1));
-                if (half) {  // the k-tile ends here: the rest of its requests, and its last fragment reads
-                    PP_DMA(pp_w0(fill, koff, 2));
-                    PP_DMA(pp_w1(fill, koff, 0));
-                    PP_DMA(pp_w1(fill, koff, 1));
-                    PP_DMA(pp_w1(fill, koff, 2));
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // ---- (1, hi)
+                rdw(ch1, JA, JB);
+                PP_DMA(pp_w1(fill, koff, 1));
+                PP_DMA(pp_w1(fill, koff, 2));
+                if (!last_k) {
+                    if (wv < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1L) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1H) : "memory");
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 bar2();
                 comp(JA, JB);
                 bar2();
-                if (!half) {
-                    // ---- (1, lo)
-                    rdx(ch1);
-                    rdw(ch1, 0, JA);
-                    PP_DMA(pp_w0(fill, koff, 2));
-                    PP_DMA(pp_w1(fill, koff, 0));
-                    bar2();
-                    comp(0, JA);
-                    bar2();
-                    // ---- (1, hi)
-                    rdw(ch1, JA, JB);
-                    PP_DMA(pp_w1(fill, koff, 1));
-                    PP_DMA(pp_w1(fill, koff, 2));
-                    if (!last_k) {
-                        if (wv < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1L) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1H) : "memory");
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    bar2();
-                    comp(JA, JB);
-                    bar2();
-                }
             }
 #undef PP_DMA
         } else {
@@ -1379,16 +1215,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 // SwiGLU) global stores after its last DMA piece -- the count the next loop trip leaves outstanding
                 interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
 #endif
-#if SWIFTK_X_EPI2SLAB
-                // two slabs per wave, used alternately: the next row block's arithmetic and slab writes need not wait for this
-                // one's row chunks to be read back (the GLU forms only: two plain slabs per wave do not fit the stage)
-                constexpr bool TWO = GLU && !SPLIT3;
-                char* slab0 = const_cast<char*>(s) + wv * ((TWO ? 2 : 1) * 16 * RSTR);
-#else
-                constexpr bool TWO = false;
-                char* slab0 = const_cast<char*>(s) + wv * (16 * RSTR);
-#endif
-                char* slab = slab0;
+                char* slab = const_cast<char*>(s) + wv * (16 * RSTR);
                 // lane-derived epilogue addresses are rebuilt from an opaque copy of the lane id: left visible, hipcc
                 // hoists ~40 loop-invariant epilogue VGPRs above the k-loop and spills them inside it
                 int elane = lane;
@@ -1402,7 +1229,6 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 for (int ii = 0; ii < MI; ++ii) {
                     // QKNORM_JVP: a tangent row block leaves before its primal block (2, 0, 3, 1) -- its rule reads the primal values
                     const int i = EPI == SWIFTK_EPI_QKNORM_JVP ? ((ii & 1) ? ii >> 1 : 2 + (ii >> 1)) : ii;
-                    if constexpr (TWO) slab = slab0 + (ii & 1) * (16 * RSTR);
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
                         f32x4 v = acc[i][j];
@@ -1514,7 +1340,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                             }
                         }
                     }
-                    if constexpr (!TWO) __builtin_amdgcn_wave_barrier();  // slab read before the next slab overwrites it
+                    __builtin_amdgcn_wave_barrier();  // slab read before the next slab overwrites it
                     if constexpr (SPLIT3) {
 #pragma unroll
                         for (int j = 0; j < NI; ++j) *reinterpret_cast<uint32_t*>(slab + r16 * RSTR + (j * 8 + 2 * g4) * 2) = lo_pk[j];
