@@ -592,3 +592,29 @@ def test_index_streams_vs_reference_golden():
     # the lap form leans on numpy drawing the same bounded integers one at a time and in bulk
     a, b = np.random.default_rng(9), np.random.default_rng(9)
     assert np.array_equal(np.array([a.integers(19) for _ in range(500)]), b.integers(19, size=500))
+
+
+def test_h5py_stand_in_is_strict(tmp_path):
+    """The image has no h5py, so the h5 loader runs against tests/era5_fixture.py's stand-in.  The stand-in must stay HONEST: it
+    serves exactly the accesses data/era5.py:58-74 makes -- `File(path, "r")` as a context manager, `f["input"][var][()]` -- and
+    refuses anything else, so a loader that drifted to another h5py idiom (slicing, `.value`, attributes, write modes) fails here
+    instead of passing against a permissive fake."""
+    import era5_fixture as fx
+    root = fx.write_tree(str(tmp_path / "era5"))
+    m = fx.install_fake_h5py()
+    path = sorted(os.listdir(os.path.join(root, "train")))[0]
+    with m.File(os.path.join(root, "train", path), "r") as f:
+        a = f["input"][fx.VARS[0]][()]
+        assert a.shape == fx.SHAPE and a.dtype == np.float32
+        assert isinstance(f["input"]["time"][()], bytes)
+        with pytest.raises(KeyError):
+            f["input"]["no_such_variable"]
+        with pytest.raises(KeyError):
+            f["forecast"]
+        with pytest.raises(AssertionError):
+            f["input"][fx.VARS[0]][:]
+        with pytest.raises(AssertionError):
+            f["input"][fx.VARS[0]][0]
+        assert not hasattr(f["input"][fx.VARS[0]], "value") and not hasattr(f, "attrs")
+    with pytest.raises(AssertionError):
+        m.File(os.path.join(root, "train", path), "w")
