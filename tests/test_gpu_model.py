@@ -491,7 +491,16 @@ def test_bf16_rollout_vs_bf16_emulating_oracle(dev):
     assert rel_l2(traj, refs[True]) < 2e-3  # the physical state itself
 
 
-def test_swiftb_bf16_every_layer_teacher_forced_vs_emulating_oracle(dev):
+@pytest.mark.parametrize("name,c", [
+    ("Swift-B", SWIFTB),
+    # the reference's larger variants at their real widths (depth cut to 2, a quarter of the grid): the fused kernel's head_dim 80 /
+    # 96 geometries, the 320- / 384-wide GEMM tiles and the odd MLP width of dim 1280 inside the model's own call sequence
+    ("468M-width-dim1280-hd80", dict(img=(64, 128), n_vars=69, n_forc=3, window=(16, 16), shift=(8, 8), patch=(2, 2), dim=1280,
+                                     heads=16, depth=2)),
+    ("664M-width-dim1536-hd96", dict(img=(64, 128), n_vars=69, n_forc=3, window=(16, 16), shift=(8, 8), patch=(2, 2), dim=1536,
+                                     heads=16, depth=2)),
+])
+def test_swiftb_bf16_every_layer_teacher_forced_vs_emulating_oracle(dev, name, c):
     """Full-depth bf16 parity, layer by layer.  The end-to-end bound of test_swiftb_full_step_vs_reference_golden is calibrated on
     a noise floor of 4.3e-2 (twelve layers amplify any admissible rounding difference), which would hide a kernel defect of that
     size.  Here every one of Swift-B's 24 branches is judged on its own: the bf16-emulating oracle runs the whole network once
@@ -502,12 +511,13 @@ def test_swiftb_bf16_every_layer_teacher_forced_vs_emulating_oracle(dev):
     import torch.nn.functional as F
     from swift_amd import ops
     seed = 21
-    net, onet = build(SWIFTB, seed, dev)
+    net, onet = build(c, seed, dev)
     m = net.model
-    d, heads, n = m.dim, m.heads, 64 * 128
+    grid = (c["img"][0] // 2, c["img"][1] // 2)
+    d, heads, n, hd = m.dim, m.heads, grid[0] * grid[1], m.dim // m.heads
     kd = ops.k_pad(torch.bfloat16, d)
-    x = det_normal((1, 69, 128, 256), seed, "x")
-    cond = det_normal((1, 72, 128, 256), seed, "cond")
+    x = det_normal((1, 69, *c["img"]), seed, "x")
+    cond = det_normal((1, 72, *c["img"]), seed, "cond")
     taps = {}
     onet(x, torch.tensor([1.1]), condition=cond, auxiliary=0.6, taps=taps, emulate_bf16="offset0")
     lat = taps["lat"].to(dev)
@@ -521,7 +531,8 @@ def test_swiftb_bf16_every_layer_teacher_forced_vs_emulating_oracle(dev):
         mod = F.linear(lat, att.norm.modulation.weight, att.norm.modulation.bias).contiguous()
         wq = ops.pad_cols(att.to_qkv.weight.detach(), kd, torch.bfloat16)
         o = torch.zeros(n, kd, dtype=torch.bfloat16, device=dev)
-        ops.qkv_attention_fused(hi, wq, att.scale.detach().reshape(-1).float(), 1, (64, 128), heads, shift, out=o.view(1, n, kd)[..., :d], k=d)
+        ops.qkv_attention_fused(hi, wq, att.scale.detach().reshape(-1).float(), 1, grid, heads, shift, out=o.view(1, n, kd)[..., :d], k=d,
+                                head_dim=hd)
         y = ops.gemm(o[:, :d], ops.pad_cols(att.wo.weight.detach(), kd, torch.bfloat16)[:, :d])
         ops.modnorm_residual_pair(y, hi, lo, att.norm.norm.weight.detach(), att.norm.norm.bias.detach(), mod, n, d)
         ea = rel_l2(ops.pair_value(hi, lo, d).cpu() - x_in, x_mid - x_in)
@@ -530,11 +541,17 @@ def test_swiftb_bf16_every_layer_teacher_forced_vs_emulating_oracle(dev):
         mod = F.linear(lat, ff.norm.modulation.weight, ff.norm.modulation.bias).contiguous()
         mlp = ff.w2.weight.shape[1]
         w1i = ff.w1.weight.detach().view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)  # rows gate_0, up_0, gate_1, up_1, ...
-        h = ops.gemm(hi[:, :d], ops.pad_cols(w1i, kd, torch.bfloat16)[:, :d], epilogue=ops.EPI_SWIGLU)
-        y = ops.gemm(h, ops.pad_cols(ff.w2.weight.detach(), ops.k_pad(torch.bfloat16, mlp), torch.bfloat16)[:, :h.shape[1]])
+        w2w = ff.w2.weight.detach()
+        if mlp & 1:  # int(8/3 * 1280) = 3413: one zero (gate, up) row pair and a zero w2 column, as swift_amd/engine.py packs them
+            w1i = torch.cat([w1i, w1i.new_zeros(2, d)], 0)
+            w2w = torch.cat([w2w, w2w.new_zeros(d, 1)], 1)
+        kh = ops.k_pad(torch.bfloat16, w2w.shape[1])
+        hbuf = torch.zeros(n, kh, dtype=torch.bfloat16, device=dev)  # (k-padding columns of w2's operand must be finite: zero)
+        ops.gemm(hi[:, :d], ops.pad_cols(w1i, kd, torch.bfloat16)[:, :d], out=hbuf[:, :w2w.shape[1]], epilogue=ops.EPI_SWIGLU)
+        y = ops.gemm(hbuf, ops.pad_cols(w2w, kh, torch.bfloat16))
         ops.modnorm_residual_pair(y, hi, lo, ff.norm.norm.weight.detach(), ff.norm.norm.bias.detach(), mod, n, d)
         ef = rel_l2(ops.pair_value(hi, lo, d).cpu() - x_mid, x_out - x_mid)
-        print(f"layer {i:2d}: attention branch rel-L2 {ea:.3e}, feed-forward branch rel-L2 {ef:.3e}")
+        print(f"{name} layer {i:2d}: attention branch rel-L2 {ea:.3e}, feed-forward branch rel-L2 {ef:.3e}")
         worst["attention"], worst["feed-forward"] = max(worst["attention"], ea), max(worst["feed-forward"], ef)
     print(f"worst branch: attention {worst['attention']:.3e}, feed-forward {worst['feed-forward']:.3e}")
     # (measured: attention 7.0e-4 .. 1.2e-3, feed-forward 1.6e-4 .. 1.8e-4 -- the asked-for 1.5e-2 would not notice a 10 x regression)
