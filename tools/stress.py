@@ -34,7 +34,7 @@ def main():
         # boundaries, two barriers per phase) must reproduce the one-barrier-per-k-tile loop bit for bit: the references below
         # are taken with the old loop (tuning key 20 = 0), every later round runs the shipped default
         L = _lib.lib()
-        pp_default = L.swiftk_get_tuning(20)
+        pp_default, ppa_default = L.swiftk_get_tuning(20), L.swiftk_get_tuning(21)
         side = torch.cuda.Stream()
         src = torch.empty(256 * 1024 * 1024, device=dev, dtype=torch.uint8)
         dst = torch.empty_like(src)
@@ -47,6 +47,7 @@ def main():
                         dst.copy_(src, non_blocking=True)
             sh = (8, 8) if it & 1 else (0, 0)
             L.swiftk_set_tuning(20, 0 if it < 2 else pp_default)  # (rounds 0 and 1 define the references: shifts (0,0) and (8,8))
+            L.swiftk_set_tuning(21, 0 if it < 2 else ppa_default)
             ct = ops.gemm_qkv_tiled(a, wq, scale, B, (gh, gw), heads, sh, k=1056)
             ot = ops.window_attention_tiled(ct, scale, (gh, gw), heads, sh)
             c = ops.gemm(a, wq, epilogue=ops.EPI_QKNORM, bias=scale)
@@ -69,7 +70,45 @@ def main():
                 print(f"B={B} round {it}: tiled and row-major attention differ", flush=True)
             del junk
         L.swiftk_set_tuning(20, pp_default)
+        L.swiftk_set_tuning(21, ppa_default)
         print(f"B={B}: {rounds} rounds done", flush=True)
+    # the other tile widths and head_dims (the 468 M / 664 M variants: 320- / 384-wide GEMM tiles = NI 10 / 12, fused kernel
+    # geometries 128 | 112 and 144 | 144 with head_dim 96's deferred pieces and VALU row sum), same protocol
+    L = _lib.lib()
+    pp_default, ppa_default = L.swiftk_get_tuning(20), L.swiftk_get_tuning(21)
+    for hd, heads_v in ((80, 16), (96, 16)):
+        d, B = hd * heads_v, 3
+        M = B * gh * gw
+        a = torch.randn(M, d, device=dev).to(torch.bfloat16)
+        wq = (torch.randn(3 * d, d, device=dev) * 0.03).to(torch.bfloat16)
+        wo = (torch.randn(d, d, device=dev) * 0.03).to(torch.bfloat16)
+        scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 200.0, 1.0, 10.0, 50.0, 99.0, 101.0, 5.0, 20.0, 48.0, 2.0, 60.0, 47.0, 49.0])).to(dev)
+        fo = torch.zeros(B, gh * gw, d, dtype=torch.bfloat16, device=dev)
+        ref = {}
+        side = torch.cuda.Stream()
+        src = torch.empty(256 * 1024 * 1024, device=dev, dtype=torch.uint8)
+        dst = torch.empty_like(src)
+        for it in range(rounds):
+            if it % 3:
+                with torch.cuda.stream(side):
+                    for _ in range(1 + it % 4):
+                        dst.copy_(src, non_blocking=True)
+            sh = (8, 8) if it & 1 else (0, 0)
+            L.swiftk_set_tuning(20, 0 if it < 2 else pp_default)
+            L.swiftk_set_tuning(21, 0 if it < 2 else ppa_default)
+            c = ops.gemm(a, wq, epilogue=ops.EPI_QKNORM, bias=scale, head_dim=hd)
+            yo = ops.gemm(a, wo)
+            ops.qkv_attention_fused(a, wq, scale, B, (gh, gw), heads_v, sh, out=fo, head_dim=hd)
+            for k, v in dict(c=c, yo=yo, fused=fo.clone()).items():
+                key = (k, sh if k == "fused" else 0)
+                if key not in ref:
+                    ref[key] = v.clone()
+                elif not torch.equal(ref[key], v):
+                    bad += 1
+                    print(f"head_dim {hd} round {it} {k} shift {sh}: outputs differ", flush=True)
+        L.swiftk_set_tuning(20, pp_default)
+        L.swiftk_set_tuning(21, ppa_default)
+        print(f"head_dim {hd}: {rounds} rounds done", flush=True)
     print("RACE SCREEN:", "CLEAN" if bad == 0 else f"{bad} mismatches")
     sys.exit(1 if bad else 0)
 
