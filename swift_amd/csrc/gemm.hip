@@ -21,6 +21,8 @@
 // 8 bf16 (1 MFMA) and everything else is byte-identical.
 #include "common.h"
 
+int g_persist_wgs = 256;  // tuning key 2: workgroups of the persistent matrix kernels (one per CU the stream may use)
+
 namespace {
 
 // silu(gate) * up in a GEMM epilogue.  bf16 output (the throughput engine): v_exp_f32 + v_rcp_f32, 1 ulp each, far below the
@@ -1469,7 +1471,6 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 // ---- optional live timing of one GEMM flavour (bench.py's roofline leg): HIP events on the launch stream ----
 int g_variant = 1;   // 0: one tile per workgroup; 1: persistent, grouped tile order, interleaved DMA
 int g_group_m = 8;   // tile rows per group in the persistent order
-int g_persist_wgs = 256;
 int g_dbg = 0;
 int g_stagger_permille = 0;  // tuning key 7: start-up phase step as a fraction (in 1/1000) of an eighth of the estimated tile time
 int g_pp = SWIFTK_X_PP;      // tuning key 20: ping-pong k-loop of the persistent kernel (bf16 operands)
@@ -1611,6 +1612,8 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 20: g_pp = value; return 0;
         case 21: g_attn_pp = value; return 0;
         case 22: g_tn_pp = value; return 0;
+        case 23: g_fwd_rownorm = value; return 0;
+        case 24: g_rownorm_dbg = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -1639,6 +1642,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 20: return g_pp;
         case 21: return g_attn_pp;
         case 22: return g_tn_pp;
+        case 23: return g_fwd_rownorm;
     }
     return SWIFTK_EINVAL;
 }

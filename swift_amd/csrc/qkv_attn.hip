@@ -679,7 +679,7 @@ extern "C" int swiftk_qkv_attention_fused(const void* x, int64_t ldx, const void
     a.dbg = g_attn_dbg >> 8;  // tuning key 4, bits 8..: timing experiments of this kernel
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nitems = B * (gh / 16) * (gw / 16) * heads;
-    int grid = 256;
+    int grid = g_persist_wgs >= 8 ? (g_persist_wgs & ~7) : g_persist_wgs;  // tuning key 2: one workgroup per CU the stream may use
     if (nitems < grid) grid = nitems >= 8 ? (nitems & ~7) : nitems;
     const bool timed = swiftk_prof_begin(SWIFTK_PROF_ATTENTION, 0, st);
     if (g_attn_pp) {
