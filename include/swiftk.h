@@ -165,18 +165,6 @@ int swiftk_modnorm_residual_pair_slabs(const float* y_slabs, int64_t ldy, int64_
 int swiftk_modnorm_residual_pair_slabs_bf16(const void* y_slabs, int64_t ldy, int64_t slab_stride, void* x_hi, int64_t ldh, void* x_lo,
                                             int64_t ldl, int lo_bits, const float* gamma, const float* beta, const float* mod,
                                             int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps, void* stream);
-/* wo / w2 and the norm above in ONE kernel, for small batches: y = bf16(A[M, K] W[d, K]^T) computed over complete rows (a
- * workgroup owns `rows_per_workgroup` = 32 or 64 rows x all d columns, so the row statistics are there and y never leaves the
- * CU), then the pair update of swiftk_modnorm_residual_pair (8-bit low part).  bf16 operands, d = 1056 or 960, K % 32 == 0,
- * K >= 64 (rows of A and W padded to a multiple of 64 elements; the pad is fetched, never multiplied), M and rows_per_sample
- * multiples of rows_per_workgroup.  Every workgroup streams the whole weight through L2, so
- * this pays while M / rows_per_workgroup is about one round of the CUs (one unit per step at 32 rows, two at 64:
- * swiftk_swinv2_forward, tuning key 23); beyond that swiftk_gemm + swiftk_modnorm_residual_pair is the faster pair.
- * Replaces the same reference lines as those two (swinv2.py:143 / :177 `to_out` / `w2`, :83-86, :211-212). */
-int swiftk_gemm_modnorm_residual_pair(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t K, void* x_hi, int64_t ldh,
-                                      void* x_lo, int64_t ldl, const float* gamma, const float* beta, const float* mod,
-                                      int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps,
-                                      int rows_per_workgroup, void* stream);
 /* fp32 [rows, lds] -> the pair form: hi [rows, ldh] bf16 with columns [cols, ldh) zeroed (GEMM k-padding), lo [rows, ldl]
  * (bf16 or uint8 by lo_bits, ldl in elements). */
 int swiftk_split_pair(const float* src, int64_t lds, void* hi, int64_t ldh, void* lo, int64_t ldl, int lo_bits, int64_t rows,
@@ -292,9 +280,7 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * barrier per k-tile (the round-1..4 loop).  Bit-equal results either way.
  * key 21 = the same choice for the k-loop inside swiftk_qkv_attention_fused (1 = ping-pong, 0 = one barrier per k-tile),
  * key 22 = the same for swiftk_gemm_tn_splitk (0: measured -2...-4.5 % per weight-gradient shape with four phases per k-tile,
- * +-0 on a training iteration; kept off),
- * key 23 = swiftk_swinv2_forward (bf16 engine) runs wo / w2 + norm as swiftk_gemm_modnorm_residual_pair up to this many units
- * per step (2; 0 = never: split-K + slab-summing norm at one unit, GEMM + norm beyond). */
+ * +-0 on a training iteration; kept off). */
 int swiftk_set_tuning(int key, int value);
 /* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
  * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default

@@ -188,8 +188,6 @@ extern int g_x3_ffsplit;  // tuning key 18
 extern int g_fwd_pepair;  // tuning key 19
 extern int g_modnorm_nt;  // tuning key 6
 extern int g_persist_wgs;  // tuning key 2: workgroups of the persistent matrix kernels (GEMM, fused to_qkv + attention)
-extern int g_fwd_rownorm;  // tuning key 23: wo / w2 + norm as one complete-row kernel up to this many units per step
-extern int g_rownorm_dbg;
 extern int g_tn_pp;  // tuning key 22: ping-pong k-loop of gemm_tn_kernel
 extern int g_attn_pp;  // tuning key 21: ping-pong k-loop of the fused to_qkv + attention kernel
 extern int g_attn_dbg;  // tuning key 4: attention ablation bits (timing experiments only)

@@ -305,20 +305,6 @@ def modnorm_residual_pair(y: torch.Tensor, x_hi: torch.Tensor, x_lo: torch.Tenso
                                              _stream()), "swiftk_modnorm_residual_pair")
 
 
-def gemm_modnorm_residual_pair(a: torch.Tensor, w: torch.Tensor, x_hi: torch.Tensor, x_lo: torch.Tensor, gamma, beta,
-                               mod: torch.Tensor, rows_per_sample: int, d: int, *, k: Optional[int] = None,
-                               rows_per_workgroup: int = 32, eps: float = 1e-6) -> None:
-    """``modnorm_residual_pair(bf16(a @ w^T), ...)`` as one kernel over complete rows (small batches; 8-bit low part):
-    a [M, >=K] bf16, w [d, >=K] bf16; ``k`` = valid K (a multiple of 32)."""
-    _dev(a, w, x_hi, x_lo, gamma, beta, mod)
-    assert a.dtype == w.dtype == x_hi.dtype == torch.bfloat16 and x_lo.dtype == torch.uint8 and mod.dtype == torch.float32
-    assert w.shape[0] == d
-    check(lib().swiftk_gemm_modnorm_residual_pair(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), k or a.shape[1],
-                                                  x_hi.data_ptr(), x_hi.stride(0), x_lo.data_ptr(), x_lo.stride(0), gamma.data_ptr(),
-                                                  beta.data_ptr(), mod.data_ptr(), mod.stride(0), a.shape[0], d, rows_per_sample,
-                                                  float(eps), rows_per_workgroup, _stream()), "swiftk_gemm_modnorm_residual_pair")
-
-
 def modnorm_residual_pair_slabs(y_slabs: torch.Tensor, x_hi: torch.Tensor, x_lo: torch.Tensor, gamma, beta, mod: torch.Tensor,
                                 rows_per_sample: int, d: int, eps: float = 1e-6) -> None:
     """``modnorm_residual_pair`` with the branch output as the sum of the two fp32 slabs y_slabs[0] + y_slabs[1] ([2, M, d]):
