@@ -261,7 +261,8 @@ int swiftk_axpby(float* out, float a, const float* x, float b, const float* y, i
 #define SWIFTK_PROF_ATTENTION 100
 int swiftk_profile_gemm(int epilogue, int64_t N);
 /* Tuning knobs (A/B measurements only): key 0 = GEMM variant (0 one tile per workgroup, 1 persistent pipeline),
- * key 1 = tile rows per group of the persistent tile order, key 2 = persistent grid size, keys 3 / 4 = ablation
+ * key 1 = tile rows per group of the persistent tile order, key 2 = persistent grid size of the GEMMs and of
+ * swiftk_qkv_attention_fused (256 = one workgroup per CU; fewer for a stream created with a CU mask), keys 3 / 4 = ablation
  * bits of the GEMM / attention kernels (timing experiments; results are wrong while set), key 5 = window-tiled q/k/v in
  * swiftk_swinv2_forward (1), key 6 = swiftk_modnorm_residual: bit 0 non-temporal residual-stream accesses, bit 1 chunked
  * kernel (3), key 7 = start-up stagger of the persistent GEMM's workgroups in 1/1000 of an eighth of a tile time (0),
