@@ -305,7 +305,7 @@ struct BwdPArgs {
     // q / k vectors, dscale [heads] accumulates d(logit scale); null = the gradients of q-hat / k-hat leave as they are
     const float* rn;
     float* dscale;
-    int dbg;  // timing experiments (tuning key 4, bits 16..): 1 no pass-A sweeps, 2 no pass-B loop, 4 no output stores, 8 no max sweep
+    int dbg;  // timing experiments (tuning key 4, bits 16..): 1 no pass-A sweeps, 2 no pass-B loop, 4 no output stores, 8 no max sweep, 16 Q image requested at the item's top
 };
 
 // Backward of the cosine-attention prologue (SWIFTK_EPI_QKNORM: x-hat = tau x / n) on a transposed accumulator set, in place:
@@ -466,10 +466,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
 
         // ------------------------------------------------------------------------------ pass A: K in bK, V in bV
         // (every wave is past the previous item: the third buffer is free; K(n) is complete, V(n) still landing)
-        dma_img(bF, qkv_base(b, h, 0), w, ldq_b);  // Q image for pass B lands under pass A
         // this lane's query row of q-hat and dO as MFMA B-operand fragments, and delta = dO . O of that row.  (Loading them
         // one item ahead, in front of the previous item's dk / dv stores, with a counted wait here was measured slower:
         // 571 against 481 us per launch -- 48 more live registers across the item boundary, spills inside the loops.)
+        if (pa.dbg & 16) dma_img(bF, qkv_base(b, h, 0), w, ldq_b);  // (A/B: the round-3 position, in front of the row fragments)
         uint4 qf[KS], dof[KS];
         float delta, rnq = 0.f, rnk = 0.f;
         {
@@ -507,6 +507,9 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of V have landed (under the maximum sweep) ...
         __builtin_amdgcn_s_barrier();                     // ... every wave's have
+        // Q image for pass B: requested only now, so that this item's row fragments above did not queue behind its 45 KB
+        // (VMEM returns in order); it has the whole of pass A to land
+        if (!(pa.dbg & 16)) dma_img(bF, qkv_base(b, h, 0), w, ldq_b);
         const float mb = mx * LOG2E;
         float l = 0.f;
         f32x16 dq[DB];

@@ -53,3 +53,16 @@ for k, name in ((0, "one workgroup per item"), (1, "persistent, LDS-DMA images")
     t = sorted(res[k]); med = t[len(t) // 2]
     print(f"{name:30s} median {med*1e3:8.1f} us  min {t[0]*1e3:8.1f} us  {flop/med/1e9:6.1f} TFLOP/s (5 products)")
 print("rel-L2 between the two:", float((outs[1].float() - outs[0].float()).norm() / outs[0].float().norm()))
+# A/B of single scheduling choices of the persistent kernel (tuning key 4, bits 16..), logit scales given, interleaved rounds
+ab = {"shipped": 0, "Q image requested at the item's top (round 3)": 16}
+rab = {k: [] for k in ab}
+for rnd in range(R + 2):
+    for k in (list(ab) if rnd % 2 == 0 else list(ab)[::-1]):
+        L.swiftk_set_tuning(4, ab[k] << 16); run(1, True); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): run(1, True)
+        e1.record(); torch.cuda.synchronize(); rab[k].append(e0.elapsed_time(e1) / 10)
+L.swiftk_set_tuning(4, 0)
+for k, t in rab.items():
+    t = sorted(t); print(f"A/B {k:48s} median {t[len(t)//2]*1e3:8.1f} us  min {t[0]*1e3:8.1f} us")
