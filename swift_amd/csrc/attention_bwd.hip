@@ -508,7 +508,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of V have landed (under the maximum sweep) ...
         __builtin_amdgcn_s_barrier();                     // ... every wave's have
         // Q image for pass B: requested only now, so that this item's row fragments above did not queue behind its 45 KB
-        // (VMEM returns in order); it has the whole of pass A to land
+        // (VMEM returns in order); it has the whole of pass A to land.  (An L2 look-ahead for the NEXT item's row fragments -- one
+        // 4-byte LDS-DMA per lane and tensor during pass B -- was measured too: 456 -> 466 us, like every such look-ahead here.)
         if (!(pa.dbg & 16)) dma_img(bF, qkv_base(b, h, 0), w, ldq_b);
         const float mb = mx * LOG2E;
         float l = 0.f;
