@@ -47,7 +47,7 @@ extern "C" {
 #define SWIFTK_EPI_SWIGLU 2    /* C[m][j] = silu(acc[m][2j]) * acc[m][2j+1]  (W rows interleaved gate/up) */
 #define SWIFTK_EPI_QKNORM 3    /* to_qkv: per token and head, q <- q/max(|q|,1e-12)*exp(min(ep0[h],ln100)),
                                   k <- k/max(|k|,1e-12), v unchanged (swinv2.py:123-127); ep0 = scale[heads]; head_dim
-                                  (80 / 88 / 96; 88 only with fp32 operands) travels in `pos_rows`, 0 = 88            */
+                                  (80 / 88 / 96; with fp32 operands 80 / 96 need M, N % 8 == 0) travels in `pos_rows`, 0 = 88 */
 #define SWIFTK_EPI_SWIGLU_BOTH 6 /* training forward of the FeedForward (swinv2.py:96-101): C = A W^T (bf16, the pre-activation the
                                   backward pass needs) AND C2[m][j] = silu(C[m][2j]) * C[m][2j+1]; C2 (bf16) = ep1, its row
                                   stride (elements) = pos_rows; bf16 operands only */

@@ -224,9 +224,9 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     for (int i = 0; i < m->depth; ++i) {
         const swiftk_layer& ly = m->layers_host[i];
         const bool shifted = do_shift && (i & 1);
-        // cosine-attention's normalise/scale prologue rides in the to_qkv epilogue (fp32 accumulators): head_dim 88 with
-        // either operand type, 80 / 96 (the 468 M / 664 M variants) with bf16 operands and an even head count
-        const bool fuse_norm = (hd == 88) || (dt == SWIFTK_BF16 && (hd == 80 || hd == 96) && m->heads % 2 == 0);
+        // cosine-attention's normalise/scale prologue rides in the to_qkv epilogue (fp32 accumulators): head_dim 88, and
+        // 80 / 96 (the 468 M / 664 M variants) with an even head count, either operand type
+        const bool fuse_norm = (hd == 88) || ((hd == 80 || hd == 96) && m->heads % 2 == 0 && M % 8 == 0);
         // bf16 operands, head_dim 80 / 88 / 96 (the 468 M variant, Swift-B, the 664 M variant): to_qkv, the cosine norm and the
         // window attention run as ONE kernel (q/k/v stay on the CU)
         if (dt == SWIFTK_BF16 && (hd == 80 || hd == 88 || hd == 96) && g_fwd_fused && m->wh == 16 && m->ww == 16) {
@@ -243,13 +243,13 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             // softmax as 4.5e-4 -- x3_exact bit 0 keeps the whole GEMM on the exact-fp32 kernel, bit 6 only the hot head pairs)
             RUN(G(xT, m->kd, ly.qkv_w, qkv, 3 * d, 3 * d, kdv, d, dt, fuse_norm ? SWIFTK_EPI_QKNORM : SWIFTK_EPI_NONE,
                   fuse_norm ? ly.scale : nullptr, nullptr, fuse_norm ? hd : 0, (x3_exact & 1) != 0));
-            // (bit 6 without bit 0 promises the hot-pair recompute: a model it cannot serve -- another head_dim, or hot pairs
+            // (bit 6 without bit 0 promises the hot-pair recompute: a model it cannot serve -- no fused norm, or hot pairs
             // without their fp32 weights -- is refused rather than run fully split)
-            if (x3 && (x3_exact & 64) && !(x3_exact & 1) && (!fuse_norm || hd != 88 || (ly.qk_exact_pairs && !ly.qkv_w_f32)))
+            if (x3 && (x3_exact & 64) && !(x3_exact & 1) && (!fuse_norm || (ly.qk_exact_pairs && !ly.qkv_w_f32)))
                 return SWIFTK_EINVAL;
             if (x3 && (x3_exact & 64) && !(x3_exact & 1) && ly.qkv_w_f32) {
                 // adaptive to_qkv of the split engine: the head pairs whose logit scale is large enough for the split product's
-                // 4.5e-6 to matter in front of the softmax are recomputed on the exact-fp32 kernel -- 528 output columns each,
+                // 4.5e-6 to matter in front of the softmax are recomputed on the exact-fp32 kernel -- 6 head_dim output columns each,
                 // written over the split result (same QK-norm epilogue, the pair's two logit scales)
                 for (int pp = 0; 2 * pp < m->heads; ++pp) {
                     if (!((ly.qk_exact_pairs >> pp) & 1)) continue;

@@ -1512,7 +1512,14 @@ int launch(const GemmArgs& g, hipStream_t st) {
                 else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 12, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
                 else hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
             }
+        } else if constexpr (EPI == SWIFTK_EPI_QKNORM) {
+            // fp32 operands: 352-wide tiles, and for the cosine-attention epilogue also the 320- / 384-wide ones (a tile must hold
+            // whole head pairs: head_dim 80 / 96, the exact engine and the split engine's hot head pairs on the larger variants)
+            if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 10, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+            else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 12, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+            else hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
         } else {
+            if (g.ni != NI) return SWIFTK_ESHAPE;
             hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
         }
     }
@@ -1704,12 +1711,12 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || (lda * es) % 16 || (ldw * es) % 16) return SWIFTK_EALIGN;
     if (((uintptr_t)C % ovec) || (ldc * os) % ovec) return SWIFTK_EALIGN;
     // QKNORM: whole heads of 3 x head_dim columns, a wave tile = two head vectors -> tile width 4 x head_dim; head_dim
-    // travels in `pos_rows` (0 = 88); fp32 operands are built for 88 only
+    // travels in `pos_rows` (0 = 88); fp32 operands: whole tiles only for 80 / 96 (M, N multiples of 8)
     int ni = 11;
     if (epilogue == SWIFTK_EPI_QKNORM) {
         const int64_t hd = pos_rows > 0 ? pos_rows : 88;
         if (!ep0 || (hd != 80 && hd != 88 && hd != 96) || N % (6 * hd) != 0) return SWIFTK_ESHAPE;
-        if (hd != 88 && dtype != SWIFTK_BF16) return SWIFTK_ESHAPE;
+        if (hd != 88 && dtype != SWIFTK_BF16 && (g_variant == 0 || (M & 7) || (N & 7))) return SWIFTK_ESHAPE;
         ni = (int)(hd / 8);
     } else if (dtype == SWIFTK_BF16 && N % 352 != 0) {  // tile width that divides N, if one does (dim 1280 / 1536 families)
         if (N % 384 == 0) ni = 12;

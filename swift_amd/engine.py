@@ -58,9 +58,10 @@ class SwinEngine:
         # product's 4.5e-6 reaches the softmax multiplied by the scale: 1.1e-4 at 25, 4.5e-4 at the clamp's 100).
         exact_mask = int(os.environ.get("SWIFTK_X3_EXACT", "80"))  # travels in the model descriptor (mo.x3_exact), per engine
         tau_max = float(os.environ.get("SWIFTK_X3_TAU", "25"))
-        adaptive = x3 and bool(exact_mask & 64) and not (exact_mask & 1) and m.heads % 2 == 0 and (m.dim // m.heads) == 88
+        adaptive = (x3 and bool(exact_mask & 64) and not (exact_mask & 1) and m.heads % 2 == 0
+                    and (m.dim // m.heads) in (80, 88, 96))
         if x3 and (exact_mask & 64) and not adaptive:
-            # the hot-pair recompute exists for head_dim 88 and an even head count only: any other shape keeps to_qkv on the exact
+            # the hot-pair recompute exists for head_dim 80 / 88 / 96 and an even head count only: any other shape keeps to_qkv on the exact
             # kernel (bit 0, the round-3 default) instead of running it fully split with no recompute (2.8e-4 on Swift-B)
             exact_mask = (exact_mask & ~64) | 1
         dt = torch.float32 if x3 else self.dtype  # activations, k-paddings and every non-GEMM kernel

@@ -475,9 +475,11 @@ def _prenorm_reference(qkv, scale, heads, hd):
     return v.reshape(B, n, -1)
 
 
-@pytest.mark.parametrize("dt,hd", [(torch.float32, 88), (torch.bfloat16, 88), (torch.bfloat16, 80), (torch.bfloat16, 96)])
+@pytest.mark.parametrize("dt,hd", [(torch.float32, 88), (torch.bfloat16, 88), (torch.bfloat16, 80), (torch.bfloat16, 96),
+                                   (torch.float32, 80), (torch.float32, 96)])
 def test_gemm_qknorm_epilogue(dev, dt, hd):
-    """head_dim 80 / 96 (dim 1280 / 1536 with 16 heads in the reference's larger variants): 320- / 384-wide GEMM tiles."""
+    """head_dim 80 / 96 (dim 1280 / 1536 with 16 heads in the reference's larger variants): 320- / 384-wide GEMM tiles, with bf16
+    and (round 5: the exact engine and the split engine's hot head pairs on those variants) fp32 operands."""
     from swift_amd import ops
     M, heads = 1024, 12
     K = ops.k_pad(dt, heads * hd)

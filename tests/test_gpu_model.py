@@ -133,6 +133,14 @@ def test_forward_other_swift_variants_vs_oracle(dev, name, c):
     e32, e16, e3 = rel_l2(y.cpu(), yo), rel_l2(yb.cpu(), yo), rel_l2(y3.cpu(), yo)
     print(f"{name}: fp32 rel-L2 {e32:.3e}, bf16x3 rel-L2 {e3:.3e}, bf16 rel-L2 {e16:.3e}")
     assert e32 < FP32_TOL and e16 < BF16_TOL and e3 < FP32_TOL
+    # the split engine's to_qkv is the ADAPTIVE form at every head_dim the QK-norm epilogue serves (80 / 88 / 96): split
+    # products, the head pairs with a large logit scale recomputed on the exact-fp32 kernel (mask bit 6 kept, bit 0 clear) --
+    # and these nets do have such pairs (scales up to ln 100)
+    eng3 = net.model._engines["bf16x3"]
+    mask = int(eng3.model.x3_exact)
+    hot = [int(eng3.model.layers_host[i].qk_exact_pairs) for i in range(c["depth"])]
+    print(f"  split engine: x3_exact mask {mask}, hot head pairs per layer {hot}")
+    assert (mask & 64) and not (mask & 1) and any(hot)
 
 
 def test_forward_batch16_vs_oracle(dev):
