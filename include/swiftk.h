@@ -474,6 +474,13 @@ int swiftk_split3(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t
 int swiftk_cast_pad(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype,
                     void* stream);
 
+/* A trainable weight's two bf16 GEMM operands from its fp32 master copy in one pass (the training engine refreshes them after every
+ * optimizer step): out [rows, ldo] = bf16(W) with zeroed row padding -- the forward operand -- and out_t [cols, ldt] = bf16(W)^T with
+ * zeroed row padding -- the "W" of the data-gradient GEMM dX = dY W.  interleave = n > 0 (rows == 2 n): output row 2 j + s takes
+ * input row s n + j, the (gate, up) interleave SWIFTK_EPI_SWIGLU wants of FeedForward.w1 (swinv2.py:96-101). */
+int swiftk_cast_pad_t(const float* W, int64_t ldw, int64_t rows, int64_t cols, void* out, int64_t ldo, void* out_t, int64_t ldt,
+                      int64_t interleave, void* stream);
+
 /*
  * to_qkv + cosine norm + shifted-window attention of one layer in one kernel (bf16; head_dim 80 / 88 / 96 = the 468 M variant,
  * Swift-B, the 664 M variant of configs/experiment/era5-swinv2-1.4-scm.yaml:21-36; 16 x 16 windows; K >= 128): the q / k / v

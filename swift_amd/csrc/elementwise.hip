@@ -1318,6 +1318,48 @@ extern "C" int swiftk_cast_pad(const float* src, int64_t lds, void* dst, int64_t
     return 0;
 }
 
+// A trainable weight's two bf16 GEMM operands in one pass over the fp32 master copy: out[r'][c] = W[r][c] (row padding zeroed up to
+// ldo) and out_t[c][r'] = the same value (padding zeroed up to ldt), r' = r or, for w1, the (gate, up)-interleaved row 2 (r % inter)
+// + r / inter.  64 x 64 tiles through LDS; both stores walk consecutive addresses.
+__global__ __launch_bounds__(256) void cast_pad_t_kernel(const float* __restrict__ W, int64_t ldw, int rows, int cols,
+                                                         bf16_t* __restrict__ out, int64_t ldo, bf16_t* __restrict__ out_t, int64_t ldt,
+                                                         int inter) {
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int rp = r0 + ty + 4 * k, c = c0 + tx;
+        float v = 0.f;
+        if (rp < rows && c < cols) {
+            const int r = inter ? (rp & 1) * inter + (rp >> 1) : rp;
+            v = W[(int64_t)r * ldw + c];
+        }
+        tile[ty + 4 * k][tx] = v;
+        if (rp < rows && c < ldo) out[(int64_t)rp * ldo + c] = f2bf(v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = c0 + ty + 4 * k, rp = r0 + tx;
+        if (c < cols && rp < ldt) out_t[(int64_t)c * ldt + rp] = f2bf(tile[tx][ty + 4 * k]);
+    }
+}
+
+extern "C" int swiftk_cast_pad_t(const float* W, int64_t ldw, int64_t rows, int64_t cols, void* out, int64_t ldo, void* out_t,
+                                 int64_t ldt, int64_t interleave, void* stream) {
+    if (!W || !out || !out_t || rows <= 0 || cols <= 0 || ldw < cols || ldo < cols || ldt < rows) return SWIFTK_EINVAL;
+    if (rows > (1 << 30) || cols > (1 << 30) || ldo > (1 << 30) || ldt > (1 << 30)) return SWIFTK_ESHAPE;
+    if (interleave < 0 || (interleave > 0 && rows != 2 * interleave)) return SWIFTK_ESHAPE;
+    const int64_t rmax = rows > ldt ? rows : ldt, cmax = cols > ldo ? cols : ldo;
+    const dim3 grid((unsigned)((cmax + 63) / 64), (unsigned)((rmax + 63) / 64));
+    if (grid.y > 65535) return SWIFTK_ESHAPE;
+    hipLaunchKernelGGL(cast_pad_t_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), W, ldw, (int)rows, (int)cols,
+                       static_cast<bf16_t*>(out), ldo, static_cast<bf16_t*>(out_t), ldt, (int)interleave);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int swiftk_split3(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int order,
                              void* stream) {
     if (!src || !dst || rows <= 0 || cols <= 0 || lds < cols || ldd < 3 * cols || (order != 0 && order != 1)) return SWIFTK_EINVAL;

@@ -56,6 +56,16 @@ def pad_cols(w: torch.Tensor, k: int, dtype: torch.dtype, out: Optional[torch.Te
     return out
 
 
+def cast_pad_t(w: torch.Tensor, out: torch.Tensor, out_t: torch.Tensor, interleave: int = 0) -> None:
+    """bf16 operand copies of an fp32 weight in one pass: ``out`` [rows, >=cols] = w (w1: rows (gate, up)-interleaved when
+    ``interleave`` = mlp), ``out_t`` [cols, >=rows] = its transpose; row paddings zeroed."""
+    _dev(w, out, out_t)
+    assert w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1 and out.dtype == out_t.dtype == torch.bfloat16
+    assert out.shape[0] == w.shape[0] and out_t.shape[0] == w.shape[1] and out.stride(1) == 1 and out_t.stride(1) == 1
+    check(lib().swiftk_cast_pad_t(w.data_ptr(), w.stride(0), w.shape[0], w.shape[1], out.data_ptr(), out.stride(0), out_t.data_ptr(),
+                                  out_t.stride(0), int(interleave), _stream()), "swiftk_cast_pad_t")
+
+
 def split3(w: torch.Tensor, order: int, cols: Optional[int] = None) -> torch.Tensor:
     """fp32 [rows, c] -> bf16 [rows, k_pad(bf16, 3 * cols)]: the three-block (hi / lo) operand of the bf16x3 engine
     (``swiftk_split3``; order 0 = activations [hi | lo | hi], 1 = weights [hi | hi | lo]).  ``cols`` >= c: zero columns are

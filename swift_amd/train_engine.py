@@ -109,6 +109,18 @@ class SwinTrainEngine:
         def tr(w, k):  # W^T operand for the data gradient
             return cast(w.detach().t().contiguous(), k)
 
+        def both(w, k, kt, inter=0):
+            """(forward operand [rows, k], data-gradient operand W^T [cols, kt]) of an fp32 weight in one pass over it;
+            ``inter`` = mlp: rows leave (gate, up)-interleaved (``swiftk_cast_pad_t``)."""
+            ctr[0] += 2
+            w = w.detach()
+            if w.dtype != torch.float32 or w.stride(1) != 1:
+                w = w.float().contiguous()
+            a = self._keep(f"c{ctr[0] - 1}", lambda: torch.empty(w.shape[0], k, dtype=_BF, device=dev0), lambda b: None)
+            b_ = self._keep(f"c{ctr[0]}", lambda: torch.empty(w.shape[1], kt, dtype=_BF, device=dev0), lambda b: None)
+            ops.cast_pad_t(w, a, b_, inter)
+            return a, b_
+
         def keep_f32(t):
             ctr[0] += 1
             t = t.detach().float()
@@ -117,17 +129,19 @@ class SwinTrainEngine:
 
         self.L = []
         for att, ff in m.transformer.layers:
-            w1i = ff.w1.weight.detach().view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)
-            w2p = ff.w2.weight.detach()
-            if mlp_e != mlp:
+            qkv, qkv_t = both(att.to_qkv.weight, self.kd, self.kqkv)
+            wo, wo_t = both(att.wo.weight, self.kd, self.kd)
+            if mlp_e != mlp:  # (the padded MLP width of dim 1280: interleave and zero-extend on the host side, then one pass each)
+                w1i = ff.w1.weight.detach().view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)
                 w1i = torch.cat([w1i, w1i.new_zeros(2 * (mlp_e - mlp), d)], 0)
-                w2p = torch.cat([w2p, w2p.new_zeros(d, mlp_e - mlp)], 1)
-            self.L.append(dict(
-                qkv=cast(att.to_qkv.weight, self.kd), qkv_t=tr(att.to_qkv.weight, self.kqkv),
-                wo=cast(att.wo.weight, self.kd), wo_t=tr(att.wo.weight, self.kd),
-                w1=cast(w1i, self.kd), w1_t=tr(w1i, self.kh),
-                w2=cast(w2p, self.kmlp), w2_t=tr(w2p, self.kd),
-                scale=att.scale.detach().reshape(-1).float().contiguous()))
+                w2p = torch.cat([ff.w2.weight.detach(), ff.w2.weight.new_zeros(d, mlp_e - mlp)], 1)
+                w1, w1_t = both(w1i, self.kd, self.kh)
+                w2, w2_t = both(w2p, self.kmlp, self.kd)
+            else:
+                w1, w1_t = both(ff.w1.weight, self.kd, self.kh, inter=mlp)
+                w2, w2_t = both(ff.w2.weight, self.kmlp, self.kd)
+            self.L.append(dict(qkv=qkv, qkv_t=qkv_t, wo=wo, wo_t=wo_t, w1=w1, w1_t=w1_t, w2=w2, w2_t=w2_t,
+                               scale=att.scale.detach().reshape(-1).float().contiguous()))
         self.pe = cast(m.patch_embed.emb.weight, self.kpe)
         self.pe_t = tr(m.patch_embed.emb.weight, self.kd)
         hw = m.head.head[0].weight.detach()

@@ -378,6 +378,21 @@ def test_modnorm_residual_pair_from_splitk_slabs(dev, lo_bits):
     assert e_bf < 3e-3 and e_bf < 2.0 * e_one
 
 
+@pytest.mark.parametrize("rows,cols,inter", [(3168, 1056, 0), (5632, 1056, 2816), (1056, 2816, 0), (276, 1056, 0), (70, 130, 35)])
+def test_cast_pad_t_both_operands(dev, rows, cols, inter):
+    """swiftk_cast_pad_t: a weight's forward operand (bf16, zero-padded rows; w1: (gate, up)-interleaved as SWIFTK_EPI_SWIGLU reads
+    it, swinv2.py:96-101) and its transpose (the data-gradient GEMM's operand) in one pass -- bit-equal to torch's casts."""
+    from swift_amd import ops
+    w = rnd((rows, cols), 71, 0.03).to(dev)
+    ko, kt = ops.k_pad(torch.bfloat16, cols), ops.k_pad(torch.bfloat16, rows)
+    out = torch.full((rows, ko), 7.0, dtype=torch.bfloat16, device=dev)
+    out_t = torch.full((cols, kt), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.cast_pad_t(w, out, out_t, inter)
+    ref = w.view(2, inter, cols).permute(1, 0, 2).reshape(rows, cols) if inter else w
+    assert torch.equal(out[:, :cols], ref.bfloat16()) and (out[:, cols:].float() == 0).all()
+    assert torch.equal(out_t[:, :rows], ref.bfloat16().t()) and (out_t[:, rows:].float() == 0).all()
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_patchify_three_sources(dev, dt):
     from oracle.swinv2 import patchify
