@@ -380,6 +380,12 @@ int swiftk_window_attention_bwd_scaled(const void* qkvh, int64_t ldq, const void
 
 /* out[c] += sum_r src[r][c]  (period == 0), or out[(r % period)][c] += src[r][c]  (bias / pos_embed gradients) */
 int swiftk_colsum(const float* src, int64_t lds, float* out, int64_t rows, int cols, int64_t period, void* stream);
+/* The patch embedding's backward bookkeeping in one pass over d(x0) [rows = samples x period, cols] (reference: autograd of
+ * `patch_embed(x) + pos_embed`, swinv2.py:309-310): bias_grad[c] += sum_r src[r][c], pos_grad[t][c] += sum_b src[b period + t][c]
+ * (fixed order, no atomics), and -- dst_bf16 != NULL -- the bf16 copy [rows, ldd] with zeroed row padding that the weight-gradient
+ * GEMM reads.  Replaces two swiftk_colsum calls and a swiftk_cast_pad. */
+int swiftk_embed_bwd_sums(const float* src, int64_t lds, float* bias_grad, float* pos_grad, void* dst_bf16, int64_t ldd, int64_t rows,
+                          int cols, int64_t period, void* stream);
 /* Backward of swiftk_linear_small (pre-activation gradient dz): dx += dz W (dx zero-filled by the caller, may be NULL),
  * dW += dz^T x, dbias += sum_b dz (dW/dbias may be NULL). */
 int swiftk_linear_small_bwd(const float* dz, int64_t lddz, const float* x, int64_t ldx, const float* W, int64_t ldw, float* dx,

@@ -534,6 +534,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ s
     }
 }
 
+// The patch embedding's three consumers of d(x0) [samples x period rows, cols] in ONE pass: bias[c] += sum over all rows,
+// pos[t][c] += sum over the samples of row (b period + t) -- a thread owns (t, c), so no atomics and a fixed summation order
+// -- and the bf16 copy (row padding zeroed) the weight-gradient GEMM reads.  A block takes 8 consecutive tokens.
+__global__ __launch_bounds__(256) void embed_bwd_sums_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ bias,
+                                                             float* __restrict__ pos, bf16_t* __restrict__ dst, int64_t ldd,
+                                                             int nsamp, int64_t period, int cols) {
+    constexpr int TB = 8;  // tokens per block (must match the launcher)
+    const int64_t t0 = (int64_t)blockIdx.x * TB;
+    for (int c = threadIdx.x; c < (dst ? (int)ldd : cols); c += 256) {
+        float sb = 0.f;
+        for (int64_t t = t0; t < min(t0 + TB, period); t += 2) {
+            float s[2] = {0.f, 0.f};
+            const bool two = t + 1 < period;
+            for (int b0 = 0; b0 < nsamp; b0 += 8) {  // two tokens x eight samples: sixteen loads in flight before anything is stored
+                float v[2][8];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        v[u][j] = (c < cols && b0 + j < nsamp && (u == 0 || two)) ? src[((int64_t)(b0 + j) * period + t + u) * lds + c] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        s[u] += v[u][j];
+                        if (dst && b0 + j < nsamp && (u == 0 || two)) dst[((int64_t)(b0 + j) * period + t + u) * ldd + c] = f2bf(v[u][j]);
+                    }
+            }
+            if (c < cols) {
+                pos[t * cols + c] += s[0];
+                if (two) pos[(t + 1) * cols + c] += s[1];
+            }
+            sb += s[0] + s[1];
+        }
+        if (c < cols) atomicAdd(bias + c, sb);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ small linear backward
 // y[b][n] = act(x[b][:] . W[n][:] + bias[n]) with B <= 64 (time-embedding MLP, modulation, logvar)
 //   dz = dy * act'(z) (act = SiLU needs y's pre-activation z; we recompute from y via saved z),
@@ -550,12 +588,18 @@ __global__ __launch_bounds__(256) void small_dgrad_kernel(const float* __restric
     for (int b0 = 0; b0 < B; b0 += 8) {
         float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int nb = min(8, B - b0);
-#pragma unroll 4
-        for (int n = n0; n < n1; ++n) {
-            const float w = W[(int64_t)n * ldw + k];
+        // (sixteen weight rows' loads in flight per thread: with four the kernel ran at a third of the HBM rate)
+        for (int nn = n0; nn < n1; nn += 16) {
+            float w[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < nb) s[j] += dz[(int64_t)(b0 + j) * lddz + n] * w;
+            for (int i = 0; i < 16; ++i) w[i] = nn + i < n1 ? W[(int64_t)(nn + i) * ldw + k] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (nn + i < n1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j < nb) s[j] += dz[(int64_t)(b0 + j) * lddz + nn + i] * w[i];
+                }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -565,15 +609,36 @@ __global__ __launch_bounds__(256) void small_dgrad_kernel(const float* __restric
 __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restrict__ dz, int64_t lddz,
                                                           const float* __restrict__ x, int64_t ldx, float* __restrict__ dW,
                                                           int64_t lddw, float* __restrict__ dbias, int B, int N, int K) {
-    const int n = blockIdx.x;
-    float db = 0.f;
-    for (int b = 0; b < B; ++b) db += dz[(int64_t)b * lddz + n];
+    // a block owns WG_ROWS consecutive rows n of dW (the modulation Linears: 50,688 rows of 4 KB -- one row per block left the
+    // kernel bound by block turnover): a thread keeps the samples' x[b][k] in registers for eight samples at a time and
+    // updates its k of every row, so eight independent read-modify-writes are in flight per thread
+    constexpr int WG_ROWS = 8;
+    const int n0 = blockIdx.x * WG_ROWS, nr = min(WG_ROWS, N - n0);
     for (int k = threadIdx.x; k < K; k += 256) {
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += dz[(int64_t)b * lddz + n] * x[(int64_t)b * ldx + k];
-        dW[(int64_t)n * lddw + k] += s;
+        float s[WG_ROWS];
+#pragma unroll
+        for (int r = 0; r < WG_ROWS; ++r) s[r] = 0.f;
+        for (int b0 = 0; b0 < B; b0 += 8) {
+            float xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = b0 + j < B ? x[(int64_t)(b0 + j) * ldx + k] : 0.f;
+#pragma unroll
+            for (int r = 0; r < WG_ROWS; ++r)
+                if (r < nr) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (b0 + j < B) s[r] += dz[(int64_t)(b0 + j) * lddz + n0 + r] * xv[j];
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < WG_ROWS; ++r)
+            if (r < nr) dW[(int64_t)(n0 + r) * lddw + k] += s[r];
     }
-    if (dbias && threadIdx.x == 0) dbias[n] += db;
+    if (dbias && threadIdx.x < nr) {
+        float db = 0.f;
+        for (int b = 0; b < B; ++b) db += dz[(int64_t)b * lddz + n0 + threadIdx.x];
+        dbias[n0 + threadIdx.x] += db;
+    }
 }
 // dz = dy * silu'(z): silu'(z) = s (1 + z (1 - s))
 __global__ void silu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dy, float* __restrict__ dz, int64_t n) {
@@ -941,6 +1006,16 @@ extern "C" int swiftk_colsum(const float* src, int64_t lds, float* out, int64_t 
     return 0;
 }
 
+extern "C" int swiftk_embed_bwd_sums(const float* src, int64_t lds, float* bias_grad, float* pos_grad, void* dst_bf16, int64_t ldd,
+                                     int64_t rows, int cols, int64_t period, void* stream) {
+    if (!src || !bias_grad || !pos_grad || rows <= 0 || cols <= 0 || period <= 0 || lds < cols) return SWIFTK_EINVAL;
+    if (rows % period || rows / period > (1 << 20) || (dst_bf16 && (ldd < cols || ldd > (1 << 30)))) return SWIFTK_ESHAPE;
+    hipLaunchKernelGGL(embed_bwd_sums_kernel, dim3((unsigned)((period + 7) / 8)), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                       lds, bias_grad, pos_grad, static_cast<bf16_t*>(dst_bf16), ldd, (int)(rows / period), period, cols);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int swiftk_linear_small_bwd(const float* dz, int64_t lddz, const float* x, int64_t ldx, const float* W, int64_t ldw,
                                        float* dx, int64_t lddx, float* dW, int64_t lddw, float* dbias, int B, int N, int K,
                                        void* stream) {
@@ -954,7 +1029,7 @@ extern "C" int swiftk_linear_small_bwd(const float* dz, int64_t lddz, const floa
     }
     if (dW) {
         if (!x) return SWIFTK_EINVAL;
-        hipLaunchKernelGGL(small_wgrad_kernel, dim3(N), dim3(256), 0, st, dz, lddz, x, ldx, dW, lddw, dbias, B, N, K);
+        hipLaunchKernelGGL(small_wgrad_kernel, dim3((N + 7) / 8), dim3(256), 0, st, dz, lddz, x, ldx, dW, lddw, dbias, B, N, K);
         SWIFTK_CHECK_LAUNCH();
     }
     return 0;

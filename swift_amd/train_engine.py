@@ -420,9 +420,9 @@ class SwinTrainEngine:
                 grads_final([p for n, p in m.transformer.layers[i].named_parameters() if "modulation" not in n])
         # ---- patch embedding: x0 = ape @ Wpe^T + b + pos
         G(m.pos_embed).view(ntok, d)  # ensure buffer exists
-        check(L.swiftk_colsum(dx.data_ptr(), d, G(m.patch_embed.emb.bias).data_ptr(), M, d, 0, _s()), "swiftk_colsum")
-        check(L.swiftk_colsum(dx.data_ptr(), d, m.pos_embed.grad.data_ptr(), M, d, ntok, _s()), "swiftk_colsum")
-        dxb = ops.pad_cols(dx, self.kd, _BF)
+        dxb = torch.empty(M, self.kd, dtype=_BF, device=dev)
+        check(L.swiftk_embed_bwd_sums(dx.data_ptr(), d, G(m.patch_embed.emb.bias).data_ptr(), m.pos_embed.grad.data_ptr(),
+                                      dxb.data_ptr(), self.kd, M, d, ntok, _s()), "swiftk_embed_bwd_sums")
         pf = m.in_channels * p1 * p2
         gpe = torch.empty(d, self.kpe, dtype=torch.float32, device=dev)  # kpe (multiple of 8) columns; the pad ones are 0
         self._wgrad(dxb, ctx["ape"], d, self.kpe, gpe, accumulate=False)

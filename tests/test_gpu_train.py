@@ -104,6 +104,51 @@ def test_tn_wgrad_rejects_what_it_cannot_read(dev):
     assert L.swiftk_gemm_tn_splitk(*args(1056, 1280, 1024, 1056, 256)) == 0
 
 
+def test_embed_bwd_sums_one_pass(dev):
+    """swiftk_embed_bwd_sums: bias and pos_embed gradients (both ACCUMULATE) and the bf16 copy of d(x0) in one pass, against torch
+    (autograd of `patch_embed(x) + pos_embed`, swinv2.py:309-310).  The per-token sums have a fixed order: bit-reproducible."""
+    from swift_amd import _lib
+    L = _lib.lib()
+    B, ntok, d, ld = 3, 200, 1056, 1088  # (200 tokens: a ragged last block of 16)
+    dx = rnd((B * ntok, d), 81).to(dev)
+    bias0, pos0 = rnd((d,), 82).to(dev), rnd((ntok, d), 83).to(dev)
+    outs = []
+    for _ in range(2):
+        bias, pos = bias0.clone(), pos0.clone()
+        dst = torch.full((B * ntok, ld), 7.0, dtype=BF, device=dev)
+        _lib.check(L.swiftk_embed_bwd_sums(dx.data_ptr(), d, bias.data_ptr(), pos.data_ptr(), dst.data_ptr(), ld, B * ntok, d, ntok, s()),
+                   "swiftk_embed_bwd_sums")
+        outs.append((bias, pos, dst))
+    bias, pos, dst = outs[0]
+    assert rel_l2((bias - bias0).cpu(), dx.sum(0).cpu()) < 1e-6
+    assert rel_l2((pos - pos0).cpu(), dx.view(B, ntok, d).sum(0).cpu()) < 1e-6
+    assert torch.equal(dst[:, :d], dx.bfloat16()) and (dst[:, d:].float() == 0).all()
+    assert torch.equal(outs[1][1], pos) and torch.equal(outs[1][2], dst)
+    # without the copy
+    bias2, pos2 = bias0.clone(), pos0.clone()
+    _lib.check(L.swiftk_embed_bwd_sums(dx.data_ptr(), d, bias2.data_ptr(), pos2.data_ptr(), None, 0, B * ntok, d, ntok, s()), "sums")
+    assert torch.equal(pos2, pos) and rel_l2(bias2.cpu(), bias.cpu()) < 1e-6
+    assert L.swiftk_embed_bwd_sums(dx.data_ptr(), d, bias2.data_ptr(), pos2.data_ptr(), None, 0, B * ntok, d, 7, s()) != 0  # rows % period
+
+
+@pytest.mark.parametrize("B,N,K", [(8, 50688, 1056), (5, 1056, 1056), (8, 13, 70), (2, 1, 1056)])
+def test_linear_small_bwd(dev, B, N, K):
+    """swiftk_linear_small_bwd (time-embedding MLP, the 2 x depth modulation Linears as one [4 depth d, d] matrix, logvar head):
+    dx = dz W, dW += dz^T x, dbias += sum_b dz against torch, including row counts that are not a multiple of the kernel's
+    eight rows per block and the wide n-chunks of the big matrix."""
+    from swift_amd import _lib
+    L = _lib.lib()
+    dz, x, w = rnd((B, N), 91).to(dev), rnd((B, K), 92).to(dev), rnd((N, K), 93, 0.03).to(dev)
+    dx = torch.zeros(B, K, device=dev)
+    dW0, db0 = rnd((N, K), 94).to(dev), rnd((N,), 95).to(dev)
+    dW, db = dW0.clone(), db0.clone()
+    _lib.check(L.swiftk_linear_small_bwd(dz.data_ptr(), N, x.data_ptr(), K, w.data_ptr(), K, dx.data_ptr(), K, dW.data_ptr(), K,
+                                         db.data_ptr(), B, N, K, s()), "swiftk_linear_small_bwd")
+    assert rel_l2(dx.cpu(), (dz.double() @ w.double()).float().cpu()) < 1e-5
+    assert rel_l2((dW - dW0).cpu(), (dz.double().t() @ x.double()).float().cpu()) < 1e-5
+    assert rel_l2((db - db0).cpu(), dz.sum(0).cpu()) < 1e-5
+
+
 def test_swiglu_fwd_bwd(dev):
     from swift_amd import _lib
     L = _lib.lib()
