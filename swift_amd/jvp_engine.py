@@ -89,14 +89,37 @@ class SwinJvpEngine:
             t = t.detach().float()
             return keep(f"f{ctr[0]}", lambda: torch.empty_like(t, memory_format=torch.contiguous_format), lambda b: b.copy_(t))
 
+        # the sCM loss runs this engine's pass and the training engine's backward on the same weights (loss.py:212-237): with bf16
+        # operands and an MLP width both engines pad alike, the four GEMM operands per layer are the training engine's (one cast
+        # per optimizer step instead of two, and no second (gate, up) interleave of w1)
+        te = getattr(m, "_train_engine", None)
+        share = te is not None and dt == torch.bfloat16 and mlp % 4 == 0
+        if share:
+            te.refresh()
+            share = te.kd == self.kd and te.kmlp == self.kmlp and len(te.L) == len(m.transformer.layers)
+        if getattr(self, "_share", share) != share:
+            self.graphs.invalidate()  # (captured sequences hold the other set of operand addresses)
+        self._share = share
+        def keep_cat(name, ts):  # fp32 concatenation written straight into its persistent buffer
+            ts = [t.float() for t in ts]
+            if name not in self._buf:
+                self._buf[name] = torch.cat(ts, 0)
+            else:
+                torch.cat(ts, 0, out=self._buf[name])
+            return self._buf[name]
+
         self.L = []
         mods_w, mods_b = [], []
-        for att, ff in m.transformer.layers:
-            w1i = ff.w1.weight.detach().view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)  # (gate_j, up_j) interleaved
-            if mlp_e != mlp:
-                w1i = torch.cat([w1i, w1i.new_zeros(2, d)], 0)
-            self.L.append(dict(qkv=cast(att.to_qkv.weight, self.kd), wo=cast(att.wo.weight, self.kd), w1=cast(w1i, self.kd),
-                               w2=cast(ff.w2.weight, self.kmlp), scale=att.scale.detach().reshape(-1).float().contiguous(),
+        for li, (att, ff) in enumerate(m.transformer.layers):
+            if share:
+                ops4 = {k: te.L[li][k] for k in ("qkv", "wo", "w1", "w2")}
+            else:
+                w1i = ff.w1.weight.detach().view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)  # (gate_j, up_j) interleaved
+                if mlp_e != mlp:
+                    w1i = torch.cat([w1i, w1i.new_zeros(2, d)], 0)
+                ops4 = dict(qkv=cast(att.to_qkv.weight, self.kd), wo=cast(att.wo.weight, self.kd), w1=cast(w1i, self.kd),
+                            w2=cast(ff.w2.weight, self.kmlp))
+            self.L.append(dict(**ops4, scale=att.scale.detach().reshape(-1).float().contiguous(),
                                g1=att.norm.norm.weight.detach().float().contiguous(),
                                b1=att.norm.norm.bias.detach().float().contiguous(),
                                g2=ff.norm.norm.weight.detach().float().contiguous(),
@@ -108,7 +131,7 @@ class SwinJvpEngine:
         if hw.shape[0] % 4:  # GEMM N granularity (1x1 patches: 69 -> 72 output columns, the zero ones unused)
             hw = torch.cat([hw, hw.new_zeros(4 - hw.shape[0] % 4, hw.shape[1])], 0)
         self.head = cast(hw, self.kd)
-        self.mod_w, self.mod_b = keep_f32(torch.cat(mods_w, 0)), keep_f32(torch.cat(mods_b, 0))
+        self.mod_w, self.mod_b = keep_cat("mod_w", mods_w), keep_cat("mod_b", mods_b)
         half = d // 2
         if "freqs" not in self._buf:
             self._buf["freqs"] = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32) / half).to(dev0)

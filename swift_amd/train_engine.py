@@ -153,7 +153,15 @@ class SwinTrainEngine:
         for att, ff in m.transformer.layers:
             mods_w += [att.norm.modulation.weight.detach(), ff.norm.modulation.weight.detach()]
             mods_b += [att.norm.modulation.bias.detach(), ff.norm.modulation.bias.detach()]
-        self.mod_w, self.mod_b = keep_f32(torch.cat(mods_w, 0)), keep_f32(torch.cat(mods_b, 0))
+        def keep_cat(name, ts):  # fp32 concatenation written straight into its persistent buffer
+            ts = [t.float() for t in ts]
+            if name not in self._buf:
+                self._buf[name] = torch.cat(ts, 0)
+            else:
+                torch.cat(ts, 0, out=self._buf[name])
+            return self._buf[name]
+
+        self.mod_w, self.mod_b = keep_cat("mod_w", mods_w), keep_cat("mod_b", mods_b)
         half = d // 2
         if "freqs" not in self._buf:
             self._buf["freqs"] = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32) / half).to(dev0)
