@@ -606,33 +606,53 @@ __global__ __launch_bounds__(256) void small_dgrad_kernel(const float* __restric
             if (j < nb) atomicAdd(dx + (int64_t)(b0 + j) * lddx + k, s[j]);
     }
 }
+template <int WG_ROWS>
 __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restrict__ dz, int64_t lddz,
                                                           const float* __restrict__ x, int64_t ldx, float* __restrict__ dW,
                                                           int64_t lddw, float* __restrict__ dbias, int B, int N, int K) {
     // a block owns WG_ROWS consecutive rows n of dW (the modulation Linears: 50,688 rows of 4 KB -- one row per block left the
     // kernel bound by block turnover): a thread keeps the samples' x[b][k] in registers for eight samples at a time and
     // updates its k of every row, so eight independent read-modify-writes are in flight per thread
-    constexpr int WG_ROWS = 8;
     const int n0 = blockIdx.x * WG_ROWS, nr = min(WG_ROWS, N - n0);
-    for (int k = threadIdx.x; k < K; k += 256) {
-        float s[WG_ROWS];
+    // the block's dz values (eight samples x eight rows per round) go through LDS once: read per use as wave-uniform global
+    // loads they made every FMA wait for a scalar load
+    __shared__ float sdz[8][WG_ROWS];
+    float s[5][WG_ROWS];  // this thread's k = threadIdx.x + 256 i, i < 5 (K <= 1280; wider K: the outer loop)
+    for (int kb = 0; kb < K; kb += 5 * 256) {
 #pragma unroll
-        for (int r = 0; r < WG_ROWS; ++r) s[r] = 0.f;
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < WG_ROWS; ++r) s[i][r] = 0.f;
         for (int b0 = 0; b0 < B; b0 += 8) {
-            float xv[8];
+            __syncthreads();
+            if (threadIdx.x < 8 * WG_ROWS) {
+                const int j = threadIdx.x / WG_ROWS, r = threadIdx.x % WG_ROWS;
+                sdz[j][r] = (b0 + j < B && r < nr) ? dz[(int64_t)(b0 + j) * lddz + n0 + r] : 0.f;
+            }
+            __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xv[j] = b0 + j < B ? x[(int64_t)(b0 + j) * ldx + k] : 0.f;
+            for (int i = 0; i < 5; ++i) {
+                const int k = kb + threadIdx.x + 256 * i;
+                if (k < K) {
+                    float xv[8];
 #pragma unroll
-            for (int r = 0; r < WG_ROWS; ++r)
-                if (r < nr) {
+                    for (int j = 0; j < 8; ++j) xv[j] = b0 + j < B ? x[(int64_t)(b0 + j) * ldx + k] : 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (b0 + j < B) s[r] += dz[(int64_t)(b0 + j) * lddz + n0 + r] * xv[j];
+                    for (int r = 0; r < WG_ROWS; ++r)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) s[i][r] += sdz[j][r] * xv[j];
                 }
+            }
         }
 #pragma unroll
-        for (int r = 0; r < WG_ROWS; ++r)
-            if (r < nr) dW[(int64_t)(n0 + r) * lddw + k] += s[r];
+        for (int i = 0; i < 5; ++i) {
+            const int k = kb + threadIdx.x + 256 * i;
+            if (k < K) {
+#pragma unroll
+                for (int r = 0; r < WG_ROWS; ++r)
+                    if (r < nr) dW[(int64_t)(n0 + r) * lddw + k] += s[i][r];
+            }
+        }
     }
     if (dbias && threadIdx.x < nr) {
         float db = 0.f;
@@ -1029,7 +1049,11 @@ extern "C" int swiftk_linear_small_bwd(const float* dz, int64_t lddz, const floa
     }
     if (dW) {
         if (!x) return SWIFTK_EINVAL;
-        hipLaunchKernelGGL(small_wgrad_kernel, dim3((N + 7) / 8), dim3(256), 0, st, dz, lddz, x, ldx, dW, lddw, dbias, B, N, K);
+        // rows per block: eight for the big concatenated matrices (block turnover), one or two for a single Linear (a few thousand
+        // rows: more blocks, so that every CU has several rows' read-modify-writes in flight)
+        if (N >= 16384) hipLaunchKernelGGL(small_wgrad_kernel<8>, dim3((N + 7) / 8), dim3(256), 0, st, dz, lddz, x, ldx, dW, lddw, dbias, B, N, K);
+        else if (N >= 4096) hipLaunchKernelGGL(small_wgrad_kernel<2>, dim3((N + 1) / 2), dim3(256), 0, st, dz, lddz, x, ldx, dW, lddw, dbias, B, N, K);
+        else hipLaunchKernelGGL(small_wgrad_kernel<1>, dim3(N), dim3(256), 0, st, dz, lddz, x, ldx, dW, lddw, dbias, B, N, K);
         SWIFTK_CHECK_LAUNCH();
     }
     return 0;
