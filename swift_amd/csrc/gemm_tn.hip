@@ -316,7 +316,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
 
 }  // namespace
 
-int g_tn_pp = 0;  // tuning key 22: ping-pong k-loop of the weight-gradient GEMM
+int g_tn_pp = 2;  // tuning key 22: ping-pong k-loop of the weight-gradient GEMM: 0 never, 1 always, 2 where it measured faster
 
 // slabs[s][N1][N2] (fp32, row stride ldc, slab stride `slab_stride`) = partial products over the s-th of `ksplit` ranges of
 // the K token rows.  P: [K, >= N1] bf16 with row stride ldp, Q: [K, >= N2] with ldq.  Shapes this kernel does not take
@@ -360,7 +360,10 @@ extern "C" int swiftk_gemm_tn_splitk(const void* P, int64_t ldp, const void* Q, 
     const int items = ntm * g.ntn * ksplit;
     const dim3 grid(items < 256 ? items : 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (g_tn_pp) {
+    // (measured twice, interleaved in one process at local batch 8, tools/tn_ab.py: to_qkv's gradient +2.6 %, w1's +2.4..3.4 %, wo's
+    // +-0, w2's -1..-1.8 % -- the tall gradients gain, the wide one loses)
+    const bool pp = g_tn_pp == 1 || (g_tn_pp == 2 && ni == 11 && N1 >= 2048);
+    if (pp) {
         if (ni == 10) hipLaunchKernelGGL((gemm_tn_kernel<10, true>), grid, dim3(NT), 0, st, g, ntm, 8);
         else if (ni == 12) hipLaunchKernelGGL((gemm_tn_kernel<12, true>), grid, dim3(NT), 0, st, g, ntm, 8);
         else hipLaunchKernelGGL((gemm_tn_kernel<11, true>), grid, dim3(NT), 0, st, g, ntm, 8);
