@@ -1489,6 +1489,7 @@ template <typename T, typename OutT, int EPI>
 int launch(const GemmArgs& g, hipStream_t st) {
     auto kern = gemm_kernel<T, OutT, EPI>;
     const int ntm = (g.M + BM - 1) / BM;
+    if (sizeof(T) == 4 && EPI != SWIFTK_EPI_QKNORM && g.ni != NI) return SWIFTK_ESHAPE;  // (fp32 operands: 352-wide tiles but for QKNORM)
     const bool timed = swiftk_prof_begin(EPI, g.N, st);
     const bool wide_ok = sizeof(OutT) != 2 || (!((uintptr_t)g.C & 15) && !(g.ldc & 7) &&
                                                !(g.N & (EPI == SWIFTK_EPI_SWIGLU || EPI == SWIFTK_EPI_SWIGLU_BOTH ? 15 : 7)));  // 16-B row chunks
@@ -1519,7 +1520,6 @@ int launch(const GemmArgs& g, hipStream_t st) {
             else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 12, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
             else hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
         } else {
-            if (g.ni != NI) return SWIFTK_ESHAPE;
             hipLaunchKernelGGL((gemm_kernel_p<T, OutT, EPI, 11, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
         }
     }
