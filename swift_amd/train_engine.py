@@ -378,15 +378,20 @@ class SwinTrainEngine:
         if grads_final is not None:
             grads_final(list(m.head.parameters()))
         dmod = torch.zeros(B, m.depth * 4 * d, dtype=torch.float32, device=dev)
+        # the backward pass's temporaries live for one layer each: one set for the whole pass (their k-paddings are zeroed once
+        # instead of once per layer; every kernel writes the valid columns only)
+        dy2, dy1 = _padded(M, self.kd, d), _padded(M, self.kd, d)
+        dh = _padded(M, max(self.kh, 2 * mlp), 2 * mlp)
+        dqkv = _padded(M, self.kqkv, 3 * d)
+        datt = torch.empty(M, self.kd, dtype=_BF, device=dev)
+        g1i = torch.empty(2 * mlp, d, dtype=torch.float32, device=dev)
         for i in reversed(range(m.depth)):
             att, ff = m.transformer.layers[i]
             W, A = self.L[i], ctx["layers"][i]
             mod = ctx["mod"]
             # ---- feed-forward branch
-            dy2 = _padded(M, self.kd, d)
             self._modnorm_bwd(A["y2"], dx, dy2, ff.norm.norm, mod[:, (2 * i + 1) * 2 * d:(2 * i + 2) * 2 * d],
                               dmod[:, (2 * i + 1) * 2 * d:(2 * i + 2) * 2 * d], M, d, ntok)
-            dh = _padded(M, max(self.kh, 2 * mlp), 2 * mlp)
             if mlp % 8 == 0:  # d(hidden) = dy2 @ w2 and the step back through silu(gate) * up in one launch
                 _gemm(dy2, W["w2_t"], dh, EPI_SWIGLU_BWD, None, A["h"], pos_rows=A["h"].stride(0), k=d)
             else:
@@ -401,20 +406,16 @@ class SwinTrainEngine:
                 self._wgrad(dy2, A["hmid"], d, mlp, g2, accumulate=False)
                 G(ff.w2.weight).add_(g2[:, :mlp0])
             _gemm(dh, W["w1_t"], dx, EPI_ACCUM)                              # residual + w1 path: dx += dh @ w1
-            g1i = torch.empty(2 * mlp, d, dtype=torch.float32, device=dev)
             self._wgrad(dh, A["xT_mid"], 2 * mlp, d, g1i, accumulate=False)
             G(ff.w1.weight).add_(g1i[:2 * mlp0].view(mlp0, 2, d).permute(1, 0, 2).reshape(2 * mlp0, d))  # undo the interleave
             # ---- attention branch
-            dy1 = _padded(M, self.kd, d)
             self._modnorm_bwd(A["y1"], dx, dy1, att.norm.norm, mod[:, (2 * i) * 2 * d:(2 * i + 1) * 2 * d],
                               dmod[:, (2 * i) * 2 * d:(2 * i + 1) * 2 * d], M, d, ntok)
-            datt = torch.empty(M, self.kd, dtype=_BF, device=dev)
             _gemm(dy1, W["wo_t"], datt, k=d)  # N = d columns written, row stride kd
             self._wgrad(dy1, A["att"], d, d, G(att.wo.weight))
             # d(q | k | v) lands in the to_qkv data-gradient GEMM's operand buffer (row stride kqkv): the attention backward applies
             # the QK-norm backward to its accumulators on their way out (head_dim 88; elsewhere a second pass rewrites the q-hat / k-hat
             # vectors in place -- v's gradient is already final)
-            dqkv = _padded(M, self.kqkv, 3 * d)
             sh = A["shift"]
             gscale = G(att.scale)  # [heads, 1, 1] fp32, contiguous: the kernel accumulates (atomicAdd) straight into it
             assert gscale.is_contiguous() and gscale.numel() == heads
