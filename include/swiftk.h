@@ -280,8 +280,8 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * fragment reads + DMA issue and back-to-back MFMAs, counted waits; needs >= 3 k-tiles per work item, else falls back), 0 = one
  * barrier per k-tile (the round-1..4 loop).  Bit-equal results either way.
  * key 21 = the same choice for the k-loop inside swiftk_qkv_attention_fused (1 = ping-pong, 0 = one barrier per k-tile),
- * key 22 = the same for swiftk_gemm_tn_splitk: 0 never, 1 always, 2 (default) where it measured faster -- 352-wide tiles and
- * N1 >= 2048 (to_qkv's and w1's gradients +2.4...3.4 %, wo's +-0, w2's -1...-1.8 %: tools/tn_ab.py). */
+ * key 22 = the same for swiftk_gemm_tn_splitk: 0 never, 1 always, 2 (default) with 352-wide tiles, where it was measured
+ * (Swift-B's four weight gradients 0...-9 % in time, -6 % per layer: tools/tn_ab.py). */
 int swiftk_set_tuning(int key, int value);
 /* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
  * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default

@@ -14,6 +14,10 @@
 // persistent grid over (tile, k-split) items, XCD-grouped tile order, fp32 slab store) follows gemm_kernel_p.
 #include "common.h"
 
+#ifndef SWIFTK_TN_G0_FIRST
+#define SWIFTK_TN_G0_FIRST 5  // pieces waves 0-3 issue in a k-tile's first phase (the rest in the second)
+#endif
+
 namespace {
 
 constexpr int BM = 256, KT = 64;
@@ -218,10 +222,12 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
                     // (pieces 0..4 -- the four P pieces and the first Q piece, real for every wave -- are this k-tile's requests so far)
                     static_assert(4 * NQ / 10 == NP - 1 && 5 * NQ / 10 == NP, "phases 0 .. NP - 1 of waves 4-7 carry pieces 0 .. 4");
                     if (q == NP - 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                } else {    // waves 0-3: everything in the first NQ - 1 phases, waited for in the last one
+                } else {    // waves 0-3: everything in the first two phases, waited for in the last one.  (Their rows are the next
+                            // k-tile's FIRST k-step: spread over NQ - 1 phases the last pieces had one phase to land and the wait
+                            // stalled every k-tile -- 4, 5 or 6 pieces up front measure alike, 7 and all ten cost again)
 #pragma unroll
                     for (int pc = 0; pc < 10; ++pc)
-                        if (pc * (NQ - 1) / 10 == q) issue_piece(fill, koff_a, koff_q, pc);
+                        if ((pc < SWIFTK_TN_G0_FIRST ? 0 : 1) == q) issue_piece(fill, koff_a, koff_q, pc);
                     if (q == NQ - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 if (q == NQ - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
 
 }  // namespace
 
-int g_tn_pp = 2;  // tuning key 22: ping-pong k-loop of the weight-gradient GEMM: 0 never, 1 always, 2 where it measured faster
+int g_tn_pp = 2;  // tuning key 22: ping-pong k-loop of the weight-gradient GEMM: 0 never, 1 always, 2 where it was measured (352-wide tiles)
 
 // slabs[s][N1][N2] (fp32, row stride ldc, slab stride `slab_stride`) = partial products over the s-th of `ksplit` ranges of
 // the K token rows.  P: [K, >= N1] bf16 with row stride ldp, Q: [K, >= N2] with ldq.  Shapes this kernel does not take
@@ -360,9 +366,10 @@ extern "C" int swiftk_gemm_tn_splitk(const void* P, int64_t ldp, const void* Q, 
     const int items = ntm * g.ntn * ksplit;
     const dim3 grid(items < 256 ? items : 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // (measured twice, interleaved in one process at local batch 8, tools/tn_ab.py: to_qkv's gradient +2.6 %, w1's +2.4..3.4 %, wo's
-    // +-0, w2's -1..-1.8 % -- the tall gradients gain, the wide one loses)
-    const bool pp = g_tn_pp == 1 || (g_tn_pp == 2 && ni == 11 && N1 >= 2048);
+    // (measured interleaved in one process at local batch 8, tools/tn_ab.py, with waves 0-3 issuing their pieces in a k-tile's first
+    // two phases: to_qkv's gradient -6.5 %, w1's -6..-9 %, w2's -3 %, wo's 0..-5 % against one barrier per k-tile; the 320- / 384-wide
+    // forms were not measured and keep the old loop)
+    const bool pp = g_tn_pp == 1 || (g_tn_pp == 2 && ni == 11);
     if (pp) {
         if (ni == 10) hipLaunchKernelGGL((gemm_tn_kernel<10, true>), grid, dim3(NT), 0, st, g, ntm, 8);
         else if (ni == 12) hipLaunchKernelGGL((gemm_tn_kernel<12, true>), grid, dim3(NT), 0, st, g, ntm, 8);
