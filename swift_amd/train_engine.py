@@ -459,6 +459,16 @@ class SwinTrainEngine:
         return dins
 
     def _modnorm_bwd(self, y, g, dy, ln, mod_slice, dmod_slice, M, d, ntok):
+        # KNOWN ISSUE (found at the end of round 5, present since round 4): with a process group active -- even a one-rank RCCL
+        # group whose collectives move nothing -- the one-kernel form of this backward (per-sample column sums by atomics into a
+        # workspace cleared by hipMemsetAsync, tuning key 16 = 1) intermittently leaves overflowing values in the norm /
+        # modulation gradients of a CRPS iteration (8 of ~30 runs of 12 iterations; 0 of 14 with the row pass + column pass
+        # form; never without a process group, never in TrigFlow / sCM).  Root cause not found yet: data-parallel runs take
+        # the two-kernel form (+2.5 % on a CRPS iteration).
+        from .dist import collectives_active
+        if collectives_active() and not getattr(self, "_mnb_two_kernel", False):
+            lib().swiftk_set_tuning(16, 0)
+            self._mnb_two_kernel = True
         if getattr(self, "_row_stats", None) is None or self._row_stats.numel() < 2 * M:
             self._row_stats = torch.empty(2 * M, dtype=torch.float32, device=y.device)
             self.graphs.invalidate()  # (captured sequences hold the old buffer's address)

@@ -95,12 +95,28 @@ for k in range(a.iters):
     loss = tr.train_step(x, t, idx, delta, 1000 * (k + 2), steps=a.steps)
     host_ms.append(1e3 * (time.perf_counter() - h0))  # time the host needs to ISSUE an iteration (it may run ahead of the GPU)
     losses.append(loss)
+    nan_report(f"iteration {k}")
 if os.environ.get("SWIFTK_SYNC_DEBUG"):
     torch.cuda.set_sync_debug_mode(0)
     for site, n in sync_sites.most_common(40):
         print(f"sync x{n}: {site}", file=sys.stderr)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
+_bad = [n for n, p in net.named_parameters() if not torch.isfinite(p).all()]
+if os.environ.get("SWIFTK_NAN_DEBUG") or _bad:  # which parameters ever saw an overflowing gradient (exp_avg_sq = inf)?
+    _inf = [(n, int((~torch.isfinite(opt.state[p]["exp_avg_sq"])).sum()), p.numel()) for n, p in net.named_parameters()
+            if p in opt.state and "exp_avg_sq" in opt.state[p] and not torch.isfinite(opt.state[p]["exp_avg_sq"]).all()]
+    print(f"parameters with non-finite exp_avg_sq: {len(_inf)}: {_inf[:40]}", file=sys.stderr)
+if _bad:  # (a non-finite parameter after the run: name the first few -- which kernel's output went wrong?)
+    print(f"NON-FINITE PARAMETERS after {a.iters} iterations: {len(_bad)} of {len(list(net.parameters()))}: {_bad[:12]}", file=sys.stderr)
+    for n, p in net.named_parameters():
+        if n in _bad[:4]:
+            bad = (~torch.isfinite(p)).flatten().nonzero().flatten()
+            st = opt.state.get(p, {})
+            ea, ev = st.get("exp_avg"), st.get("exp_avg_sq")
+            print(f"  {n}: {bad.numel()} of {p.numel()} elements, flat indices {int(bad[0])}..{int(bad[-1])}; exp_avg non-finite "
+                  f"{int((~torch.isfinite(ea)).sum()) if ea is not None else None}, |exp_avg| max {float(ea[torch.isfinite(ea)].abs().max()) if ea is not None else None:.3e}; "
+                  f"exp_avg_sq non-finite {int((~torch.isfinite(ev)).sum()) if ev is not None else None}", file=sys.stderr)
 print("host issue time per iteration (ms):", " ".join(f"{h:.0f}" for h in host_ms), file=sys.stderr)
 print("loss per iteration (warm-up included):", " ".join(f"{float(l):.4f}" for l in losses), file=sys.stderr)
 PEAK = 2.5e15  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
