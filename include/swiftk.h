@@ -354,6 +354,13 @@ int swiftk_modnorm_bwd(const void* y, int64_t ldy, const float* g, void* dy, int
                        const float* beta, const float* mod, int64_t ldmod, float* dgamma, float* dbeta, float* dmod,
                        int64_t lddmod, float* row_stats, int64_t M, int d, int64_t rows_per_sample, float eps, int dtype,
                        void* stream);
+/* The same for a caller that keeps `workspace` (>= 2 * (M / rows_per_sample) * d floats) ZERO between calls: the one-kernel form
+ * only (SWIFTK_ESHAPE where swiftk_modnorm_bwd would take the two-kernel form), without the per-call clear -- the finishing kernel
+ * zeroes the sums it has read, so the workspace is zero again on return. */
+int swiftk_modnorm_bwd_ws0(const void* y, int64_t ldy, const float* g, void* dy, int64_t lddy, const float* gamma,
+                           const float* beta, const float* mod, int64_t ldmod, float* dgamma, float* dbeta, float* dmod,
+                           int64_t lddmod, float* workspace, int64_t M, int d, int64_t rows_per_sample, float eps, int dtype,
+                           void* stream);
 
 /* Backward of SWIFTK_EPI_QKNORM: qkvh / dqkvh [M, ld] (normalised values and their gradients), rn [M, 3*heads] the
  * 1/max(|.|,1e-12) factors the epilogue stored through ep1 -> dqkv [M, ldo] (raw projections), dscale[heads] += .

@@ -111,6 +111,7 @@ _SIGS = {
     "swiftk_swiglu_fwd": ([_p, _l, _p, _l, _l, _i, _i, _p], _i),
     "swiftk_swiglu_bwd": ([_p, _l, _p, _l, _p, _l, _l, _i, _i, _p], _i),
     "swiftk_modnorm_bwd": ([_p, _l, _p, _p, _l, _p, _p, _p, _l, _p, _p, _p, _l, _p, _l, _i, _l, _f, _i, _p], _i),
+    "swiftk_modnorm_bwd_ws0": ([_p, _l, _p, _p, _l, _p, _p, _p, _l, _p, _p, _p, _l, _p, _l, _i, _l, _f, _i, _p], _i),
     "swiftk_qknorm_bwd": ([_p, _p, _l, _p, _p, _l, _p, _p, _l, _i, _i, _i, _p], _i),
     "swiftk_window_attention_bwd_qknorm": ([_p, _l, _p, _p, _l, _p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_window_attention_bwd": ([_p, _l, _p, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),

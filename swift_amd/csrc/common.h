@@ -170,6 +170,19 @@ struct AttnPipeArgs {
 };
 int swiftk_launch_attn_pipe(const AttnPipeArgs& a, hipStream_t st);
 
+// Zero n floats with an ORDINARY kernel on the caller's stream.  Not hipMemsetAsync: round 5 traced an intermittent overflow of
+// atomically accumulated sums (swiftk_modnorm_bwd's per-sample column sums, 4 of 8 data-parallel CRPS runs against 0 of 20) to a
+// workspace cleared by hipMemsetAsync right in front of the accumulating kernel -- with a process group's event traffic on the
+// stream the fill was not reliably ordered in front of the atomics.  A kernel launch is.
+__global__ __launch_bounds__(256) static void swiftk_zero_f32_kernel(float* __restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
+}
+static inline int swiftk_zero_f32(float* p, int64_t n, hipStream_t st) {
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(swiftk_zero_f32_kernel, dim3((unsigned)(blocks < 1024 ? (blocks < 1 ? 1 : blocks) : 1024)), dim3(256), 0, st, p, n);
+    return (int)hipGetLastError();
+}
+
 // live per-kernel timing (bench.py's roofline legs; state lives in gemm.hip): a launch of kind `kind` (a GEMM
 // epilogue code, or SWIFTK_PROF_ATTENTION) with matching n is bracketed by HIP events on its own stream
 bool swiftk_prof_begin(int kind, int n, hipStream_t st);

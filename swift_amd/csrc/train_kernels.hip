@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void modnorm_bwd_fused_kernel(const T* __restr
 }
 
 // ... and the outputs from the per-sample sums: one thread per column
-__global__ __launch_bounds__(256) void modnorm_bwd_finish_kernel(const float* __restrict__ psum, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void modnorm_bwd_finish_kernel(float* __restrict__ psum, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, const float* __restrict__ mod,
                                                                  int64_t ldmod, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                  float* __restrict__ dmod, int64_t lddmod, int nb, int d) {
@@ -367,6 +367,10 @@ __global__ __launch_bounds__(256) void modnorm_bwd_finish_kernel(const float* __
     float dg = 0.f, db = 0.f;
     for (int b = 0; b < nb; ++b) {
         const float a1 = psum[(int64_t)b * d + col], a2 = psum[(int64_t)(nb + b) * d + col];
+        // the sums are consumed: leave the workspace zero for the next call (the launcher clears it itself only when it cannot
+        // know that -- first use, or after the two-kernel form kept row statistics there)
+        psum[(int64_t)b * d + col] = 0.f;
+        psum[(int64_t)(nb + b) * d + col] = 0.f;
         const float sc1 = 1.0f + mod[b * ldmod + col];
         dg = fmaf(sc1, a1, dg);
         db = fmaf(sc1, a2, db);
@@ -941,10 +945,10 @@ extern "C" int swiftk_swiglu_bwd(const void* h, int64_t ldh, const void* dout, i
     return 0;
 }
 
-extern "C" int swiftk_modnorm_bwd(const void* y, int64_t ldy, const float* g, void* dy, int64_t lddy, const float* gamma,
-                                  const float* beta, const float* mod, int64_t ldmod, float* dgamma, float* dbeta, float* dmod,
-                                  int64_t lddmod, float* row_stats, int64_t M, int d, int64_t rows_per_sample, float eps,
-                                  int dtype, void* stream) {
+static int modnorm_bwd_impl(const void* y, int64_t ldy, const float* g, void* dy, int64_t lddy, const float* gamma,
+                            const float* beta, const float* mod, int64_t ldmod, float* dgamma, float* dbeta, float* dmod,
+                            int64_t lddmod, float* row_stats, int64_t M, int d, int64_t rows_per_sample, float eps,
+                            int dtype, void* stream, bool ws_zero) {
     if (!y || !g || !dy || !gamma || !beta || !mod || !dgamma || !dbeta || !dmod || !row_stats || M <= 0 || rows_per_sample <= 0)
         return SWIFTK_EINVAL;
     if (d % 4 || d > 1536 || M % rows_per_sample) return SWIFTK_ESHAPE;
@@ -958,7 +962,9 @@ extern "C" int swiftk_modnorm_bwd(const void* y, int64_t ldy, const float* g, vo
     if (g_modnorm_bwd_fused > 0 && rows_per_sample % rpbf == 0 && rows_per_sample >= d) {
         const unsigned grid = (unsigned)(M / rpbf);
         const int nb = (int)(M / rows_per_sample);
-        if (hipMemsetAsync(row_stats, 0, sizeof(float) * 2 * nb * d, st) != hipSuccess) return SWIFTK_EINVAL;
+        // psum [2][nb][d] must be zero on entry: cleared here, unless the caller keeps the workspace zero between calls
+        // (swiftk_modnorm_bwd_ws0: modnorm_bwd_finish_kernel zeroes what it has read)
+        if (!ws_zero && swiftk_zero_f32(row_stats, 2 * (int64_t)nb * d, st) != 0) return SWIFTK_EINVAL;
 #define SWIFTK_MNB(TT, SL)                                                                                                        \
     hipLaunchKernelGGL((modnorm_bwd_fused_kernel<TT, SL>), dim3(grid), dim3(256), 0, st, static_cast<const TT*>(y), ldy, g,       \
                        static_cast<TT*>(dy), lddy, gamma, mod, ldmod, row_stats, M, d, rows_per_sample, eps, rpbf)
@@ -975,6 +981,7 @@ extern "C" int swiftk_modnorm_bwd(const void* y, int64_t ldy, const float* g, vo
         SWIFTK_CHECK_LAUNCH();
         return 0;
     }
+    if (ws_zero) return SWIFTK_ESHAPE;  // (the two-kernel form keeps row statistics in the workspace: it cannot stay zero)
     const unsigned grid_rows = (unsigned)((M + 3) / 4);
     const int rpb = 256;
     const dim3 grid_cols((unsigned)(((d >> 2) + 63) / 64), (unsigned)((M / rows_per_sample) * ((rows_per_sample + rpb - 1) / rpb)));
@@ -1015,6 +1022,22 @@ extern "C" int swiftk_qknorm_bwd(const void* qkvh, const void* dqkvh, int64_t ld
                                  heads, head_dim, inplace));
     SWIFTK_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int swiftk_modnorm_bwd(const void* y, int64_t ldy, const float* g, void* dy, int64_t lddy, const float* gamma,
+                                  const float* beta, const float* mod, int64_t ldmod, float* dgamma, float* dbeta, float* dmod,
+                                  int64_t lddmod, float* row_stats, int64_t M, int d, int64_t rows_per_sample, float eps,
+                                  int dtype, void* stream) {
+    return modnorm_bwd_impl(y, ldy, g, dy, lddy, gamma, beta, mod, ldmod, dgamma, dbeta, dmod, lddmod, row_stats, M, d, rows_per_sample,
+                            eps, dtype, stream, false);
+}
+
+extern "C" int swiftk_modnorm_bwd_ws0(const void* y, int64_t ldy, const float* g, void* dy, int64_t lddy, const float* gamma,
+                                      const float* beta, const float* mod, int64_t ldmod, float* dgamma, float* dbeta, float* dmod,
+                                      int64_t lddmod, float* workspace, int64_t M, int d, int64_t rows_per_sample, float eps,
+                                      int dtype, void* stream) {
+    return modnorm_bwd_impl(y, ldy, g, dy, lddy, gamma, beta, mod, ldmod, dgamma, dbeta, dmod, lddmod, workspace, M, d, rows_per_sample,
+                            eps, dtype, stream, true);
 }
 
 extern "C" int swiftk_colsum(const float* src, int64_t lds, float* out, int64_t rows, int cols, int64_t period, void* stream) {

@@ -459,24 +459,39 @@ class SwinTrainEngine:
         return dins
 
     def _modnorm_bwd(self, y, g, dy, ln, mod_slice, dmod_slice, M, d, ntok):
-        # KNOWN ISSUE (found at the end of round 5, present since round 4): with a process group active -- even a one-rank RCCL
-        # group whose collectives move nothing -- the one-kernel form of this backward (per-sample column sums by atomics into a
-        # workspace cleared by hipMemsetAsync, tuning key 16 = 1) intermittently leaves overflowing values in the norm /
-        # modulation gradients of a CRPS iteration (8 of ~30 runs of 12 iterations; 0 of 14 with the row pass + column pass
-        # form; never without a process group, never in TrigFlow / sCM).  Root cause not found yet: data-parallel runs take
-        # the two-kernel form (+2.5 % on a CRPS iteration).
-        from .dist import collectives_active
-        if collectives_active() and not getattr(self, "_mnb_two_kernel", False):
-            lib().swiftk_set_tuning(16, 0)
-            self._mnb_two_kernel = True
-        if getattr(self, "_row_stats", None) is None or self._row_stats.numel() < 2 * M:
-            self._row_stats = torch.empty(2 * M, dtype=torch.float32, device=y.device)
+        # the per-sample column sums of the one-kernel form live in a workspace this engine keeps ZERO between calls
+        # (``swiftk_modnorm_bwd_ws0``: the finishing kernel zeroes what it read) -- no clear per call.  SWIFTK_MNB_MODE picks
+        # another form for A/B runs: "memset" = the per-call hipMemsetAsync of rounds 4-5, "two" = row pass + column pass.
+        # (Round 5 traced an intermittent overflow of exactly these sums in data-parallel CRPS runs to the "memset" form:
+        # DESIGN section 10.)
+        mode = os.environ.get("SWIFTK_MNB_MODE", "ws0")
+        need = 2 * M
+        if getattr(self, "_row_stats", None) is None or self._row_stats.numel() < need:
+            self._row_stats = torch.zeros(need, dtype=torch.float32, device=y.device)
             self.graphs.invalidate()  # (captured sequences hold the old buffer's address)
-        check(lib().swiftk_modnorm_bwd(y.data_ptr(), y.stride(0), g.data_ptr(), dy.data_ptr(), dy.stride(0),
-                                       ln.weight.detach().float().data_ptr(), ln.bias.detach().float().data_ptr(),
-                                       mod_slice.data_ptr(), mod_slice.stride(0), self._grad_buf(ln.weight).data_ptr(),
-                                       self._grad_buf(ln.bias).data_ptr(), dmod_slice.data_ptr(), dmod_slice.stride(0),
-                                       self._row_stats.data_ptr(), M, d, ntok, 1e-6, BF16, _s()), "swiftk_modnorm_bwd")
+        L = lib()
+        args = (y.data_ptr(), y.stride(0), g.data_ptr(), dy.data_ptr(), dy.stride(0), ln.weight.detach().float().data_ptr(),
+                ln.bias.detach().float().data_ptr(), mod_slice.data_ptr(), mod_slice.stride(0), self._grad_buf(ln.weight).data_ptr(),
+                self._grad_buf(ln.bias).data_ptr(), dmod_slice.data_ptr(), dmod_slice.stride(0))
+        tail = (M, d, ntok, 1e-6, BF16, _s())
+        if mode == "ws0":
+            rc = L.swiftk_modnorm_bwd_ws0(*args, self._row_stats.data_ptr(), *tail)
+            if rc == 0:
+                return
+            if rc != -2:  # anything but SWIFTK_ESHAPE (shapes the one-kernel form does not take: the two-kernel form below)
+                check(rc, "swiftk_modnorm_bwd_ws0")
+            if getattr(self, "_row_stats2", None) is None or self._row_stats2.numel() < need:
+                self._row_stats2 = torch.empty(need, dtype=torch.float32, device=y.device)  # (row statistics: not the zero workspace)
+                self.graphs.invalidate()
+            check(L.swiftk_modnorm_bwd(*args, self._row_stats2.data_ptr(), *tail), "swiftk_modnorm_bwd")
+            return
+        if getattr(self, "_row_stats2", None) is None or self._row_stats2.numel() < need:
+            self._row_stats2 = torch.empty(need, dtype=torch.float32, device=y.device)
+            self.graphs.invalidate()
+        if mode == "two" and not getattr(self, "_mnb_two_kernel", False):
+            L.swiftk_set_tuning(16, 0)
+            self._mnb_two_kernel = True
+        check(L.swiftk_modnorm_bwd(*args, self._row_stats2.data_ptr(), *tail), "swiftk_modnorm_bwd")
 
     def _small_bwd(self, dz, x, lin, want_dx=True, w=None, dW=None, db=None):
         w = lin.weight.detach().float().contiguous() if w is None else w

@@ -280,7 +280,7 @@ def test_crps_iterations_with_a_process_group_stay_finite():
     """Regression guard for an intermittent overflow of the norm / modulation / embedding gradients seen at the end of round 5:
     twelve multistep-CRPS iterations at Swift-B size, local batch 8, with a one-rank RCCL group (the data-parallel code path:
     early-announced all-reduces, sync, fused optimizer) must end with a finite loss and finite parameters.  (The overflow hit
-    8 of ~30 such runs with the one-kernel ModulatedNorm backward; data-parallel runs take the two-kernel form since.)"""
+    8 of ~30 such runs while swiftk_modnorm_bwd cleared its workspace with hipMemsetAsync: DESIGN section 10.)"""
     import json
     import torch
     if not torch.cuda.is_available():
