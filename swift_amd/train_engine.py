@@ -53,6 +53,13 @@ def _transpose(src, rows, cols, ldd=None):
     return dst
 
 
+def _zeros(*shape, device):
+    """fp32 zeros that a kernel is about to ACCUMULATE into (atomics / read-modify-write), cleared by an ordinary fill kernel on the
+    current stream: ``torch.zeros`` may clear through ``hipMemsetAsync``, which round 5 found not reliably ordered in front of an
+    accumulating kernel once a process group's event waits sit on the stream."""
+    return torch.empty(*shape, dtype=torch.float32, device=device).fill_(0.0)
+
+
 def _padded(rows, width, valid):
     """[rows, width] bf16 GEMM operand whose columns [valid, width) are zero (the k-padding a GEMM may read); the kernel
     that fills it writes columns [0, valid) only -- zeroing 32 pad columns instead of the whole buffer."""
@@ -377,7 +384,7 @@ class SwinTrainEngine:
         G(m.head.head[0].weight).add_(gh_pad[:po])
         if grads_final is not None:
             grads_final(list(m.head.parameters()))
-        dmod = torch.zeros(B, m.depth * 4 * d, dtype=torch.float32, device=dev)
+        dmod = _zeros(B, m.depth * 4 * d, device=dev)
         # the backward pass's temporaries live for one layer each: one set for the whole pass (their k-paddings are zeroed once
         # instead of once per layer; every kernel writes the valid columns only)
         dy2, dy1 = _padded(M, self.kd, d), _padded(M, self.kd, d)
@@ -497,7 +504,7 @@ class SwinTrainEngine:
         w = lin.weight.detach().float().contiguous() if w is None else w
         B, N = dz.shape
         K = w.shape[1]
-        dx = torch.zeros(B, K, dtype=torch.float32, device=dz.device) if want_dx else None
+        dx = _zeros(B, K, device=dz.device) if want_dx else None
         dW = self._grad_buf(lin.weight) if dW is None else dW
         db = (self._grad_buf(lin.bias) if lin is not None and lin.bias is not None else None) if db is None else db
         check(lib().swiftk_linear_small_bwd(dz.data_ptr(), dz.stride(0), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
@@ -514,7 +521,7 @@ class SwinTrainEngine:
         # buffer cost two 214-MB fills and 48 ATen adds per iteration)
         B, K = dmod.shape[0], self.mod_w.shape[1]
         lat = ctx["lat"]
-        dlat = torch.zeros(B, K, dtype=torch.float32, device=dev)
+        dlat = _zeros(B, K, device=dev)
         check(lib().swiftk_linear_small_bwd(dmod.data_ptr(), dmod.stride(0), None, 0, self.mod_w.data_ptr(), self.mod_w.stride(0),
                                             dlat.data_ptr(), K, None, 0, None, B, dmod.shape[1], K, _s()), "swiftk_linear_small_bwd")
         r = 0
