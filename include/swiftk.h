@@ -165,6 +165,18 @@ int swiftk_modnorm_residual_pair_slabs(const float* y_slabs, int64_t ldy, int64_
 int swiftk_modnorm_residual_pair_slabs_bf16(const void* y_slabs, int64_t ldy, int64_t slab_stride, void* x_hi, int64_t ldh, void* x_lo,
                                             int64_t ldl, int lo_bits, const float* gamma, const float* beta, const float* mod,
                                             int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps, void* stream);
+/* wo / w2 and the norm above in ONE kernel, for small batches: y = bf16(A[M, K] W[d, K]^T) computed over complete rows (a
+ * workgroup owns `rows_per_workgroup` = 32 or 64 rows x all d columns, so the row statistics are there and y never leaves the
+ * CU), then the pair update of swiftk_modnorm_residual_pair (8-bit low part).  bf16 operands, d = 1056 or 960, K % 32 == 0,
+ * K >= 64 (rows of A and W padded to a multiple of 64 elements; the pad is fetched, never multiplied), M and rows_per_sample
+ * multiples of rows_per_workgroup.  Every workgroup streams the whole weight through L2, so
+ * this pays while M / rows_per_workgroup is about one round of the CUs (one unit per step at 32 rows, two at 64:
+ * swiftk_swinv2_forward, tuning key 23); beyond that swiftk_gemm + swiftk_modnorm_residual_pair is the faster pair.
+ * Replaces the same reference lines as those two (swinv2.py:143 / :177 `to_out` / `w2`, :83-86, :211-212). */
+int swiftk_gemm_modnorm_residual_pair(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t K, void* x_hi, int64_t ldh,
+                                      void* x_lo, int64_t ldl, const float* gamma, const float* beta, const float* mod,
+                                      int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps,
+                                      int rows_per_workgroup, void* stream);
 /* fp32 [rows, lds] -> the pair form: hi [rows, ldh] bf16 with columns [cols, ldh) zeroed (GEMM k-padding), lo [rows, ldl]
  * (bf16 or uint8 by lo_bits, ldl in elements). */
 int swiftk_split_pair(const float* src, int64_t lds, void* hi, int64_t ldh, void* lo, int64_t ldl, int lo_bits, int64_t rows,
@@ -250,6 +262,15 @@ int swiftk_unit_checksum(const float* x, double* out, double* scratch, int B, in
 int swiftk_axpby(float* out, float a, const float* x, float b, const float* y, int64_t n, void* stream);
 
 /*
+ * p[0..n) = 0.0f by an ORDINARY kernel on `stream`: what every caller uses in front of a kernel that accumulates into p
+ * (atomics or read-modify-write: the loss sums of training/loss.py:117-160,306-445, the flat gradient buffer behind
+ * trainer.py:219-247's optimizer.zero_grad, the RMSE sums of training/validate.py:96-110).  Round 5 traced an intermittent
+ * overflow of atomically accumulated sums to a workspace cleared by hipMemsetAsync in front of the accumulating kernel
+ * (DESIGN, "the gradient overflow"); tuning key 25 = 1 restores that clear for diagnosis (tools/zero_order_stress.py).
+ */
+int swiftk_zero_f32(float* p, int64_t n, void* stream);
+
+/*
  * Measurement hooks (bench.py's roofline leg; not on the reference's path).  After
  * swiftk_profile_gemm(epilogue, N) every swiftk_gemm launch with that epilogue (and that N, if
  * N != 0) is bracketed by a HIP event pair recorded on its launch stream; swiftk_profile_collect
@@ -281,7 +302,10 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * barrier per k-tile (the round-1..4 loop).  Bit-equal results either way.
  * key 21 = the same choice for the k-loop inside swiftk_qkv_attention_fused (1 = ping-pong, 0 = one barrier per k-tile),
  * key 22 = the same for swiftk_gemm_tn_splitk: 0 never, 1 always, 2 (default) with 352-wide tiles, where it was measured
- * (Swift-B's four weight gradients 0...-9 % in time, -6 % per layer: tools/tn_ab.py). */
+ * (Swift-B's four weight gradients 0...-9 % in time, -6 % per layer: tools/tn_ab.py),
+ * key 23 = swiftk_swinv2_forward (bf16 engine) runs wo / w2 + norm as swiftk_gemm_modnorm_residual_pair up to this many units
+ * per step (0 = never: split-K + slab-summing norm at one unit, GEMM + norm beyond),
+ * key 25 = swiftk_zero_f32 (and the library's internal clears) through hipMemsetAsync instead of a kernel (0; diagnosis only). */
 int swiftk_set_tuning(int key, int value);
 /* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
  * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default

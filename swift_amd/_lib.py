@@ -84,6 +84,7 @@ _SIGS = {
     "swiftk_cast_pad": ([_p, _l, _p, _l, _l, _l, _i, _p], _i),
     "swiftk_split3": ([_p, _l, _p, _l, _l, _l, _i, _p], _i),
     "swiftk_axpby": ([_p, _f, _p, _f, _p, _l, _p], _i),
+    "swiftk_zero_f32": ([_p, _l, _p], _i),
     "swiftk_unit_checksum": ([_p, _p, _p, _i, _l, _p], _i),
     "swiftk_timestep_embed_jvp": ([_p, _p, _p, _p, _i, _i, _f, _p], _i),
     "swiftk_silu_jvp": ([_p, _p, _p, _p, _l, _p], _i),
@@ -97,6 +98,7 @@ _SIGS = {
     "swiftk_modnorm_residual_pair_slabs_bf16": ([_p, _l, _l, _p, _l, _p, _l, _i, _p, _p, _p, _l, _l, _i, _l, _f, _p], _i),
     "swiftk_embed_bwd_sums": ([_p, _l, _p, _p, _p, _l, _l, _i, _l, _p], _i),
     "swiftk_cast_pad_t": ([_p, _l, _l, _l, _p, _l, _p, _l, _l, _p], _i),
+    "swiftk_gemm_modnorm_residual_pair": ([_p, _l, _p, _l, _l, _p, _l, _p, _l, _p, _p, _p, _l, _l, _i, _l, _f, _i, _p], _i),
     "swiftk_gemm_jvp": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _i, _p, _p, _i, _p, _l, _p], _i),
     "swiftk_ensemble_sums": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "swiftk_rmse_sums": ([_p, _p, _l, _p, _p, _i, _i, _i, _i, _p], _i),

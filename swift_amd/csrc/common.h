@@ -177,11 +177,14 @@ int swiftk_launch_attn_pipe(const AttnPipeArgs& a, hipStream_t st);
 __global__ __launch_bounds__(256) static void swiftk_zero_f32_kernel(float* __restrict__ p, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
 }
-static inline int swiftk_zero_f32(float* p, int64_t n, hipStream_t st) {
+static inline int swiftk_zero_f32_launch(float* p, int64_t n, hipStream_t st) {
     const int64_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(swiftk_zero_f32_kernel, dim3((unsigned)(blocks < 1024 ? (blocks < 1 ? 1 : blocks) : 1024)), dim3(256), 0, st, p, n);
     return (int)hipGetLastError();
 }
+
+extern "C" int swiftk_zero_f32(float* p, int64_t n, void* stream);  // (elementwise.hip: the exported form, tuning key 25)
+extern int g_zero_memset;  // tuning key 25
 
 // live per-kernel timing (bench.py's roofline legs; state lives in gemm.hip): a launch of kind `kind` (a GEMM
 // epilogue code, or SWIFTK_PROF_ATTENTION) with matching n is bracketed by HIP events on its own stream
@@ -201,6 +204,8 @@ extern int g_x3_ffsplit;  // tuning key 18
 extern int g_fwd_pepair;  // tuning key 19
 extern int g_modnorm_nt;  // tuning key 6
 extern int g_persist_wgs;  // tuning key 2: workgroups of the persistent matrix kernels (GEMM, fused to_qkv + attention)
+extern int g_fwd_rownorm;  // tuning key 23: wo / w2 + norm as one complete-row kernel up to this many units per step
+extern int g_rownorm_dbg;
 extern int g_tn_pp;  // tuning key 22: ping-pong k-loop of gemm_tn_kernel
 extern int g_attn_pp;  // tuning key 21: ping-pong k-loop of the fused to_qkv + attention kernel
 extern int g_attn_dbg;  // tuning key 4: attention ablation bits (timing experiments only)

@@ -1390,6 +1390,17 @@ extern "C" int swiftk_counter_add(int64_t* counter, int64_t value, void* stream)
     return 0;
 }
 
+int g_zero_memset = 0;  // tuning key 25 (diagnosis only): 1 = swiftk_zero_f32 clears with hipMemsetAsync, the round-4/5 form
+
+extern "C" int swiftk_zero_f32(float* p, int64_t n, void* stream) {
+    if (!p || n < 0) return SWIFTK_EINVAL;
+    if (n == 0) return 0;
+    if (((uintptr_t)p & 3)) return SWIFTK_EALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (g_zero_memset) return (int)hipMemsetAsync(p, 0, sizeof(float) * (size_t)n, st);
+    return swiftk_zero_f32_launch(p, n, st);
+}
+
 extern "C" int swiftk_axpby(float* out, float a, const float* x, float b, const float* y, int64_t n, void* stream) {
     if (!out || !x || !y || n <= 0) return SWIFTK_EINVAL;
     if (((uintptr_t)out & 15) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return SWIFTK_EALIGN;

@@ -221,6 +221,13 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     const int64_t half_tile = (dt == SWIFTK_BF16 ? 64 : 32) / 2;
     const int64_t kdv = (m->kd - d == half_tile) ? d : m->kd;
     const bool do_shift = (m->sh != 0) || (m->sw != 0);
+    // small batches, bf16 engine: wo / w2 and their ModulatedNorm as one complete-row kernel (gemm_rownorm.hip) -- 32-row
+    // workgroups while those fill at most one round of the persistent grid's CUs, 64-row ones beyond
+    int rn_rows = 0;
+    if (pair && lo_bits == 8 && B <= g_fwd_rownorm && (d == 1056 || d == 960) && kdv % 32 == 0 && m->kmlp % 32 == 0) {
+        rn_rows = (M / 32 <= g_persist_wgs) ? 32 : 64;
+        if (ntok % rn_rows) rn_rows = 0;
+    }
     for (int i = 0; i < m->depth; ++i) {
         const swiftk_layer& ly = m->layers_host[i];
         const bool shifted = do_shift && (i & 1);
@@ -262,7 +269,10 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
                                         shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
         }
-        if (splitk && g_fwd_splitk >= 2) {
+        if (rn_rows) {
+            RUN(swiftk_gemm_modnorm_residual_pair(att, m->kd, ly.wo_w, m->kd, kdv, xT, m->kd, xlo, d, ly.ln1_g, ly.ln1_b,
+                                                  mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok, 1e-6f, rn_rows, stream));
+        } else if (splitk && g_fwd_splitk >= 2) {
             RUN(swiftk_gemm_splitk_bf16(att, m->kd, ly.wo_w, m->kd, yslab, d, M * d, M, d, kdv, 2, stream));
             RUN(swiftk_modnorm_residual_pair_slabs_bf16(yslab, d, M * d, xT, m->kd, xlo, d, lo_bits, ly.ln1_g, ly.ln1_b,
                                                         mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
@@ -292,6 +302,11 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             continue;
         }
         RUN(G(xT, m->kd, ly.w1_w, hmid, m->kmlp, 2 * m->mlp, kdv, d, dt, SWIFTK_EPI_SWIGLU, nullptr, nullptr, 0, (x3_exact & 4) != 0));
+        if (rn_rows) {
+            RUN(swiftk_gemm_modnorm_residual_pair(hmid, m->kmlp, ly.w2_w, m->kmlp, m->kmlp, xT, m->kd, xlo, d, ly.ln2_g, ly.ln2_b,
+                                                  mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d, ntok, 1e-6f, rn_rows, stream));
+            continue;
+        }
         if (splitk && g_fwd_splitk >= 2) {
             RUN(swiftk_gemm_splitk_bf16(hmid, m->kmlp, ly.w2_w, m->kmlp, yslab, d, M * d, M, d, m->kmlp, 2, stream));
             RUN(swiftk_modnorm_residual_pair_slabs_bf16(yslab, d, M * d, xT, m->kd, xlo, d, lo_bits, ly.ln2_g, ly.ln2_b,

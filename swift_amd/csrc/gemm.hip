@@ -1619,6 +1619,9 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 20: g_pp = value; return 0;
         case 21: g_attn_pp = value; return 0;
         case 22: g_tn_pp = value; return 0;
+        case 23: g_fwd_rownorm = value; return 0;
+        case 24: g_rownorm_dbg = value; return 0;
+        case 25: g_zero_memset = value; return 0;
     }
     return SWIFTK_EINVAL;
 }
@@ -1647,6 +1650,8 @@ extern "C" int swiftk_get_tuning(int key) {
         case 20: return g_pp;
         case 21: return g_attn_pp;
         case 22: return g_tn_pp;
+        case 23: return g_fwd_rownorm;
+        case 25: return g_zero_memset;
     }
     return SWIFTK_EINVAL;
 }

@@ -91,13 +91,13 @@ class _ERA5Base(Dataset):
 
     # -- flat per-channel vectors for the fused rollout kernel -------------------------------
     def rollout_stats(self, delta: int, device) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """(mean_x, std_x, std_t) over the target channels, with zero_field folded in.
+        """(mean_x, std_x, std_t) over the target channels with ONE delta everywhere, zero_field folded in.
 
-        The rollout (generate.py:120-131) un-standardises the state and re-standardises the sum with the DEFAULT delta
-        (SST zeroed both times, era5.py:135-149) but the residual with ``delta = interval``: zeroed too unless the interval
-        is 24.  Interval != 24: mean 0 / std 1 / residual-std 0 (every quantity of the channel stays 0).  Interval 24:
-        mean 0 / std 0 / the real residual std -- ``swiftk_rollout_update`` reads std 0 as "the standardised value of this
-        channel is forced to zero": physical output = residual * std_t, next standardised state = 0, as the reference.
+        This is what the multistep CRPS loss applies (loss.py:402-406: ``unstandardize_t``, ``unstandardize_x`` and
+        ``standardize_x`` all take the batch's delta): with delta != 24 the SST channel is zeroed by every one of the three
+        calls (mean 0 / std 1 / residual-std 0: every quantity of the channel stays 0); with delta == 24 nothing is zeroed and
+        the channel keeps its real statistics.  The generate / validation rollout mixes deltas (state at the DEFAULT delta,
+        residual at the interval): ``swift_amd.rollout.update_stats`` derives its vectors from these.
         """
         key = (int(delta), str(device))
         cache = self.__dict__.setdefault("_rollout_stats_cache", {})
@@ -110,12 +110,9 @@ class _ERA5Base(Dataset):
         if float(np.abs(np.asarray(tm).reshape(-1)[:nv]).max()) != 0.0 and self.residual:
             raise ValueError("residual targets are expected to have zero mean (era5.py:100)")
         st = torch.as_tensor(np.asarray(ts), dtype=torch.float32).reshape(-1)[:nv].clone()
-        if "sea_surface_temperature" in self.variables:
+        if "sea_surface_temperature" in self.variables and delta != 24:
             i = list(self.variables).index("sea_surface_temperature")
-            if delta != 24:
-                mx[i], sx[i], st[i] = 0.0, 1.0, 0.0
-            else:
-                mx[i], sx[i] = 0.0, 0.0
+            mx[i], sx[i], st[i] = 0.0, 1.0, 0.0
         cache[key] = (mx.to(device), sx.to(device), st.to(device))
         return cache[key]
 

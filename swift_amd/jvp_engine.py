@@ -58,8 +58,19 @@ class SwinJvpEngine:
     def refresh(self):
         m, dt = self.m, self.dt
         stamp = tuple((p.data_ptr(), p._version) for p in m.parameters())
-        if stamp == self._stamp:
+        # the GEMM operands may be the TRAINING engine's (below): their addresses are part of what a captured sequence baked in,
+        # so the engine's identity and its operand addresses belong to the stamp -- a recreated training engine, a
+        # reallocated operand buffer or ``net.to(...)`` would otherwise leave the replays reading freed memory
+        te = getattr(m, "_train_engine", None)
+        te_key = None
+        if te is not None and dt == torch.bfloat16:
+            te.refresh()
+            te_key = (id(te),) + tuple(l[k].data_ptr() for l in te.L for k in ("qkv", "wo", "w1", "w2"))
+        if stamp == self._stamp and te_key == getattr(self, "_te_key", None):
             return
+        if te_key != getattr(self, "_te_key", None) and getattr(self, "_share", False):
+            self.graphs.invalidate()
+        self._te_key = te_key
         ptrs = tuple(p.data_ptr() for p in m.parameters())  # captured sequences read some parameters in place
         if ptrs != getattr(self, "_ptrs", None):
             if getattr(self, "_ptrs", None) is not None:
@@ -92,10 +103,8 @@ class SwinJvpEngine:
         # the sCM loss runs this engine's pass and the training engine's backward on the same weights (loss.py:212-237): with bf16
         # operands and an MLP width both engines pad alike, the four GEMM operands per layer are the training engine's (one cast
         # per optimizer step instead of two, and no second (gate, up) interleave of w1)
-        te = getattr(m, "_train_engine", None)
         share = te is not None and dt == torch.bfloat16 and mlp % 4 == 0
         if share:
-            te.refresh()
             share = te.kd == self.kd and te.kmlp == self.kmlp and len(te.L) == len(m.transformer.layers)
         if getattr(self, "_share", share) != share:
             self.graphs.invalidate()  # (captured sequences hold the other set of operand addresses)

@@ -315,6 +315,20 @@ def modnorm_residual_pair(y: torch.Tensor, x_hi: torch.Tensor, x_lo: torch.Tenso
                                              _stream()), "swiftk_modnorm_residual_pair")
 
 
+def gemm_modnorm_residual_pair(a: torch.Tensor, w: torch.Tensor, x_hi: torch.Tensor, x_lo: torch.Tensor, gamma, beta,
+                               mod: torch.Tensor, rows_per_sample: int, d: int, *, k: Optional[int] = None,
+                               rows_per_workgroup: int = 32, eps: float = 1e-6) -> None:
+    """``modnorm_residual_pair(bf16(a @ w^T), ...)`` as one kernel over complete rows (small batches; 8-bit low part):
+    a [M, >=K] bf16, w [d, >=K] bf16; ``k`` = valid K (a multiple of 32)."""
+    _dev(a, w, x_hi, x_lo, gamma, beta, mod)
+    assert a.dtype == w.dtype == x_hi.dtype == torch.bfloat16 and x_lo.dtype == torch.uint8 and mod.dtype == torch.float32
+    assert w.shape[0] == d
+    check(lib().swiftk_gemm_modnorm_residual_pair(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), k or a.shape[1],
+                                                  x_hi.data_ptr(), x_hi.stride(0), x_lo.data_ptr(), x_lo.stride(0), gamma.data_ptr(),
+                                                  beta.data_ptr(), mod.data_ptr(), mod.stride(0), a.shape[0], d, rows_per_sample,
+                                                  float(eps), rows_per_workgroup, _stream()), "swiftk_gemm_modnorm_residual_pair")
+
+
 def modnorm_residual_pair_slabs(y_slabs: torch.Tensor, x_hi: torch.Tensor, x_lo: torch.Tensor, gamma, beta, mod: torch.Tensor,
                                 rows_per_sample: int, d: int, eps: float = 1e-6) -> None:
     """``modnorm_residual_pair`` with the branch output as the sum of the two fp32 slabs y_slabs[0] + y_slabs[1] ([2, M, d]):
@@ -339,6 +353,23 @@ def axpby(a: float, x: torch.Tensor, b: float, y: torch.Tensor, out: Optional[to
     check(lib().swiftk_axpby(out.data_ptr(), float(a), x.data_ptr(), float(b), y.data_ptr(), x.numel(), _stream()),
           "swiftk_axpby")
     return out
+
+
+def zero_acc_(t: torch.Tensor) -> torch.Tensor:
+    """Zero a contiguous fp32 device tensor that a kernel is about to ACCUMULATE into (atomics / read-modify-write) with the
+    library's own fill kernel on the current stream (``swiftk_zero_f32``).  Every zero-then-accumulate site of the training
+    path goes through here or ``zeros_acc``: what clears the target is then a known, ordinary kernel launch -- not whatever
+    ``torch.zeros`` / ``Tensor.zero_`` lower to (round 5's intermittent gradient overflow went away with a ``hipMemsetAsync``
+    in front of an accumulating kernel; DESIGN "the gradient overflow")."""
+    _dev(t)
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    check(lib().swiftk_zero_f32(t.data_ptr(), t.numel(), _stream()), "swiftk_zero_f32")
+    return t
+
+
+def zeros_acc(*shape, device) -> torch.Tensor:
+    """``zero_acc_`` of a fresh fp32 tensor."""
+    return zero_acc_(torch.empty(*shape, dtype=torch.float32, device=device))
 
 
 def unit_checksum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

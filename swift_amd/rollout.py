@@ -36,17 +36,21 @@ def unit_seed(member: int, ic: int) -> int:
 
 def update_stats(dataset, interval: int, device):
     """(mean_x, std_x, std_t) for ``ops.rollout_update``, shared by the generate rollout and the in-training validation
-    rollout.  std_t is None for a non-residual dataset (generate.py:132-136, validate.py:112-116: the output is the next
-    standardised state, the trajectory gets ``unstandardize_x`` of it -- with the SST channel, if present, zeroed by
-    ``zero_field`` at the default delta, data/era5.py:135-170)."""
+    rollout.  Both un-standardise the state and re-standardise the sum with the DEFAULT delta (SST zeroed both times,
+    data/era5.py:135-149) but the residual with ``delta = interval`` (generate.py:120-131): zeroed too unless the interval is
+    24.  So an SST channel is handed over as mean 0 / std 0 -- ``swiftk_rollout_update`` reads std 0 as "the standardised
+    value of this channel is forced to zero" -- with residual-std 0 (interval != 24) or the real one (interval 24: physical
+    output = residual * std_t, next standardised state = 0, as the reference).  std_t is None for a non-residual dataset
+    (generate.py:132-136, validate.py:112-116: the output is the next standardised state, the trajectory gets
+    ``unstandardize_x`` of it).  (The multistep CRPS loss uses ONE delta throughout and takes ``dataset.rollout_stats``
+    as it is: with delta 24 its SST channel keeps the real std_x, loss.py:402-406.)"""
     residual = getattr(dataset, "residual", False)
     mx, sx, st = dataset.rollout_stats(int(interval) if residual else 6, device)
-    if not residual:
-        if "sea_surface_temperature" in dataset.variables:
-            sx = sx.clone()
-            sx[list(dataset.variables).index("sea_surface_temperature")] = 0.0
-        st = None
-    return mx, sx, st
+    if "sea_surface_temperature" in dataset.variables:
+        i = list(dataset.variables).index("sea_surface_temperature")
+        mx, sx = mx.clone(), sx.clone()
+        mx[i], sx[i] = 0.0, 0.0
+    return mx, sx, (st if residual else None)
 
 
 class LazyForcings:

@@ -54,10 +54,9 @@ def _transpose(src, rows, cols, ldd=None):
 
 
 def _zeros(*shape, device):
-    """fp32 zeros that a kernel is about to ACCUMULATE into (atomics / read-modify-write), cleared by an ordinary fill kernel on the
-    current stream: ``torch.zeros`` may clear through ``hipMemsetAsync``, which round 5 found not reliably ordered in front of an
-    accumulating kernel once a process group's event waits sit on the stream."""
-    return torch.empty(*shape, dtype=torch.float32, device=device).fill_(0.0)
+    """fp32 zeros that a kernel is about to ACCUMULATE into (atomics / read-modify-write), cleared by the library's own fill kernel
+    on the current stream (``ops.zeros_acc``: one helper for every such site, DESIGN "the gradient overflow")."""
+    return ops.zeros_acc(*shape, device=device)
 
 
 def _padded(rows, width, valid):
@@ -214,7 +213,7 @@ class SwinTrainEngine:
     @staticmethod
     def _grad_buf(p):
         if p.grad is None:
-            p.grad = torch.zeros_like(p, dtype=torch.float32)
+            p.grad = _zeros(*p.shape, device=p.device)  # (accumulated into by the backward kernels)
         return p.grad
 
     def activation_bytes(self, B: int) -> int:
@@ -368,6 +367,11 @@ class SwinTrainEngine:
         L = lib()
         po = m.out_channels * m.patch_size[0] * m.patch_size[1]
         G = self._grad_buf
+        # the ModulatedNorm backward's column-sum workspace is kept zero by its own finishing kernel; a pass that was aborted between
+        # the two kernels (a failed launch, an exception in between) would leave sums behind that every later pass adds to its
+        # LayerNorm / modulation gradients -- so each pass re-establishes the invariant with ONE clear up front
+        if getattr(self, "_row_stats", None) is not None and self._row_stats.numel() >= 2 * B * d:
+            ops.zero_acc_(self._row_stats[:2 * B * d])
         # ---- head: tok = xT_final @ Whead^T ; dtok = patchify(dout)
         dtok = ops.patchify([dout.contiguous().float()], [1.0], m.patch_size, self.kpo, _BF)  # [M, kpo] bf16, pad zero
         # feature order of the head is (c, p1, p2) while patchify emits (p1, p2, c): permute columns accordingly
@@ -467,14 +471,14 @@ class SwinTrainEngine:
 
     def _modnorm_bwd(self, y, g, dy, ln, mod_slice, dmod_slice, M, d, ntok):
         # the per-sample column sums of the one-kernel form live in a workspace this engine keeps ZERO between calls
-        # (``swiftk_modnorm_bwd_ws0``: the finishing kernel zeroes what it read) -- no clear per call.  SWIFTK_MNB_MODE picks
-        # another form for A/B runs: "memset" = the per-call hipMemsetAsync of rounds 4-5, "two" = row pass + column pass.
-        # (Round 5 traced an intermittent overflow of exactly these sums in data-parallel CRPS runs to the "memset" form:
-        # DESIGN section 10.)
+        # (``swiftk_modnorm_bwd_ws0``: the finishing kernel zeroes what it read, and every backward pass clears it once up front) --
+        # no clear per call.  SWIFTK_MNB_MODE picks another form for A/B runs: "clear" = a clear per call inside the library (a
+        # kernel; ``swiftk_set_tuning(25, 1)`` turns every library clear into the hipMemsetAsync of rounds 4-5, the form in which
+        # data-parallel CRPS runs intermittently overflowed exactly these sums), "two" = row pass + column pass.
         mode = os.environ.get("SWIFTK_MNB_MODE", "ws0")
         need = 2 * M
         if getattr(self, "_row_stats", None) is None or self._row_stats.numel() < need:
-            self._row_stats = torch.zeros(need, dtype=torch.float32, device=y.device)
+            self._row_stats = _zeros(need, device=y.device)
             self.graphs.invalidate()  # (captured sequences hold the old buffer's address)
         L = lib()
         args = (y.data_ptr(), y.stride(0), g.data_ptr(), dy.data_ptr(), dy.stride(0), ln.weight.detach().float().data_ptr(),

@@ -159,9 +159,9 @@ class TrigFlowLoss(_LossBase):
         res = eng.forward(srcs, scales, t, aux, want_logvar=want_lv)
         Fx, lv, ctx = res if want_lv else (res[0], None, res[1])
         wv, wl = self._w(dev)
-        loss = torch.zeros(1, device=dev)
+        loss = ops.zeros_acc(1, device=dev)  # (atomically accumulated: cleared by the library's own kernel)
         dF = torch.empty_like(Fx)
-        dlv = torch.zeros(B, device=dev) if want_lv else None
+        dlv = ops.zeros_acc(B, device=dev) if want_lv else None
         check(lib().swiftk_trigflow_loss(Fx.data_ptr(), vt.data_ptr(), None if lv is None else lv.contiguous().data_ptr(),
                                          wv.data_ptr(), wl.data_ptr(), loss.data_ptr(), dF.data_ptr(),
                                          None if dlv is None else dlv.data_ptr(), sd, B, C, H, W, 1.0, st), "swiftk_trigflow_loss")
@@ -261,9 +261,9 @@ class SCMLoss(_LossBase):
                                       float(r), sd, target.data_ptr(), ss.data_ptr(), B, per, st), "swiftk_scm_target")
         # (F - F.detach() - g)^2 == (1 * F - target)^2 with target = F.detach() + g held constant
         wv, wl = self._w(dev)
-        loss = torch.zeros(1, device=dev)
+        loss = ops.zeros_acc(1, device=dev)  # (atomically accumulated: cleared by the library's own kernel)
         dFx = torch.empty_like(Fx)
-        dlv = torch.zeros(B, device=dev) if want_lv else None
+        dlv = ops.zeros_acc(B, device=dev) if want_lv else None
         check(lib().swiftk_trigflow_loss(Fx.data_ptr(), target.data_ptr(), None if lv is None else lv.contiguous().data_ptr(),
                                          wv.data_ptr(), wl.data_ptr(), loss.data_ptr(), dFx.data_ptr(),
                                          None if dlv is None else dlv.data_ptr(), 1.0, B, C, H, W, 1.0, st), "swiftk_trigflow_loss")
@@ -381,7 +381,7 @@ class CRPSLoss(_LossBase):
                     else:
                         ops.axpby(-sd, out, 0.0, out, out=preds[e])
         wv, wl = self._w(dev)
-        loss = torch.zeros(1, device=dev)
+        loss = ops.zeros_acc(1, device=dev)  # (atomically accumulated: cleared by the library's own kernel)
         dpreds = torch.empty_like(preds)
         check(lib().swiftk_crps_loss(preds.data_ptr(), target.data_ptr(), wv.data_ptr(), wl.data_ptr(), loss.data_ptr(),
                                      dpreds.data_ptr(), E, B, C, H, W, float(self.alpha), 1.0, st), "swiftk_crps_loss")

@@ -21,7 +21,7 @@ from typing import Iterable, Optional
 import torch
 import torch.distributed as tdist
 
-from .. import dist
+from .. import dist, ops
 from .loss import CRPSLoss, SCMLoss, TrigFlowLoss
 
 
@@ -49,7 +49,9 @@ class GradAllReduce(torch.nn.Module):
         params = [p for p in self.module.parameters() if p.requires_grad]
         if self._flat is None:
             n = sum(p.numel() for p in params)
-            self._flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+            dev = params[0].device
+            # (the backward kernels ACCUMULATE into this buffer: on the GPU it is cleared by the library's own fill kernel)
+            self._flat = ops.zeros_acc(n, device=dev) if dev.type == "cuda" else torch.zeros(n, dtype=torch.float32, device=dev)
             o = 0
             for p in params:
                 p.grad = self._flat[o:o + p.numel()].view_as(p)
@@ -57,7 +59,11 @@ class GradAllReduce(torch.nn.Module):
         return self._flat
 
     def zero_grad_flat(self):
-        self.flatten_grads().zero_()
+        flat = self.flatten_grads()
+        if flat.is_cuda:
+            ops.zero_acc_(flat)
+        else:
+            flat.zero_()
         self._pending, self._ranges = [], []
 
     @staticmethod
@@ -109,16 +115,21 @@ class GradAllReduce(torch.nn.Module):
         import time
         return time.perf_counter()
 
-    def calibrate_serial(self, reps: int = 3) -> float:
+    def calibrate_serial(self, reps: int = 3, in_place: bool = False) -> float:
         """Milliseconds one blocking all-reduce of the whole flat gradient buffer takes (best of ``reps``): the yardstick the
-        exposed wait of an iteration is compared with (on a scratch buffer of the same size: the gradients are not touched)."""
+        exposed wait of an iteration is compared with.  By default on a scratch buffer of the same size, so the gradients are
+        not touched -- a second 4 B per parameter (2.7 GB at 664 M parameters), which a caller inside a running job must not
+        allocate behind the memory plan's back (the CRPS loss sizes its resident rollout steps from free memory once):
+        ``in_place=True`` reduces the gradient buffer itself, for callers that know its contents are dead (between an optimiser
+        step and the next ``zero_grad_flat()``: the trainer's tick)."""
         flat = self.flatten_grads()
         if not self._active():
             self.serial_ms = 0.0
             return 0.0
         import time
         best = None
-        probe = torch.zeros_like(flat)  # (a scratch copy of the same size: gloo's SUM would scale the gradients themselves)
+        # (a scratch copy of the same size: gloo's SUM would scale live gradients themselves)
+        probe = flat if in_place else torch.zeros_like(flat)
         for _ in range(reps):
             if flat.is_cuda:
                 torch.cuda.synchronize(flat.device)
@@ -128,6 +139,7 @@ class GradAllReduce(torch.nn.Module):
                 torch.cuda.synchronize(flat.device)
             dt = (time.perf_counter() - t0) * 1e3
             best = dt if best is None else min(best, dt)
+        del probe
         self.serial_ms = best
         return best
 
@@ -403,8 +415,10 @@ class Trainer:
             if tdist.is_initialized():
                 # per-rank gradient all-reduce record of this tick (what a first multi-GPU run is read by): serial time of the
                 # collective (calibrated once, between iterations), mean exposed wait per iteration, overlap fraction
+                # (in place: the optimiser step has consumed this iteration's gradients and the next iteration starts with
+                # zero_grad_flat() -- no second gradient-sized buffer appears behind the CRPS loss's memory plan)
                 if self.ddp.serial_ms is None and self.ddp._flat is not None:
-                    self.ddp.calibrate_serial()
+                    self.ddp.calibrate_serial(in_place=True)
                 mine = self.ddp.allreduce_stats()
                 self.ddp._timing, self.ddp._announced_hist = [], []
                 per_rank = [None] * world

@@ -46,14 +46,14 @@ def RMSE_rollout(sampler: Callable[..., torch.Tensor], dataloader, dataset, targ
         if w_lat is None:
             w_lat = _lat_weights(dataset, H, device)
         phys = torch.empty_like(X)
-        sq = torch.zeros(1 + nv, device=device)
+        sq = ops.zeros_acc(1 + nv, device=device)
         for i in range(target_interval):
             forc = dataset.standardize_x(torch.stack([dataset.get_forcings(int(j) + i) for j in idx], 0)).to(device).float()
             Y = sampler((X, forc.contiguous()), generator=rng)
             ops.rollout_update(X, Y, mx, sx, st, phys=phys)           # residual: phys = unstd(X) + unstd_t(Y); X <- std(phys)
             if (i + 1) % per_day == 0 or i == 0:
                 day = (i + 1) // per_day
-                sq.zero_()
+                ops.zero_acc_(sq)  # (swiftk_rmse_sums accumulates atomically)
                 tgt = TS[:, day]
                 check(lib().swiftk_rmse_sums(phys.data_ptr(), tgt.data_ptr(), TS.stride(0), w_lat.data_ptr(), sq.data_ptr(), B, nv,
                                              H, W, torch.cuda.current_stream().cuda_stream), "swiftk_rmse_sums")

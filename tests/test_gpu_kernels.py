@@ -393,6 +393,73 @@ def test_cast_pad_t_both_operands(dev, rows, cols, inter):
     assert torch.equal(out_t[:, :rows], ref.bfloat16().t()) and (out_t[:, rows:].float() == 0).all()
 
 
+@pytest.mark.parametrize("d", [1056, 960])
+@pytest.mark.parametrize("K,ldk", [(1056, 1088), (2816, 2816), (960, 960), (64, 64)])
+@pytest.mark.parametrize("rows", [32, 64])
+def test_gemm_modnorm_residual_pair_complete_rows(dev, rows, K, ldk, d):
+    """Round 5, small batches: wo / w2 and their ModulatedNorm as ONE kernel over complete rows
+    (swiftk_gemm_modnorm_residual_pair, gemm_rownorm.hip).  Its y is the bf16 rounding of the fp32-accumulated product -- the
+    k order of the tiled GEMM, so bit-equal to swiftk_gemm's bf16 output -- and its update is modnorm_residual_pair's arithmetic:
+    against the two-kernel path (same y; the row sums associate differently) and against the oracle's ModulatedNorm on the
+    fp64 product rounded to bf16 (swinv2.py:83-86, 211-212).  K = 1056 in rows of 1088 ends half-way into a 64-wide k-tile (33
+    k-steps: a partial activation super-stage); K = 64 is the two-step minimum."""
+    from oracle.swinv2 import modulated_norm
+    from swift_amd import ops
+    B, rps = 3, 128
+    M = B * rps
+    a, w, x = rnd((M, ldk), 61), rnd((d, ldk), 62, 0.03), rnd((M, d), 63)
+    a[:, K:] = float("nan")  # columns beyond K are never read into a product
+    w[:, K:] = float("nan")
+    ad, wd = to_dt(a, torch.bfloat16, dev), to_dt(w, torch.bfloat16, dev)
+    p = {"n.norm.weight": 1 + 0.1 * rnd((d,), 14), "n.norm.bias": 0.1 * rnd((d,), 15),
+         "n.modulation.weight": 0.02 * rnd((2 * d, d), 16), "n.modulation.bias": 0.1 * rnd((2 * d,), 17)}
+    lat = rnd((B, d), 18)
+    mod = torch.nn.functional.linear(lat, p["n.modulation.weight"], p["n.modulation.bias"]).to(dev)
+    g, b = p["n.norm.weight"].to(dev), p["n.norm.bias"].to(dev)
+    ld = ops.k_pad(torch.bfloat16, d)
+    hi, lo = ops.split_pair(x.to(dev), ld, 8)
+    hi[:, d:] = 7.0
+    x_in = ops.pair_value(hi, lo, d).cpu()
+    ops.gemm_modnorm_residual_pair(ad, wd, hi, lo, g, b, mod, rps, d, k=K, rows_per_workgroup=rows)
+    got = ops.pair_value(hi, lo, d).cpu()
+    assert torch.isfinite(got).all() and (hi[:, d:].float() == 7.0).all()
+    # the two-kernel path on the same operands
+    hi2, lo2 = ops.split_pair(x.to(dev), ld, 8)
+    a0, w0 = ad.clone(), wd.clone()
+    a0[:, K:] = 0
+    w0[:, K:] = 0
+    y = ops.gemm(a0, w0)  # (zero k-padding adds nothing: the same fp32 sums)
+    ops.modnorm_residual_pair(y, hi2, lo2, g, b, mod, rps, d)
+    e2 = rel_l2(got, ops.pair_value(hi2, lo2, d).cpu())
+    diff_hi = float((hi2[:, :d] != hi[:, :d]).float().mean())
+    y64 = ad[:, :K].float().cpu().double() @ wd[:, :K].float().cpu().double().T
+    ref = x_in.view(B, rps, d) + modulated_norm(y64.float().bfloat16().float().view(B, rps, d), lat, p, "n.")
+    e = rel_l2(got, ref.view(M, d))
+    print(f"complete-row GEMM + norm ({rows} rows, K {K}, d {d}): vs GEMM + norm kernels {e2:.2e} (hi differs on {diff_hi:.1e}), vs oracle {e:.2e}")
+    assert e2 < 2e-6 and diff_hi < 1e-3
+    assert e < 2e-4  # (the fp64 product rounds to another bf16 than the fp32-accumulated one on ~1e-3 of the elements)
+
+
+def test_gemm_modnorm_residual_pair_rejects(dev):
+    from swift_amd import _lib, ops
+    d, K, M = 1056, 1056, 128
+    a = torch.zeros(M, K, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(d, K, dtype=torch.bfloat16, device=dev)
+    hi = torch.zeros(M, 1088, dtype=torch.bfloat16, device=dev)
+    lo = torch.zeros(M, d, dtype=torch.uint8, device=dev)
+    g = torch.ones(d, device=dev)
+    mod = torch.zeros(2, 2 * d, device=dev)
+    for kw, exc in (({"rows_per_workgroup": 48}, "SHAPE"), ({"k": 1040}, "SHAPE"), ({"k": 32}, "SHAPE")):
+        with pytest.raises(RuntimeError):
+            ops.gemm_modnorm_residual_pair(a, w, hi, lo, g, g, mod, 64, d, **kw)
+    with pytest.raises(RuntimeError):  # rows of a workgroup must be of one sample
+        ops.gemm_modnorm_residual_pair(a, w, hi, lo, g, g, mod, 48, d, rows_per_workgroup=32)
+    with pytest.raises(RuntimeError):  # another width
+        ops.gemm_modnorm_residual_pair(a, torch.zeros(1280, K, dtype=torch.bfloat16, device=dev), torch.zeros(M, 1280, dtype=torch.bfloat16, device=dev),
+                                       torch.zeros(M, 1280, dtype=torch.uint8, device=dev), torch.ones(1280, device=dev),
+                                       torch.ones(1280, device=dev), torch.zeros(2, 2560, device=dev), 64, 1280)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_patchify_three_sources(dev, dt):
     from oracle.swinv2 import patchify

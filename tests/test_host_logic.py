@@ -77,7 +77,25 @@ def test_dataset_interface_matches_oracle_stats():
     ds2 = SyntheticERA5Dataset(["2m_temperature", "sea_surface_temperature"], [], img_resolution=(8, 16), random_stats=True)
     mx, sx, stt = ds2.rollout_stats(6, "cpu")
     assert (float(mx[1]), float(sx[1]), float(stt[1])) == (0.0, 1.0, 0.0)
+    # delta 24 zeroes nothing (zero_field returns early): the one-delta statistics -- what the multistep CRPS loss applies,
+    # loss.py:402-406 -- keep the channel's real values, so its update coefficient std_t / std_x is finite
     mx24, sx24, st24 = ds2.rollout_stats(24, "cpu")
+    assert float(sx24[1]) == float(np.asarray(ds2.x_stds).reshape(-1)[1]) != 0.0
+    assert float(mx24[1]) == float(np.asarray(ds2.x_means).reshape(-1)[1])
+    assert float(st24[1]) == float(np.asarray(ds2.t_stds[24]).reshape(-1)[1]) != 0.0
+    for d in (6, 12, 24):
+        _, sxd, std = ds2.rollout_stats(d, "cpu")
+        assert bool(torch.isfinite(std / sxd).all())
+    g0 = torch.Generator().manual_seed(5)
+    C0, P0 = torch.randn(2, 2, 8, 16, generator=g0), torch.randn(2, 2, 8, 16, generator=g0)
+    for d in (6, 24):  # the loss's condition update cond + pred * st / sx against the reference's three calls with ONE delta
+        m_, s_, t_ = (v.view(1, -1, 1, 1) for v in ds2.rollout_stats(d, "cpu"))
+        Cd = ds2.zero_field(C0.clone(), d)  # what the dataset hands the loss: standardised with this delta
+        ref = ds2.standardize_x(ds2.unstandardize_x(Cd.clone(), d) + ds2.unstandardize_t(P0.clone(), d), d)
+        assert torch.allclose(Cd + P0 * (t_ / s_), ref, atol=2e-5)
+    # the generate / validation rollout mixes deltas: its vectors carry the std-0 marker (rollout.update_stats)
+    from swift_amd.rollout import update_stats
+    mx24, sx24, st24 = update_stats(ds2, 24, "cpu")
     assert (float(mx24[1]), float(sx24[1])) == (0.0, 0.0) and float(st24[1]) == float(np.asarray(ds2.t_stds[24]).reshape(-1)[1]) != 0.0
     # the flat statistics against the reference's own sequence (generate.py:120-131: unstandardize_x and standardize_x with the
     # DEFAULT delta, unstandardize_t with delta = interval), with the update formula of swiftk_rollout_update restated in torch
@@ -86,7 +104,7 @@ def test_dataset_interface_matches_oracle_stats():
         X, Y = torch.randn(2, 2, 8, 16, generator=g), torch.randn(2, 2, 8, 16, generator=g)
         phys_ref = ds2.unstandardize_x(X.clone()) + ds2.unstandardize_t(Y.clone(), delta=interval)
         next_ref = ds2.standardize_x(phys_ref.clone())
-        mx, sx, stt = (v.view(1, -1, 1, 1) for v in ds2.rollout_stats(interval, "cpu"))
+        mx, sx, stt = (v.view(1, -1, 1, 1) for v in update_stats(ds2, interval, "cpu"))
         if interval == 24:
             assert float(phys_ref[:, 1].abs().sum()) > 0 and float(next_ref[:, 1].abs().sum()) == 0.0  # SST: residual kept, state zeroed
         X0 = X.clone()
@@ -339,10 +357,9 @@ def test_rollout_update_stats_non_residual_sst():
         ds = SyntheticERA5Dataset(names, ["f0"], img_resolution=(4, 8), length=16, seed=3, random_stats=True, residual=residual)
         mx, sx, st = update_stats(ds, 6, "cpu")
         assert (st is None) == (not residual)
+        assert float(mx[1]) == 0.0 and float(sx[1]) == 0.0 and float(sx[0]) != 0.0 and float(sx[2]) != 0.0
         if residual:
-            assert float(mx[1]) == 0.0 and float(sx[1]) == 1.0 and float(st[1]) == 0.0
-        else:
-            assert float(sx[1]) == 0.0 and float(sx[0]) != 0.0 and float(sx[2]) != 0.0
+            assert float(st[1]) == 0.0
         eng = RolloutEngine.__new__(RolloutEngine)
         eng.dataset, eng.interval, eng.residual, eng._stats = ds, 6, residual, None
         got = eng.stats(torch.device("cpu"))
