@@ -69,6 +69,9 @@ constexpr int EPI_BIAS_POS_PAIR = 11;  // internal: SWIFTK_EPI_BIAS_POS leaving 
 #ifndef SWIFTK_X_FEWREADS
 #define SWIFTK_X_FEWREADS 0
 #endif
+#ifndef SWIFTK_X_NOSILU
+#define SWIFTK_X_NOSILU 0
+#endif
 // cache policy of the bf16 output tiles' 16-B stores: 0 = default, 1 = nt, 2 = sc1 (write-through, line not kept in the
 // XCD's L2), 3 = sc0 sc1.  The outputs are written once and never re-read by the kernel; a round of 32 tiles per XCD writes
 // 5.8 MB through a 4 MB L2 that should be holding the W panel the XCD re-reads every round.
@@ -1277,8 +1280,13 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                             *reinterpret_cast<uint32_t*>(slab + r16 * RSTR + (j * 8 + 2 * g4) * 2) = hp;
                         } else if constexpr (EPI == SWIFTK_EPI_SWIGLU) {
                             // silu(g) * u with v_exp_f32 / v_rcp_f32 (1 ulp each; the libm forms cost ~30 VALU apiece)
+#if SWIFTK_X_NOSILU  // timing probe with WRONG results (round 6): the epilogue without its transcendentals = the bound of any cheaper sigmoid
+                            const float h0 = v[0] * v[1];
+                            const float h1 = v[2] * v[3];
+#else
                             const float h0 = v[0] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[0])) * v[1];
                             const float h1 = v[2] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[2])) * v[3];
+#endif
                             *reinterpret_cast<uint32_t*>(slab + r16 * RSTR + (j * 8 + 2 * g4) * 2) = pack_bf16(h0, h1);
                         } else {
                             *reinterpret_cast<uint2*>(slab + r16 * RSTR + (j * 16 + 4 * g4) * 2) =

@@ -98,7 +98,7 @@ struct FusedArgs {
     int64_t ldx_b, ldw_b, ldo;
     int B, gh, gw, heads, sh, sw;
     int nk, khalf;      // k-tiles, and whether the last one is half full
-    int dbg;            // timing experiments: 1 = skip the attention core, 2 = every item reads head 0's weights
+    int dbg;            // timing experiments: 1 = skip the attention core, 2 = every item reads head 0's weights, 4 = no parking writes, 8 = no norm + no parking writes
 };
 
 __device__ __forceinline__ int win_token(int wy, int wx, int j, int gh, int gw, int sh, int sw) {
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
             char* qk_tile = smem + (wn ? OFF_K : OFF_Q);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
+                if (a.dbg & 8) continue;  // (timing probe, WRONG results: no norm arithmetic and no parking writes at all)
                 float ss = 0.f;
 #pragma unroll
                 for (int j = 0; j < (HD + 15) / 16; ++j) {  // the head vector's blocks; head_dim 88 ends inside block 5 (lanes g4 < 2)
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
                 ss += __shfl_xor(ss, 32, 64);
                 const float f = tau / fmaxf(sqrtf(ss), 1e-12f);
                 const int row = wm * 64 + i * 16 + r16;
+                if (a.dbg & 4) continue;  // (timing probe, WRONG results: the k-loop -> core hand-off without its 135 KB of LDS writes)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     const int lc = 16 * j + 4 * g4;  // this lane's 4 columns of the wave's 144 (never straddle: 88 % 4 == 0)
@@ -447,6 +449,10 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
                         *reinterpret_cast<uint2*>(qk_tile + row * ROW + lc * 2) =
                             make_uint2(pack_bf16(v[0] * f, v[1] * f), pack_bf16(v[2] * f, v[3] * f));
                     } else if (lc < HD + nv) {
+                        // (V rows are 192 B = 48 banks apart, so the 16 rows of one ds_write_b64 fall on four bank groups.  Round 6
+                        // XOR-ed the 8-B chunk index with (row >> 2) & 3 on both sides -- conflict-free writes, same read footprint,
+                        // parity-green -- and measured +-0 (profiles/r06c_qkv_handoff_probe.txt): the hand-off is bound by the VALU
+                        // issue of the two waves of a SIMD, not by LDS; the plain layout stays)
                         *reinterpret_cast<uint2*>(smem + OFF_V + row * VROW + (lc - HD + v0) * 2) =
                             make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
                     }
@@ -587,12 +593,7 @@ __global__ __launch_bounds__(NT) void qkv_attn_kernel(FusedArgs a, int nitems) {
             }
         };
         if (!(a.dbg & 1)) {
-            // both waves of a SIMD arrive here from the same barrier and would run their matrix and VALU phases in step:
-            // the second-dispatched half starts a fraction of a chunk later (dbg bits 4..: units of 64 cycles; timing experiments)
-            if (wv >= 4 && (a.dbg >> 2)) __builtin_amdgcn_s_sleep(1);
-            if (wv >= 4 && (a.dbg >> 2) >= 2) __builtin_amdgcn_s_sleep(2);
-            if (wv >= 4 && (a.dbg >> 2) >= 4) __builtin_amdgcn_s_sleep(4);
-            if (wv >= 4 && (a.dbg >> 2) >= 8) __builtin_amdgcn_s_sleep(8);
+            // (a start-up stagger of waves 4-7 against their SIMD partners was measured in round 3: +-0, removed in round 6)
             if (online) core(std::true_type{}); else core(std::false_type{});
         }
         float l = (a.dbg & 1) ? 1.f : o[DB - 1][12];

@@ -103,10 +103,11 @@ if os.environ.get("SWIFTK_SYNC_DEBUG"):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
 _bad = [n for n, p in net.named_parameters() if not torch.isfinite(p).all()]
-if os.environ.get("SWIFTK_NAN_DEBUG") or _bad:  # which parameters ever saw an overflowing gradient (exp_avg_sq = inf)?
-    _inf = [(n, int((~torch.isfinite(opt.state[p]["exp_avg_sq"])).sum()), p.numel()) for n, p in net.named_parameters()
-            if p in opt.state and "exp_avg_sq" in opt.state[p] and not torch.isfinite(opt.state[p]["exp_avg_sq"]).all()]
-    print(f"parameters with non-finite exp_avg_sq: {len(_inf)}: {_inf[:40]}", file=sys.stderr)
+# which parameters ever saw an overflowing gradient (exp_avg_sq = inf)?  Always checked: the second moment remembers an overflow of
+# ANY iteration of the run, also where nan_to_num kept the parameters finite (the round-5 data-parallel overflow, DESIGN)
+_inf = [(n, int((~torch.isfinite(opt.state[p]["exp_avg_sq"])).sum()), p.numel()) for n, p in net.named_parameters()
+        if p in opt.state and "exp_avg_sq" in opt.state[p] and not torch.isfinite(opt.state[p]["exp_avg_sq"]).all()]
+print(f"OVERFLOW-CHECK parameters with non-finite exp_avg_sq: {len(_inf)}: {_inf[:40]}", file=sys.stderr)
 if _bad:  # (a non-finite parameter after the run: name the first few -- which kernel's output went wrong?)
     print(f"NON-FINITE PARAMETERS after {a.iters} iterations: {len(_bad)} of {len(list(net.parameters()))}: {_bad[:12]}", file=sys.stderr)
     for n, p in net.named_parameters():
