@@ -535,6 +535,11 @@ def main():
             for e in list(getattr(net.model, "_engines", {}).values()):
                 e._ws = None
             gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                line["generate_e2e"] = generate_e2e_leg()
+            except Exception as e:  # noqa: BLE001
+                line["generate_e2e"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             line["training"] = training_leg()
         print(json.dumps(line), flush=True)
     if grouped:
@@ -564,6 +569,45 @@ def training_leg():
             out[name] = {k: rec[k] for k in ("metric", "value", "unit", "samples_per_s", "what", "roofline", "peak_mem_gib", "allreduce") if k in rec}
         except Exception as e:  # noqa: BLE001 -- the forecast metric above must still be printed
             out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
+def generate_e2e_leg(members: int = 12, ics: int = 2, steps: int = 12):
+    """The disk-included rate of the forecast job: ``python -m swift_amd.generate --synthetic`` as a child
+    process -- the CLI a user runs (generate.py:23-43) -- for members x ics units x steps lead steps in ONE batch, once per raw
+    output format, into a scratch directory that is removed afterwards.  The figure is the CLI's own clock around
+    rollout_and_save (forcing staging, the device-resident rollout, device -> pinned ring -> store writes; model construction
+    and imports excluded), so it sits beside the loop rate of this line's headline.  A reported extra; failures are recorded."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    out = {"what": f"swift_amd.generate --synthetic --dtype bf16: {members} members x {ics} ICs x {steps} steps, one batch of {members * ics} "
+                   "units, output streamed step by step through a pinned ring; rate = sample-steps / seconds inside rollout_and_save "
+                   "(generate.py:48-154), store writes included", "unit": "sample-steps/s"}
+    root = os.path.dirname(os.path.abspath(__file__))
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    for dump in ("numpy", "zarr"):
+        d = tempfile.mkdtemp(prefix="swiftk_e2e_", dir=base)
+        try:
+            env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            p = subprocess.run([sys.executable, "-m", "swift_amd.generate", "--input", d, "--synthetic", "--members", str(members),
+                                "--samples", str(ics), "--steps", str(steps), "--batch", str(members * ics), "--dtype", "bf16", "--dump", dump],
+                               capture_output=True, text=True, timeout=600, env=env, cwd=root)
+            m = re.search(r"Took ([0-9.]+) seconds: (\d+) sample-steps, ([0-9.]+) sample-steps/s", p.stdout + p.stderr)
+            if p.returncode != 0 or not m:
+                raise RuntimeError(f"rc {p.returncode}: {(p.stderr or p.stdout)[-200:]}")
+            nbytes = sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(d) for f in fs)
+            out[dump] = {"value": float(m.group(3)), "seconds": float(m.group(1)), "sample_steps": int(m.group(2)),
+                         "store_gb": nbytes / 1e9, "store_gb_per_s": nbytes / 1e9 / float(m.group(1)),
+                         "scratch": "tmpfs" if base else "tmp"}
+        except Exception as e:  # noqa: BLE001
+            out[dump] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
     return out
 
 

@@ -266,7 +266,7 @@ int swiftk_axpby(float* out, float a, const float* x, float b, const float* y, i
  * (atomics or read-modify-write: the loss sums of training/loss.py:117-160,306-445, the flat gradient buffer behind
  * trainer.py:219-247's optimizer.zero_grad, the RMSE sums of training/validate.py:96-110).  Round 5 traced an intermittent
  * overflow of atomically accumulated sums to a workspace cleared by hipMemsetAsync in front of the accumulating kernel
- * (DESIGN, "the gradient overflow"); tuning key 25 = 1 restores that clear for diagnosis (tools/zero_order_stress.py).
+ * (DESIGN, "the gradient overflow"); tuning key 25 restores that clear for diagnosis (tools/overflow_campaign.sh).
  */
 int swiftk_zero_f32(float* p, int64_t n, void* stream);
 
@@ -305,7 +305,8 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * (Swift-B's four weight gradients 0...-9 % in time, -6 % per layer: tools/tn_ab.py),
  * key 23 = swiftk_swinv2_forward (bf16 engine) runs wo / w2 + norm as swiftk_gemm_modnorm_residual_pair up to this many units
  * per step (0 = never: split-K + slab-summing norm at one unit, GEMM + norm beyond),
- * key 25 = swiftk_zero_f32 (and the library's internal clears) through hipMemsetAsync instead of a kernel (0; diagnosis only). */
+ * key 25 = clears through hipMemsetAsync instead of a kernel (0; diagnosis only; bit 1 = the library's internal clears --
+ * swiftk_modnorm_bwd's workspace, swiftk_scm_target's scratch --, bit 2 = swiftk_zero_f32). */
 int swiftk_set_tuning(int key, int value);
 /* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
  * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default

@@ -183,7 +183,7 @@ static inline int swiftk_zero_f32_launch(float* p, int64_t n, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-extern "C" int swiftk_zero_f32(float* p, int64_t n, void* stream);  // (elementwise.hip: the exported form, tuning key 25)
+int swiftk_zero_f32_impl(float* p, int64_t n, void* stream, int who);  // (elementwise.hip; who = 1: a clear inside the library, tuning key 25)
 extern int g_zero_memset;  // tuning key 25
 
 // live per-kernel timing (bench.py's roofline legs; state lives in gemm.hip): a launch of kind `kind` (a GEMM

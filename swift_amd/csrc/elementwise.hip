@@ -1390,16 +1390,19 @@ extern "C" int swiftk_counter_add(int64_t* counter, int64_t value, void* stream)
     return 0;
 }
 
-int g_zero_memset = 0;  // tuning key 25 (diagnosis only): 1 = swiftk_zero_f32 clears with hipMemsetAsync, the round-4/5 form
+int g_zero_memset = 0;  // tuning key 25 (diagnosis only), bit mask: 1 = the library's internal clears (swiftk_modnorm_bwd's column-sum
+                        // workspace, swiftk_scm_target's scratch), 2 = the exported swiftk_zero_f32 -- through hipMemsetAsync, the round-4/5 form
 
-extern "C" int swiftk_zero_f32(float* p, int64_t n, void* stream) {
+int swiftk_zero_f32_impl(float* p, int64_t n, void* stream, int who) {
     if (!p || n < 0) return SWIFTK_EINVAL;
     if (n == 0) return 0;
     if (((uintptr_t)p & 3)) return SWIFTK_EALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (g_zero_memset) return (int)hipMemsetAsync(p, 0, sizeof(float) * (size_t)n, st);
+    if (g_zero_memset & who) return (int)hipMemsetAsync(p, 0, sizeof(float) * (size_t)n, st);
     return swiftk_zero_f32_launch(p, n, st);
 }
+
+extern "C" int swiftk_zero_f32(float* p, int64_t n, void* stream) { return swiftk_zero_f32_impl(p, n, stream, 2); }
 
 extern "C" int swiftk_axpby(float* out, float a, const float* x, float b, const float* y, int64_t n, void* stream) {
     if (!out || !x || !y || n <= 0) return SWIFTK_EINVAL;

@@ -1091,7 +1091,7 @@ extern "C" int swiftk_scm_target(const float* F, const float* dxt, const float* 
                                  void* stream) {
     if (!F || !dxt || !xt_over_sd || !dF || !t || !target || !ss_scratch || B <= 0 || per_sample <= 0) return SWIFTK_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (swiftk_zero_f32(ss_scratch, B, stream) != 0) return SWIFTK_EINVAL;  // (a kernel, not hipMemsetAsync: common.h)
+    if (swiftk_zero_f32_impl(ss_scratch, B, stream, 1) != 0) return SWIFTK_EINVAL;  // (a kernel, not hipMemsetAsync: common.h)
     const dim3 grid((unsigned)grid_for(per_sample, 256, 512), (unsigned)B);
     hipLaunchKernelGGL(scm_g_kernel, grid, dim3(256), 0, st, F, dxt, xt_over_sd, dF, t, r, sigma_data, target, ss_scratch,
                        per_sample);

@@ -41,6 +41,77 @@ def get_torch_device(as_torch_device: bool = True):
     return d if as_torch_device else d.type
 
 
+def _parse_cpulist(text: str):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def numa_cpus_of_gpu(pci_bus_id: str, sysfs: str = "/sys") -> Optional[set]:
+    """The CPUs of the NUMA node a GPU hangs off (``<sysfs>/bus/pci/devices/<id>/numa_node`` -> ``.../node/nodeN/cpulist``), or
+    None where the kernel does not say (node -1, no sysfs entry)."""
+    try:
+        with open(os.path.join(sysfs, "bus", "pci", "devices", pci_bus_id.lower(), "numa_node")) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")) as f:
+            return _parse_cpulist(f.read()) or None
+    except (OSError, ValueError):
+        return None
+
+
+def bind_to_gpu_numa_node(local_rank: Optional[int] = None, local_world: Optional[int] = None, sysfs: str = "/sys") -> Optional[set]:
+    """Pin this rank's host threads (forcing readers, pinned-ring writers, the launch thread) to the CPUs next to its GPU, so that
+    the 3.4 GB/s per rank of pinned staging / output traffic stays on the GPU's own socket -- the reference leaves placement to
+    the launcher (scripts/aurora-general.sh:74-91 binds ranks with ``--cpu-bind``).  When several local ranks share a node its
+    CPUs are dealt out evenly.  Best effort: returns the CPU set applied, or None (no GPU, no sysfs information, affinity not
+    permitted, ``SWIFTK_NUMA_BIND=0``).  Called by ``setup_torch`` after the rank has selected its device."""
+    if os.environ.get("SWIFTK_NUMA_BIND", "1") in ("", "0") or not hasattr(os, "sched_setaffinity"):
+        return None
+    if local_rank is None:
+        local_rank = get_local_rank()
+    if local_world is None:
+        local_world = _env_int("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", default=get_world_size())
+    try:
+        n = torch.cuda.device_count()
+        if n == 0:
+            return None
+        ids = [_pci_bus_id(i) for i in range(n)]
+    except Exception:  # noqa: BLE001 -- placement is an optimisation, never an error
+        return None
+    mine = numa_cpus_of_gpu(ids[local_rank % n], sysfs) if ids[local_rank % n] else None
+    if not mine:
+        return None
+    # ranks whose GPUs share this node split its CPUs (in rank order) instead of piling onto all of them
+    same = [r for r in range(max(local_world, 1)) if ids[r % n] and numa_cpus_of_gpu(ids[r % n], sysfs) == mine]
+    allowed = sorted(mine & set(os.sched_getaffinity(0)))
+    if len(same) > 1 and len(allowed) >= len(same) and local_rank in same:
+        k = same.index(local_rank)
+        per = len(allowed) // len(same)
+        allowed = allowed[k * per:(k + 1) * per]
+    if not allowed:
+        return None
+    try:
+        os.sched_setaffinity(0, allowed)
+    except OSError:
+        return None
+    return set(allowed)
+
+
+def _pci_bus_id(i: int) -> Optional[str]:
+    """``0000:c1:00.0`` of device i, from the driver's sysfs listing via the properties torch caches (no kernel launch)."""
+    try:
+        p = torch.cuda.get_device_properties(i)
+        return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def collectives_active() -> bool:
     """True when a process group exists: the collectives of the data path (weight broadcast, output all-gather, gradient
     all-reduce, barriers) then run through it -- also in a group of ONE rank (``setup_torch(single_rank_group=True)``),
@@ -62,6 +133,10 @@ def setup_torch(backend: Optional[str] = None, timeout_s: int = 1800, single_ran
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         torch.cuda.set_device(get_local_rank() % torch.cuda.device_count())
+        if world > 1:  # one rank per GPU on one node: host threads next to the rank's own GPU (round 6)
+            cpus = bind_to_gpu_numa_node()
+            if cpus:
+                _log.info("rank %d: host threads bound to %d CPUs of GPU %d's NUMA node", get_rank(), len(cpus), get_local_rank())
     if single_rank_group is None:
         single_rank_group = os.environ.get("SWIFTK_SINGLE_RANK_GROUP", "0") not in ("", "0")
     if (world > 1 or single_rank_group) and not dist.is_initialized():

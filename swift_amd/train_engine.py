@@ -473,7 +473,7 @@ class SwinTrainEngine:
         # the per-sample column sums of the one-kernel form live in a workspace this engine keeps ZERO between calls
         # (``swiftk_modnorm_bwd_ws0``: the finishing kernel zeroes what it read, and every backward pass clears it once up front) --
         # no clear per call.  SWIFTK_MNB_MODE picks another form for A/B runs: "clear" = a clear per call inside the library (a
-        # kernel; ``swiftk_set_tuning(25, 1)`` turns every library clear into the hipMemsetAsync of rounds 4-5, the form in which
+        # kernel; ``swiftk_set_tuning(25, 1)`` turns the library's internal clears into the hipMemsetAsync of rounds 4-5, the form in which
         # data-parallel CRPS runs intermittently overflowed exactly these sums), "two" = row pass + column pass.
         mode = os.environ.get("SWIFTK_MNB_MODE", "ws0")
         need = 2 * M

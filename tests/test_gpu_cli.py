@@ -100,6 +100,14 @@ def test_train_then_generate_cli(tmp_path):
     np.testing.assert_array_equal(np.load(f), a)
     met2 = json.load(open(rdir / "output" / "latest" / "evaluation_metrics.json"))
     assert met2.keys() == met.keys() and all(met2[k] == pytest.approx(met[k], rel=1e-6) for k in met)
+    # round 6: two ranks and NO --dump: the multi-rank default is metrics only (no raw store: 3.4 GB/s per rank into one filesystem)
+    os.remove(rdir / "output" / "latest" / "evaluation_metrics.json")
+    os.remove(f)
+    run(["swift_amd.generate", "--gpus", "2", "--input", str(rdir), "--members", "2", "--steps", "3", "--samples", "3", "--batch",
+         "3"], cwd=str(tmp_path), env={"SWIFTK_ALLOW_SHARED_GPU": "1", "SWIFTK_DIST_BACKEND": "gloo"})
+    met3 = json.load(open(rdir / "output" / "latest" / "evaluation_metrics.json"))
+    assert met3.keys() == met.keys() and all(met3[k] == pytest.approx(met[k], rel=1e-6) for k in met)
+    assert not os.path.exists(f) and not os.path.exists(str(f)[:-4] + ".none")
 
 
 def test_train_cli_5p6deg_one_by_one_patches(tmp_path):

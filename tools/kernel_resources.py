@@ -9,7 +9,7 @@ files = [a for a in sys.argv[1:] if a.endswith(".hip")] or sorted(f for f in os.
 
 
 def demangle(names):
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
     return [re.sub(r"\(anonymous namespace\)::", "", o).split("(")[0].replace("void ", "") for o in out]
 
 

@@ -108,6 +108,15 @@ _bad = [n for n, p in net.named_parameters() if not torch.isfinite(p).all()]
 _inf = [(n, int((~torch.isfinite(opt.state[p]["exp_avg_sq"])).sum()), p.numel()) for n, p in net.named_parameters()
         if p in opt.state and "exp_avg_sq" in opt.state[p] and not torch.isfinite(opt.state[p]["exp_avg_sq"]).all()]
 print(f"OVERFLOW-CHECK parameters with non-finite exp_avg_sq: {len(_inf)}: {_inf[:40]}", file=sys.stderr)
+for n, p in net.named_parameters():  # where inside a tensor: contiguous ranges? a stride?  (first few partially hit tensors)
+    if any(n == q[0] and q[1] < q[2] for q in _inf[:60]) and sum(1 for _ in [0]) and n.count("layers.0.") + n.count("layers.11."):
+        ix = (~torch.isfinite(opt.state[p]["exp_avg_sq"])).flatten().nonzero().flatten().tolist()
+        runs, a0 = [], ix[0]
+        for u, v in zip(ix, ix[1:] + [None]):
+            if v != u + 1:
+                runs.append((a0, u))
+                a0 = v
+        print(f"OVERFLOW-WHERE {n} {tuple(p.shape)}: {len(ix)} elements in {len(runs)} runs: {runs[:12]}", file=sys.stderr)
 if _bad:  # (a non-finite parameter after the run: name the first few -- which kernel's output went wrong?)
     print(f"NON-FINITE PARAMETERS after {a.iters} iterations: {len(_bad)} of {len(list(net.parameters()))}: {_bad[:12]}", file=sys.stderr)
     for n, p in net.named_parameters():

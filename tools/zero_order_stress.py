@@ -4,7 +4,7 @@
 like the eager backward pass of a data-parallel CRPS iteration -- GEMM-sized neighbours on the stream, a one-rank RCCL group
 whose asynchronous all-reduces put cross-stream event waits on the stream -- with the workspace cleared per call by
 
-  memset : hipMemsetAsync                       (``swiftk_set_tuning(25, 1)``: the round-4/5 library)
+  memset : hipMemsetAsync                       (``swiftk_set_tuning(25, 3)``: the round-4/5 library)
   kernel : the library's fill kernel            (what ships)
   ws0    : nothing per call; the finishing kernel leaves the workspace zero (what the training engine uses)
 
@@ -62,7 +62,7 @@ print(f"# {CALLS} calls per configuration, M = {M}, d = {d}, process group: {tdi
 
 for mode in ("memset", "kernel", "ws0"):
     for coll in ((False, True) if USE_GROUP else (False,)):
-        L.swiftk_set_tuning(25, 1 if mode == "memset" else 0)
+        L.swiftk_set_tuning(25, 3 if mode == "memset" else 0)
         fn = L.swiftk_modnorm_bwd_ws0 if mode == "ws0" else L.swiftk_modnorm_bwd
         ops.zero_acc_(ws)
         torch.cuda.synchronize()
