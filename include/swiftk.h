@@ -264,11 +264,14 @@ int swiftk_axpby(float* out, float a, const float* x, float b, const float* y, i
 /*
  * p[0..n) = 0.0f by an ORDINARY kernel on `stream`: what every caller uses in front of a kernel that accumulates into p
  * (atomics or read-modify-write: the loss sums of training/loss.py:117-160,306-445, the flat gradient buffer behind
- * trainer.py:219-247's optimizer.zero_grad, the RMSE sums of training/validate.py:96-110).  Round 5 traced an intermittent
- * overflow of atomically accumulated sums to a workspace cleared by hipMemsetAsync in front of the accumulating kernel
- * (DESIGN, "the gradient overflow"); tuning key 25 restores that clear for diagnosis (tools/overflow_campaign.sh).
+ * trainer.py:219-247's optimizer.zero_grad, the RMSE sums of training/validate.py:96-110).  Never hipMemsetAsync: as a node of a
+ * replayed HIP graph it writes a stale fill pattern under the HIP 7.0.x runtime PyTorch bundles (DESIGN section 11;
+ * tools/memset_graph_repro.hip); tuning key 25 restores that clear for diagnosis (tools/overflow_campaign.sh).
  */
 int swiftk_zero_f32(float* p, int64_t n, void* stream);
+/* Diagnosis (tuning key 25 bit 4): out26[0] = checks run, [1..4] = non-zero dwords a clear left behind by dword index mod 4,
+ * [5..8] = largest magnitude bits by index mod 4, [9] = samples taken, [10..17] / [18..25] = sample indices / bits. */
+int swiftk_zero_check_report(unsigned long long* out26);
 
 /*
  * Measurement hooks (bench.py's roofline leg; not on the reference's path).  After
@@ -306,7 +309,8 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * key 23 = swiftk_swinv2_forward (bf16 engine) runs wo / w2 + norm as swiftk_gemm_modnorm_residual_pair up to this many units
  * per step (0 = never: split-K + slab-summing norm at one unit, GEMM + norm beyond),
  * key 25 = clears through hipMemsetAsync instead of a kernel (0; diagnosis only; bit 1 = the library's internal clears --
- * swiftk_modnorm_bwd's workspace, swiftk_scm_target's scratch --, bit 2 = swiftk_zero_f32). */
+ * swiftk_modnorm_bwd's workspace, swiftk_scm_target's scratch --, bit 2 = swiftk_zero_f32, bit 4 = a check kernel behind
+ * swiftk_modnorm_bwd's clear records what it left non-zero: swiftk_zero_check_report). */
 int swiftk_set_tuning(int key, int value);
 /* The current value of a tuning key (SWIFTK_EINVAL for an unknown key; every valid value is >= 0 or a plain bit mask):
  * what a measurement harness records so that its report names the kernels that actually ran.  Key 11 = the default

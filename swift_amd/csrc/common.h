@@ -170,10 +170,10 @@ struct AttnPipeArgs {
 };
 int swiftk_launch_attn_pipe(const AttnPipeArgs& a, hipStream_t st);
 
-// Zero n floats with an ORDINARY kernel on the caller's stream.  Not hipMemsetAsync: round 5 traced an intermittent overflow of
-// atomically accumulated sums (swiftk_modnorm_bwd's per-sample column sums, 4 of 8 data-parallel CRPS runs against 0 of 20) to a
-// workspace cleared by hipMemsetAsync right in front of the accumulating kernel -- with a process group's event traffic on the
-// stream the fill was not reliably ordered in front of the atomics.  A kernel launch is.
+// Zero n floats with an ORDINARY kernel on the caller's stream.  Not hipMemsetAsync: captured into a HIP graph and replayed on the
+// null stream, a memset writes a STALE fill pattern under the HIP 7.0.x runtime PyTorch bundles (the node does not own its pattern:
+// zeros turn into later launches' kernel arguments) -- what overflowed swiftk_modnorm_bwd's atomically accumulated column sums in
+// round 5 (standalone: tools/memset_graph_repro.hip).  A kernel node carries its arguments by value.
 __global__ __launch_bounds__(256) static void swiftk_zero_f32_kernel(float* __restrict__ p, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
 }
@@ -185,6 +185,8 @@ static inline int swiftk_zero_f32_launch(float* p, int64_t n, hipStream_t st) {
 
 int swiftk_zero_f32_impl(float* p, int64_t n, void* stream, int who);  // (elementwise.hip; who = 1: a clear inside the library, tuning key 25)
 extern int g_zero_memset;  // tuning key 25
+int swiftk_zero_check_enable();
+int swiftk_zero_check_launch(const float* p, int64_t n, void* stream);  // (no-op unless key 25 bit 4 was set)
 
 // live per-kernel timing (bench.py's roofline legs; state lives in gemm.hip): a launch of kind `kind` (a GEMM
 // epilogue code, or SWIFTK_PROF_ATTENTION) with matching n is bracketed by HIP events on its own stream

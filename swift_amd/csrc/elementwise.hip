@@ -1404,6 +1404,63 @@ int swiftk_zero_f32_impl(float* p, int64_t n, void* stream, int who) {
 
 extern "C" int swiftk_zero_f32(float* p, int64_t n, void* stream) { return swiftk_zero_f32_impl(p, n, stream, 2); }
 
+// Diagnosis of the round-5 overflow (tuning key 25, bit 4): a check kernel right behind a clear counts what the clear left
+// non-zero -- per dword index mod 4, with the largest magnitude and a few (index, bits) samples -- into a small device record
+// that swiftk_zero_check_report copies out.  The record is allocated when the bit is set (never inside a stream capture).
+namespace {
+struct ZeroCheck {
+    unsigned long long calls, bad[4];
+    unsigned int worst[4];
+    unsigned int n_samples, sample_idx[8], sample_bits[8];
+};
+ZeroCheck* g_zero_check = nullptr;
+
+__global__ __launch_bounds__(256) void zero_check_kernel(const unsigned int* __restrict__ p, int64_t n, ZeroCheck* rec) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&rec->calls, 1ull);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned int v = p[i];
+        if (v != 0u) {
+            atomicAdd(&rec->bad[i & 3], 1ull);
+            atomicMax(&rec->worst[i & 3], v & 0x7fffffffu);
+            const unsigned int k = atomicAdd(&rec->n_samples, 1u);
+            if (k < 8) {
+                rec->sample_idx[k] = (unsigned int)i;
+                rec->sample_bits[k] = v;
+            }
+        }
+    }
+}
+}  // namespace
+
+int swiftk_zero_check_enable() {
+    if (g_zero_check) return 0;
+    if (hipMalloc(reinterpret_cast<void**>(&g_zero_check), sizeof(ZeroCheck)) != hipSuccess) return SWIFTK_EINVAL;
+    return hipMemset(g_zero_check, 0, sizeof(ZeroCheck)) == hipSuccess ? 0 : SWIFTK_EINVAL;
+}
+
+int swiftk_zero_check_launch(const float* p, int64_t n, void* stream) {
+    if (!g_zero_check) return 0;
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(zero_check_kernel, dim3((unsigned)(blocks < 256 ? (blocks < 1 ? 1 : blocks) : 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const unsigned int*>(p), n, g_zero_check);
+    return (int)hipGetLastError();
+}
+
+/* out[0] = checks run, out[1..4] = non-zero dwords found by index mod 4, out[5..8] = largest |bits| by index mod 4,
+ * out[9] = samples, out[10..17] = sample indices, out[18..25] = sample bits (device synchronisation; diagnosis only) */
+extern "C" int swiftk_zero_check_report(unsigned long long* out26) {
+    if (!out26) return SWIFTK_EINVAL;
+    for (int i = 0; i < 26; ++i) out26[i] = 0;
+    if (!g_zero_check) return 0;
+    ZeroCheck h;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&h, g_zero_check, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return SWIFTK_EINVAL;
+    out26[0] = h.calls;
+    for (int i = 0; i < 4; ++i) { out26[1 + i] = h.bad[i]; out26[5 + i] = h.worst[i]; }
+    out26[9] = h.n_samples;
+    for (int i = 0; i < 8; ++i) { out26[10 + i] = h.sample_idx[i]; out26[18 + i] = h.sample_bits[i]; }
+    return 0;
+}
+
 extern "C" int swiftk_axpby(float* out, float a, const float* x, float b, const float* y, int64_t n, void* stream) {
     if (!out || !x || !y || n <= 0) return SWIFTK_EINVAL;
     if (((uintptr_t)out & 15) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return SWIFTK_EALIGN;

@@ -1629,7 +1629,9 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 22: g_tn_pp = value; return 0;
         case 23: g_fwd_rownorm = value; return 0;
         case 24: g_rownorm_dbg = value; return 0;
-        case 25: g_zero_memset = value; return 0;
+        case 25:
+            g_zero_memset = value;
+            return (value & 4) ? swiftk_zero_check_enable() : 0;
     }
     return SWIFTK_EINVAL;
 }

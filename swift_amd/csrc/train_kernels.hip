@@ -965,6 +965,7 @@ static int modnorm_bwd_impl(const void* y, int64_t ldy, const float* g, void* dy
         // psum [2][nb][d] must be zero on entry: cleared here, unless the caller keeps the workspace zero between calls
         // (swiftk_modnorm_bwd_ws0: modnorm_bwd_finish_kernel zeroes what it has read)
         if (!ws_zero && swiftk_zero_f32_impl(row_stats, 2 * (int64_t)nb * d, stream, 1) != 0) return SWIFTK_EINVAL;
+        if (!ws_zero && (g_zero_memset & 4)) swiftk_zero_check_launch(row_stats, 2 * (int64_t)nb * d, stream);  // (diagnosis: what did the clear leave?)
 #define SWIFTK_MNB(TT, SL)                                                                                                        \
     hipLaunchKernelGGL((modnorm_bwd_fused_kernel<TT, SL>), dim3(grid), dim3(256), 0, st, static_cast<const TT*>(y), ldy, g,       \
                        static_cast<TT*>(dy), lddy, gamma, mod, ldmod, row_stats, M, d, rows_per_sample, eps, rpbf)

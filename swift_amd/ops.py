@@ -358,9 +358,9 @@ def axpby(a: float, x: torch.Tensor, b: float, y: torch.Tensor, out: Optional[to
 def zero_acc_(t: torch.Tensor) -> torch.Tensor:
     """Zero a contiguous fp32 device tensor that a kernel is about to ACCUMULATE into (atomics / read-modify-write) with the
     library's own fill kernel on the current stream (``swiftk_zero_f32``).  Every zero-then-accumulate site of the training
-    path goes through here or ``zeros_acc``: what clears the target is then a known, ordinary kernel launch -- not whatever
-    ``torch.zeros`` / ``Tensor.zero_`` lower to (round 5's intermittent gradient overflow went away with a ``hipMemsetAsync``
-    in front of an accumulating kernel; DESIGN "the gradient overflow")."""
+    path goes through here or ``zeros_acc``: what clears the target is then a known, ordinary kernel launch -- never a device
+    memset, which, captured into a HIP graph and replayed on the null stream, writes a stale pattern under this PyTorch's HIP
+    runtime (round 5's gradient overflow: DESIGN section 11, ``tools/memset_graph_repro.hip``)."""
     _dev(t)
     assert t.dtype == torch.float32 and t.is_contiguous()
     check(lib().swiftk_zero_f32(t.data_ptr(), t.numel(), _stream()), "swiftk_zero_f32")

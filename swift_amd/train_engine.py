@@ -55,7 +55,7 @@ def _transpose(src, rows, cols, ldd=None):
 
 def _zeros(*shape, device):
     """fp32 zeros that a kernel is about to ACCUMULATE into (atomics / read-modify-write), cleared by the library's own fill kernel
-    on the current stream (``ops.zeros_acc``: one helper for every such site, DESIGN "the gradient overflow")."""
+    on the current stream (``ops.zeros_acc``: one helper for every such site)."""
     return ops.zeros_acc(*shape, device=device)
 
 
@@ -473,8 +473,8 @@ class SwinTrainEngine:
         # the per-sample column sums of the one-kernel form live in a workspace this engine keeps ZERO between calls
         # (``swiftk_modnorm_bwd_ws0``: the finishing kernel zeroes what it read, and every backward pass clears it once up front) --
         # no clear per call.  SWIFTK_MNB_MODE picks another form for A/B runs: "clear" = a clear per call inside the library (a
-        # kernel; ``swiftk_set_tuning(25, 1)`` turns the library's internal clears into the hipMemsetAsync of rounds 4-5, the form in which
-        # data-parallel CRPS runs intermittently overflowed exactly these sums), "two" = row pass + column pass.
+        # kernel; ``swiftk_set_tuning(25, 1)`` turns the library's internal clears into the hipMemsetAsync of rounds 4-5, which as a
+        # node of a replayed HIP graph writes a stale pattern: DESIGN section 11), "two" = row pass + column pass.
         mode = os.environ.get("SWIFTK_MNB_MODE", "ws0")
         need = 2 * M
         if getattr(self, "_row_stats", None) is None or self._row_stats.numel() < need:

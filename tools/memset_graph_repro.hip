@@ -28,7 +28,7 @@
     } while (0)
 
 struct Big {
-    unsigned long long v[24];  // 192 bytes of by-value kernel arguments
+    unsigned long long v[440];  // 3,520 bytes of by-value kernel arguments: 32 such launches per replay wrap a MB-sized kernarg ring quickly
 };
 
 __global__ void check_kernel(const unsigned int* ws, int n, unsigned long long* bad, unsigned int* worst) {
@@ -44,8 +44,12 @@ __global__ void poison_kernel(float* ws, int n) {
 }
 __global__ void churn_kernel(float* p, Big b) {
     unsigned long long s = 0;
-    for (int k = 0; k < 24; ++k) s += b.v[k];
+    for (int k = 0; k < 440; k += 55) s += b.v[k];
     if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = (float)(s & 0xff);
+}
+
+__global__ void ptr_kernel(float* a, float* b, float* c, float* d, int k) {
+    if (threadIdx.x == 0) a[0] = b[0] + c[0] + d[0] + (float)k;
 }
 
 static hipGraphExec_t capture(hipStream_t cap, float* ws, int n, unsigned long long* bad, unsigned int* worst) {
@@ -81,7 +85,7 @@ int main(int argc, char** argv) {
     hipStream_t cap;
     CK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
     int failing = 0;
-    // churn bits: 1 = eager hipMemsetAsync(other, 0x7f), 2 = eager kernels with 192 B of by-value arguments, 4 = pageable H2D copies,
+    // churn bits: 1 = eager hipMemsetAsync(other, 0x7f), 2 = eager kernels with 3.5 KB of by-value arguments (0x7f bytes), 4 = pageable H2D copies,
     // 8 = a second graph with its own (0x7f) memset node replayed in between
     for (int stream_kind = 0; stream_kind < 2; ++stream_kind)
         for (int churn = 0; churn < 16; ++churn) {
@@ -103,10 +107,11 @@ int main(int argc, char** argv) {
             Big b;
             for (int r = 0; r < replays; ++r) {
                 CK(hipGraphLaunch(exec, st));
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < 32; ++k) {
                     if (churn & 1) CK(hipMemsetAsync(other + 64 * k, 0x7f, 4096 + 16 * k, st));
                     if (churn & 2) {
-                        for (int q = 0; q < 24; ++q) b.v[q] = 0x7f7f7f7f7f7f7f7full ^ (unsigned long long)(r * 8 + k + q);
+                        for (int q = 0; q < 440; ++q) b.v[q] = 0x7f7f7f7f7f7f7f7full;
+                        b.v[0] ^= (unsigned long long)(r * 32 + k);
                         hipLaunchKernelGGL(churn_kernel, dim3(1), dim3(64), 0, st, scratch, b);
                     }
                     if (churn & 4) CK(hipMemcpyAsync(scratch, pageable.data() + 64 * k, 4096, hipMemcpyHostToDevice, st));
@@ -133,5 +138,66 @@ int main(int argc, char** argv) {
             if (st) CK(hipStreamDestroy(st));
         }
     printf("%d of 32 configurations saw a replayed memset node leave non-zero data behind\n", failing);
+
+    // ---- second experiment: the shape of the training loop's graphs.  Graph A = `before` kernel nodes with pointer arguments,
+    // the memset node, the check kernel, the poison kernel, `before` more kernel nodes; then `others` further graphs of 300 kernel
+    // nodes each are captured and instantiated AFTER A (what a training loop does: forward slots, backward passes, the tangent
+    // pass), and all of them are replayed in turn.
+    int failing2 = 0;
+    for (int flags = 0; flags < 2; ++flags)
+        for (int before = 0; before <= 300; before += 300)
+            for (int others = 0; others <= 6; others += 6) {
+                CK(hipMemset(bad, 0, 32));
+                CK(hipMemset(worst, 0, 16));
+                CK(hipMemset(ws, 0, sizeof(float) * n));
+                auto many = [&](hipStream_t s_, int count, int salt) {
+                    for (int k = 0; k < count; ++k)
+                        hipLaunchKernelGGL(ptr_kernel, dim3(1), dim3(64), 0, s_, scratch + 16 * ((k + salt) & 1023), other + 16 * ((k + salt) & 1023),
+                                           scratch + 8 * ((k + salt) & 1023), other + 8 * ((k + salt) & 1023), k);
+                };
+                auto inst = [&](hipGraph_t g) {
+                    hipGraphExec_t e;
+                    if (flags) CK(hipGraphInstantiateWithFlags(&e, g, hipGraphInstantiateFlagAutoFreeOnLaunch));
+                    else CK(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
+                    CK(hipGraphDestroy(g));
+                    return e;
+                };
+                hipGraph_t g;
+                CK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+                many(cap, before, 0);
+                CK(hipMemsetAsync(ws, 0, sizeof(float) * n, cap));
+                hipLaunchKernelGGL(check_kernel, dim3((n + 255) / 256), dim3(256), 0, cap, reinterpret_cast<const unsigned int*>(ws), n, bad, worst);
+                hipLaunchKernelGGL(poison_kernel, dim3((n + 255) / 256), dim3(256), 0, cap, ws, n);
+                many(cap, before, 7);
+                CK(hipStreamEndCapture(cap, &g));
+                hipGraphExec_t A = inst(g);
+                std::vector<hipGraphExec_t> Bs;
+                for (int o = 0; o < others; ++o) {
+                    CK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+                    many(cap, 300, 13 * o);
+                    if (o & 1) CK(hipMemsetAsync(other, 0x7f, 4096, cap));
+                    CK(hipStreamEndCapture(cap, &g));
+                    Bs.push_back(inst(g));
+                }
+                for (int r = 0; r < replays / 4; ++r) {
+                    CK(hipGraphLaunch(A, nullptr));
+                    for (auto e : Bs) CK(hipGraphLaunch(e, nullptr));
+                    many(nullptr, 16, r);
+                    if ((r & 31) == 31) CK(hipStreamSynchronize(nullptr));
+                }
+                CK(hipDeviceSynchronize());
+                unsigned long long hb[4];
+                unsigned int hw[4];
+                CK(hipMemcpy(hb, bad, 32, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hw, worst, 16, hipMemcpyDeviceToHost));
+                printf("big graphs: instantiate flags=%s, %3d kernel nodes either side of the memset node, %d other graphs: non-zero dwords by index "
+                       "mod 4: %llu %llu %llu %llu (largest bits %#x %#x %#x %#x)\n", flags ? "AutoFreeOnLaunch" : "default", before, others, hb[0],
+                       hb[1], hb[2], hb[3], hw[0], hw[1], hw[2], hw[3]);
+                fflush(stdout);
+                failing2 += (hb[0] + hb[1] + hb[2] + hb[3]) != 0;
+                CK(hipGraphExecDestroy(A));
+                for (auto e : Bs) CK(hipGraphExecDestroy(e));
+            }
+    printf("%d of 8 big-graph configurations saw a replayed memset node leave non-zero data behind\n", failing2);
     return 0;
 }

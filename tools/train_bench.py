@@ -17,11 +17,13 @@ ap.add_argument("--iters", type=int, default=6); ap.add_argument("--depth", type
 ap.add_argument("--loss", default="crps", choices=["crps", "scm", "trigflow"])
 ap.add_argument("--opt", default="adamw", choices=["adamw", "muon"])
 ap.add_argument("--dim", type=int, default=1056); ap.add_argument("--heads", type=int, default=12)  # 1280 / 16, 1536 / 16: the larger variants
+ap.add_argument("--grad-digest", default=None, help="write per-parameter gradient norms of the first and the last iteration here (JSON)")
 ap.add_argument("--dist", type=int, default=1, help="1: run the gradient collectives for real (a one-rank RCCL group unless launched "
                 "under torchrun), so that the record carries the all-reduce's serial time, exposed wait and overlap fraction")
 a = ap.parse_args()
 dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
 torch.cuda.set_device(dev)
+torch.manual_seed(1234)  # (the losses draw their latents from the global generator: two runs see the same draws)
 if a.dist:
     import socket
     import torch.distributed as tdist
@@ -72,10 +74,18 @@ def nan_report(tag):  # SWIFTK_NAN_DEBUG=1: where does a non-finite value first 
     print(f"[nan-debug] {tag}: loss {float(loss):.4f}; non-finite params {len(bad_p)} {bad_p[:3]}; non-finite grads {len(bad_g)} {bad_g[:3]}", file=sys.stderr)
 
 
+digest = {}
+def grad_digest(tag):  # per-tensor (L2 norm, sum) of the gradients as the optimiser saw them (after the all-reduce), fp64 on the device
+    if a.grad_digest:
+        digest[tag] = {n: [float(p.grad.double().norm()), float(p.grad.double().sum())] for n, p in net.named_parameters() if p.grad is not None}
+
+
 for _ in range(3):  # warm-up: operand prep and allocator, then the HIP-graph capture of every launch sequence, then one replay
     loss = tr.train_step(x, t, idx, delta, 1000, steps=a.steps)
     losses.append(loss)
     nan_report(f"warm-up {_}")
+    if _ == 0:
+        grad_digest("first")
 torch.cuda.synchronize()
 if os.environ.get("SWIFTK_SYNC_DEBUG"):  # list every call that makes the host wait for the GPU inside the timed iterations
     import collections, traceback, warnings
@@ -102,6 +112,10 @@ if os.environ.get("SWIFTK_SYNC_DEBUG"):
         print(f"sync x{n}: {site}", file=sys.stderr)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
+grad_digest("last")
+if a.grad_digest:
+    with open(a.grad_digest, "w") as f:
+        json.dump(digest, f)
 _bad = [n for n, p in net.named_parameters() if not torch.isfinite(p).all()]
 # which parameters ever saw an overflowing gradient (exp_avg_sq = inf)?  Always checked: the second moment remembers an overflow of
 # ANY iteration of the run, also where nan_to_num kept the parameters finite (the round-5 data-parallel overflow, DESIGN)
@@ -127,6 +141,16 @@ if _bad:  # (a non-finite parameter after the run: name the first few -- which k
             print(f"  {n}: {bad.numel()} of {p.numel()} elements, flat indices {int(bad[0])}..{int(bad[-1])}; exp_avg non-finite "
                   f"{int((~torch.isfinite(ea)).sum()) if ea is not None else None}, |exp_avg| max {float(ea[torch.isfinite(ea)].abs().max()) if ea is not None else None:.3e}; "
                   f"exp_avg_sq non-finite {int((~torch.isfinite(ev)).sum()) if ev is not None else None}", file=sys.stderr)
+if os.environ.get("SWIFTK_TUNE", "").startswith("25:") and int(os.environ["SWIFTK_TUNE"].split(",")[0][3:]) & 4:
+    import ctypes
+    from swift_amd import _lib
+    rep = (ctypes.c_ulonglong * 26)()
+    _lib.lib().swiftk_zero_check_report(rep)
+    import struct
+    f = lambda b: struct.unpack("f", struct.pack("I", int(b) & 0xffffffff))[0]
+    print(f"ZERO-CHECK {rep[0]} clears checked; non-zero dwords left behind by index mod 4: {list(rep[1:5])}; largest |value| by index mod 4: "
+          f"{[f(b) for b in rep[5:9]]}; samples (index, bits, as float): {[(int(rep[10 + k]), hex(rep[18 + k]), f(rep[18 + k])) for k in range(min(int(rep[9]), 8))]}",
+          file=sys.stderr)
 print("host issue time per iteration (ms):", " ".join(f"{h:.0f}" for h in host_ms), file=sys.stderr)
 print("loss per iteration (warm-up included):", " ".join(f"{float(l):.4f}" for l in losses), file=sys.stderr)
 PEAK = 2.5e15  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
