@@ -365,11 +365,30 @@ def main():
         lib.swiftk_profile_gemm(_lib.EPI_SWIGLU, mlp2)
     sync()
     timed[0] = True
+    memset_prof = None
+    if os.environ.get("SWIFTK_BENCH_MEMSET_SITES"):  # diagnosis: which host call sites issue device memsets inside a step?
+        from torch.profiler import ProfilerActivity, profile
+        memset_prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True)
+        memset_prof.__enter__()
     t0 = time.perf_counter()
     for _ in range(K):
         step()
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0  # this rank's own work is done; what follows is waiting for the slowest rank
+    if memset_prof is not None:
+        import collections
+        memset_prof.__exit__(None, None, None)
+        sites = collections.Counter()
+        for e in memset_prof.events():
+            if "memset" in e.name.lower() and e.device_type == torch.autograd.DeviceType.CPU:
+                par, chain = e.cpu_parent, []
+                while par is not None and len(chain) < 4:
+                    chain.append(par.name)
+                    par = par.cpu_parent
+                sites[(e.name, " <- ".join(chain), " | ".join([s_ for s_ in (e.stack or []) if "site-packages" not in s_][:4]))] += 1
+        print(f"MEMSET-SITES over {K} timed steps: {sum(sites.values())} runtime memset calls", file=sys.stderr)
+        for (nm, chain, stack), c in sites.most_common(20):
+            print(f"  x{c:4d} {nm} under [{chain}] at [{stack}]", file=sys.stderr)
     sync()
     dt = time.perf_counter() - t0
     timed[0] = False
