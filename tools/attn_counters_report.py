@@ -10,11 +10,11 @@ def load(prefix):
     for d in (prefix + "_1", prefix + "_2"):
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if "qkv_attn" in r["Kernel_Name"] or "gemm_kernel_p" in r["Kernel_Name"] or "gemm_tn_kernel" in r["Kernel_Name"]:
+                if any(k in r["Kernel_Name"] for k in ("qkv_attn", "gemm_kernel_p", "gemm_tn_kernel", "gemm_rownorm_kernel")):
                     c[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if "qkv_attn" in r["Kernel_Name"] or "gemm_kernel_p" in r["Kernel_Name"] or "gemm_tn_kernel" in r["Kernel_Name"]:
+                if any(k in r["Kernel_Name"] for k in ("qkv_attn", "gemm_kernel_p", "gemm_tn_kernel", "gemm_rownorm_kernel")):
                     dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     m = {k: sum(v[1:]) / max(len(v) - 1, 1) for k, v in c.items()}  # (first launch of a process dropped)
     m["dur_ns"] = sum(sorted(dur)[: max(len(dur) // 2, 1)]) / max(len(dur) // 2, 1)  # faster half: the un-throttled launches
