@@ -209,6 +209,96 @@ def cpu_baseline(state, samples: int):
                        f"threads_swept; the reference itself measured 6.0 s on 8 threads of the build container (BASELINE.md section 2)")
 
 
+def _cpu_topology():
+    """[(logical cpu, socket, core)] from /proc/cpuinfo (empty when it does not say)."""
+    out, cur = [], {}
+    try:
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                cur = {"cpu": int(v)}
+            elif k == "physical id":
+                cur["socket"] = int(v)
+            elif k == "core id":
+                cur["core"] = int(v)
+                if "cpu" in cur and "socket" in cur:
+                    out.append((cur["cpu"], cur["socket"], cur["core"]))
+    except (OSError, ValueError):
+        return []
+    return out
+
+
+def cpu_worker(threads: int, cpus: str, samples: int):
+    """Child of cpu_baseline_parallel: one oracle forecast step at a time on its own CPUs; prints its per-step seconds as JSON."""
+    if cpus:
+        try:
+            os.sched_setaffinity(0, {int(c) for c in cpus.split(",")})
+        except OSError:
+            pass
+    import torch
+
+    from oracle import sampler as osamp
+    from oracle.swinv2 import OracleNet, SwinCfg
+    from swift_amd.utils.detinit import det_normal, swinv2_state
+
+    torch.set_num_threads(threads)
+    state = swinv2_state(grid=(64, 128), in_channels=2 * NV + NF, out_channels=NV, patch_size=(2, 2), depth=12, dim=1056, heads=12, seed=1234)
+    cfg = SwinCfg(img_resolution=IMG, in_channels=2 * NV + NF, out_channels=NV, window_size=(16, 16), shift_size=(8, 8),
+                  patch_size=(2, 2), depth=12, dim=1056, heads=12, auxiliary_dim=1)
+    onet = OracleNet(cfg, state, NV, NV + NF)
+    cond, lat = det_normal((1, NV + NF, *IMG), 1, "cond"), det_normal((1, NV, *IMG), 1, "lat")
+    run = lambda: osamp.scm_solver(onet, lat, cond, 0.6, num_steps=1, sigma_min=0.02, sigma_max=200.0)
+    run()
+    ts = []
+    for _ in range(samples):
+        t0 = time.perf_counter()
+        run()
+        ts.append(time.perf_counter() - t0)
+    print(json.dumps({"seconds": ts}), flush=True)
+
+
+def cpu_baseline_parallel(threads: int = 32, samples: int = 2, max_workers: int = 8):
+    """The metric is a THROUGHPUT over independent (member, IC) units, so what the host can do is several oracle forecasts side by
+    side, each on its own cores: K = physical cores / `threads` worker processes (whole workers per socket, first hardware thread
+    of each core), every one running `samples` timed sample-steps after a warm-up, all started together.  Aggregate rate =
+    sum over workers of 1 / (its median seconds per step) -- the workers overlap for all but their start-up skew."""
+    topo = _cpu_topology()
+    sockets = {}
+    for cpu, sk, core in topo:
+        sockets.setdefault(sk, {}).setdefault(core, cpu)  # first hardware thread of each physical core
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = None
+    sets = []
+    for sk in sorted(sockets):
+        cpus = sorted(c for c in sockets[sk].values() if allowed is None or c in allowed)
+        for k in range(len(cpus) // threads):
+            sets.append(cpus[k * threads:(k + 1) * threads])
+    sets = sets[:max_workers]
+    if len(sets) < 2:
+        return None
+    me = os.path.abspath(__file__)
+    procs = [subprocess.Popen([sys.executable, me, "--cpu-worker", str(threads), ",".join(map(str, cs)), str(samples)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                              env=dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))) for cs in sets]
+    per = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+            per.append(json.loads(next(ln for ln in out.splitlines() if ln.startswith("{")))["seconds"])
+        except Exception:  # noqa: BLE001 -- a worker that failed contributes nothing
+            p.kill()
+    if len(per) < 2:
+        return None
+    med = [sorted(t)[len(t) // 2] for t in per]
+    return dict(value=sum(1.0 / m for m in med), unit="sample-steps/s", workers=len(per), threads_per_worker=threads, cores=len(per) * threads,
+                seconds_per_step_by_worker=[round(m, 2) for m in med],
+                what=f"{len(per)} oracle processes side by side, {threads} threads each on their own physical cores (whole workers per socket), "
+                     f"{samples} timed sample-steps per worker after one warm-up; aggregate = sum of the workers' 1 / median")
+
+
 def unit_inputs(units, dev, slabs: int = 1):
     """Initial standardised states [B, 69, H, W] and the pre-staged forcings [slabs, B, 3, H, W] (one slab
     per lead step, resident before the timed region); keyed by the unit's IC, so the members of an IC share them (as they
@@ -227,6 +317,8 @@ def unit_inputs(units, dev, slabs: int = 1):
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":  # child of cpu_baseline_parallel: never touches the GPU
+        return cpu_worker(int(sys.argv[2]), sys.argv[3], int(sys.argv[4]))
     a = parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a.gpus))
@@ -544,7 +636,19 @@ def main():
                 except Exception as e:  # noqa: BLE001 -- a reported extra must not take the metric's line down
                     line[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not a.no_extras and a.cpu_steps > 0:
-            line["cpu_baseline"] = cpu_baseline(state, a.cpu_steps)
+            cb = cpu_baseline(state, a.cpu_steps)
+            # the metric is a throughput over independent units: several oracle forecasts side by side use the host better than one
+            # forecast on many threads (128 threads on one forecast are 2.8 x SLOWER than 32: NUMA).  The larger figure is the baseline.
+            try:
+                par = cpu_baseline_parallel(threads=int(cb["cores"]) if int(cb["cores"]) in (16, 32, 64) else 32)
+            except Exception as e:  # noqa: BLE001
+                par = {"error": f"{type(e).__name__}: {e}"[:200]}
+            if par and "value" in par and par["value"] > cb["value"]:
+                cb = dict(cb, single_process={k: cb[k] for k in ("value", "cores", "sample")}, value=par["value"], cores=par["cores"],
+                          parallel=par, sample=par["what"] + "; one process alone: " + cb["sample"])
+            elif par:
+                cb["parallel"] = par
+            line["cpu_baseline"] = cb
             line["vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
         if world == 1 and not a.no_extras and a.solver == "scm" and nsteps == 1:
             # the children plan their resident activations around what other processes hold: hand the forecast path's
