@@ -258,7 +258,7 @@ def cpu_worker(threads: int, cpus: str, samples: int):
     print(json.dumps({"seconds": ts}), flush=True)
 
 
-def cpu_baseline_parallel(threads: int = 32, samples: int = 2, max_workers: int = 8):
+def cpu_baseline_parallel(threads: int = 32, samples: int = 1, max_workers: int = 8):
     """The metric is a THROUGHPUT over independent (member, IC) units, so what the host can do is several oracle forecasts side by
     side, each on its own cores: K = physical cores / `threads` worker processes (whole workers per socket, first hardware thread
     of each core), every one running `samples` timed sample-steps after a warm-up, all started together.  Aggregate rate =
