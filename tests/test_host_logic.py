@@ -506,15 +506,63 @@ def test_zarrlite_reads_compressed_chunks_or_names_the_compressor(tmp_path):
             f.parent.mkdir(parents=True, exist_ok=True)
             f.write_bytes(enc(blk.tobytes()))
         np.testing.assert_array_equal(zarrlite.read_array(str(root), "v"), a)
+    # Blosc (zarr's default compressor): without numcodecs the container is parsed by zarrlite._blosc1_decode and the inner streams
+    # by pyarrow's LZ4 / Zstd codecs.  The chunks here are ASSEMBLED BY HAND from the c-blosc 1.x chunk layout around real codec
+    # streams (c-blosc itself is not in this image): split shuffled blocks, a short last block, a stream stored raw, a stored chunk
+    import struct
+    pa = pytest.importorskip("pyarrow")
+
+    def blosc1(data: bytes, typesize: int, blocksize: int, codec: str, shuffle: bool, dont_split: bool = False, raw_stream: int = -1):
+        fmt = {"lz4_raw": 1, "zstd": 4, "zlib": 3}[codec]
+        nblocks = (len(data) + blocksize - 1) // blocksize
+        flags = (1 if shuffle else 0) | (0x10 if dont_split else 0) | (fmt << 5)
+        body, starts = b"", []
+        k = 0
+        for i in range(nblocks):
+            blk = data[i * blocksize:(i + 1) * blocksize]
+            if shuffle and typesize > 1:
+                n = len(blk) // typesize
+                blk = np.frombuffer(blk, np.uint8, n * typesize).reshape(n, typesize).T.tobytes() + blk[n * typesize:]
+            split = (not dont_split) and len(blk) == blocksize and typesize <= 16 and blocksize // typesize >= 128
+            ns = typesize if split else 1
+            ne = len(blk) // ns
+            starts.append(16 + 4 * nblocks + len(body))
+            for j in range(ns):
+                st = blk[j * ne:(j + 1) * ne]
+                enc = zlib.compress(st) if codec == "zlib" else pa.compress(st, codec=codec, asbytes=True)
+                if k == raw_stream or len(enc) >= len(st):
+                    enc = st  # stored raw: its length equals the uncompressed size
+                body += struct.pack("<i", len(enc)) + enc
+                k += 1
+        head = bytes([2, 1, flags, typesize]) + struct.pack("<iii", len(data), blocksize, 16 + 4 * nblocks + len(body))
+        return head + struct.pack(f"<{nblocks}i", *starts) + body
+
+    smooth = np.cumsum(rng.standard_normal(5000)).astype(np.float32)  # compressible after the byte shuffle, like a weather field
+    raw = smooth.tobytes()  # 20,000 bytes: two whole 8,192-byte blocks (split into 4 streams each) and a short last one (one stream)
+    for codec, shuffle, dont_split, raw_stream in (("lz4_raw", True, False, -1), ("zstd", True, False, 2), ("lz4_raw", False, False, -1),
+                                                   ("lz4_raw", True, True, -1), ("zlib", True, False, -1)):
+        assert zarrlite._blosc1_decode(blosc1(raw, 4, 8192, codec, shuffle, dont_split, raw_stream)) == raw
+    stored = bytes([2, 1, 0x2 | (1 << 5), 4]) + struct.pack("<iii", len(raw), 8192, 16 + len(raw)) + raw
+    assert zarrlite._blosc1_decode(stored) == raw and zarrlite._blosc1_decode(bytes([2, 1, 0x21, 4]) + struct.pack("<iii", 0, 0, 16)) == b""
+    for bad in (b"\x02\x01\x21", bytes([2, 1, 0x01, 4]) + struct.pack("<iii", 100, 8192, 40) + bytes(24),          # truncated; BloscLZ
+                bytes([2, 1, 0x25, 4]) + struct.pack("<iii", 100, 8192, 40) + bytes(24)):                           # bit shuffle
+        with pytest.raises((ValueError, NotImplementedError)):
+            zarrlite._blosc1_decode(bad)
+    cut = blosc1(raw, 4, 8192, "lz4_raw", True)
+    with pytest.raises(Exception):
+        zarrlite._blosc1_decode(cut[:len(cut) // 2] + bytes(len(cut) - len(cut) // 2))  # a damaged chunk raises, it does not decode to garbage
     root = tmp_path / "blosc.zarr"
     (root / "v").mkdir(parents=True)
-    (root / "v" / ".zarray").write_text(json.dumps(dict(zarr_format=2, shape=[2], chunks=[2], dtype="<f4", fill_value=0.0, order="C", filters=None,
+    (root / "v" / ".zarray").write_text(json.dumps(dict(zarr_format=2, shape=[5000], chunks=[5000], dtype="<f4", fill_value=0.0, order="C", filters=None,
                                                         compressor={"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0})))
-    (root / "v" / "0").write_bytes(b"\x02\x01\x21\x04" + bytes(20))
+    (root / "v" / "0").write_bytes(blosc1(raw, 4, 8192, "lz4_raw", True))
+    np.testing.assert_array_equal(zarrlite.read_array(str(root), "v"), smooth)
+    (root / "v" / ".zarray").write_text(json.dumps(dict(zarr_format=2, shape=[2], chunks=[2], dtype="<f4", fill_value=0.0, order="C", filters=None,
+                                                        compressor={"id": "lzo", "level": 3})))
     try:
         import numcodecs  # noqa: F401
     except ImportError:
-        with pytest.raises(NotImplementedError, match=r"id='blosc'.*cname='lz4'.*numcodecs"):
+        with pytest.raises(NotImplementedError, match=r"id='lzo'.*numcodecs"):  # an unknown compressor is NAMED, not guessed at
             zarrlite.read_array(str(root), "v")
 
 
