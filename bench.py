@@ -381,6 +381,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # what this process's HIP runtime does with a captured memset: recorded beside the numbers; the library itself
+    # never captures one
+    hip_rt = None
+    if rank == 0 and not a.no_extras:
+        try:
+            from swift_amd.graphs import memset_node_probe
+            hip_rt = dict(memset_node_probe(dev, replays=60), what="a hipMemsetAsync captured into a HIP graph and replayed on the null stream "
+                          "with eager launches in between: memset_node_clean = False is the stale-fill-pattern bug of HIP 7.0.x that overflowed "
+                          "round 5's gradients (tools/memset_graph_repro.hip); kernel_clear_clean is the library's own clear under the same replay")
+        except Exception as e:  # noqa: BLE001
+            hip_rt = {"error": f"{type(e).__name__}: {e}"[:200]}
     if a.rollout:
         line = rollout_mode(a, eng, dev, rank, world, B, dtype, rccl, sync)
         if rank == 0:
@@ -562,6 +573,7 @@ def main():
                        "forcings": f"{n_slabs} pre-staged slabs [B, 3, 128, 256], one per lead step",
                        "parallelism": f"units sharded over {world} GPU(s), no data-path collective on the state"},
             "rccl": rccl,
+            "hip_runtime": hip_rt,
             "per_rank": dict(per_rank, what="per rank, over the timed region: compute_ms = step start to the output collective (HIP "
                              "events on the launch stream), collective_ms = the all-gather of per-unit checksums, barrier_wait_ms = idle "
                              "at the closing barrier (the slowest rank shows ~0)"),

@@ -98,3 +98,50 @@ class GraphCache:
                 s.copy_(x)
         graph.replay()
         return out
+
+
+def memset_node_probe(device=None, replays: int = 120) -> dict:
+    """Does THIS process's HIP runtime replay a captured ``hipMemsetAsync`` correctly?  Under the runtime PyTorch 2.10.0+rocm7.0
+    bundles (HIP 7.0.51831) a memset node replayed on the null stream -- torch's default stream -- writes whatever bytes later eager
+    launches left where its fill pattern was (standalone: ``tools/memset_graph_repro.hip``); HIP 7.2 is clean.
+    This library never captures a memset (``swiftk_zero_f32`` is a kernel), so the answer does not affect it: it is what a user
+    who wraps these modules in graphs of their own wants to know, and what ``bench.py`` records beside its numbers.
+
+    Two tiny graphs clear a 16-KB buffer -- one with the library's fill kernel, one with ``hipMemsetAsync`` (tuning key 25, restored
+    afterwards) -- and are replayed in turn with eager launches in between whose scalar arguments are easy to recognise.  Returns
+    {"kernel_clear_clean": bool (must be True), "memset_node_clean": bool, "memset_node_bad_replays": n, "replays": n}.  A clean
+    answer for the memset node is weaker evidence than a dirty one: whether the stale slot is overwritten within the probe's few
+    thousand launches depends on the process's state (a fresh process shows it in a quarter of the replays)."""
+    from . import ops
+    from ._lib import lib
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    L = lib()
+    with torch.cuda.device(dev):
+        ws_k, ws_m = torch.ones(4096, device=dev), torch.ones(4096, device=dev)
+        a, b = torch.ones(1024, device=dev), torch.ones(1024, device=dev)
+        host = torch.full((1024,), 3.0e38)
+        before = L.swiftk_get_tuning(25)
+        torch.cuda.synchronize()
+        gk, gm = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        try:
+            with capture(gk):
+                ops.zero_acc_(ws_k)
+            L.swiftk_set_tuning(25, 2)
+            with capture(gm):
+                ops.zero_acc_(ws_m)
+        finally:
+            L.swiftk_set_tuning(25, before)
+        bad_k = bad_m = 0
+        for r in range(replays):
+            ws_k.fill_(1.0)
+            ws_m.fill_(1.0)
+            gk.replay()
+            gm.replay()
+            for k in range(96):  # eager traffic: its kernel arguments / staged copies are what a stale pattern picks up
+                ops.axpby(3.0e38, a, -3.0e38, b, out=b)
+                if k % 24 == 0:
+                    a.copy_(host)  # (a pageable host-to-device copy: the runtime's staging path)
+            bad_k += int(bool((ws_k != 0).any()))
+            bad_m += int(bool((ws_m != 0).any()))
+    return {"kernel_clear_clean": bad_k == 0, "memset_node_clean": bad_m == 0, "memset_node_bad_replays": bad_m, "replays": replays,
+            "hip_runtime": getattr(torch.version, "hip", None)}
