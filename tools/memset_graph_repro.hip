@@ -48,6 +48,14 @@ __global__ void churn_kernel(float* p, Big b) {
     if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = (float)(s & 0xff);
 }
 
+__global__ void check_copy_kernel(const unsigned int* ws, int n, unsigned long long* bad) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && ws[i] != 0x3f800000u) atomicAdd(bad, 1ull);
+}
+__global__ void poison2_kernel(float* ws, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ws[i] = 2.0f;
+}
 __global__ void ptr_kernel(float* a, float* b, float* c, float* d, int k) {
     if (threadIdx.x == 0) a[0] = b[0] + c[0] + d[0] + (float)k;
 }
@@ -199,5 +207,49 @@ int main(int argc, char** argv) {
                 for (auto e : Bs) CK(hipGraphExecDestroy(e));
             }
     printf("%d of 8 big-graph configurations saw a replayed memset node leave non-zero data behind\n", failing2);
+
+    // ---- third experiment: the OTHER runtime-owned node a captured launch sequence contains -- a device-to-device hipMemcpyAsync
+    // (what torch's copy_ / clone() capture as).  Graph: memcpy(ws <- src, src all 1.0f) -> check (every dword must be 0x3f800000)
+    // -> poison (ws := 2.0f), replayed on the null stream under the same eager churn.
+    {
+        float* src;
+        CK(hipMalloc(&src, sizeof(float) * n));
+        hipLaunchKernelGGL(poison_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, src, n);  // src := 1.0f
+        CK(hipDeviceSynchronize());
+        int failing3 = 0;
+        for (int churn = 0; churn < 8; ++churn) {
+            CK(hipMemset(bad, 0, 32));
+            CK(hipMemset(worst, 0, 16));
+            hipGraph_t g;
+            hipGraphExec_t exec;
+            CK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+            CK(hipMemcpyAsync(ws, src, sizeof(float) * n, hipMemcpyDeviceToDevice, cap));
+            hipLaunchKernelGGL(check_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, cap, reinterpret_cast<const unsigned int*>(ws), n, bad);
+            hipLaunchKernelGGL(poison2_kernel, dim3((n + 255) / 256), dim3(256), 0, cap, ws, n);
+            CK(hipStreamEndCapture(cap, &g));
+            CK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
+            CK(hipGraphDestroy(g));
+            Big b;
+            for (int r = 0; r < replays; ++r) {
+                CK(hipGraphLaunch(exec, nullptr));
+                for (int k = 0; k < 32; ++k) {
+                    if (churn & 1) CK(hipMemsetAsync(other + 64 * k, 0x7f, 4096 + 16 * k, nullptr));
+                    if (churn & 2) {
+                        for (int q = 0; q < 440; ++q) b.v[q] = 0x7f7f7f7f7f7f7f7full;
+                        hipLaunchKernelGGL(churn_kernel, dim3(1), dim3(64), 0, nullptr, scratch, b);
+                    }
+                    if (churn & 4) CK(hipMemcpyAsync(scratch, pageable.data() + 64 * k, 4096, hipMemcpyHostToDevice, nullptr));
+                }
+                if ((r & 63) == 63) CK(hipStreamSynchronize(nullptr));
+            }
+            CK(hipDeviceSynchronize());
+            unsigned long long hb[4];
+            CK(hipMemcpy(hb, bad, 32, hipMemcpyDeviceToHost));
+            printf("memcpy node, null stream, churn=%d: dwords that are not the source's 1.0f after the replayed copy: %llu\n", churn, hb[0]);
+            failing3 += hb[0] != 0;
+            CK(hipGraphExecDestroy(exec));
+        }
+        printf("%d of 8 configurations saw a replayed device-to-device memcpy node deliver wrong data\n", failing3);
+    }
     return 0;
 }
