@@ -385,11 +385,15 @@ def main():
     # never captures one
     hip_rt = None
     if rank == 0 and not a.no_extras:
-        try:
-            from swift_amd.graphs import memset_node_probe
-            hip_rt = dict(memset_node_probe(dev, replays=60), what="a hipMemsetAsync captured into a HIP graph and replayed on the null stream "
-                          "with eager launches in between: memset_node_clean = False is the stale-fill-pattern bug of HIP 7.0.x that overflowed "
-                          "round 5's gradients (tools/memset_graph_repro.hip); kernel_clear_clean is the library's own clear under the same replay")
+        try:  # (in a fresh child process: whether the stale slot is overwritten within a short probe depends on the process's state --
+            # a fresh interpreter shows the HIP 7.0.x bug in a quarter of the replays, this one, with its pools warm, often in none)
+            code = ("import json, sys; sys.path.insert(0, %r); from swift_amd.graphs import memset_node_probe; "
+                    "print('PROBE ' + json.dumps(memset_node_probe()))" % os.path.dirname(os.path.abspath(__file__)))
+            pr = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+            hip_rt = json.loads(next(ln for ln in pr.stdout.splitlines() if ln.startswith("PROBE "))[6:])
+            hip_rt["what"] = ("a hipMemsetAsync captured into a HIP graph and replayed on the null stream with eager launches in between, in a fresh "
+                              "process: memset_node_clean = False is the stale-fill-pattern bug of HIP 7.0.x that overflowed round 5's gradients "
+                              "(tools/memset_graph_repro.hip, DESIGN section 11); kernel_clear_clean is the library's own clear under the same replay")
         except Exception as e:  # noqa: BLE001
             hip_rt = {"error": f"{type(e).__name__}: {e}"[:200]}
     if a.rollout:
