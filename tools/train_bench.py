@@ -123,7 +123,7 @@ _inf = [(n, int((~torch.isfinite(opt.state[p]["exp_avg_sq"])).sum()), p.numel())
         if p in opt.state and "exp_avg_sq" in opt.state[p] and not torch.isfinite(opt.state[p]["exp_avg_sq"]).all()]
 print(f"OVERFLOW-CHECK parameters with non-finite exp_avg_sq: {len(_inf)}: {_inf[:40]}", file=sys.stderr)
 for n, p in net.named_parameters():  # where inside a tensor: contiguous ranges? a stride?  (first few partially hit tensors)
-    if any(n == q[0] and q[1] < q[2] for q in _inf[:60]) and sum(1 for _ in [0]) and n.count("layers.0.") + n.count("layers.11."):
+    if any(n == q[0] and q[1] < q[2] for q in _inf[:60]) and ("layers.0." in n or "layers.11." in n):
         ix = (~torch.isfinite(opt.state[p]["exp_avg_sq"])).flatten().nonzero().flatten().tolist()
         runs, a0 = [], ix[0]
         for u, v in zip(ix, ix[1:] + [None]):
