@@ -72,6 +72,11 @@ constexpr int EPI_BIAS_POS_PAIR = 11;  // internal: SWIFTK_EPI_BIAS_POS leaving 
 #ifndef SWIFTK_X_NOSILU
 #define SWIFTK_X_NOSILU 0
 #endif
+// SWIGLU_BWD epilogue: R > 0 = a rolling window of R saved pre-activation chunks per lane (R loads in flight) instead of two groups of four.
+// Measured in round 6 (profiles/r06m_gemm_ab_bwdroll.txt): R = 8 +3.3 %, R = 10 +4.2 % SLOWER (bit-equal): the epilogue is not short of loads in flight
+#ifndef SWIFTK_X_BWDROLL
+#define SWIFTK_X_BWDROLL 0
+#endif
 // cache policy of the bf16 output tiles' 16-B stores: 0 = default, 1 = nt, 2 = sc1 (write-through, line not kept in the
 // XCD's L2), 3 = sc0 sc1.  The outputs are written once and never re-read by the kernel; a round of 32 tiles per XCD writes
 // 5.8 MB through a 4 MB L2 that should be holding the W panel the XCD re-reads every round.
@@ -1109,6 +1114,42 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                         if (jh + jj < NI && m < g.M && nb < g.N) b[jj] = *reinterpret_cast<const uint4*>(H + (int64_t)m * ldh + 2 * nb);
                     }
                 };
+#if SWIFTK_X_BWDROLL
+                // (round 6 experiment) a ROLLING window over the tile's MI x NI saved pre-activation chunks: chunk q + R is requested the
+                // moment chunk q has been consumed, so R loads per lane stay in flight throughout (the grouped form swings between 4 and 8)
+                constexpr int R = SWIFTK_X_BWDROLL;
+                uint4 hr[R];
+                auto load_one = [&](int q) -> uint4 {
+                    const int i = q / NI, j = q - i * NI;
+                    const int m = m0 + wm * 64 + i * 16 + (elane & 15);
+                    const int nb = n0 + wn * WT + j * 16 + 4 * g4;
+                    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+                    if (m < g.M && nb < g.N) r = *reinterpret_cast<const uint4*>(H + (int64_t)m * ldh + 2 * nb);
+                    return r;
+                };
+#pragma unroll
+                for (int q = 0; q < R; ++q) hr[q] = load_one(q);
+#pragma unroll
+                for (int q = 0; q < MI * NI; ++q) {
+                    const int i = q / NI, j = q - i * NI;
+                    const int m = m0 + wm * 64 + i * 16 + (elane & 15);
+                    const int nb = n0 + wn * WT + j * 16 + 4 * g4;
+                    const f32x4 v = acc[i][j];
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const uint4 hq = hr[q % R];
+                    if (q + R < MI * NI) hr[q % R] = load_one(q + R);
+                    const uint32_t hw[4] = {hq.x, hq.y, hq.z, hq.w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gt = __uint_as_float(hw[e] << 16), up = __uint_as_float(hw[e] & 0xffff0000u);
+                        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-gt));
+                        o[e] = pack_bf16(v[e] * up * (sg + gt * sg * (1.0f - sg)), v[e] * gt * sg);
+                    }
+                    if (m < g.M && nb < g.N)
+                        *reinterpret_cast<uint4*>(C + (int64_t)m * g.ldc + 2 * nb) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+#else
                 load_group(0, hb[0]);
 #pragma unroll
                 for (int gidx = 0; gidx < NG; ++gidx) {
@@ -1136,6 +1177,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                         }
                     }
                 }
+#endif
             } else
             if constexpr (EPI == SWIFTK_EPI_SWIGLU_BOTH) {
                 // training forward: the pre-activation h (the backward pass needs gate and up) AND silu(gate) * up leave in
