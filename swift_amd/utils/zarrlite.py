@@ -328,3 +328,68 @@ def read_array(root: str, name: str) -> np.ndarray:
 def read_attrs(root: str, name: str = "") -> dict:
     with open(os.path.join(root, name, ".zattrs")) as f:
         return json.load(f)
+
+
+def list_arrays(root: str) -> List[str]:
+    """Names of the arrays of a (flat) group: sub-directories with a ``.zarray`` (consolidated metadata is not needed)."""
+    return sorted(n for n in os.listdir(root) if os.path.isfile(os.path.join(root, n, ".zarray")))
+
+
+def array_info(root: str, name: str) -> Tuple[tuple, np.dtype, List[str]]:
+    """(shape, dtype, dimension names) of an array; dimension names from xarray's ``_ARRAY_DIMENSIONS`` attribute ([] without)."""
+    with open(os.path.join(root, name, ".zarray")) as f:
+        meta = json.load(f)
+    try:
+        dims = list(read_attrs(root, name).get("_ARRAY_DIMENSIONS", []))
+    except OSError:
+        dims = []
+    return tuple(meta["shape"]), np.dtype(meta["dtype"]), dims
+
+
+def read_region(root: str, name: str, sel: Sequence) -> np.ndarray:
+    """``array[sel]`` for a tuple of ints / slices (step 1) over the leading axes, touching only the chunks the selection meets --
+    what an evaluation that walks a 100-GB forecast store one initial condition at a time needs (``read_array`` loads everything).
+    Integer entries drop their axis, as in numpy."""
+    with open(os.path.join(root, name, ".zarray")) as f:
+        meta = json.load(f)
+    decode = _chunk_decoder(meta, os.path.join(root, name))
+    raw = meta.get("compressor") is None and not meta.get("filters")
+    if meta.get("order", "C") != "C":
+        raise NotImplementedError(f"{os.path.join(root, name)}: Fortran-ordered chunks are not supported")
+    shape, chunks, dt = tuple(meta["shape"]), tuple(meta["chunks"]), np.dtype(meta["dtype"])
+    fill = meta.get("fill_value")
+    fill = np.nan if fill == "NaN" else (0 if fill is None else fill)
+    sel = tuple(sel) + (slice(None),) * (len(shape) - len(sel))
+    lo, hi, drop = [], [], []
+    for ax, (s_, n) in enumerate(zip(sel, shape)):
+        if isinstance(s_, (int, np.integer)):
+            i = int(s_) + (n if s_ < 0 else 0)
+            if not 0 <= i < n:
+                raise IndexError(f"{name}: index {s_} out of range for axis {ax} of size {n}")
+            lo.append(i); hi.append(i + 1); drop.append(ax)
+        else:
+            a, b, st = s_.indices(n)
+            if st != 1:
+                raise NotImplementedError("read_region: slices with a step")
+            lo.append(a); hi.append(max(a, b))
+    out = np.full([h - l for l, h in zip(lo, hi)], fill, dtype=dt)
+    sep = meta.get("dimension_separator", ".")
+    grid = [range(l // c, (h - 1) // c + 1) if h > l else range(0) for l, h, c in zip(lo, hi, chunks)]
+    for idx in np.ndindex(*[len(g) for g in grid]):
+        cidx = [g[i] for g, i in zip(grid, idx)]
+        p = os.path.join(root, name, sep.join(str(i) for i in cidx))
+        if not os.path.exists(p):
+            continue
+        if raw:
+            blk = np.memmap(p, dtype=dt, mode="r", shape=chunks) if os.path.getsize(p) == int(np.prod(chunks)) * dt.itemsize else \
+                np.fromfile(p, dtype=dt).reshape(chunks)
+        else:
+            with open(p, "rb") as f:
+                blk = np.frombuffer(bytes(decode(f.read())), dtype=dt).reshape(chunks)
+        src, dst = [], []
+        for ci, c, l, h in zip(cidx, chunks, lo, hi):
+            a, b = max(l, ci * c), min(h, (ci + 1) * c)
+            src.append(slice(a - ci * c, b - ci * c))
+            dst.append(slice(a - l, b - l))
+        out[tuple(dst)] = blk[tuple(src)]
+    return out.reshape([n for ax, n in enumerate(out.shape) if ax not in drop]) if drop else out

@@ -736,6 +736,48 @@ def test_ensemble_metrics_vs_reference_golden(dev):
             assert float(got[f"{name}_{v}_x"]) == pytest.approx(float(r[i]), rel=5e-5)
 
 
+def test_store_to_store_evaluation_cli_on_the_device(dev, tmp_path):
+    """``python -m swift_amd.eval.metrics --truth T.zarr --pred P.zarr`` (reference eval/metrics.py:157-280) through the real
+    ``swiftk_ensemble_sums``: a 12-member forecast store with a levelled variable against the oracle's restatement of the reference
+    functions, and the structured evaluation_metrics.json beside the store."""
+    import json
+    from oracle import metrics as omet
+    from swift_amd.eval import metrics as em
+    from swift_amd.utils import zarrlite
+    rng = np.random.default_rng(11)
+    names = ["2m_temperature", "temperature_500", "temperature_850", "temperature_1000"]
+    H, W, B, N, steps = 32, 64, 2, 12, 3
+    lat = np.linspace(-88, 88, H)
+    t_all = np.datetime64("2021-06-01T00") + np.arange(12) * np.timedelta64(6, "h")
+    pred = str(tmp_path / "out" / "output-2i-3s-12m-6h.zarr")
+    os.makedirs(os.path.dirname(pred))
+    ch = zarrlite.create_forecast_store(pred, names, t_all[[1, 4]], lat, np.arange(W) * 5.625, members=N, steps=steps, interval=6)
+    traj = rng.standard_normal((B, N, steps + 1, 4, H, W)).astype(np.float32)
+    for b in range(B):
+        for n in range(N):
+            zarrlite.write_unit(pred, ch, b, n, traj[b, n])
+    truth = str(tmp_path / "truth.zarr")
+    zarrlite.create_group(truth)
+    zarrlite.write_full(truth, "time", t_all.astype("datetime64[ns]").astype(np.int64), ["time"], {"units": "nanoseconds since 1970-01-01"})
+    zarrlite.write_full(truth, "latitude", lat.astype(np.float32), ["latitude"])
+    f2, f3 = rng.standard_normal((12, H, W)).astype(np.float32), rng.standard_normal((12, 3, H, W)).astype(np.float32)
+    zarrlite.write_full(truth, "2m_temperature", f2, ["time", "latitude", "longitude"])
+    zarrlite.write_full(truth, "temperature", f3, ["time", "level", "latitude", "longitude"])
+    flat = em.main(["--truth", truth, "--pred", pred])
+    doc = json.load(open(os.path.join(os.path.dirname(pred), "evaluation_metrics.json")))
+    assert set(doc) == {"metadata", "metrics"} and doc["metadata"]["truth_file"] == truth and set(doc["metrics"]) == {"rmse", "crps", "ssr"}
+    assert set(doc["metrics"]["crps"]) == {"0", "6", "12", "18"} and len(doc["metrics"]["rmse"]["18"]) == 4
+    idx = np.array([1, 4])
+    for j in range(steps + 1):
+        P = torch.from_numpy(traj[:, :, j]).double()
+        Y = torch.cat([torch.from_numpy(f2[idx + j])[:, None], torch.from_numpy(f3[idx + j])], 1).double()
+        for name, fn in (("rmse", omet.rmse), ("crps", omet.crps), ("ssr", omet.spread_skill_ratio)):
+            r = fn(P, Y, lat)
+            for i, v in enumerate(["2m_temperature", "temperature_50", "temperature_100", "temperature_150"]):  # (levels named by position)
+                assert flat[f"{name}_{v}_{6 * j}h"] == pytest.approx(float(r[i]), rel=5e-5), (name, v, j)
+                assert doc["metrics"][name][str(6 * j)][v] == pytest.approx(float(r[i]), rel=5e-5)
+
+
 def test_race_screen_pipelined_kernels(dev):
     """tools/stress.py in short form: the LDS-DMA pipelined kernels (counted-vmcnt hand-overs, LDS overlays) must give
     bit-identical results run after run, also with competing HBM traffic on a second stream."""

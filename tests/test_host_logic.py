@@ -566,6 +566,78 @@ def test_zarrlite_reads_compressed_chunks_or_names_the_compressor(tmp_path):
             zarrlite.read_array(str(root), "v")
 
 
+def test_store_to_store_evaluation_matches_the_oracle_metrics(tmp_path):
+    """``python -m swift.eval.metrics --truth T.zarr --pred P.zarr`` (eval/metrics.py:157-280) without zarr / xarray: the forecast
+    store as ``generate`` writes it, a truth store with ITS OWN time encoding (hours since 2020, gzip-compressed chunks, a longer time
+    axis), walked one initial condition at a time.  The device kernel is replaced by its definition in torch; every metric of every
+    lead / variable / level must equal the oracle's restatement of the reference functions on the whole arrays."""
+    import gzip
+    import json
+    from oracle import metrics as om
+    from swift_amd.eval import metrics as em
+    from swift_amd.utils import zarrlite
+    rng = np.random.default_rng(3)
+    names = ["2m_temperature", "geopotential_500", "geopotential_850"]
+    H, W, B, N, steps, interval = 4, 8, 3, 3, 2, 12
+    lat = np.linspace(-80, 80, H)
+    t_all = np.datetime64("2020-01-01T00") + np.arange(20) * np.timedelta64(6, "h")
+    init = t_all[[2, 5, 9]]
+    pred = str(tmp_path / "run" / "output-3i-2s-3m-12h.zarr")
+    os.makedirs(os.path.dirname(pred))
+    ch = zarrlite.create_forecast_store(pred, names, init, lat, np.arange(W) * 45.0, members=N, steps=steps, interval=interval)
+    traj = rng.standard_normal((B, N, steps + 1, 3, H, W)).astype(np.float32)
+    for b in range(B):
+        for n in range(N):
+            zarrlite.write_unit(pred, ch, b, n, traj[b, n])
+    truth = str(tmp_path / "truth.zarr")
+    zarrlite.create_group(truth)
+    zarrlite.write_full(truth, "time", (np.arange(20) * 6).astype(np.int64), ["time"], {"units": "hours since 2020-01-01 00:00:00", "calendar": "proleptic_gregorian"})
+    zarrlite.write_full(truth, "latitude", lat.astype(np.float32), ["latitude"])
+    fields = {"2m_temperature": rng.standard_normal((20, H, W)).astype(np.float32), "geopotential": rng.standard_normal((20, 2, H, W)).astype(np.float32)}
+    for v, arr in fields.items():   # compressed, chunked along time by 7: the reader must decode and stitch
+        d = os.path.join(truth, v)
+        os.makedirs(d)
+        chunks = (7,) + arr.shape[1:]
+        json.dump(dict(zarr_format=2, shape=list(arr.shape), chunks=list(chunks), dtype="<f4", compressor={"id": "gzip", "level": 1}, fill_value=0.0,
+                       order="C", filters=None), open(os.path.join(d, ".zarray"), "w"))
+        json.dump({"_ARRAY_DIMENSIONS": ["time"] + (["level"] if arr.ndim == 4 else []) + ["latitude", "longitude"]}, open(os.path.join(d, ".zattrs"), "w"))
+        for i in range(3):
+            blk = np.zeros(chunks, np.float32)
+            part = arr[7 * i:7 * i + 7]
+            blk[:len(part)] = part
+            open(os.path.join(d, ".".join([str(i)] + ["0"] * (arr.ndim - 1))), "wb").write(gzip.compress(blk.tobytes()))
+
+    def sums(p, y, lat_):   # the four sums of swiftk_ensemble_sums (include/swiftk.h), in torch on the CPU
+        p, y = torch.from_numpy(p).double(), torch.from_numpy(y).double()
+        w = np.cos(np.deg2rad(lat_))
+        w = torch.from_numpy(w / w.mean()).view(1, 1, -1, 1)
+        s0 = ((p.mean(1) - y) ** 2 * w).sum((-2, -1))
+        s1 = ((p - y.unsqueeze(1)).abs() * w.unsqueeze(1)).sum((1, -2, -1))
+        s2 = ((p.unsqueeze(2) - p.unsqueeze(1)).abs() * w.view(1, 1, 1, 1, -1, 1)).sum((1, 2, -2, -1))
+        s3 = (p.var(1) * w).sum((-2, -1))
+        return torch.stack([s0, s1, s2, s3], -1).numpy()
+
+    flat = em.evaluate_stores(truth, pred, sums_fn=sums, log=lambda *_: None)
+    assert len(flat) == 3 * 3 * 3  # metrics x leads x (1 + 2 level) variables
+    idx = np.array([2, 5, 9])
+    for j, h in enumerate((0, 12, 24)):
+        tgt = idx + h // 6
+        for key, p_arr, y_arr in (("2m_temperature", traj[:, :, j, 0:1], fields["2m_temperature"][tgt][:, None]),
+                                  ("geopotential_50", traj[:, :, j, 1:2], fields["geopotential"][tgt][:, 0:1]),
+                                  ("geopotential_100", traj[:, :, j, 2:3], fields["geopotential"][tgt][:, 1:2])):
+            P, Y = torch.from_numpy(p_arr).double(), torch.from_numpy(y_arr).double()
+            assert flat[f"rmse_{key}_{h}h"] == pytest.approx(float(om.rmse(P, Y, lat)[0]), rel=1e-9)
+            assert flat[f"crps_{key}_{h}h"] == pytest.approx(float(om.crps(P, Y, lat)[0]), rel=1e-9, abs=1e-12)
+            assert flat[f"ssr_{key}_{h}h"] == pytest.approx(float(om.spread_skill_ratio(P, Y, lat)[0]), rel=1e-9)
+    st = em.structure(flat)
+    assert set(st) == {"rmse", "crps", "ssr"} and set(st["crps"]) == {"0", "12", "24"} and set(st["ssr"]["24"]) == {"2m_temperature", "geopotential_50", "geopotential_100"}
+    # an initial time the truth store does not hold is an error that says so
+    zarrlite.write_full(pred, "time", (init + np.timedelta64(1, "h")).astype("datetime64[ns]").astype(np.int64), ["time"],
+                        {"units": "nanoseconds since 1970-01-01", "calendar": "proleptic_gregorian"})
+    with pytest.raises(ValueError, match="not in the truth store"):
+        em.evaluate_stores(truth, pred, sums_fn=sums, log=lambda *_: None)
+
+
 def test_finetune_keeps_its_own_optimizer_and_cli_floats():
     """Hydra keys a defaults entry by group AND package: the experiment's `override /optimizer: muon` must not reach the
     `/optimizer: adamw` that finetune/multistep.yaml packages at finetune.optimizer (reference finetune = AdamW lr 1e-5)."""
