@@ -72,6 +72,12 @@ constexpr int EPI_BIAS_POS_PAIR = 11;  // internal: SWIFTK_EPI_BIAS_POS leaving 
 #ifndef SWIFTK_X_NOSILU
 #define SWIFTK_X_NOSILU 0
 #endif
+// patch embedding: 1 = tile rows walked sample-fastest so that a pos_embed block is shared by an XCD's whole window (TileIter).
+// Measured in round 6 (profiles/r06o_posperm_ab.txt): 2,161 us against 2,098 us per launch at 96 units in storage order -- the
+// epilogue does not wait for pos_embed's Infinity-Cache fetches; off
+#ifndef SWIFTK_X_POSPERM
+#define SWIFTK_X_POSPERM 0
+#endif
 // SWIGLU_BWD epilogue: R > 0 = a rolling window of R saved pre-activation chunks per lane (R loads in flight) instead of two groups of four.
 // Measured in round 6 (profiles/r06m_gemm_ab_bwdroll.txt): R = 8 +3.3 %, R = 10 +4.2 % SLOWER (bit-equal): the epilogue is not short of loads in flight
 #ifndef SWIFTK_X_BWDROLL
@@ -456,12 +462,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
 // issued between MFMA groups instead of in one burst after the barrier.
 struct TileIter {
     int ntm, ntn, gm;  // tile rows, tile cols, group height
+    int pb, pt;        // > 1: tile rows are walked sample-fastest (pb samples of pt tile rows each), see below
     __device__ __forceinline__ void coords(int t, int& tm, int& tn) const {
         const int per = gm * ntn;
         const int grp = t / per, r = t - grp * per;
         const int rows = min(gm, ntm - grp * gm);
         tn = r / rows;
         tm = grp * gm + (r - tn * rows);
+        // (SWIFTK_X_POSPERM experiment, off: patch embedding with the tile rows walked sample-fastest -- an XCD's window then covers
+        // the SAME token block of eight samples, so a pos_embed block is fetched once per window instead of once per sample)
+        if (pb > 1) tm = (tm % pb) * pt + tm / pb;
     }
 };
 
@@ -486,7 +496,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wv >> 1, wn = wv & 1;
-    const TileIter it{ntm, g.ntn, gm};
+#if SWIFTK_X_POSPERM
+    const bool posperm = EPI == EPI_BIAS_POS_PAIR && g.ep1 && g.pos_rows >= BM && g.pos_rows % BM == 0 && g.M % g.pos_rows == 0 && g.ksplit == 1;
+    const TileIter it{ntm, g.ntn, gm, posperm ? (int)(g.M / g.pos_rows) : 0, posperm ? (int)(g.pos_rows / BM) : 0};
+#else
+    const TileIter it{ntm, g.ntn, gm, 0, 0};
+#endif
     // work item = (output tile, k-split): with ksplit > 1 (weight gradients: few output tiles, K = all tokens) each
     // split accumulates its k-range into its own fp32 slab C + split*c_split; a reduce kernel sums the slabs
     const int ksplit = g.ksplit;
