@@ -134,6 +134,14 @@ int swiftk_window_attention(const void* qkv, int64_t ldq, void* out, int64_t ldo
 int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, void* xcopy, int64_t ldc, const float* gamma,
                             const float* beta, const float* mod, int64_t ldmod, int64_t M, int d, int64_t rows_per_sample,
                             float eps, int dtype, void* stream);
+/* The same update for the split engine (SWIFTK_BF16X3; fp32 y and x): besides x (and the optional fp32 copy) the new rows leave as
+ * the NEXT GEMM's operand blocks x3 [M, ld3] bf16 = [hi | lo | hi] over d columns each + zero k-padding -- bit for bit what
+ * swiftk_split3(order 0) makes of the fp32 rows, without the pass that re-reads them (10 B per element and a launch less per
+ * ModulatedNorm; 4 more where no fp32 copy is needed).  SWIFTK_ESHAPE where the 16-row chunk kernel does not apply
+ * (rows_per_sample % 16, d % 8, ld3 - 3 d not a whole number of 16-B chunks up to one k-tile): run the two-step form. */
+int swiftk_modnorm_residual_split3(const float* y, int64_t ldy, float* x, float* xcopy, int64_t ldc, void* x3, int64_t ld3,
+                                   const float* gamma, const float* beta, const float* mod, int64_t ldmod, int64_t M, int d,
+                                   int64_t rows_per_sample, float eps, void* stream);
 
 /*
  * The same update on the bf16 engine's PAIR form of the residual stream: x is held as x_hi = bf16(x), which IS the next
@@ -308,6 +316,7 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * (Swift-B's four weight gradients 0...-9 % in time, -6 % per layer: tools/tn_ab.py),
  * key 23 = swiftk_swinv2_forward (bf16 engine) runs wo / w2 + norm as swiftk_gemm_modnorm_residual_pair up to this many units
  * per step (0 = never: split-K + slab-summing norm at one unit, GEMM + norm beyond),
+ * key 26 = split engine: the fp32 ModulatedNorm writes the next GEMM's operand blocks itself (1; 0 = fp32 copy + swiftk_split3),
  * key 25 = clears through hipMemsetAsync instead of a kernel (0; diagnosis only; bit 1 = the library's internal clears --
  * swiftk_modnorm_bwd's workspace, swiftk_scm_target's scratch --, bit 2 = swiftk_zero_f32, bit 4 = a check kernel behind
  * swiftk_modnorm_bwd's clear records what it left non-zero: swiftk_zero_check_report). */

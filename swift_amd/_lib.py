@@ -85,6 +85,7 @@ _SIGS = {
     "swiftk_split3": ([_p, _l, _p, _l, _l, _l, _i, _p], _i),
     "swiftk_axpby": ([_p, _f, _p, _f, _p, _l, _p], _i),
     "swiftk_zero_f32": ([_p, _l, _p], _i),
+    "swiftk_modnorm_residual_split3": ([_p, _l, _p, _p, _l, _p, _l, _p, _p, _p, _l, _l, _i, _l, _f, _p], _i),
     "swiftk_zero_check_report": ([_p], _i),
     "swiftk_unit_checksum": ([_p, _p, _p, _i, _l, _p], _i),
     "swiftk_timestep_embed_jvp": ([_p, _p, _p, _p, _i, _i, _f, _p], _i),

@@ -131,7 +131,8 @@ template <typename T, int SLOTS>
 __global__ __launch_bounds__(256, SWIFTK_MN_OCC) void modnorm_chunk_kernel(const T* __restrict__ y, int64_t ldy, float* __restrict__ x,
                                                             T* __restrict__ xc, int64_t ldc, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ mod,
-                                                            int64_t ldmod, int64_t M, int d, int64_t rps, float eps, int nt_x) {
+                                                            int64_t ldmod, int64_t M, int d, int64_t rps, float eps, int nt_x,
+                                                            bf16_t* __restrict__ x3 = nullptr, int64_t ld3 = 0, int64_t kv3 = 0) {
     const bool NT_X = nt_x & 1;
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -205,7 +206,22 @@ __global__ __launch_bounds__(256, SWIFTK_MN_OCC) void modnorm_chunk_kernel(const
                 for (int e = 0; e < 8; ++e) xr[i][e] += (v[i][e] * rstd) * P[e] + Q[e];
                 if (NT_X) store8_nt(x + row * d + 8 * c, xr[i]); else store8<float>(x + row * d + 8 * c, xr[i]);
                 if (xc) store8<T>(xc + row * ldc + 8 * c, xr[i]);
+                if (x3) {
+                    // split engine (round 6): the row leaves as the NEXT GEMM's operand blocks [hi | lo | hi] as well -- bit for bit what
+                    // swiftk_split3(order 0) makes of the fp32 row (hi = bf16(v), lo = bf16(v - hi)), without the pass that re-reads it
+                    float lo[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) lo[e] = xr[i][e] - bf2f(f2bf(xr[i][e]));
+                    bf16_t* r3 = x3 + row * ld3 + 8 * c;
+                    store8<bf16_t>(r3, xr[i]);
+                    store8<bf16_t>(r3 + kv3, lo);
+                    store8<bf16_t>(r3 + 2 * kv3, xr[i]);
+                }
             }
+        }
+        if (x3) {  // zero k-padding behind the three blocks (at most one 128-B k-tile row: 8 chunks)
+            const int pad = (int)((ld3 - 3 * kv3) >> 3);
+            if (lane < pad) *reinterpret_cast<uint4*>(x3 + row * ld3 + 3 * kv3 + 8 * lane) = make_uint4(0u, 0u, 0u, 0u);
         }
     };
     load_row(row0, ya, xa);
@@ -1157,6 +1173,31 @@ extern "C" int swiftk_modnorm_residual(const void* y, int64_t ldy, float* x, voi
         return SWIFTK_EINVAL;
     }
 #undef SWIFTK_MODNORM
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
+}
+
+int g_x3_normsplit = 1;  // tuning key 26: split engine, the fp32 ModulatedNorm writes the next GEMM's (hi, lo, hi) operand blocks itself
+
+extern "C" int swiftk_modnorm_residual_split3(const float* y, int64_t ldy, float* x, float* xcopy, int64_t ldc, void* x3, int64_t ld3,
+                                              const float* gamma, const float* beta, const float* mod, int64_t ldmod, int64_t M, int d,
+                                              int64_t rows_per_sample, float eps, void* stream) {
+    if (!y || !x || !x3 || !gamma || !beta || !mod || M <= 0 || d <= 0 || rows_per_sample <= 0) return SWIFTK_EINVAL;
+    // the chunked kernel only (whole 16-row chunks inside one sample); anything else: swiftk_modnorm_residual + swiftk_split3
+    if (d % 8 || d > 2048 || rows_per_sample % MN_ROWS || !(g_modnorm_nt & 2) || ld3 < 3 * (int64_t)d || (ld3 - 3 * (int64_t)d) > 64 * 8 ||
+        (ld3 - 3 * (int64_t)d) % 8)
+        return SWIFTK_ESHAPE;
+    if (((uintptr_t)y & 15) || (ldy * 4) % 16 || ((uintptr_t)x & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)mod & 15) ||
+        (ldmod % 4) || (xcopy && (((uintptr_t)xcopy & 15) || (ldc * 4) % 16)) || ((uintptr_t)x3 & 15) || (ld3 * 2) % 16)
+        return SWIFTK_EALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int cgrid = (int)((M + MN_ROWS - 1) / MN_ROWS);
+    if (d <= 3 * 512)
+        hipLaunchKernelGGL((modnorm_chunk_kernel<float, 3>), dim3(cgrid), dim3(256), 0, st, y, ldy, x, xcopy, ldc, gamma, beta, mod, ldmod, M, d,
+                           rows_per_sample, eps, g_modnorm_nt, static_cast<bf16_t*>(x3), ld3, (int64_t)d);
+    else
+        hipLaunchKernelGGL((modnorm_chunk_kernel<float, 4>), dim3(cgrid), dim3(256), 0, st, y, ldy, x, xcopy, ldc, gamma, beta, mod, ldmod, M, d,
+                           rows_per_sample, eps, g_modnorm_nt, static_cast<bf16_t*>(x3), ld3, (int64_t)d);
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }

@@ -144,6 +144,23 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     char* a3h = ws + L.a3h;
     // C = epilogue(A W^T) over the M token rows: `kpass` is the K handed to swiftk_gemm in the one-product engines (the padded
     // width, or the valid one when it ends half-way into the last k-tile), `kvalid` the number of meaningful columns of A
+    const void* a3_holds = nullptr;  // split engine: the fp32 tensor whose [hi | lo | hi] blocks currently sit in a3 (d columns), if any
+    // x += ModulatedNorm(y) of the fp32 / split engines.  Split engine: the norm writes the next GEMM's operand blocks into a3 in the
+    // same pass (tuning key 26) -- and no fp32 operand copy when `need_copy` is false (nobody but that GEMM reads it)
+    auto NORM = [&](const void* yv, const float* g_, const float* b_, const float* mod_, bool need_copy) -> int {
+        if (x3 && g_x3_normsplit && (d & 3) == 0) {
+            const int64_t ld3 = swiftk_gemm_k_pad(SWIFTK_BF16, 3 * (int64_t)d);
+            const int rc = swiftk_modnorm_residual_split3(static_cast<const float*>(yv), d, x, need_copy ? static_cast<float*>(xT) : nullptr, m->kd, a3,
+                                                          ld3, g_, b_, mod_, ldmod, M, d, ntok, 1e-6f, stream);
+            if (rc == 0) {
+                a3_holds = xT;
+                return 0;
+            }
+            if (rc != SWIFTK_ESHAPE) return rc;
+        }
+        a3_holds = nullptr;
+        return swiftk_modnorm_residual(yv, d, x, xT, m->kd, g_, b_, mod_, ldmod, M, d, ntok, 1e-6f, dt, stream);
+    };
     auto G = [&](const void* A, int64_t lda, const void* Wm, void* Cm, int64_t ldc, int64_t N, int64_t kpass, int64_t kvalid,
                  int out_dt, int epi, const float* e0, const float* e1, int64_t pr, bool exact = false) -> int {
         // the exact-fp32 engine's products: two-level accumulation (gemm.hip).  The split engine's two exact GEMMs keep one chain:
@@ -154,7 +171,9 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
         if (!x3 || exact) return swiftk_gemm(A, lda, Wm, lda, Cm, ldc, M, N, kpass, dt, out_dt, epi, e0, e1, pr, stream);
         const int64_t kv = (kvalid + 3) & ~(int64_t)3;  // (columns [kvalid, kv) of A are zero k-padding; the weight has them too)
         const int64_t ld3 = swiftk_gemm_k_pad(SWIFTK_BF16, 3 * kv);
-        RUN(swiftk_split3(static_cast<const float*>(A), lda, a3, ld3, M, kv, 0, stream));
+        // (a3_holds: the ModulatedNorm that produced A wrote its operand blocks into a3 itself -- swiftk_modnorm_residual_split3)
+        if (!(a3_holds == A && kv == d)) RUN(swiftk_split3(static_cast<const float*>(A), lda, a3, ld3, M, kv, 0, stream));
+        a3_holds = nullptr;  // (this GEMM's caller may overwrite a3 next)
         const int64_t k3 = ((3 * kv) % 64 == 32 && ld3 >= 3 * kv + 32) ? 3 * kv : ld3;
         return swiftk_gemm(a3, ld3, Wm, ld3, Cm, ldc, M, N, k3, SWIFTK_BF16, SWIFTK_F32, epi, e0, e1, pr, stream);
     };
@@ -266,6 +285,8 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
                                     ly.scale + 2 * pp, nullptr, hd, stream));
                 }
             }
+            // (round 6 also let the fp32 attention kernel write wo's [hi | lo | hi] operand blocks itself -- 8 B per element and a launch less:
+            // 100.0 against 99.9 sample-steps/s, nothing; taken out again)
             RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
                                         shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
         }
@@ -285,20 +306,19 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             if (pair)
                 RUN(swiftk_modnorm_residual_pair(y, d, xT, m->kd, xlo, d, lo_bits, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d,
                                                  ldmod, M, d, ntok, 1e-6f, stream));
-            else
-                RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok,
-                                            1e-6f, dt, stream));
+            else  // (split engine with the fused FeedForward: w1 is the only reader of this norm's output -- no fp32 operand copy)
+                RUN(NORM(y, ly.ln1_g, ly.ln1_b, mod + (int64_t)(2 * i) * 2 * d, !ff_split));
         }
         if (ff_split) {
             const int64_t kv = (d + 3) & ~(int64_t)3, ld3 = swiftk_gemm_k_pad(SWIFTK_BF16, 3 * kv);
-            RUN(swiftk_split3(static_cast<const float*>(xT), m->kd, a3, ld3, M, kv, 0, stream));
+            if (a3_holds != xT) RUN(swiftk_split3(static_cast<const float*>(xT), m->kd, a3, ld3, M, kv, 0, stream));
+            a3_holds = nullptr;
             const int64_t k3 = ((3 * kv) % 64 == 32 && ld3 >= 3 * kv + 32) ? 3 * kv : ld3;
             RUN(swiftk_gemm(a3, ld3, ly.w1_w, ld3, a3h, ld3h, M, 2 * m->mlp, k3, SWIFTK_BF16, SWIFTK_BF16, SWIFTK_EPI_SWIGLU_SPLIT3, nullptr,
                             nullptr, kvh, stream));
             const int64_t k3h = ((3 * kvh) % 64 == 32 && ld3h >= 3 * kvh + 32) ? 3 * kvh : ld3h;
             RUN(swiftk_gemm(a3h, ld3h, ly.w2_w, ld3h, y, d, M, d, k3h, SWIFTK_BF16, SWIFTK_F32, SWIFTK_EPI_NONE, nullptr, nullptr, 0, stream));
-            RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d, ntok, 1e-6f,
-                                        dt, stream));
+            RUN(NORM(y, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, true));  // (the next to_qkv's hot pairs / the head read xT)
             continue;
         }
         RUN(G(xT, m->kd, ly.w1_w, hmid, m->kmlp, 2 * m->mlp, kdv, d, dt, SWIFTK_EPI_SWIGLU, nullptr, nullptr, 0, (x3_exact & 4) != 0));
@@ -324,8 +344,7 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             RUN(swiftk_modnorm_residual_pair(y, d, xT, m->kd, xlo, d, lo_bits, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, ldmod,
                                              M, d, ntok, 1e-6f, stream));
         else
-            RUN(swiftk_modnorm_residual(y, d, x, xT, m->kd, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d,
-                                        ntok, 1e-6f, dt, stream));
+            RUN(NORM(y, ly.ln2_g, ly.ln2_b, mod + (int64_t)(2 * i + 1) * 2 * d, true));
     }
 
     // the head's output width rounded up to the GEMM's N granularity (head_w carries zero rows there: 69 -> 72 for 1x1 patches)

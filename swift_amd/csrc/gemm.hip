@@ -1686,6 +1686,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 22: g_tn_pp = value; return 0;
         case 23: g_fwd_rownorm = value; return 0;
         case 24: g_rownorm_dbg = value; return 0;
+        case 26: g_x3_normsplit = value; return 0;
         case 25:
             g_zero_memset = value;
             return (value & 4) ? swiftk_zero_check_enable() : 0;
@@ -1719,6 +1720,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 22: return g_tn_pp;
         case 23: return g_fwd_rownorm;
         case 25: return g_zero_memset;
+        case 26: return g_x3_normsplit;
     }
     return SWIFTK_EINVAL;
 }

@@ -736,6 +736,36 @@ def test_ensemble_metrics_vs_reference_golden(dev):
             assert float(got[f"{name}_{v}_x"]) == pytest.approx(float(r[i]), rel=5e-5)
 
 
+@pytest.mark.parametrize("d,rps,copy", [(1056, 8192, True), (1056, 8192, False), (1280, 4096, True), (96, 64, True)])
+def test_modnorm_residual_split3_is_norm_plus_split_bit_for_bit(dev, d, rps, copy):
+    """Round 6, split engine: swiftk_modnorm_residual_split3 = swiftk_modnorm_residual (fp32, swinv2.py:83-86,211-212) followed by
+    swiftk_split3(order 0) of the new rows, in one pass -- x, the optional fp32 copy and the [hi | lo | hi] operand blocks with their
+    zero k-padding must be BIT-EQUAL to the two-step form."""
+    from swift_amd import _lib, ops
+    L = _lib.lib()
+    B = 2
+    M = B * rps
+    y, x0 = rnd((M, d), 81).to(dev), rnd((M, d), 82).to(dev)
+    gamma, beta = (1 + 0.1 * rnd((d,), 83)).to(dev), (0.1 * rnd((d,), 84)).to(dev)
+    mod = (0.3 * rnd((B, 2 * d), 85)).to(dev)
+    kd, ld3 = ops.k_pad(torch.float32, d), ops.k_pad(torch.bfloat16, 3 * d)
+    st = torch.cuda.current_stream().cuda_stream
+    xa, ca = x0.clone(), torch.full((M, kd), 7.0, device=dev)
+    _lib.check(L.swiftk_modnorm_residual(y.data_ptr(), d, xa.data_ptr(), ca.data_ptr(), kd, gamma.data_ptr(), beta.data_ptr(), mod.data_ptr(), 2 * d,
+                                         M, d, rps, 1e-6, _lib.F32, st), "modnorm")
+    a3 = torch.full((M, ld3), 3.0, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.swiftk_split3(ca.data_ptr(), kd, a3.data_ptr(), ld3, M, d, 0, st), "split3")
+    xb, cb = x0.clone(), torch.full((M, kd), 7.0, device=dev)
+    b3 = torch.full((M, ld3), 3.0, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.swiftk_modnorm_residual_split3(y.data_ptr(), d, xb.data_ptr(), cb.data_ptr() if copy else None, kd, b3.data_ptr(), ld3, gamma.data_ptr(),
+                                                beta.data_ptr(), mod.data_ptr(), 2 * d, M, d, rps, 1e-6, st), "modnorm_split3")
+    assert torch.equal(xa, xb) and torch.equal(a3.view(torch.int16), b3.view(torch.int16))
+    assert torch.equal(ca[:, :d], cb[:, :d]) if copy else bool((cb == 7.0).all())
+    # shapes the chunk kernel does not take are refused (the forward then runs the two-step form)
+    assert L.swiftk_modnorm_residual_split3(y.data_ptr(), d, xb.data_ptr(), None, kd, b3.data_ptr(), ld3, gamma.data_ptr(), beta.data_ptr(), mod.data_ptr(),
+                                            2 * d, M, d, rps + 8, 1e-6, st) == -2
+
+
 def test_store_to_store_evaluation_cli_on_the_device(dev, tmp_path):
     """``python -m swift_amd.eval.metrics --truth T.zarr --pred P.zarr`` (reference eval/metrics.py:157-280) through the real
     ``swiftk_ensemble_sums``: a 12-member forecast store with a levelled variable against the oracle's restatement of the reference
