@@ -47,7 +47,11 @@ extern "C" {
 #define SWIFTK_EPI_SWIGLU 2    /* C[m][j] = silu(acc[m][2j]) * acc[m][2j+1]  (W rows interleaved gate/up) */
 #define SWIFTK_EPI_QKNORM 3    /* to_qkv: per token and head, q <- q/max(|q|,1e-12)*exp(min(ep0[h],ln100)),
                                   k <- k/max(|k|,1e-12), v unchanged (swinv2.py:123-127); ep0 = scale[heads]; head_dim
-                                  (80 / 88 / 96; with fp32 operands 80 / 96 need M, N % 8 == 0) travels in `pos_rows`, 0 = 88 */
+                                  (80 / 88 / 96; with fp32 operands 80 / 96 need M, N % 8 == 0) travels in `pos_rows`, 0 = 88.
+                                  pos_rows = -head_dim (fp32 operands and output, whole tiles): the [q | k]-ONLY form -- W still points at
+                                  [q | k | v] row triples and C at [q | k | v] column triples, but N counts 2 head_dim columns per head:
+                                  the v rows are skipped and the v columns of C left untouched (the split engine's hot head pairs:
+                                  only q-hat and k-hat meet in the logits; one 352-wide tile column per pair instead of two) */
 #define SWIFTK_EPI_SWIGLU_BOTH 6 /* training forward of the FeedForward (swinv2.py:96-101): C = A W^T (bf16, the pre-activation the
                                   backward pass needs) AND C2[m][j] = silu(C[m][2j]) * C[m][2j+1]; C2 (bf16) = ep1, its row
                                   stride (elements) = pos_rows; bf16 operands only */
@@ -317,6 +321,7 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * key 23 = swiftk_swinv2_forward (bf16 engine) runs wo / w2 + norm as swiftk_gemm_modnorm_residual_pair up to this many units
  * per step (0 = never: split-K + slab-summing norm at one unit, GEMM + norm beyond),
  * key 26 = split engine: the fp32 ModulatedNorm writes the next GEMM's operand blocks itself (1; 0 = fp32 copy + swiftk_split3),
+ * key 27 = split engine: the hot head pairs' exact to_qkv recompute covers their q and k columns only (1; 0 = q, k and v),
  * key 25 = clears through hipMemsetAsync instead of a kernel (0; diagnosis only; bit 1 = the library's internal clears --
  * swiftk_modnorm_bwd's workspace, swiftk_scm_target's scratch --, bit 2 = swiftk_zero_f32, bit 4 = a check kernel behind
  * swiftk_modnorm_bwd's clear records what it left non-zero: swiftk_zero_check_report). */

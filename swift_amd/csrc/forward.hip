@@ -10,6 +10,7 @@ int g_fwd_pair = 2;   // tuning key 12: bf16 engine's residual stream: 2 = (bf16
 int g_f32_chunk_k = 256;  // tuning key 13: fp32-operand GEMMs of the forward accumulate in chains of this many k (0 = one chain over K)
 int g_fwd_splitk = 2;  // tuning key 14: 2 = bf16 slabs, 1 = fp32 slabs
 int g_fwd_pepair = 1;  // tuning key 19: the patch embedding's epilogue writes the pair form itself
+int g_x3_qkonly = 1;  // tuning key 27: split engine, the hot head pairs' exact recompute covers q and k only (v keeps its split product)
 int g_x3_ffsplit = 1;  // tuning key 18: split engine, w1 writes w2's operand blocks itself  // tuning key 14: wo / w2 as two k-ranges into fp32 slabs when their tiles fill less than half the chip (one unit per step)
 int g_fwd_fused = 1;  // tuning key 8 (A/B only): 0 = to_qkv and window attention as two kernels (q/k/v window-tiled through HBM)
 
@@ -280,6 +281,13 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
                 for (int pp = 0; 2 * pp < m->heads; ++pp) {
                     if (!((ly.qk_exact_pairs >> pp) & 1)) continue;
                     const int64_t c0 = (int64_t)pp * 6 * hd;
+                    // only q-hat and k-hat meet in the logits: the pair's two [q | k] column pairs (4 head_dim columns = ONE 352-wide
+                    // tile column at head_dim 88, where the whole [q | k | v] x 2 range takes two) are recomputed; v keeps its split
+                    // product (tuning key 27; pos_rows < 0 = the [q | k]-only form of SWIFTK_EPI_QKNORM)
+                    if (g_x3_qkonly &&
+                        swiftk_gemm(xT, m->kd, static_cast<const float*>(ly.qkv_w_f32) + c0 * m->kd, m->kd, static_cast<float*>(qkv) + c0, 3 * d, M,
+                                    4 * hd, kdv, SWIFTK_F32, SWIFTK_F32, SWIFTK_EPI_QKNORM, ly.scale + 2 * pp, nullptr, -(int64_t)hd, stream) == 0)
+                        continue;
                     RUN(swiftk_gemm(xT, m->kd, static_cast<const float*>(ly.qkv_w_f32) + c0 * m->kd, m->kd,
                                     static_cast<float*>(qkv) + c0, 3 * d, M, 6 * hd, kdv, SWIFTK_F32, SWIFTK_F32, SWIFTK_EPI_QKNORM,
                                     ly.scale + 2 * pp, nullptr, hd, stream));

@@ -142,6 +142,7 @@ struct GemmArgs {
     int pos_rows;
     int ntn;
     int ni;   // W-side MFMA tiles per wave of the persistent kernel's geometry: 10 / 11 / 12 = 320 / 352 / 384 columns per tile
+    int qk_only = 0;  // SWIFTK_EPI_QKNORM with fp32 operands: W rows / C columns are [q|k] pairs picked out of [q|k|v] triples (swiftk_gemm, pos_rows < 0)
     int dbg;  // tuning experiments only: 1 = no DMA in the loop, 2 = no barrier (both give wrong results)
     int khalf;         // the last k-tile holds data in its first half only (K = 16.5 tiles for d = 1056)
     int touch;         // persistent kernel: L2 look-ahead requests on (aligned shapes only: M % 256 == 0, N % tile width == 0)
@@ -222,13 +223,14 @@ __device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, float b) {
 // `rn` (optional, training): 1/max(|.|, 1e-12) of every q / k vector, [M][N/88] fp32 (1 for v), for the backward pass.
 template <int NI>
 __device__ __forceinline__ void qknorm_tile(f32x4 (&acc)[MI][NI], int lane, int c0, const float* __restrict__ scale,
-                                            float* __restrict__ rn = nullptr, int mrow0 = 0, int M = 0, int nvec = 0) {
+                                            float* __restrict__ rn = nullptr, int mrow0 = 0, int M = 0, int nvec = 0, bool qk_only = false) {
     constexpr int HD = 8 * NI;  // the wave tile's 16*NI columns are two head vectors: 80 / 88 / 96 for NI = 10 / 11 / 12
     const int g4 = lane >> 4;
     const int vA = c0 / HD, vB = vA + 1;
-    const int kA = vA % 3, kB = vB % 3;
-    const float tauA = kA == 0 ? expf(fminf(scale[vA / 3], 4.605170185988092f)) : 1.0f;
-    const float tauB = kB == 0 ? expf(fminf(scale[vB / 3], 4.605170185988092f)) : 1.0f;
+    // (qk_only: the columns are [q | k] pairs -- vector v is q or k of head v / 2 -- instead of [q | k | v] triples)
+    const int kA = qk_only ? (vA & 1) : vA % 3, kB = qk_only ? (vB & 1) : vB % 3;
+    const float tauA = kA == 0 ? expf(fminf(scale[qk_only ? vA >> 1 : vA / 3], 4.605170185988092f)) : 1.0f;
+    const float tauB = kB == 0 ? expf(fminf(scale[qk_only ? vB >> 1 : vB / 3], 4.605170185988092f)) : 1.0f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         float sa = 0.f, sb = 0.f;
@@ -557,6 +559,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
         for (int i = 0; i < 6; ++i) {
             int rb = tn * BN + (wv + 8 * i) * 8;
             rb = rb < g.N ? rb : g.N - 8;
+            if constexpr (sizeof(T) == 4 && EPI == SWIFTK_EPI_QKNORM)  // [q | k] pairs out of to_qkv's [q | k | v] row triples: skip the v rows
+                if (g.qk_only) rb += (rb / (2 * HD)) * HD;
             wbase[i] = g.W + (int64_t)rb * g.ldw_b;
         }
     };
@@ -1035,7 +1039,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
             it.coords(tile / ksplit, tm, tn);
             const int m0 = tm * BM, n0 = tn * BN;
             if constexpr (EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED)
-                qknorm_tile<NI>(acc, lane, n0 + wn * WT, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / HD);
+                qknorm_tile<NI>(acc, lane, n0 + wn * WT, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / HD, sizeof(T) == 4 && g.qk_only);
             float qf[MI / 2][4];  // QKNORM_JVP: (f_A, f_B, f c_A, f c_B) per primal row block
             if constexpr (EPI == SWIFTK_EPI_QKNORM_JVP) {
                 int qlane = lane;  // (opaque copy: nothing of the tangent rule is hoisted above the k-loop)
@@ -1502,7 +1506,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                         const float h1 = swiglu_out<OutT>(v[2], v[3]);
                         store2<OutT>(C + (int64_t)m * g.ldc + (nb >> 1), h0, h1);
                     } else {
-                        store4<OutT>(C + (int64_t)m * g.ldc + nb, v[0], v[1], v[2], v[3]);
+                        int nbo = nb;
+                        if constexpr (sizeof(T) == 4 && EPI == SWIFTK_EPI_QKNORM)  // ... and land in the q, k columns of the [q | k | v] output
+                            if (g.qk_only) nbo += (nb / (2 * HD)) * HD;
+                        store4<OutT>(C + (int64_t)m * g.ldc + nbo, v[0], v[1], v[2], v[3]);
                     }
                 }
             }
@@ -1555,6 +1562,9 @@ int launch(const GemmArgs& g, hipStream_t st) {
     auto kern = gemm_kernel<T, OutT, EPI>;
     const int ntm = (g.M + BM - 1) / BM;
     if (sizeof(T) == 4 && EPI != SWIFTK_EPI_QKNORM && g.ni != NI) return SWIFTK_ESHAPE;  // (fp32 operands: 352-wide tiles but for QKNORM)
+    // [q | k]-only form: fp32 operands and output, whole tiles, the persistent kernel (the only one that remaps W rows / C columns)
+    if (g.qk_only && (sizeof(T) != 4 || sizeof(OutT) != 4 || EPI != SWIFTK_EPI_QKNORM || g_variant == 0 || (g.M & 7) || (g.N & 7) || g.ep1))
+        return SWIFTK_ESHAPE;
     const bool timed = swiftk_prof_begin(EPI, g.N, st);
     const bool wide_ok = sizeof(OutT) != 2 || (!((uintptr_t)g.C & 15) && !(g.ldc & 7) &&
                                                !(g.N & (EPI == SWIFTK_EPI_SWIGLU || EPI == SWIFTK_EPI_SWIGLU_BOTH ? 15 : 7)));  // 16-B row chunks
@@ -1687,6 +1697,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 23: g_fwd_rownorm = value; return 0;
         case 24: g_rownorm_dbg = value; return 0;
         case 26: g_x3_normsplit = value; return 0;
+        case 27: g_x3_qkonly = value; return 0;
         case 25:
             g_zero_memset = value;
             return (value & 4) ? swiftk_zero_check_enable() : 0;
@@ -1721,6 +1732,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 23: return g_fwd_rownorm;
         case 25: return g_zero_memset;
         case 26: return g_x3_normsplit;
+        case 27: return g_x3_qkonly;
     }
     return SWIFTK_EINVAL;
 }
@@ -1787,9 +1799,15 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     // QKNORM: whole heads of 3 x head_dim columns, a wave tile = two head vectors -> tile width 4 x head_dim; head_dim
     // travels in `pos_rows` (0 = 88); fp32 operands: whole tiles only for 80 / 96 (M, N multiples of 8)
     int ni = 11;
+    int qk_only = 0;
+    if (epilogue == SWIFTK_EPI_QKNORM && pos_rows < 0) {  // [q | k] pairs only (see the header): head_dim = -pos_rows
+        qk_only = 1;
+        pos_rows = -pos_rows;
+        if (dtype != SWIFTK_F32 || out_dtype != SWIFTK_F32 || N % (4 * pos_rows) != 0) return SWIFTK_ESHAPE;
+    }
     if (epilogue == SWIFTK_EPI_QKNORM) {
         const int64_t hd = pos_rows > 0 ? pos_rows : 88;
-        if (!ep0 || (hd != 80 && hd != 88 && hd != 96) || N % (6 * hd) != 0) return SWIFTK_ESHAPE;
+        if (!ep0 || (hd != 80 && hd != 88 && hd != 96) || N % ((qk_only ? 4 : 6) * hd) != 0) return SWIFTK_ESHAPE;
         if (hd != 88 && dtype != SWIFTK_BF16 && (g_variant == 0 || (M & 7) || (N & 7))) return SWIFTK_ESHAPE;
         ni = (int)(hd / 8);
     } else if (dtype == SWIFTK_BF16 && N % 352 != 0) {  // tile width that divides N, if one does (dim 1280 / 1536 families)
@@ -1812,6 +1830,7 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     g.ep1 = ep1;
     g.pos_rows = (int)pos_rows;
     g.ni = ni;
+    g.qk_only = qk_only;
     g.ntn = (int)((N + 32 * ni - 1) / (32 * ni));
     g.dbg = g_dbg;
     g.ksplit = ksplit;

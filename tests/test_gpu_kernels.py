@@ -766,6 +766,33 @@ def test_modnorm_residual_split3_is_norm_plus_split_bit_for_bit(dev, d, rps, cop
                                             2 * d, M, d, rps + 8, 1e-6, st) == -2
 
 
+@pytest.mark.parametrize("hd,npairs", [(88, 1), (88, 3), (96, 2), (80, 1)])
+def test_gemm_qknorm_qk_only_form_equals_the_full_form_on_q_and_k(dev, hd, npairs):
+    """Round 6, split engine: SWIFTK_EPI_QKNORM with pos_rows = -head_dim recomputes only the [q | k] column pairs of head pairs whose
+    weights sit as [q | k | v] row triples (to_qkv.weight as stored, swinv2.py:119-127) -- bit-equal to the full form on the q and k
+    columns, the v columns of the output untouched."""
+    from swift_amd import _lib
+    L = _lib.lib()
+    M, K = 2048, 1056 if hd == 88 else 16 * hd
+    heads = 2 * npairs
+    a = rnd((M, K), 95).to(dev)
+    w = (0.03 * rnd((3 * heads * hd, K), 96)).to(dev)
+    scale = torch.log(torch.tensor([10.0, 60.0] * npairs)).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    full = torch.zeros(M, 3 * heads * hd, device=dev)
+    _lib.check(L.swiftk_gemm(a.data_ptr(), K, w.data_ptr(), K, full.data_ptr(), 3 * heads * hd, M, 3 * heads * hd, K, _lib.F32, _lib.F32,
+                             _lib.EPI_QKNORM, scale.data_ptr(), None, hd, st), "full")
+    part = torch.full((M, 3 * heads * hd), 7.0, device=dev)
+    _lib.check(L.swiftk_gemm(a.data_ptr(), K, w.data_ptr(), K, part.data_ptr(), 3 * heads * hd, M, 2 * heads * hd, K, _lib.F32, _lib.F32,
+                             _lib.EPI_QKNORM, scale.data_ptr(), None, -hd, st), "qk only")
+    f3, p3 = full.view(M, heads, 3, hd), part.view(M, heads, 3, hd)
+    assert torch.equal(f3[:, :, :2], p3[:, :, :2]) and bool((p3[:, :, 2] == 7.0).all())
+    assert float(f3[:, :, 0].norm(dim=-1).min()) > 5.0  # (q rows carry their logit scale: the epilogue did run)
+    # refused where it cannot apply: bf16 operands
+    assert L.swiftk_gemm(a.bfloat16().data_ptr(), K, w.bfloat16().data_ptr(), K, part.data_ptr(), 3 * heads * hd, M, 2 * heads * hd, K, _lib.BF16,
+                         _lib.F32, _lib.EPI_QKNORM, scale.data_ptr(), None, -hd, st) == -2
+
+
 def test_store_to_store_evaluation_cli_on_the_device(dev, tmp_path):
     """``python -m swift_amd.eval.metrics --truth T.zarr --pred P.zarr`` (reference eval/metrics.py:157-280) through the real
     ``swiftk_ensemble_sums``: a 12-member forecast store with a levelled variable against the oracle's restatement of the reference
