@@ -74,6 +74,8 @@ extern "C" {
                                   |logit| <= exp(min(scale, ln 100)): where <= 48 softmax needs no row maximum */
 #define SWIFTK_ATTN_TILED 4    /* `qkv` is window-tiled (swiftk_gemm_qkv_tiled): [B][window][head][q|k|v][256][head_dim] bf16, windows
                                   of the grid rolled by (shift_h, shift_w); needs PRENORM, bf16, head_dim 88; ldq unused */
+#define SWIFTK_ATTN_PV_BF16X3 8 /* fp32 operands (the split engine): the logits and the softmax stay exact fp32, O = P V runs as three bf16 MFMA
+                                  products of (hi, lo)-split operands (the dropped lo x lo term: 2^-18 relative) */
 #define SWIFTK_ATTN_NO_PIPE 2  /* tuning: keep the one-workgroup-per-item kernel even where the pipelined one applies */
 
 /* Most (member, IC) units one swiftk_swinv2_forward call takes (BASELINE configs[3] puts 96 on a GPU). */
@@ -321,7 +323,9 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * key 23 = swiftk_swinv2_forward (bf16 engine) runs wo / w2 + norm as swiftk_gemm_modnorm_residual_pair up to this many units
  * per step (0 = never: split-K + slab-summing norm at one unit, GEMM + norm beyond),
  * key 26 = split engine: the fp32 ModulatedNorm writes the next GEMM's operand blocks itself (1; 0 = fp32 copy + swiftk_split3),
- * key 27 = split engine: the hot head pairs' exact to_qkv recompute covers their q and k columns only (1; 0 = q, k and v),
+ * key 27 = split engine's exact to_qkv recompute: 2 = each hot head alone, q, k and v (default; needs the head mask in
+ * swiftk_layer.qk_exact_pairs), 1 = the hot pairs' q and k columns only, 0 = the hot pairs whole,
+ * key 28 = split engine: the fp32 attention kernel's P V as three bf16 products (1; 0 = exact fp32 like its q k^T),
  * key 25 = clears through hipMemsetAsync instead of a kernel (0; diagnosis only; bit 1 = the library's internal clears --
  * swiftk_modnorm_bwd's workspace, swiftk_scm_target's scratch --, bit 2 = swiftk_zero_f32, bit 4 = a check kernel behind
  * swiftk_modnorm_bwd's clear records what it left non-zero: swiftk_zero_check_report). */
@@ -568,9 +572,11 @@ typedef struct swiftk_layer {
     const float* ln2_b;
     const void* qkv_w_f32;   /* SWIFTK_BF16X3 with x3_exact bit 6 (adaptive to_qkv), else NULL: to_qkv.weight as fp32 operands
                                 [3*heads*hd, kd] beside the split form in qkv_w                                              */
-    int32_t qk_exact_pairs;  /* ... and which PAIRS of heads (bit p = heads 2p, 2p+1) are recomputed on the exact-fp32 kernel:
+    int32_t qk_exact_pairs;  /* ... and which PAIRS of heads (bits 0..15: bit p = heads 2p, 2p+1) are recomputed on the exact-fp32 kernel:
                                 those whose logit scale exp(min(scale, ln 100)) exceeds the packer's threshold -- the split
-                                product's 4.5e-6 reaches the softmax multiplied by that scale                                */
+                                product's 4.5e-6 reaches the softmax multiplied by that scale.  Bits 16..31 (optional, models of up
+                                to 16 heads): the hot HEADS themselves (bit 16 + h); when given, each is recomputed alone (one tile
+                                column per hot head instead of two per pair) and the pair's other head keeps the split product   */
 } swiftk_layer;
 
 typedef struct swiftk_model {

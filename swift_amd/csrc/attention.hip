@@ -32,6 +32,7 @@ struct AttnArgs {
     int64_t ldq, ldo;
     int gh, gw, heads, sh, sw, nwx, nw;
     int prenorm;  // q, k arrive L2-normalised (and q scaled) from the to_qkv GEMM epilogue
+    int pv3;      // fp32 kernel: O = P V as three bf16 products of split operands (SWIFTK_ATTN_PV_BF16X3)
 };
 
 // token index (row-major, un-rolled grid) of window-local token j of window w: roll(-s)[p] = x[(p+s) mod n]
@@ -230,7 +231,11 @@ __global__ __launch_bounds__(NT) void attn_bf16_kernel(AttnArgs a) {
 
 constexpr int VSTR32 = 96;  // floats per V row
 
-template <int HD>
+// PV3 (round 6, the split engine): S = q k^T and the softmax stay on the exact-fp32 MFMA -- the logits are where operand rounding is
+// amplified -- but O = P V runs as THREE bf16 MFMA products of (hi, lo)-split operands, P_hi V_hi + P_lo V_hi + P_hi V_lo (the dropped
+// P_lo V_lo term is 2^-18 relative), at 16 / 3 times the fp32 matrix rate: the V image is staged as two bf16 images (hi, lo; the
+// bf16 kernel's 192-B rows and transposed reads), the probabilities are split where they are packed into operands.
+template <int HD, bool PV3>
 __global__ __launch_bounds__(NT) void attn_f32_kernel(AttnArgs a) {
     static_assert(HD % 8 == 0 && HD <= 96, "head_dim (fp32 path)");
     constexpr int KSTR32 = HD + 4;      // floats per K row: 16 consecutive rows land on 16 distinct 4-bank groups
@@ -320,6 +325,65 @@ __global__ __launch_bounds__(NT) void attn_f32_kernel(AttnArgs a) {
 
     // swap the LDS image K -> V
     __syncthreads();
+    f32x16 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    if constexpr (PV3) {
+        static_assert(2 * WTOK * VSTR <= (int)sizeof(sKV), "the two bf16 V images must fit into the fp32 K / V buffer");
+        char* imH = reinterpret_cast<char*>(sKV);
+        char* imL = imH + WTOK * VSTR;
+        if (tid < 256) {
+            const float* src = qkv + (tok0 + window_token(a, w, tid)) * a.ldq + head * 3 * HD + 2 * HD;
+#pragma unroll
+            for (int c = 0; c < VSTR / 8; ++c) {  // 8-B pieces of the 192-B rows: HD / 4 of data, the rest zero
+                uint2 h = make_uint2(0u, 0u), lo = make_uint2(0u, 0u);
+                if (c < NF4) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + 4 * c);
+                    h = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+                    lo = make_uint2(pack_bf16(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u)),
+                                    pack_bf16(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u)));
+                }
+                *reinterpret_cast<uint2*>(imH + tid * VSTR + 8 * c) = h;
+                *reinterpret_cast<uint2*>(imL + tid * VSTR + 8 * c) = lo;
+            }
+        }
+        __syncthreads();
+        // O^T[d][q] += V^T[d][key] P^T[key][q]: the S^T accumulators are the B operand, V^T fragments by transposed reads with the k
+        // order permuted to match (attn_bf16_kernel's scheme), once per image
+        const int i16 = lane & 15;
+        const int vbase = (4 * hh + (i16 >> 2)) * VSTR + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                uint32_t ph[4], pl[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p0 = s[kb][8 * s2 + 2 * e], p1 = s[kb][8 * s2 + 2 * e + 1];
+                    ph[e] = pack_bf16(p0, p1);
+                    pl[e] = pack_bf16(p0 - __uint_as_float(ph[e] << 16), p1 - __uint_as_float(ph[e] & 0xffff0000u));
+                }
+                const uint4 pH = make_uint4(ph[0], ph[1], ph[2], ph[3]), pL = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                const int roff = (kb * 32 + s2 * 16) * VSTR + vbase;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    auto frag = [&](const char* im) {
+                        const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(im + roff + db * 64));
+                        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(im + roff + db * 64 + 8 * VSTR));
+                        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+                    };
+                    const bf16x8 vH = frag(imH), vL = frag(imL);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vH, __builtin_bit_cast(bf16x8, pH), o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vH, __builtin_bit_cast(bf16x8, pL), o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vL, __builtin_bit_cast(bf16x8, pH), o[db], 0, 0, 0);
+                }
+            }
+        }
+    } else {
     if (tid < 256) {
         const float* src = qkv + (tok0 + window_token(a, w, tid)) * a.ldq + head * 3 * HD + 2 * HD;
 #pragma unroll
@@ -331,11 +395,6 @@ __global__ __launch_bounds__(NT) void attn_f32_kernel(AttnArgs a) {
     }
     __syncthreads();
 
-    f32x16 o[DB];
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
@@ -346,6 +405,7 @@ __global__ __launch_bounds__(NT) void attn_f32_kernel(AttnArgs a) {
             for (int db = 0; db < DB; ++db)
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[db * 32], s[kb][r], o[db], 0, 0, 0);
         }
+    }
 
     const float rl = 1.0f / l;
     float* dst = static_cast<float*>(a.out) + (tok0 + window_token(a, w, wv * 32 + c32)) * a.ldo + head * HD;
@@ -365,8 +425,10 @@ int launch_hd(const AttnArgs& a, int B, int dtype, hipStream_t st) {
     const int grid = B * a.nw * a.heads;
     if (dtype == SWIFTK_BF16)
         hipLaunchKernelGGL(attn_bf16_kernel<HD>, dim3(grid), dim3(NT), 0, st, a);
+    else if (a.pv3)
+        hipLaunchKernelGGL((attn_f32_kernel<HD, true>), dim3(grid), dim3(NT), 0, st, a);
     else
-        hipLaunchKernelGGL(attn_f32_kernel<HD>, dim3(grid), dim3(NT), 0, st, a);
+        hipLaunchKernelGGL((attn_f32_kernel<HD, false>), dim3(grid), dim3(NT), 0, st, a);
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }
@@ -398,6 +460,7 @@ extern "C" int swiftk_window_attention(const void* qkv, int64_t ldq, void* out, 
     a.nwx = gw / 16;
     a.nw = (gh / 16) * (gw / 16);
     a.prenorm = prenorm ? 1 : 0;
+    a.pv3 = (dtype == SWIFTK_F32 && (flags & SWIFTK_ATTN_PV_BF16X3)) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (prenorm && dtype == SWIFTK_BF16 && (head_dim == 80 || head_dim == 88 || head_dim == 96) &&
         !(flags & SWIFTK_ATTN_NO_PIPE)) {

@@ -10,7 +10,8 @@ int g_fwd_pair = 2;   // tuning key 12: bf16 engine's residual stream: 2 = (bf16
 int g_f32_chunk_k = 256;  // tuning key 13: fp32-operand GEMMs of the forward accumulate in chains of this many k (0 = one chain over K)
 int g_fwd_splitk = 2;  // tuning key 14: 2 = bf16 slabs, 1 = fp32 slabs
 int g_fwd_pepair = 1;  // tuning key 19: the patch embedding's epilogue writes the pair form itself
-int g_x3_qkonly = 1;  // tuning key 27: split engine, the hot head pairs' exact recompute covers q and k only (v keeps its split product)
+int g_x3_attnpv = 1;  // tuning key 28: split engine, P V of the fp32 attention kernel as three bf16 products
+int g_x3_qkonly = 2;  // tuning key 27: split engine's exact to_qkv recompute: 2 = each hot head alone (q, k, v), 1 = hot pairs' q and k, 0 = hot pairs
 int g_x3_ffsplit = 1;  // tuning key 18: split engine, w1 writes w2's operand blocks itself  // tuning key 14: wo / w2 as two k-ranges into fp32 slabs when their tiles fill less than half the chip (one unit per step)
 int g_fwd_fused = 1;  // tuning key 8 (A/B only): 0 = to_qkv and window attention as two kernels (q/k/v window-tiled through HBM)
 
@@ -278,13 +279,27 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
                 // adaptive to_qkv of the split engine: the head pairs whose logit scale is large enough for the split product's
                 // 4.5e-6 to matter in front of the softmax are recomputed on the exact-fp32 kernel -- 6 head_dim output columns each,
                 // written over the split result (same QK-norm epilogue, the pair's two logit scales)
+                // (round 6) the packer may name the hot HEADS themselves (bits 16..31 of qk_exact_pairs, models of up to 16 heads): then each
+                // is recomputed alone -- its [q | k | v], N = 3 head_dim, is ONE 352-wide tile column where the pair's [q | k | v] x 2 takes
+                // two (427 against 840 us at 8 units) -- and the pair's cold head keeps the split product like every other cold head.
+                // Tuning key 27: 2 = per hot head (default), 1 = the pair's q and k columns only (the same cost, but the hot head's v is
+                // then a split product: 9.9e-5 instead of 8.9e-5 on the Swift-B golden -- the v of a peaked softmax is not averaged
+                // down over 256 keys), 0 = whole pairs
+                const int hot_heads = (ly.qk_exact_pairs >> 16) & 0xffff;
+                if (g_x3_qkonly >= 2 && hot_heads && m->heads <= 16) {
+                    for (int h = 0; h < m->heads; ++h) {
+                        if (!((hot_heads >> h) & 1)) continue;
+                        const int64_t c0 = (int64_t)h * 3 * hd;
+                        RUN(swiftk_gemm(xT, m->kd, static_cast<const float*>(ly.qkv_w_f32) + c0 * m->kd, m->kd, static_cast<float*>(qkv) + c0, 3 * d, M,
+                                        3 * hd, kdv, SWIFTK_F32, SWIFTK_F32, SWIFTK_EPI_QKNORM, ly.scale + h, nullptr, hd, stream));
+                    }
+                } else
                 for (int pp = 0; 2 * pp < m->heads; ++pp) {
                     if (!((ly.qk_exact_pairs >> pp) & 1)) continue;
                     const int64_t c0 = (int64_t)pp * 6 * hd;
-                    // only q-hat and k-hat meet in the logits: the pair's two [q | k] column pairs (4 head_dim columns = ONE 352-wide
-                    // tile column at head_dim 88, where the whole [q | k | v] x 2 range takes two) are recomputed; v keeps its split
-                    // product (tuning key 27; pos_rows < 0 = the [q | k]-only form of SWIFTK_EPI_QKNORM)
-                    if (g_x3_qkonly &&
+                    // key 27 = 1: only q-hat and k-hat meet in the logits: the pair's two [q | k] column pairs (4 head_dim columns = ONE
+                    // 352-wide tile column) are recomputed; v keeps its split product (pos_rows < 0 = the [q | k]-only form of QKNORM)
+                    if (g_x3_qkonly == 1 &&
                         swiftk_gemm(xT, m->kd, static_cast<const float*>(ly.qkv_w_f32) + c0 * m->kd, m->kd, static_cast<float*>(qkv) + c0, 3 * d, M,
                                     4 * hd, kdv, SWIFTK_F32, SWIFTK_F32, SWIFTK_EPI_QKNORM, ly.scale + 2 * pp, nullptr, -(int64_t)hd, stream) == 0)
                         continue;
@@ -296,7 +311,8 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
             // (round 6 also let the fp32 attention kernel write wo's [hi | lo | hi] operand blocks itself -- 8 B per element and a launch less:
             // 100.0 against 99.9 sample-steps/s, nothing; taken out again)
             RUN(swiftk_window_attention(qkv, 3 * d, att, m->kd, ly.scale, B, gh, gw, m->heads, hd, shifted ? m->sh : 0,
-                                        shifted ? m->sw : 0, dt, fuse_norm ? SWIFTK_ATTN_PRENORM : 0, stream));
+                                        shifted ? m->sw : 0, dt, (fuse_norm ? SWIFTK_ATTN_PRENORM : 0) | (x3 && g_x3_attnpv ? SWIFTK_ATTN_PV_BF16X3 : 0),
+                                        stream));
         }
         if (rn_rows) {
             RUN(swiftk_gemm_modnorm_residual_pair(att, m->kd, ly.wo_w, m->kd, kdv, xT, m->kd, xlo, d, ly.ln1_g, ly.ln1_b,

@@ -229,8 +229,11 @@ __device__ __forceinline__ void qknorm_tile(f32x4 (&acc)[MI][NI], int lane, int 
     const int vA = c0 / HD, vB = vA + 1;
     // (qk_only: the columns are [q | k] pairs -- vector v is q or k of head v / 2 -- instead of [q | k | v] triples)
     const int kA = qk_only ? (vA & 1) : vA % 3, kB = qk_only ? (vB & 1) : vB % 3;
-    const float tauA = kA == 0 ? expf(fminf(scale[qk_only ? vA >> 1 : vA / 3], 4.605170185988092f)) : 1.0f;
-    const float tauB = kB == 0 ? expf(fminf(scale[qk_only ? vB >> 1 : vB / 3], 4.605170185988092f)) : 1.0f;
+    // (nvec > 0: vectors at or beyond it lie outside the matrix -- N = 3 head_dim, ONE head, leaves the tile's fourth vector empty --
+    // and must not read a logit scale: their accumulators are never stored)
+    const bool inA = nvec <= 0 || vA < nvec, inB = nvec <= 0 || vB < nvec;
+    const float tauA = kA == 0 && inA ? expf(fminf(scale[qk_only ? vA >> 1 : vA / 3], 4.605170185988092f)) : 1.0f;
+    const float tauB = kB == 0 && inB ? expf(fminf(scale[qk_only ? vB >> 1 : vB / 3], 4.605170185988092f)) : 1.0f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         float sa = 0.f, sb = 0.f;
@@ -251,8 +254,8 @@ __device__ __forceinline__ void qknorm_tile(f32x4 (&acc)[MI][NI], int lane, int 
         if (rn && g4 == 0) {
             const int m = mrow0 + i * 16 + (lane & 15);
             if (m < M) {
-                rn[(int64_t)m * nvec + vA] = kA == 2 ? 1.0f : 1.0f / fmaxf(sqrtf(sa), 1e-12f);
-                rn[(int64_t)m * nvec + vB] = kB == 2 ? 1.0f : 1.0f / fmaxf(sqrtf(sb), 1e-12f);
+                if (inA) rn[(int64_t)m * nvec + vA] = kA == 2 ? 1.0f : 1.0f / fmaxf(sqrtf(sa), 1e-12f);
+                if (inB) rn[(int64_t)m * nvec + vB] = kB == 2 ? 1.0f : 1.0f / fmaxf(sqrtf(sb), 1e-12f);
             }
         }
 #pragma unroll
@@ -1698,6 +1701,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 24: g_rownorm_dbg = value; return 0;
         case 26: g_x3_normsplit = value; return 0;
         case 27: g_x3_qkonly = value; return 0;
+        case 28: g_x3_attnpv = value; return 0;
         case 25:
             g_zero_memset = value;
             return (value & 4) ? swiftk_zero_check_enable() : 0;
@@ -1733,6 +1737,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 25: return g_zero_memset;
         case 26: return g_x3_normsplit;
         case 27: return g_x3_qkonly;
+        case 28: return g_x3_attnpv;
     }
     return SWIFTK_EINVAL;
 }
@@ -1807,7 +1812,10 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
     }
     if (epilogue == SWIFTK_EPI_QKNORM) {
         const int64_t hd = pos_rows > 0 ? pos_rows : 88;
-        if (!ep0 || (hd != 80 && hd != 88 && hd != 96) || N % ((qk_only ? 4 : 6) * hd) != 0) return SWIFTK_ESHAPE;
+        // whole head pairs (a wave tile is two head vectors); fp32 operands also take whole single heads (N % 3 head_dim: the split
+        // engine recomputes ONE hot head, whose [q | k | v] is one tile column with its fourth vector empty)
+        const int64_t unit = qk_only ? 4 * hd : (dtype == SWIFTK_F32 && out_dtype == SWIFTK_F32 ? 3 * hd : 6 * hd);
+        if (!ep0 || (hd != 80 && hd != 88 && hd != 96) || N % unit != 0) return SWIFTK_ESHAPE;
         if (hd != 88 && dtype != SWIFTK_BF16 && (g_variant == 0 || (M & 7) || (N & 7))) return SWIFTK_ESHAPE;
         ni = (int)(hd / 8);
     } else if (dtype == SWIFTK_BF16 && N % 352 != 0) {  // tile width that divides N, if one does (dim 1280 / 1536 families)

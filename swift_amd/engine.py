@@ -100,8 +100,14 @@ class SwinEngine:
                 for pp in range(heads // 2):
                     if float(tau[2 * pp:2 * pp + 2].max()) > tau_max:
                         hot |= 1 << pp
+                if heads <= 16:  # the hot heads themselves in bits 16..31 (include/swiftk.h): each is recomputed alone
+                    for h in range(heads):
+                        if float(tau[h]) > tau_max:
+                            hot |= 1 << (16 + h)
+                    if hot & (1 << 31):
+                        hot -= 1 << 32  # (the field is a signed 32-bit integer)
                 layers[i].qk_exact_pairs = hot
-                layers[i].qkv_w_f32 = gemm_w(att.to_qkv.weight, kd, exact=True) if hot else None
+                layers[i].qkv_w_f32 = gemm_w(att.to_qkv.weight, kd, exact=True) if hot & 0xffff else None
             layers[i].wo_w = gemm_w(att.wo.weight, kd, exact=bool(exact_mask & 2))
             layers[i].w1_w = gemm_w(w1i, kd, exact=bool(exact_mask & 4))
             layers[i].w2_w = gemm_w(ff.w2.weight, kmlp, exact=bool(exact_mask & 8))

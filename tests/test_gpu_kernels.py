@@ -793,6 +793,58 @@ def test_gemm_qknorm_qk_only_form_equals_the_full_form_on_q_and_k(dev, hd, npair
                          _lib.F32, _lib.EPI_QKNORM, scale.data_ptr(), None, -hd, st) == -2
 
 
+@pytest.mark.parametrize("hd,heads", [(88, 12), (96, 4), (80, 2)])
+def test_gemm_qknorm_single_head_form_equals_the_full_form(dev, hd, heads):
+    """Round 6, split engine: SWIFTK_EPI_QKNORM with fp32 operands takes ONE head (N = 3 head_dim: one tile column whose fourth vector
+    is empty) -- what recomputes a hot head alone.  Every head, the LAST one included (no logit scale is read past the array), must
+    come out bit-equal to its columns of the whole-matrix call, the other columns untouched."""
+    from swift_amd import _lib
+    L = _lib.lib()
+    M, K = 1024, 1056 if hd == 88 else 16 * hd
+    a = rnd((M, K), 98).to(dev)
+    w = (0.03 * rnd((3 * heads * hd, K), 99)).to(dev)
+    scale = torch.log(torch.linspace(8.0, 90.0, heads)).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    N = 3 * heads * hd
+    full = torch.zeros(M, N, device=dev)
+    _lib.check(L.swiftk_gemm(a.data_ptr(), K, w.data_ptr(), K, full.data_ptr(), N, M, N, K, _lib.F32, _lib.F32, _lib.EPI_QKNORM, scale.data_ptr(), None,
+                             hd, st), "full")
+    for h in (0, heads // 2, heads - 1):
+        part = torch.full((M, N), 7.0, device=dev)
+        c0 = h * 3 * hd
+        _lib.check(L.swiftk_gemm(a.data_ptr(), K, w.data_ptr() + c0 * K * 4, K, part.data_ptr() + c0 * 4, N, M, 3 * hd, K, _lib.F32, _lib.F32,
+                                 _lib.EPI_QKNORM, scale.data_ptr() + 4 * h, None, hd, st), "one head")
+        assert torch.equal(part[:, c0:c0 + 3 * hd], full[:, c0:c0 + 3 * hd])
+        rest = torch.ones(N, dtype=torch.bool)
+        rest[c0:c0 + 3 * hd] = False
+        assert bool((part[:, rest.to(dev)] == 7.0).all())
+
+
+@pytest.mark.parametrize("hd,heads,shift", [(88, 12, (8, 8)), (80, 4, (0, 0)), (96, 2, (3, 5)), (64, 2, (0, 0))])
+def test_window_attention_fp32_with_split_pv_vs_exact(dev, hd, heads, shift):
+    """Round 6, split engine: SWIFTK_ATTN_PV_BF16X3 keeps q k^T and the softmax on the exact-fp32 MFMA and runs O = P V as three bf16
+    products of (hi, lo)-split operands (swinv2.py:129-136).  Against the all-fp32 kernel: 2^-17-grade (the dropped lo x lo term and
+    the operands' 16-bit mantissas), i.e. at the level of the split GEMMs' own 4.5e-6; one logit scale at the clamp."""
+    from swift_amd import _lib, ops
+    L = _lib.lib()
+    B, gh, gw = 2, 32, 32
+    d = heads * hd
+    M = B * gh * gw
+    qkv = rnd((M, 3 * d), 97).to(dev)
+    scale = torch.log(torch.tensor([10.0] * (heads - 1) + [100.0])).to(dev)
+    kd = ops.k_pad(torch.float32, d)
+    st = torch.cuda.current_stream().cuda_stream
+    ref, got = torch.zeros(M, kd, device=dev), torch.zeros(M, kd, device=dev)
+    _lib.check(L.swiftk_window_attention(qkv.data_ptr(), 3 * d, ref.data_ptr(), kd, scale.data_ptr(), B, gh, gw, heads, hd, shift[0], shift[1],
+                                         _lib.F32, 0, st), "attention")
+    _lib.check(L.swiftk_window_attention(qkv.data_ptr(), 3 * d, got.data_ptr(), kd, scale.data_ptr(), B, gh, gw, heads, hd, shift[0], shift[1],
+                                         _lib.F32, 8, st), "attention, split P V")
+    err = rel_l2(got[:, :d].cpu(), ref[:, :d].cpu())
+    worst = float((got - ref)[:, :d].abs().max() / ref[:, :d].abs().max())
+    print(f"  fp32 attention, P V as three bf16 products vs exact (head_dim {hd}): rel-L2 {err:.2e}, max {worst:.2e}")
+    assert 0 < err < 1.5e-5 and worst < 6e-5
+
+
 def test_store_to_store_evaluation_cli_on_the_device(dev, tmp_path):
     """``python -m swift_amd.eval.metrics --truth T.zarr --pred P.zarr`` (reference eval/metrics.py:157-280) through the real
     ``swiftk_ensemble_sums``: a 12-member forecast store with a levelled variable against the oracle's restatement of the reference
