@@ -318,7 +318,8 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * fragment reads + DMA issue and back-to-back MFMAs, counted waits; needs >= 3 k-tiles per work item, else falls back), 0 = one
  * barrier per k-tile (the round-1..4 loop).  Bit-equal results either way.
  * key 21 = the same choice for the k-loop inside swiftk_qkv_attention_fused (1 = ping-pong, 0 = one barrier per k-tile),
- * key 22 = the same for swiftk_gemm_tn_splitk: 0 never, 1 always, 2 (default) with 352-wide tiles, where it was measured
+ * key 22 = the same for swiftk_gemm_tn_splitk: 1 always (default; measured at all three tile widths), 2 with 352-wide tiles only, 0 never
+ *          (384-wide tiles take it at every setting)
  * (Swift-B's four weight gradients 0...-9 % in time, -6 % per layer: tools/tn_ab.py),
  * key 23 = swiftk_swinv2_forward (bf16 engine) runs wo / w2 + norm as swiftk_gemm_modnorm_residual_pair up to this many units
  * per step (0 = never: split-K + slab-summing norm at one unit, GEMM + norm beyond),

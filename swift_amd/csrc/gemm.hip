@@ -1610,16 +1610,20 @@ int launch(const GemmArgs& g, hipStream_t st) {
 template <int EPI>
 int launch_paired(const GemmArgs& g, hipStream_t st) {
     const int ntm = (g.M + BM - 1) / BM;
+    // (the pair-output epilogue keeps NI packed low parts beside the accumulators: at NI = 12 that is 204 of the 256 registers before
+    // any address, and the 384-wide instantiation spilled 8-10 of them -- its caller takes 352-wide tiles instead)
+    constexpr bool W384 = EPI != EPI_BIAS_POS_PAIR;
+    if (!W384 && g.ni == 12) return SWIFTK_ESHAPE;
     const bool timed = swiftk_prof_begin(EPI, g.N, st);
     const int ntiles = ntm * g.ntn;
     const int grid = ntiles < g_persist_wgs ? ntiles : g_persist_wgs;
     if (pp_ok(g)) {
         if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 10, true>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
-        else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 12, true>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+        else if (W384 && g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, W384 ? 12 : 11, true>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
         else hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 11, true>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
     } else {
         if (g.ni == 10) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 10, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
-        else if (g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 12, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
+        else if (W384 && g.ni == 12) hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, W384 ? 12 : 11, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
         else hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI, 11, false>), dim3(grid), dim3(NT), 0, st, g, ntm, g_group_m);
     }
     if (timed) swiftk_prof_end(st);
@@ -1944,11 +1948,8 @@ extern "C" int swiftk_gemm_bias_pos_pair(const void* A, int64_t lda, const void*
     if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)hi & 15) || ((uintptr_t)lo & 15) || ((uintptr_t)bias & 15) ||
         ((uintptr_t)pos & 15) || (lda * 2) % 16 || (ldw * 2) % 16 || ldh % 8 || ldl % 16)
         return SWIFTK_EALIGN;
-    int ni = 11;
-    if (N % 352) {
-        if (N % 384 == 0) ni = 12;
-        else if (N % 320 == 0) ni = 10;
-    }
+    // 320-wide tiles where they divide N (dim 1280); dim 1536 takes the 352-wide ones with a partly filled last column (launch_paired)
+    const int ni = N % 352 && N % 320 == 0 ? 10 : 11;
     GemmArgs g;
     g.A = static_cast<const char*>(A);
     g.W = static_cast<const char*>(W);

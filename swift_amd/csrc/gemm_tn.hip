@@ -322,7 +322,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(TnArgs g, int ntm, int gm) 
 
 }  // namespace
 
-int g_tn_pp = 2;  // tuning key 22: ping-pong k-loop of the weight-gradient GEMM: 0 never, 1 always, 2 where it was measured (352-wide tiles)
+int g_tn_pp = 1;  // tuning key 22: ping-pong k-loop of the weight-gradient GEMM: 1 always (default), 2 352-wide tiles only, 0 never (384-wide tiles: always)
 
 // slabs[s][N1][N2] (fp32, row stride ldc, slab stride `slab_stride`) = partial products over the s-th of `ksplit` ranges of
 // the K token rows.  P: [K, >= N1] bf16 with row stride ldp, Q: [K, >= N2] with ldq.  Shapes this kernel does not take
@@ -367,16 +367,16 @@ extern "C" int swiftk_gemm_tn_splitk(const void* P, int64_t ldp, const void* Q, 
     const dim3 grid(items < 256 ? items : 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // (measured interleaved in one process at local batch 8, tools/tn_ab.py, with waves 0-3 issuing their pieces in a k-tile's first
-    // two phases: to_qkv's gradient -6.5 %, w1's -6..-9 %, w2's -3 %, wo's 0..-5 % against one barrier per k-tile; the 320- / 384-wide
-    // forms were not measured and keep the old loop)
-    const bool pp = g_tn_pp == 1 || (g_tn_pp == 2 && ni == 11);
+    // two phases: to_qkv's gradient -6.5 %, w1's -6..-9 %, w2's -3 %, wo's 0..-5 % against one barrier per k-tile; round 6, the larger
+    // variants' widths, `tn_ab.py 8 7 1280` / `1536`, bit-equal: 320-wide tiles -3.4 % per layer's gradients, 384-wide -10 %.  The
+    // 384-wide one-barrier form spilled three registers and is gone: key 22 = 0 / 2 still take the ping-pong loop there)
+    const bool pp = g_tn_pp == 1 || (g_tn_pp == 2 && ni == 11) || ni == 12;
     if (pp) {
         if (ni == 10) hipLaunchKernelGGL((gemm_tn_kernel<10, true>), grid, dim3(NT), 0, st, g, ntm, 8);
         else if (ni == 12) hipLaunchKernelGGL((gemm_tn_kernel<12, true>), grid, dim3(NT), 0, st, g, ntm, 8);
         else hipLaunchKernelGGL((gemm_tn_kernel<11, true>), grid, dim3(NT), 0, st, g, ntm, 8);
     } else {
         if (ni == 10) hipLaunchKernelGGL((gemm_tn_kernel<10, false>), grid, dim3(NT), 0, st, g, ntm, 8);
-        else if (ni == 12) hipLaunchKernelGGL((gemm_tn_kernel<12, false>), grid, dim3(NT), 0, st, g, ntm, 8);
         else hipLaunchKernelGGL((gemm_tn_kernel<11, false>), grid, dim3(NT), 0, st, g, ntm, 8);
     }
     SWIFTK_CHECK_LAUNCH();

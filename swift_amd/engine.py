@@ -67,9 +67,11 @@ class SwinEngine:
         dt = torch.float32 if x3 else self.dtype  # activations, k-paddings and every non-GEMM kernel
         d, heads, depth, mlp = m.dim, m.heads, m.depth, m.mlp_dim
         p1, p2 = m.patch_size
-        # int(8/3 * dim) is odd for some widths (1280 -> 3413): one zero (gate, up) row pair makes w1's N a multiple of 4;
-        # the extra SwiGLU column is silu(0) * 0 = 0 and lands in w2's zero K padding
-        mlp_e = mlp + (mlp & 1)
+        # int(8/3 * dim) is odd for some widths (1280 -> 3413): zero (gate, up) row pairs up to a multiple of 8 make w1's N a
+        # multiple of 16, which the persistent GEMM's whole-tile path wants of a SwiGLU output (16-byte row chunks of N / 2 bf16
+        # columns; N = 6828 sent the 468 M variant's w1 to the one-tile-per-workgroup kernel: 0.38 of peak against 0.50); the
+        # extra SwiGLU columns are silu(0) * 0 = 0 and land in w2's zero K padding
+        mlp_e = (mlp + 7) // 8 * 8
         kd, kmlp, kpe = ops.k_pad(dt, d), ops.k_pad(dt, mlp_e), ops.k_pad(dt, m.in_channels * p1 * p2)
         keep = []
 
@@ -92,7 +94,7 @@ class SwinEngine:
             w1 = ff.w1.weight.detach()
             w1i = w1.view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)  # rows: gate_0, up_0, gate_1, up_1, ...
             if mlp_e != mlp:
-                w1i = torch.cat([w1i, w1i.new_zeros(2, d)], 0)
+                w1i = torch.cat([w1i, w1i.new_zeros(2 * (mlp_e - mlp), d)], 0)
             layers[i].qkv_w = gemm_w(att.to_qkv.weight, kd, exact=bool(exact_mask & 1))
             if adaptive:
                 tau = torch.exp(torch.clamp(att.scale.detach().reshape(-1).float(), max=math.log(100.0))).cpu()

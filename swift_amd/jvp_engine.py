@@ -77,7 +77,7 @@ class SwinJvpEngine:
                 self.graphs.invalidate()
             self._ptrs = ptrs
         d, mlp = m.dim, m.mlp_dim
-        mlp_e = self.mlp_e = mlp + (mlp & 1)  # odd MLP widths (dim 1280 -> 3413): one zero (gate, up) row pair, as in SwinEngine
+        mlp_e = self.mlp_e = (mlp + 7) // 8 * 8  # odd MLP widths (dim 1280 -> 3413): zero (gate, up) row pairs, as in SwinEngine
         self.kd, self.kmlp = ops.k_pad(dt, d), ops.k_pad(dt, mlp_e)
         self.kpe = ops.k_pad(dt, m.in_channels * m.patch_size[0] * m.patch_size[1])
         dev0 = m.pos_embed.device
@@ -103,7 +103,7 @@ class SwinJvpEngine:
         # the sCM loss runs this engine's pass and the training engine's backward on the same weights (loss.py:212-237): with bf16
         # operands and an MLP width both engines pad alike, the four GEMM operands per layer are the training engine's (one cast
         # per optimizer step instead of two, and no second (gate, up) interleave of w1)
-        share = te is not None and dt == torch.bfloat16 and mlp % 4 == 0
+        share = te is not None and dt == torch.bfloat16 and getattr(te, "mlp_e", None) == mlp_e
         if share:
             share = te.kd == self.kd and te.kmlp == self.kmlp and len(te.L) == len(m.transformer.layers)
         if getattr(self, "_share", share) != share:
@@ -125,7 +125,7 @@ class SwinJvpEngine:
             else:
                 w1i = ff.w1.weight.detach().view(2, mlp, d).permute(1, 0, 2).reshape(2 * mlp, d)  # (gate_j, up_j) interleaved
                 if mlp_e != mlp:
-                    w1i = torch.cat([w1i, w1i.new_zeros(2, d)], 0)
+                    w1i = torch.cat([w1i, w1i.new_zeros(2 * (mlp_e - mlp), d)], 0)
                 ops4 = dict(qkv=cast(att.to_qkv.weight, self.kd), wo=cast(att.wo.weight, self.kd), w1=cast(w1i, self.kd),
                             w2=cast(ff.w2.weight, self.kmlp))
             self.L.append(dict(**ops4, scale=att.scale.detach().reshape(-1).float().contiguous(),

@@ -96,7 +96,7 @@ class SwinTrainEngine:
         d, mlp = m.dim, m.mlp_dim
         # int(8/3 dim) need not be a multiple of 4 (dim 1280 -> 3413): zero (gate, up) rows of w1 / zero columns of w2 bring
         # the MLP width to the GEMMs' granularity (N % 4, split-K rows % 8); silu(0) * 0 = 0 feeds w2's zero columns
-        mlp_e = self.mlp_e = (mlp + 3) // 4 * 4
+        mlp_e = self.mlp_e = (mlp + 7) // 8 * 8
         self.kd, self.kmlp = ops.k_pad(_BF, d), ops.k_pad(_BF, mlp_e)
         self.kpe = ops.k_pad(_BF, m.in_channels * m.patch_size[0] * m.patch_size[1])
         self.kqkv = ops.k_pad(_BF, 3 * d)
