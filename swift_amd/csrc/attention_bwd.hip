@@ -133,10 +133,17 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
     const int c32 = lane & 31, hh = lane >> 5, i16 = lane & 15;
     const int vbase = (4 * hh + (i16 >> 2)) * STR + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
     const int my_tok = wtoken(a, w, wv * 32 + c32);  // the query (pass A) / key (pass B) this lane's column stands for
-    const bf16_t* my_qkv = a.qkvh + (tok0 + my_tok) * a.ldq + head * 3 * HD;
-    const bf16_t* my_o = a.o + (tok0 + my_tok) * a.ldo + head * HD;
-    const bf16_t* my_do = a.d_o + (tok0 + my_tok) * a.ldo + head * HD;
-    bf16_t* my_dqkv = a.dqkvh + (tok0 + my_tok) * a.ldd + head * 3 * HD;
+    // this lane's rows are addressed from the token index each time they are needed (through an opaque copy: hipcc would otherwise
+    // build the four 64-bit row pointers up here and carry them -- spilled -- through both passes; all the kernel keeps is my_tok)
+    auto tok = [&]() {
+        int t = my_tok;
+        asm volatile("" : "+v"(t));
+        return tok0 + t;
+    };
+#define MY_QKV (a.qkvh + tok() * a.ldq + head * 3 * HD)
+#define MY_O (a.o + tok() * a.ldo + head * HD)
+#define MY_DO (a.d_o + tok() * a.ldo + head * HD)
+#define MY_DQKV (a.dqkvh + tok() * a.ldd + head * 3 * HD)
 
     // ---------------------------------------------------------------- pass A images: K -> imgA, V -> imgB
     if (tid < 256) {
@@ -145,12 +152,12 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
         stage_row<HD>(imgB, tid, src + 2 * HD);
     }
     uint4 qf[KS], dof[KS];
-    row_frags<HD, KS>(my_qkv, hh, qf);
-    row_frags<HD, KS>(my_do, hh, dof);
+    row_frags<HD, KS>(MY_QKV, hh, qf);
+    row_frags<HD, KS>(MY_DO, hh, dof);
     float delta;
     {
         uint4 of[KS];
-        row_frags<HD, KS>(my_o, hh, of);
+        row_frags<HD, KS>(MY_O, hh, of);
         float s = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) s += dot8(dof[ks], of[ks]);
@@ -213,18 +220,23 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
             for (int db = 0; db < DB; ++db) dq[db] = mfma(tr_frag(imgA, kb * 32 + s2 * 16, db, vbase), ds, dq[db]);
         }
     }
-    store_t<HD>(my_dqkv, dq, hh);
+    store_t<HD>(MY_DQKV, dq, hh);
     __syncthreads();
 
     // ---------------------------------------------------------------- pass B images: Q -> imgA, dO -> imgB
     if (tid < 256) {
-        const int t = wtoken(a, w, tid);
-        stage_row<HD>(imgA, tid, a.qkvh + (tok0 + t) * a.ldq + head * 3 * HD);
-        stage_row<HD>(imgB, tid, a.d_o + (tok0 + t) * a.ldo + head * HD);
+        int etid = tid;  // (opaque: the staging token is recomputed here, not carried from pass A's staging)
+        asm volatile("" : "+v"(etid));
+        const int t = wtoken(a, w, etid);
+        stage_row<HD>(imgA, etid, a.qkvh + (tok0 + t) * a.ldq + head * 3 * HD);
+        stage_row<HD>(imgB, etid, a.d_o + (tok0 + t) * a.ldo + head * HD);
     }
     uint4 kf[KS], vf[KS];
-    row_frags<HD, KS>(my_qkv + HD, hh, kf);
-    row_frags<HD, KS>(my_qkv + 2 * HD, hh, vf);
+    {
+        const bf16_t* r = MY_QKV;
+        row_frags<HD, KS>(r + HD, hh, kf);
+        row_frags<HD, KS>(r + 2 * HD, hh, vf);
+    }
     __syncthreads();
 
     f32x16 dk[DB], dv[DB];
@@ -268,8 +280,15 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
             }
         }
     }
-    store_t<HD>(my_dqkv + HD, dk, hh);
-    store_t<HD>(my_dqkv + 2 * HD, dv, hh);
+    {
+        bf16_t* r = MY_DQKV;
+        store_t<HD>(r + HD, dk, hh);
+        store_t<HD>(r + 2 * HD, dv, hh);
+    }
+#undef MY_QKV
+#undef MY_O
+#undef MY_DO
+#undef MY_DQKV
 }
 
 
@@ -284,14 +303,28 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
 // <= 48 lets offset 0 stand in), a second sweep rebuilds S^T block by block and accumulates
 //     l += e,   dq^T += kh^T [e o (dP^T - delta)],     e = exp(S^T - m),
 // with the 1/l factor -- a per-lane scalar, a lane owns one query column -- applied to dq once at the end.
-constexpr int ROW88 = 176, TILE88 = 256 * ROW88;
-constexpr int OSLAB88 = 16 * ROW88;   // wave-private output staging: 16 rows per round
-constexpr int BWD_LDS = 3 * TILE88 + 64 + 3 * 1024 + 8 * OSLAB88 + 64;   // 160,896 B (the last 64: per-head logit-scale gradient sums)
+// Round 6: templated on head_dim -- 80 (the 468 M variant: 160-B rows, five whole k-steps, 40 pieces per image, 146,560 B of LDS) and
+// 96 (the 664 M variant: 192-B rows, 48 pieces; three 48-KB images leave room for 8-row output slabs only: four staging rounds per
+// accumulator set instead of two, 162,944 B) beside 88.  Their row strides are not conflict-free as 176 B happens to be (40 / 48
+// dwords: 2- / 4-way on the 16-B row reads); the images still travel by lane-linear DMA, which rules a padded stride out.
+template <int HD>
+struct PipeGeom {
+    static constexpr int ROW = 2 * HD, TILE = 256 * ROW;  // image: 256 window rows of one head vector, row-major
+    static constexpr int KS = (HD + 15) / 16;             // 16-wide k-steps over head_dim: 5 / 5.5 / 6
+    static constexpr int CPR = HD / 8;                    // 16-B chunks per row
+    static constexpr int NPQ = TILE / 1024;               // 1-KiB DMA pieces per image: 40 / 44 / 48
+    static constexpr int NPW = (NPQ + 7) / 8;             // piece slots per wave
+    static constexpr int OR = HD > 88 ? 8 : 16;           // rows per round of the wave-private output staging
+    static constexpr int OSLAB = OR * ROW;
+    static constexpr int NSTORE = (32 / OR) * ((OR * CPR + 63) / 64);  // dwordx4 stores a wave issues per accumulator set
+    static constexpr int LDS = 3 * TILE + 64 + 3 * 1024 + 8 * OSLAB + 64;  // 88: 160,896 B (the last 64: per-head logit-scale gradient sums)
+};
 
-__device__ __forceinline__ uint4 tr_frag88(const char* img, int base_row, int db, int vbase) {
-    const char* p = img + base_row * ROW88 + vbase + db * 64;
+template <int ROW>
+__device__ __forceinline__ uint4 tr_frag_row(const char* img, int base_row, int db, int vbase) {
+    const char* p = img + base_row * ROW + vbase + db * 64;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 8 * ROW88));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 8 * ROW));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(uint4, v);
@@ -314,10 +347,11 @@ struct BwdPArgs {
 // 4 hh .. 4 hh + 3 of chunk 4 db + g, i.e. for even g the low (hh = 0) or high (hh = 1) half of the chunk the hh = 0 lane holds
 // and for odd g the same of the hh = 1 lane's chunk: one exchange of two dwords per k-step with lane ^ 32.
 //   dx = rn (tau d(x-hat) - x-hat (x-hat . d(x-hat)) / tau);   returns x-hat . d(x-hat) (= tau x d(tau)'s share of this row)
-__device__ __forceinline__ float qknorm_bwd_acc(f32x16 (&acc)[DB], const uint4 (&f)[6], int hh, float tau, float rn) {
+template <int HD, int KS>
+__device__ __forceinline__ float qknorm_bwd_acc(f32x16 (&acc)[DB], const uint4 (&f)[KS], int hh, float tau, float rn) {
     uint32_t up[DB][4][2];
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         const int db = ks >> 1, ge = 2 * (ks & 1);
         const uint32_t r0 = __shfl_xor(hh ? f[ks].x : f[ks].z, 32, 64), r1 = __shfl_xor(hh ? f[ks].y : f[ks].w, 32, 64);
         up[db][ge][0] = hh ? r0 : f[ks].x;
@@ -330,7 +364,7 @@ __device__ __forceinline__ float qknorm_bwd_acc(f32x16 (&acc)[DB], const uint4 (
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (db * 32 + g * 8 >= 88) continue;  // (rows d >= 88 of the accumulators are never stored; their contents are arbitrary)
+            if (db * 32 + g * 8 >= HD) continue;  // (rows d >= 88 of the accumulators are never stored; their contents are arbitrary)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const uint32_t w = up[db][g][e >> 1];
@@ -343,7 +377,7 @@ __device__ __forceinline__ float qknorm_bwd_acc(f32x16 (&acc)[DB], const uint4 (
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (db * 32 + g * 8 >= 88) continue;
+            if (db * 32 + g * 8 >= HD) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const uint32_t w = up[db][g][e >> 1];
@@ -353,19 +387,21 @@ __device__ __forceinline__ float qknorm_bwd_acc(f32x16 (&acc)[DB], const uint4 (
     return dot;
 }
 
+template <int HD>
 __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
-    constexpr int HD = 88, KS = 6, CPR = 11, NPQ = TILE88 / 1024;  // 44 pieces per image
+    using G = PipeGeom<HD>;
+    constexpr int KS = G::KS, CPR = G::CPR, NPQ = G::NPQ, ROWB = G::ROW, TILEB = G::TILE, OSLABB = G::OSLAB, OR = G::OR, BWD_LDS = G::LDS;
     const BwdArgs& a = pa.a;
     __shared__ __attribute__((aligned(16))) char smem[BWD_LDS];
-    float* st_m = reinterpret_cast<float*>(smem + 3 * TILE88 + 64);
+    float* st_m = reinterpret_cast<float*>(smem + 3 * TILEB + 64);
     float* st_il = st_m + 256;
     float* st_dl = st_m + 512;
     float* st_ds = reinterpret_cast<float*>(smem + BWD_LDS - 64);  // [16] d(logit scale) sums of this workgroup (zeroed with the rest)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c32 = lane & 31, hh = lane >> 5, i16 = lane & 15;
-    const int vbase = (4 * hh + (i16 >> 2)) * ROW88 + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
-    char* oslab = smem + 3 * TILE88 + 64 + 3 * 1024 + wv * OSLAB88;
+    const int vbase = (4 * hh + (i16 >> 2)) * ROWB + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
+    char* oslab = smem + 3 * TILEB + 64 + 3 * 1024 + wv * OSLABB;
     const int64_t ntok = (int64_t)a.gh * a.gw;
     // A transposed accumulator set X^T[d][row] (row = this lane's c32 of the wave's 32 window rows) leaves through the
     // wave's LDS slab, 16 rows per round: written as the 8-B pieces the MFMA layout yields, read back as 16-B chunks of
@@ -374,26 +410,26 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
     // memory path -- more than the kernel's arithmetic costs.
     auto store_rows = [&](const f32x16 (&acc)[DB], int w_, int64_t tok0_, int col0) {
 #pragma unroll
-        for (int rnd = 0; rnd < 2; ++rnd) {
-            if ((c32 >> 4) == rnd) {
+        for (int rnd = 0; rnd < 32 / OR; ++rnd) {
+            if ((c32 / OR) == rnd) {
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int d = db * 32 + g * 8 + hh * 4;
-                        if (d < 88)
-                            *reinterpret_cast<uint2*>(oslab + (c32 & 15) * ROW88 + d * 2) =
+                        if (d < HD)
+                            *reinterpret_cast<uint2*>(oslab + (c32 & (OR - 1)) * ROWB + d * 2) =
                                 make_uint2(pack_bf16(acc[db][4 * g], acc[db][4 * g + 1]), pack_bf16(acc[db][4 * g + 2], acc[db][4 * g + 3]));
                     }
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < (OR * CPR + 63) / 64; ++t) {
                 const int c = lane + 64 * t;
-                if (c < 16 * 11) {
-                    const int row = c / 11, cc = c - row * 11;
-                    const uint4 v = *reinterpret_cast<const uint4*>(oslab + row * ROW88 + cc * 16);
-                    const int tok = wtoken(a, w_, wv * 32 + rnd * 16 + row);
+                if (c < OR * CPR) {
+                    const int row = c / CPR, cc = c - row * CPR;
+                    const uint4 v = *reinterpret_cast<const uint4*>(oslab + row * ROWB + cc * 16);
+                    const int tok = wtoken(a, w_, wv * 32 + rnd * OR + row);
                     *reinterpret_cast<uint4*>(a.dqkvh + (tok0_ + tok) * a.ldd + col0 + cc * 8) = v;
                 }
             }
@@ -435,18 +471,18 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
     auto dma_img = [&](int buf, const char* base, int w_, int64_t ld_b) {
         const char* bs = pin(base);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < G::NPW; ++i) {
             int p = wv + 8 * i;
             p = p >= NPQ ? p - NPQ : p;
             const int c = p * 64 + lane;
             const int row = c / CPR, cc = c - row * CPR;
-            dma_piece(lds0 + buf * TILE88 + p * 1024, bs, (uint32_t)(wtoken(a, w_, row) * (int)ld_b) + 16u * cc);
+            dma_piece(lds0 + buf * TILEB + p * 1024, bs, (uint32_t)(wtoken(a, w_, row) * (int)ld_b) + 16u * cc);
         }
     };
     auto qkv_base = [&](int b, int h, int part) {
-        return reinterpret_cast<const char*>(a.qkvh) + (int64_t)b * ntok * ldq_b + (int64_t)(h * 3 + part) * ROW88;
+        return reinterpret_cast<const char*>(a.qkvh) + (int64_t)b * ntok * ldq_b + (int64_t)(h * 3 + part) * ROWB;
     };
-    auto do_base = [&](int b, int h) { return reinterpret_cast<const char*>(a.d_o) + (int64_t)b * ntok * ldo_b + (int64_t)h * ROW88; };
+    auto do_base = [&](int b, int h) { return reinterpret_cast<const char*>(a.d_o) + (int64_t)b * ntok * ldo_b + (int64_t)h * ROWB; };
 
     int b, w, h;
     decode(first, b, w, h);
@@ -487,8 +523,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
             for (int ks = 0; ks < KS; ++ks) sd += dot8(dof[ks], of[ks]);
             delta = sd + __shfl_xor(sd, 32, 64);
         }
-        const char* imK = smem + bK * TILE88;
-        const char* imV = smem + bV * TILE88;
+        const char* imK = smem + bK * TILEB;
+        const char* imV = smem + bV * TILEB;
         float mx = 0.f;
         if (online) {
             mx = -INFINITY;
@@ -499,7 +535,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
                 for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
-                    sc = mfma(*reinterpret_cast<const uint4*>(imK + (kb * 32 + c32) * ROW88 + ks * 32 + hh * 16), qf[ks], sc);
+                    sc = mfma(*reinterpret_cast<const uint4*>(imK + (kb * 32 + c32) * ROWB + ks * 32 + hh * 16), qf[ks], sc);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
             }
@@ -525,8 +561,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
             for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                sc = mfma(*reinterpret_cast<const uint4*>(imK + (kb * 32 + c32) * ROW88 + ks * 32 + hh * 16), qf[ks], sc);
-                dp = mfma(*reinterpret_cast<const uint4*>(imV + (kb * 32 + c32) * ROW88 + ks * 32 + hh * 16), dof[ks], dp);
+                sc = mfma(*reinterpret_cast<const uint4*>(imK + (kb * 32 + c32) * ROWB + ks * 32 + hh * 16), qf[ks], sc);
+                dp = mfma(*reinterpret_cast<const uint4*>(imV + (kb * 32 + c32) * ROWB + ks * 32 + hh * 16), dof[ks], dp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -538,7 +574,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
             for (int s2 = 0; s2 < 2; ++s2) {
                 const uint4 ds = pack8(sc, s2);
 #pragma unroll
-                for (int db = 0; db < DB; ++db) dq[db] = mfma(tr_frag88(imK, kb * 32 + s2 * 16, db, vbase), ds, dq[db]);
+                for (int db = 0; db < DB; ++db) dq[db] = mfma(tr_frag_row<ROWB>(imK, kb * 32 + s2 * 16, db, vbase), ds, dq[db]);
             }
         }
         l += __shfl_xor(l, 32, 64);
@@ -557,11 +593,11 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
         // this lane's key row of K and V as MFMA B-operand fragments: straight from the images, which are still intact
         uint4 kf[KS], vf[KS];
         {
-            const char* krow = imK + (wv * 32 + c32) * ROW88;
-            const char* vrow = imV + (wv * 32 + c32) * ROW88;
+            const char* krow = imK + (wv * 32 + c32) * ROWB;
+            const char* vrow = imV + (wv * 32 + c32) * ROWB;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                if (ks == KS - 1) {  // 5.5 k-steps: the last one has one real 16-B chunk
+                if (ks == KS - 1 && (HD & 15)) {  // head_dim 88 = 5.5 k-steps: the last one has one real 16-B chunk
                     const uint4 tk = *reinterpret_cast<const uint4*>(krow + (2 * ks) * 16);
                     const uint4 tv = *reinterpret_cast<const uint4*>(vrow + (2 * ks) * 16);
                     kf[ks] = hh ? make_uint4(0, 0, 0, 0) : tk;
@@ -578,7 +614,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
         if (pa.rn) {
             // d(q-hat) -> dq, and this item's share of d(logit scale) = sum over the window's queries of q-hat . d(q-hat)
             // (every row is counted by both lane halves; no gradient where the clamp at ln 100 is active, swinv2.py:125)
-            const float dot = qknorm_bwd_acc(dq, qf, hh, expf(fminf(pa.scale[h], 4.605170185988092f)), rnq);
+            const float dot = qknorm_bwd_acc<HD, KS>(dq, qf, hh, expf(fminf(pa.scale[h], 4.605170185988092f)), rnq);
             const float tot = 0.5f * wave_sum(dot);
             if (lane == 0 && pa.scale[h] < 4.605170185988092f) atomicAdd(st_ds + h, tot);
         }
@@ -586,7 +622,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
             store_rows(dq, w, tok0, h * 3 * HD);  // (the dO image lands under the dq stores)
             // VMEM retires in issue order and the dO pieces are older than the six row stores: leaving exactly those outstanding
             // is enough for the image -- the stores drain under pass B instead of in front of it
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NSTORE) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -594,8 +630,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
         if (has_next) {                // the next item's K image lands under pass B
             dma_img(bV, qkv_base(nb, nh, 1), nwn, ldq_b);
         }
-        const char* imQ = smem + bF * TILE88;
-        const char* imO = smem + bK * TILE88;
+        const char* imQ = smem + bF * TILEB;
+        const char* imO = smem + bK * TILEB;
         f32x16 dk[DB], dv[DB];
 #pragma unroll
         for (int db = 0; db < DB; ++db)
@@ -608,8 +644,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
             for (int r = 0; r < 16; ++r) sq[r] = dp[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                sq = mfma(*reinterpret_cast<const uint4*>(imQ + (qb * 32 + c32) * ROW88 + ks * 32 + hh * 16), kf[ks], sq);
-                dp = mfma(*reinterpret_cast<const uint4*>(imO + (qb * 32 + c32) * ROW88 + ks * 32 + hh * 16), vf[ks], dp);
+                sq = mfma(*reinterpret_cast<const uint4*>(imQ + (qb * 32 + c32) * ROWB + ks * 32 + hh * 16), kf[ks], sq);
+                dp = mfma(*reinterpret_cast<const uint4*>(imO + (qb * 32 + c32) * ROWB + ks * 32 + hh * 16), vf[ks], dp);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {  // P and dS overwrite S and dP in place (this phase runs at the register limit)
@@ -630,15 +666,15 @@ __global__ __launch_bounds__(NT) void attn_bwd_pipe_kernel(BwdPArgs pa) {
                 const uint4 pf = pack8(sq, s2), df = pack8(dp, s2);
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
-                    dv[db] = mfma(tr_frag88(imO, qb * 32 + s2 * 16, db, vbase), pf, dv[db]);
-                    dk[db] = mfma(tr_frag88(imQ, qb * 32 + s2 * 16, db, vbase), df, dk[db]);
+                    dv[db] = mfma(tr_frag_row<ROWB>(imO, qb * 32 + s2 * 16, db, vbase), pf, dv[db]);
+                    dk[db] = mfma(tr_frag_row<ROWB>(imQ, qb * 32 + s2 * 16, db, vbase), df, dk[db]);
                 }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next K image (it had the whole pass) ...
         __builtin_amdgcn_s_barrier();  // ... every wave's; and every wave is done with the Q and dO images
         if (has_next) dma_img(bF, qkv_base(nb, nh, 2), nwn, ldq_b);  // next V over the dead Q image: lands under the stores below
-        if (pa.rn) qknorm_bwd_acc(dk, kf, hh, 1.0f, rnk);    // d(k-hat) -> dk
+        if (pa.rn) qknorm_bwd_acc<HD, KS>(dk, kf, hh, 1.0f, rnk);    // d(k-hat) -> dk
         if (!(pa.dbg & 4)) {                                 // and under the next item's maximum sweep
             store_rows(dk, w, tok0, h * 3 * HD + HD);
             store_rows(dv, w, tok0, h * 3 * HD + 2 * HD);
@@ -703,7 +739,7 @@ static int attn_bwd_impl(const void* qkvh, int64_t ldq, const void* o, const voi
     a.nw = (gh / 16) * (gw / 16);
     const dim3 grid(B * a.nw * heads);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (head_dim == 88 && g_attn_bwd_pipe && ntok_bytes_ok(a)) {
+    if (g_attn_bwd_pipe && ntok_bytes_ok(a)) {
         BwdPArgs pa;
         pa.a = a;
         pa.scale = scale;
@@ -718,7 +754,9 @@ static int attn_bwd_impl(const void* qkvh, int64_t ldq, const void* o, const voi
         pa.dbg = g_attn_dbg >> 16;
         int pgrid = 256;
         if (pa.nitems < pgrid) pgrid = pa.nitems >= 8 ? (pa.nitems & ~7) : pa.nitems;
-        hipLaunchKernelGGL(attn_bwd_pipe_kernel, dim3(pgrid), dim3(NT), 0, st, pa);
+        if (head_dim == 80) hipLaunchKernelGGL(attn_bwd_pipe_kernel<80>, dim3(pgrid), dim3(NT), 0, st, pa);
+        else if (head_dim == 96) hipLaunchKernelGGL(attn_bwd_pipe_kernel<96>, dim3(pgrid), dim3(NT), 0, st, pa);
+        else hipLaunchKernelGGL(attn_bwd_pipe_kernel<88>, dim3(pgrid), dim3(NT), 0, st, pa);
         SWIFTK_CHECK_LAUNCH();
         return 0;
     }

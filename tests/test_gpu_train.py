@@ -326,18 +326,20 @@ def test_gemm_jvp_swiglu_paired_rows(dev, Mh, dim, mlp, keep):
 
 @pytest.mark.parametrize("B", [2, 16])  # 16: 768 items on 256 persistent workgroups (buffer rotation, cross-item prefetch)
 @pytest.mark.parametrize("shift", [(0, 0), (8, 8)])
-def test_window_attention_bwd(dev, shift, B):
+@pytest.mark.parametrize("hd", [88, 80, 96])  # 80 / 96: the persistent kernel templated on head_dim (round 6)
+def test_window_attention_bwd(dev, shift, B, hd):
     from oracle.swinv2 import window_token_index
     from swift_amd import _lib, ops
     L = _lib.lib()
-    grid, heads, hd = (32, 32), 12, 88
+    grid, heads = (32, 32), 12
+    W3, D, LDP = 3 * heads * hd, heads * hd, 3 * heads * hd + 32
     n = grid[0] * grid[1]
     scale = torch.log(torch.tensor([10.0, 3.0, 30.0, 60.0, 1.0, 10.0, 50.0, 20.0, 15.0, 5.0, 20.0, 10.0]))
     pre = _prenorm(rnd((B, n, 3 * heads * hd), 13), scale, heads, hd).to(dev).to(BF)
     o = ops.window_attention(pre, None, grid, heads, shift, flags=_lib.ATTN_PRENORM)
     do = rnd((B, n, heads * hd), 14).to(dev).to(BF)
     dpre = torch.empty_like(pre)
-    rc = L.swiftk_window_attention_bwd(pre.data_ptr(), 3168, o.data_ptr(), do.data_ptr(), 1056, dpre.data_ptr(), B, grid[0],
+    rc = L.swiftk_window_attention_bwd(pre.data_ptr(), W3, o.data_ptr(), do.data_ptr(), D, dpre.data_ptr(), B, grid[0],
                                        grid[1], heads, hd, shift[0], shift[1], _lib.BF16, s())
     assert rc == 0
     idx = window_token_index(grid, (16, 16), shift)
@@ -357,31 +359,31 @@ def test_window_attention_bwd(dev, shift, B):
     d_old = torch.empty_like(pre)
     L.swiftk_set_tuning(9, 0)
     try:
-        assert L.swiftk_window_attention_bwd(pre.data_ptr(), 3168, o.data_ptr(), do.data_ptr(), 1056, d_old.data_ptr(), B, grid[0],
+        assert L.swiftk_window_attention_bwd(pre.data_ptr(), W3, o.data_ptr(), do.data_ptr(), D, d_old.data_ptr(), B, grid[0],
                                              grid[1], heads, hd, shift[0], shift[1], _lib.BF16, s()) == 0
     finally:
         L.swiftk_set_tuning(9, 1)
     assert rel_l2(dpre.float().cpu(), d_old.float().cpu()) < 1e-2
     # with the logit scales at hand, heads whose bound is <= 48 skip the row-maximum sweep (offset 0): same gradients
     d_s = torch.empty_like(pre)
-    assert L.swiftk_window_attention_bwd_scaled(pre.data_ptr(), 3168, o.data_ptr(), do.data_ptr(), 1056, d_s.data_ptr(), 3168,
+    assert L.swiftk_window_attention_bwd_scaled(pre.data_ptr(), W3, o.data_ptr(), do.data_ptr(), D, d_s.data_ptr(), W3,
                                                 scale.to(dev).data_ptr(), B, grid[0], grid[1], heads, hd, shift[0], shift[1],
                                                 _lib.BF16, s()) == 0
     assert rel_l2(d_s.float().cpu(), dpre.float().cpu()) < 1e-2
     # the training engine's form: gradients written with their own row stride (the next GEMM's k-padded operand buffer) ...
-    d_p = torch.full((B, n, 3200), 7.0, dtype=torch.bfloat16, device=dev)
-    assert L.swiftk_window_attention_bwd_scaled(pre.data_ptr(), 3168, o.data_ptr(), do.data_ptr(), 1056, d_p.data_ptr(), 3200,
+    d_p = torch.full((B, n, LDP), 7.0, dtype=torch.bfloat16, device=dev)
+    assert L.swiftk_window_attention_bwd_scaled(pre.data_ptr(), W3, o.data_ptr(), do.data_ptr(), D, d_p.data_ptr(), LDP,
                                                 scale.to(dev).data_ptr(), B, grid[0], grid[1], heads, hd, shift[0], shift[1],
                                                 _lib.BF16, s()) == 0
-    assert torch.equal(d_p[..., :3168], d_s) and bool((d_p[..., 3168:] == 7.0).all())
+    assert torch.equal(d_p[..., :W3], d_s) and bool((d_p[..., W3:] == 7.0).all())
     # ... and the QK-norm backward in place on it (q-hat / k-hat vectors rewritten, v untouched) == the out-of-place call
     rn = (torch.rand(B * n, 3 * heads, device=dev) + 0.5).contiguous()
     sc = scale.to(dev).float().contiguous()
     ds_a, ds_b = torch.zeros(heads, device=dev), torch.zeros(heads, device=dev)
-    out_a = torch.full((B, n, 3200), 7.0, dtype=torch.bfloat16, device=dev)
-    assert L.swiftk_qknorm_bwd(pre.data_ptr(), d_s.data_ptr(), 3168, rn.data_ptr(), out_a.data_ptr(), 3200, sc.data_ptr(),
+    out_a = torch.full((B, n, LDP), 7.0, dtype=torch.bfloat16, device=dev)
+    assert L.swiftk_qknorm_bwd(pre.data_ptr(), d_s.data_ptr(), W3, rn.data_ptr(), out_a.data_ptr(), LDP, sc.data_ptr(),
                                ds_a.data_ptr(), B * n, heads, hd, _lib.BF16, s()) == 0
-    assert L.swiftk_qknorm_bwd(pre.data_ptr(), d_p.data_ptr(), 3168, rn.data_ptr(), d_p.data_ptr(), 3200, sc.data_ptr(),
+    assert L.swiftk_qknorm_bwd(pre.data_ptr(), d_p.data_ptr(), W3, rn.data_ptr(), d_p.data_ptr(), LDP, sc.data_ptr(),
                                ds_b.data_ptr(), B * n, heads, hd, _lib.BF16, s()) == 0
     assert torch.equal(out_a, d_p)
     assert torch.allclose(ds_a, ds_b, rtol=1e-4, atol=1e-4 * float(ds_a.abs().max()))
@@ -394,19 +396,19 @@ def test_window_attention_bwd(dev, shift, B):
     sc2[3] = math.log(150.0)
     pre2 = _prenorm(rnd((B, n, 3 * heads * hd), 13), sc2.cpu(), heads, hd).to(dev).to(BF)
     o2 = ops.window_attention(pre2, None, grid, heads, shift, flags=_lib.ATTN_PRENORM)
-    two = torch.full((B, n, 3200), 7.0, dtype=torch.bfloat16, device=dev)
+    two = torch.full((B, n, LDP), 7.0, dtype=torch.bfloat16, device=dev)
     ds_two, ds_one = torch.zeros(heads, device=dev), torch.zeros(heads, device=dev)
-    assert L.swiftk_window_attention_bwd_scaled(pre2.data_ptr(), 3168, o2.data_ptr(), do.data_ptr(), 1056, two.data_ptr(), 3200,
+    assert L.swiftk_window_attention_bwd_scaled(pre2.data_ptr(), W3, o2.data_ptr(), do.data_ptr(), D, two.data_ptr(), LDP,
                                                 sc2.data_ptr(), B, grid[0], grid[1], heads, hd, shift[0], shift[1], _lib.BF16, s()) == 0
-    assert L.swiftk_qknorm_bwd(pre2.data_ptr(), two.data_ptr(), 3168, rn.data_ptr(), two.data_ptr(), 3200, sc2.data_ptr(),
+    assert L.swiftk_qknorm_bwd(pre2.data_ptr(), two.data_ptr(), W3, rn.data_ptr(), two.data_ptr(), LDP, sc2.data_ptr(),
                                ds_two.data_ptr(), B * n, heads, hd, _lib.BF16, s()) == 0
-    one = torch.full((B, n, 3200), 7.0, dtype=torch.bfloat16, device=dev)
-    assert L.swiftk_window_attention_bwd_qknorm(pre2.data_ptr(), 3168, o2.data_ptr(), do.data_ptr(), 1056, one.data_ptr(), 3200,
+    one = torch.full((B, n, LDP), 7.0, dtype=torch.bfloat16, device=dev)
+    assert L.swiftk_window_attention_bwd_qknorm(pre2.data_ptr(), W3, o2.data_ptr(), do.data_ptr(), D, one.data_ptr(), LDP,
                                                 sc2.data_ptr(), rn.data_ptr(), ds_one.data_ptr(), B, grid[0], grid[1], heads, hd,
                                                 shift[0], shift[1], _lib.BF16, s()) == 0
     torch.cuda.synchronize()
-    assert bool((one[..., 3168:] == 7.0).all())
-    e12 = rel_l2(one[..., :3168].float().cpu(), two[..., :3168].float().cpu())
+    assert bool((one[..., W3:] == 7.0).all())
+    e12 = rel_l2(one[..., :W3].float().cpu(), two[..., :W3].float().cpu())
     eds = float((ds_one - ds_two).abs().max() / ds_two.abs().max())
     print(f"attention bwd + QK-norm bwd in one launch vs two: dqkv rel-L2 {e12:.3e}, dscale {eds:.3e}")
     assert e12 < 1e-2 and eds < 1e-2
@@ -426,9 +428,9 @@ def test_window_attention_bwd(dev, shift, B):
     want[..., 0, :] = rnc[..., 0:1] * (tau * gh_[..., 0, :] - xh[..., 0, :] * dotq / tau)
     dotk = (xh[..., 1, :] * gh_[..., 1, :]).sum(-1, keepdim=True)
     want[..., 1, :] = rnc[..., 1:2] * (gh_[..., 1, :] - xh[..., 1, :] * dotk)
-    got = one[..., :3168].float().cpu().view(B, n, heads, 3, hd)
+    got = one[..., :W3].float().cpu().view(B, n, heads, 3, hd)
     for part, name in enumerate("qkv"):
-        e1, e2 = rel_l2(got[..., part, :], want[..., part, :]), rel_l2(two[..., :3168].float().cpu().view(B, n, heads, 3, hd)[..., part, :], want[..., part, :])
+        e1, e2 = rel_l2(got[..., part, :], want[..., part, :]), rel_l2(two[..., :W3].float().cpu().view(B, n, heads, 3, hd)[..., part, :], want[..., part, :])
         print(f"  d{name} vs fp32 chain rule: one launch {e1:.3e}, two launches {e2:.3e}")
         assert e1 < 2.5e-2 and e1 <= e2 * 1.1, name
     ds_want = dotq.sum(dim=(0, 1)).view(-1) * (sc2.cpu() < math.log(100.0))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Attention backward at the training shape (local batch x 32 windows x 12 heads): persistent LDS-DMA kernel (tuning key 9 = 1)
-against the one-workgroup-per-item kernel (0), interleaved rounds.   usage: attn_bwd_ab.py [batch] [rounds]"""
+against the one-workgroup-per-item kernel (0), interleaved rounds.   usage: attn_bwd_ab.py [batch] [rounds] [head_dim] [heads]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,20 +8,23 @@ from swift_amd import _lib
 dev = torch.device("cuda"); L = _lib.lib()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-gh, gw, heads, hd = 64, 128, 12, 88
+hd = int(sys.argv[3]) if len(sys.argv) > 3 else 88
+heads = int(sys.argv[4]) if len(sys.argv) > 4 else 12
+gh, gw = 64, 128
+W3, D = 3 * heads * hd, (heads * hd + 63) // 64 * 64
 n = gh * gw
 torch.manual_seed(0)
 pre = torch.nn.functional.normalize(torch.randn(B, n, heads, 3, hd, device=dev), dim=-1)
 pre[..., 0, :] *= 10.0
 pre = pre.reshape(B, n, -1).bfloat16()
-o = torch.randn(B, n, 1088, device=dev).bfloat16() * 0.1
-do = torch.randn(B, n, 1088, device=dev).bfloat16()
+o = torch.randn(B, n, D, device=dev).bfloat16() * 0.1
+do = torch.randn(B, n, D, device=dev).bfloat16()
 outs = {k: torch.zeros_like(pre) for k in (0, 1)}
 st = lambda: torch.cuda.current_stream().cuda_stream
 scale = torch.log(torch.full((heads,), 10.0, device=dev))
 def run(k, scaled=False):
     L.swiftk_set_tuning(9, k)
-    rc = L.swiftk_window_attention_bwd_scaled(pre.data_ptr(), 3168, o.data_ptr(), do.data_ptr(), 1088, outs[k].data_ptr(), 3168,
+    rc = L.swiftk_window_attention_bwd_scaled(pre.data_ptr(), W3, o.data_ptr(), do.data_ptr(), D, outs[k].data_ptr(), W3,
                                               scale.data_ptr() if scaled else None, B, gh, gw, heads, hd, 8, 8, _lib.BF16, st())
     assert rc == 0
 res = {0: [], 1: []}

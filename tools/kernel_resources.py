@@ -13,8 +13,12 @@ def demangle(names):
     return [re.sub(r"\(anonymous namespace\)::", "", o).split("(")[0].replace("void ", "") for o in out]
 
 
+NO_SLP = {"gemm.hip", "gemm_tn.hip", "gemm_rownorm.hip", "qkv_attn.hip"}  # the Makefile's per-file -fno-slp-vectorize: same code as shipped
+
+
 def one(f):
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize",
+    extra = ["-fno-slp-vectorize"] if os.path.basename(f) in NO_SLP else []
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", *extra,
                         "-Rpass-analysis=kernel-resource-usage", "-c", f, "-o", "/dev/null"], cwd=CSRC, capture_output=True, text=True)
     rows, cur = [], None
     for ln in r.stderr.splitlines():
