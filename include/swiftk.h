@@ -179,6 +179,14 @@ int swiftk_modnorm_residual_pair_slabs(const float* y_slabs, int64_t ldy, int64_
 int swiftk_modnorm_residual_pair_slabs_bf16(const void* y_slabs, int64_t ldy, int64_t slab_stride, void* x_hi, int64_t ldh, void* x_lo,
                                             int64_t ldl, int lo_bits, const float* gamma, const float* beta, const float* mod,
                                             int64_t ldmod, int64_t M, int d, int64_t rows_per_sample, float eps, void* stream);
+/* The pair update of swiftk_modnorm_residual_pair (8-bit low part, d = 1056 or 1280, contiguous y / low-part rows) for a y that
+ * arrives as two bf16 k-half slabs [M, d] (slab 1 at y_slabs + slab_stride elements): y = bf16(slab 0 + slab 1), the halves added
+ * in fp32 and rounded once, wherever slab 1 exists.  `tail` = NULL: everywhere (behind swiftk_gemm_splitk_bf16); else the three
+ * numbers swiftk_gemm_tail_split_bf16 reported (d = 1056 only): slab 1 is read under the tiles that GEMM split and nowhere else.
+ * (swinv2.py:77-86 behind :112-113 / :134.) */
+int swiftk_modnorm_residual_pair_halves_bf16(const void* y_slabs, int64_t slab_stride, const int64_t* tail, void* x_hi, int64_t ldh,
+                                             void* x_lo, const float* gamma, const float* beta, const float* mod, int64_t ldmod,
+                                             int64_t M, int d, int64_t rows_per_sample, float eps, void* stream);
 /* wo / w2 and the norm above in ONE kernel, for small batches: y = bf16(A[M, K] W[d, K]^T) computed over complete rows (a
  * workgroup owns `rows_per_workgroup` = 32 or 64 rows x all d columns, so the row statistics are there and y never leaves the
  * CU), then the pair update of swiftk_modnorm_residual_pair (8-bit low part).  bf16 operands, d = 1056 or 960, K % 32 == 0,
@@ -327,6 +335,8 @@ int swiftk_profile_gemm(int epilogue, int64_t N);
  * key 27 = split engine's exact to_qkv recompute: 2 = each hot head alone, q, k and v (default; needs the head mask in
  * swiftk_layer.qk_exact_pairs), 1 = the hot pairs' q and k columns only, 0 = the hot pairs whole,
  * key 28 = split engine: the fp32 attention kernel's P V as three bf16 products (1; 0 = exact fp32 like its q k^T),
+ * key 29 = small batches of the bf16 engine (default 3): bit 0 = wo / w2 through swiftk_gemm_tail_split_bf16 where the persistent
+ *          walk's last round is at most half full, bit 1 = swiftk_modnorm_residual_pair_halves_bf16 behind the one-unit split-K,
  * key 25 = clears through hipMemsetAsync instead of a kernel (0; diagnosis only; bit 1 = the library's internal clears --
  * swiftk_modnorm_bwd's workspace, swiftk_scm_target's scratch --, bit 2 = swiftk_zero_f32, bit 4 = a check kernel behind
  * swiftk_modnorm_bwd's clear records what it left non-zero: swiftk_zero_check_report). */
@@ -373,6 +383,16 @@ int swiftk_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, f
  * rounded once as a plain bf16 GEMM rounds its output.  The forecast path's wo / w2 at one unit per step. */
 int swiftk_gemm_splitk_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* slabs, int64_t ldc, int64_t slab_stride,
                             int64_t M, int64_t N, int64_t K, int ksplit, void* stream);
+/* y = A[M, K] W[N, K]^T (bf16, N % 352 == 0: the d-wide Linears wo / w2, swinv2.py:112-113 / :134) for batches whose tile count leaves
+ * the persistent walk a last round that is at most half full (T = ceil(M / 256) N / 352 tiles on G = 256 workgroups, 0 < T % G <= G / 2,
+ * T > G: 3, 4, 6 .. units per step): the first T - T % G tiles are computed whole into slab 0, the others as two k-halves into slabs 0
+ * and 1 (slabs + slab_stride elements), so that every workgroup gets its whole tiles and at most one half -- the last round costs half
+ * a tile time.  tail[3] (out) describes where slab 1 exists, for swiftk_modnorm_residual_pair_halves_bf16: the first row of the tile
+ * group holding the first split tile (a multiple of 256), the first split tile in the walk's order (groups of tail[2] tile rows, column-
+ * major inside a group), and that group height; slab 1 is written under split tiles only.  SWIFTK_ESHAPE when the shape leaves no such
+ * round (use swiftk_gemm). */
+int swiftk_gemm_tail_split_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* slabs, int64_t ldc, int64_t slab_stride,
+                                int64_t M, int64_t N, int64_t K, int64_t* tail, void* stream);
 /* The same weight gradient without the transposed copies (TN form; autograd of the Linears at swinv2.py:96-98,112-113,134):
  *   slabs[s][N1, ldc] (fp32) = sum over the s-th of `ksplit` ranges of the K token rows of P[m, 0..N1)^T * Q[m, 0..N2)
  * P = dY [K, ldp], Q = X [K, ldq], bf16, token-major as the forward / backward passes leave them.  K % 64 == 0,

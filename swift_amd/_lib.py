@@ -97,6 +97,8 @@ _SIGS = {
     "swiftk_swiglu_jvp": ([_p, _p, _l, _p, _p, _l, _l, _i, _i, _p], _i),
     "swiftk_gemm_bias_pos_pair": ([_p, _l, _p, _l, _p, _l, _p, _l, _l, _l, _l, _p, _p, _l, _p], _i),
     "swiftk_gemm_splitk_bf16": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _l, _i, _p], _i),
+    "swiftk_gemm_tail_split_bf16": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _l, _p, _p], _i),
+    "swiftk_modnorm_residual_pair_halves_bf16": ([_p, _l, _p, _p, _l, _p, _p, _p, _p, _l, _l, _i, _l, _f, _p], _i),
     "swiftk_modnorm_residual_pair_slabs_bf16": ([_p, _l, _l, _p, _l, _p, _l, _i, _p, _p, _p, _l, _l, _i, _l, _f, _p], _i),
     "swiftk_embed_bwd_sums": ([_p, _l, _p, _p, _p, _l, _l, _i, _l, _p], _i),
     "swiftk_cast_pad_t": ([_p, _l, _l, _l, _p, _l, _p, _l, _l, _p], _i),

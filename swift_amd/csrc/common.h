@@ -206,6 +206,7 @@ extern int g_x3_ffsplit;  // tuning key 18
 extern int g_x3_normsplit;  // tuning key 26
 extern int g_x3_qkonly;  // tuning key 27
 extern int g_x3_attnpv;  // tuning key 28
+extern int g_fwd_tail;   // tuning key 29 (forward.hip)
 extern int g_fwd_pepair;  // tuning key 19
 extern int g_modnorm_nt;  // tuning key 6
 extern int g_persist_wgs;  // tuning key 2: workgroups of the persistent matrix kernels (GEMM, fused to_qkv + attention)

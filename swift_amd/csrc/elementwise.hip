@@ -434,11 +434,16 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int NC>
+// Y2 (round 6, small batches): y arrives as two bf16 k-half slabs of the producing GEMM for the rows from `rows2` on (y1 = slab 1; rows
+// below rows2 have slab 0 only): the halves are added in fp32 and rounded to bf16 once -- the value a whole-K tile would have
+// rounded to, up to that one extra rounding -- and the kernel goes on as for one y
+template <int NC, bool Y2 = false>
 __global__ __launch_bounds__(256, SWIFTK_MNPK_OCC) void modnorm_pair_packed_kernel(const bf16_t* __restrict__ y, const bf16_t* xh, bf16_t* xh_out,
                                                                     int64_t ldh, uint8_t* __restrict__ xl, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, const float* __restrict__ mod,
-                                                                    int64_t ldmod, int64_t M, int64_t rps, float eps, int nt) {
+                                                                    int64_t ldmod, int64_t M, int64_t rps, float eps, int nt,
+                                                                    const bf16_t* __restrict__ y1 = nullptr, int64_t rows2 = 0,
+                                                                    int tail_from = 0, int gm = 8) {
     constexpr int D = 8 * NC, NS = (4 * NC + 63) / 64;
     // (measured, 96 units: low part non-temporal 1.465 ms, plain 1.477; hi loads non-temporal 1.555 -- hi stays cached, it is the
     // next GEMM's operand; all forms of this kernel move their bytes at 4.5-4.9 TB/s, the rate a device copy reaches here)
@@ -447,7 +452,18 @@ __global__ __launch_bounds__(256, SWIFTK_MNPK_OCC) void modnorm_pair_packed_kern
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     __shared__ __attribute__((aligned(16))) float sP[D], sQ[D];
-    const int64_t blk_sample = ((int64_t)blockIdx.x * MN_ROWS) / rps;
+    // Y2: the two-slab chunks (the last ones) are dealt evenly among the others -- every R-th workgroup takes one -- instead of forming
+    // the tail of the launch, where their two request phases would have nothing to hide behind
+    int64_t chunk = blockIdx.x;
+    if constexpr (Y2) {
+        const int64_t C = M / MN_ROWS, C2 = C - rows2 / MN_ROWS;
+        if (C2 > 0 && C2 < C) {
+            const int64_t R = C / C2, k = chunk / R;
+            if (chunk % R == R - 1 && k < C2) chunk = (C - C2) + k;
+            else chunk -= k < C2 ? k : C2;
+        }
+    }
+    const int64_t blk_sample = (chunk * MN_ROWS) / rps;
     {
         const float* mrow = mod + blk_sample * ldmod;
         for (int c = threadIdx.x; c < NC; c += 256) {
@@ -466,7 +482,7 @@ __global__ __launch_bounds__(256, SWIFTK_MNPK_OCC) void modnorm_pair_packed_kern
         }
     }
     __syncthreads();
-    const int64_t r0 = (int64_t)blockIdx.x * MN_ROWS + 4 * wv;  // (the launcher guarantees M % 16 == 0)
+    const int64_t r0 = chunk * MN_ROWS + 4 * wv;  // (the launcher guarantees M % 16 == 0)
     if (r0 >= M) return;
     const bf16_t* yb = y + r0 * D;
     uint8_t* lb = xl + r0 * D;
@@ -482,12 +498,49 @@ __global__ __launch_bounds__(256, SWIFTK_MNPK_OCC) void modnorm_pair_packed_kern
     const bool live = VL >= 64 || lane < VL;                                                                                \
     const int colc = lane + 64 * (s) - R0 * NC - (up ? NC : 0); /* column chunk inside the row */                           \
     const uint32_t hoff = (uint32_t)((R0 + (up ? 1 : 0)) * (int)ldh + 8 * colc)  /* (4 rows x ldh elements: fits 32 bits) */
+    bool y_loaded = false;
+    if constexpr (Y2) {
+        // rows with two halves (wave-uniform: rows2 is a multiple of the 16-row chunk): both slabs' chunks are requested back to back and
+        // added BEFORE the hi / lo requests go out -- the second slab's registers are free again by then (154 registers, three waves per
+        // SIMD, as the one-y form).  Measured against everything requested up front (190 registers, two waves per SIMD): 60.0 against
+        // 62.5 us at four units, 18.6 against 20.0 us at one (`profiles/r06zb_small_batch_tail_split.txt`)
+        if (r0 >= rows2) {
+            uint4 tq[NS];
+            const bf16_t* yb1 = y1 + r0 * D;
+            // the producing GEMM's tile of a chunk, in its walk's order (TileIter: groups of gm tile rows, column-major inside a group; 256 x 352
+            // tiles = 44 chunks wide): slab 1 exists under tiles >= tail_from only (tail_from = 0: everywhere)
+            const int ntm = (int)((M + 255) >> 8), grp_rows = gm * (NC / 44);
+            static_for<0, NS>([&](auto S_) {
+                SWIFTK_SLOT(S_);
+                yq[s] = tq[s] = make_uint4(0u, 0u, 0u, 0u);
+                if (live) {
+                    yq[s] = load_q_nt(yb + 8 * (64 * s + lane));
+                    const int tm = (int)((r0 + R0 + (up ? 1 : 0)) >> 8), grp = tm / gm, rows = min(gm, ntm - grp * gm);
+                    const int tile = grp * grp_rows + (colc / 44) * rows + (tm - grp * gm);
+                    if (tile >= tail_from) tq[s] = load_q_nt(yb1 + 8 * (64 * s + lane));
+                }
+            });
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                raw8<bf16_t> ta, tb;
+                ta.q = yq[s];
+                tb.q = tq[s];
+                float va[8], vb[8];
+                unpack_raw(ta, va);
+                unpack_raw(tb, vb);
+                yq[s] = make_uint4(pack_bf16(va[0] + vb[0], va[1] + vb[1]), pack_bf16(va[2] + vb[2], va[3] + vb[3]),
+                                   pack_bf16(va[4] + vb[4], va[5] + vb[5]), pack_bf16(va[6] + vb[6], va[7] + vb[7]));
+            }
+            y_loaded = true;
+        }
+    }
     static_for<0, NS>([&](auto S_) {
         SWIFTK_SLOT(S_);
-        yq[s] = hq[s] = make_uint4(0u, 0u, 0u, 0u);
+        if (!y_loaded) yq[s] = make_uint4(0u, 0u, 0u, 0u);
+        hq[s] = make_uint4(0u, 0u, 0u, 0u);
         lq[s] = make_uint2(0u, 0u);
         if (live) {
-            yq[s] = load_q_nt(yb + 8 * (64 * s + lane));
+            if (!y_loaded) yq[s] = load_q_nt(yb + 8 * (64 * s + lane));
             hq[s] = load_q(hb + hoff);
             if (lo_nt) {
                 typedef __attribute__((ext_vector_type(2))) uint32_t u2;
@@ -1232,6 +1285,32 @@ extern "C" int swiftk_modnorm_residual_pair_slabs_bf16(const void* y_slabs, int6
     if (slab_stride <= 0 || slab_stride % 8) return SWIFTK_EINVAL;
     return modnorm_pair_impl(y_slabs, ldy, slab_stride, x_hi, ldh, x_lo, ldl, lo_bits, gamma, beta, mod, ldmod, M, d,
                              rows_per_sample, eps, stream, nullptr, true);
+}
+
+extern "C" int swiftk_modnorm_residual_pair_halves_bf16(const void* y_slabs, int64_t slab_stride, const int64_t* tail, void* x_hi, int64_t ldh,
+                                                        void* x_lo, const float* gamma, const float* beta, const float* mod, int64_t ldmod,
+                                                        int64_t M, int d, int64_t rows_per_sample, float eps, void* stream) {
+    if (!y_slabs || !x_hi || !x_lo || !gamma || !beta || !mod || M <= 0 || rows_per_sample <= 0 || slab_stride <= 0) return SWIFTK_EINVAL;
+    const int64_t rows_from = tail ? tail[0] : 0;
+    const int tail_from = tail ? (int)tail[1] : 0, gm = tail ? (int)tail[2] : 8;
+    if ((d != 1056 && d != 1280) || M % MN_ROWS || rows_per_sample % MN_ROWS || rows_from < 0 || rows_from > M || rows_from % MN_ROWS || ldh < d ||
+        slab_stride < M * d || tail_from < 0 || gm < 1 || (tail_from > 0 && d != 1056))
+        return SWIFTK_ESHAPE;
+    if (((uintptr_t)y_slabs & 15) || (slab_stride * 2) % 16 || ((uintptr_t)x_hi & 15) || (ldh * 2) % 16 || ((uintptr_t)x_lo & 7) ||
+        ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)mod & 15) || (ldmod % 4))
+        return SWIFTK_EALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int cgrid = (int)(M / MN_ROWS);
+    const bf16_t* y0 = static_cast<const bf16_t*>(y_slabs);
+    bf16_t* hi = static_cast<bf16_t*>(x_hi);
+    if (d == 1056)
+        hipLaunchKernelGGL((modnorm_pair_packed_kernel<132, true>), dim3(cgrid), dim3(256), 0, st, y0, hi, hi, ldh, static_cast<uint8_t*>(x_lo), gamma,
+                           beta, mod, ldmod, M, rows_per_sample, eps, g_modnorm_nt, y0 + slab_stride, rows_from, tail_from, gm);
+    else
+        hipLaunchKernelGGL((modnorm_pair_packed_kernel<160, true>), dim3(cgrid), dim3(256), 0, st, y0, hi, hi, ldh, static_cast<uint8_t*>(x_lo), gamma,
+                           beta, mod, ldmod, M, rows_per_sample, eps, g_modnorm_nt, y0 + slab_stride, rows_from, tail_from, gm);
+    SWIFTK_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int swiftk_split_pair(const float* src, int64_t lds, void* hi, int64_t ldh, void* lo, int64_t ldl, int lo_bits,

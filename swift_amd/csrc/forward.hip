@@ -9,6 +9,8 @@ int g_x3_exact = 17;  // tuning key 11: the DEFAULT mask a host binding copies i
 int g_fwd_pair = 2;   // tuning key 12: bf16 engine's residual stream: 2 = (bf16 hi, 8-bit lo) pair, 1 = (bf16 hi, bf16 lo), 0 = fp32 + copy
 int g_f32_chunk_k = 256;  // tuning key 13: fp32-operand GEMMs of the forward accumulate in chains of this many k (0 = one chain over K)
 int g_fwd_splitk = 2;  // tuning key 14: 2 = bf16 slabs, 1 = fp32 slabs
+int g_fwd_tail = 3;    // tuning key 29: bit 0 = wo / w2 with the walk's last round as two k-halves where that round is at most half full
+                       // (3, 4, 6, 11, 12 .. units per step at dim 1056), bit 1 = the packed two-slab norm behind the one-unit split-K
 int g_fwd_pepair = 1;  // tuning key 19: the patch embedding's epilogue writes the pair form itself
 int g_x3_attnpv = 1;  // tuning key 28: split engine, P V of the fp32 attention kernel as three bf16 products
 int g_x3_qkonly = 2;  // tuning key 27: split engine's exact to_qkv recompute: 2 = each hot head alone (q, k, v), 1 = hot pairs' q and k, 0 = hot pairs
@@ -62,6 +64,14 @@ inline bool small_m_splitk(const swiftk_model* m, int64_t M) {
     return false;
 }
 
+// wo / w2 of the bf16 pair engine with the persistent walk's last round as k-halves (swiftk_gemm_tail_split_bf16): the shapes it takes
+// (352-wide tiles, 8-bit low parts, the packed norm's widths); the GEMM entry itself decides whether M leaves such a round
+inline bool tail_split_shape(const swiftk_model* m, int64_t M) {
+    if (!(m->dtype == SWIFTK_BF16 && (g_fwd_tail & 1) && g_fwd_pair >= 2 && m->dim == 1056 && M % 16 == 0)) return false;
+    const int64_t tiles = ((M + 255) / 256) * (m->dim / 352), r = tiles % g_persist_wgs;
+    return tiles > g_persist_wgs && r > 0 && 2 * r <= g_persist_wgs;
+}
+
 Layout make_layout(const swiftk_model* m, int B) {
     const int64_t es = m->dtype == SWIFTK_BF16 ? 2 : 4;
     const int64_t ntok = (int64_t)(m->H / m->p1) * (m->W / m->p2), M = ntok * B, d = m->dim;
@@ -78,7 +88,7 @@ Layout make_layout(const swiftk_model* m, int B) {
     L.qkv = o; o += al(M * 3 * d * es);
     L.att = o; o += al(M * m->kd * es);
     L.y = o; o += al(M * d * es);
-    L.yslab = o; o += small_m_splitk(m, M) ? al(2 * M * d * 4) : 0;  // two fp32 slabs of the split-K wo / w2 (one unit per step)
+    L.yslab = o; o += small_m_splitk(m, M) ? al(2 * M * d * 4 + 8192) : tail_split_shape(m, M) ? al(2 * M * d * 2 + 8192) : 0;  // two fp32 slabs of the split-K wo / w2 (one unit per step)
     L.hmid = o; o += al(M * m->kmlp * es);
     L.tok = o; o += al(M * (int64_t)((m->out_ch * m->p1 * m->p2 + 3) & ~3) * 4);
     L.kscr = o;
@@ -207,6 +217,11 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
     void* xlo = ws + L.xlo;
     const int lo_bits = g_fwd_pair == 1 ? 16 : 8;
     const bool splitk = pair && small_m_splitk(m, M);
+    const bool tail = pair && lo_bits == 8 && !splitk && tail_split_shape(m, M);
+    // stride between the two bf16 slabs: M d elements would put slab 1 a multiple of 16.5 MiB behind slab 0 -- the norm kernel's two
+    // requests per chunk would meet the same memory channels; 17 x 256 B more spreads them
+    const int64_t SS = M * d + 2176;
+    const bool halves_norm = (g_fwd_tail & 2) && lo_bits == 8 && (d == 1056 || d == 1280) && M % 16 == 0;  // packed two-slab norm
     float* yslab = reinterpret_cast<float*>(ws + L.yslab);
     const bool pe_pair = pair && lo_bits == 8 && d % 16 == 0 && m->kpe % 64 == 0 && g_fwd_pepair;
     if (pe_pair) {
@@ -317,9 +332,18 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
         if (rn_rows) {
             RUN(swiftk_gemm_modnorm_residual_pair(att, m->kd, ly.wo_w, m->kd, kdv, xT, m->kd, xlo, d, ly.ln1_g, ly.ln1_b,
                                                   mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok, 1e-6f, rn_rows, stream));
+        } else if (tail) {
+            int64_t tail3[3] = {0, 0, 8};
+            RUN(swiftk_gemm_tail_split_bf16(att, m->kd, ly.wo_w, m->kd, yslab, d, SS, M, d, kdv, tail3, stream));
+            RUN(swiftk_modnorm_residual_pair_halves_bf16(yslab, SS, tail3, xT, m->kd, xlo, ly.ln1_g, ly.ln1_b,
+                                                         mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
         } else if (splitk && g_fwd_splitk >= 2) {
-            RUN(swiftk_gemm_splitk_bf16(att, m->kd, ly.wo_w, m->kd, yslab, d, M * d, M, d, kdv, 2, stream));
-            RUN(swiftk_modnorm_residual_pair_slabs_bf16(yslab, d, M * d, xT, m->kd, xlo, d, lo_bits, ly.ln1_g, ly.ln1_b,
+            RUN(swiftk_gemm_splitk_bf16(att, m->kd, ly.wo_w, m->kd, yslab, d, SS, M, d, kdv, 2, stream));
+            if (halves_norm)
+                RUN(swiftk_modnorm_residual_pair_halves_bf16(yslab, SS, nullptr, xT, m->kd, xlo, ly.ln1_g, ly.ln1_b,
+                                                             mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
+            else
+            RUN(swiftk_modnorm_residual_pair_slabs_bf16(yslab, d, SS, xT, m->kd, xlo, d, lo_bits, ly.ln1_g, ly.ln1_b,
                                                         mod + (int64_t)(2 * i) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
         } else if (splitk) {
             RUN(swiftk_gemm_splitk(att, m->kd, ly.wo_w, m->kd, yslab, d, M * d, M, d, kdv, SWIFTK_BF16, 2, stream));
@@ -351,9 +375,20 @@ extern "C" int swiftk_swinv2_forward(const swiftk_model* m, const float* src0, i
                                                   mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d, ntok, 1e-6f, rn_rows, stream));
             continue;
         }
+        if (tail) {
+            int64_t tail3[3] = {0, 0, 8};
+            RUN(swiftk_gemm_tail_split_bf16(hmid, m->kmlp, ly.w2_w, m->kmlp, yslab, d, SS, M, d, m->kmlp, tail3, stream));
+            RUN(swiftk_modnorm_residual_pair_halves_bf16(yslab, SS, tail3, xT, m->kd, xlo, ly.ln2_g, ly.ln2_b,
+                                                         mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
+            continue;
+        }
         if (splitk && g_fwd_splitk >= 2) {
-            RUN(swiftk_gemm_splitk_bf16(hmid, m->kmlp, ly.w2_w, m->kmlp, yslab, d, M * d, M, d, m->kmlp, 2, stream));
-            RUN(swiftk_modnorm_residual_pair_slabs_bf16(yslab, d, M * d, xT, m->kd, xlo, d, lo_bits, ly.ln2_g, ly.ln2_b,
+            RUN(swiftk_gemm_splitk_bf16(hmid, m->kmlp, ly.w2_w, m->kmlp, yslab, d, SS, M, d, m->kmlp, 2, stream));
+            if (halves_norm)
+                RUN(swiftk_modnorm_residual_pair_halves_bf16(yslab, SS, nullptr, xT, m->kd, xlo, ly.ln2_g, ly.ln2_b,
+                                                             mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
+            else
+            RUN(swiftk_modnorm_residual_pair_slabs_bf16(yslab, d, SS, xT, m->kd, xlo, d, lo_bits, ly.ln2_g, ly.ln2_b,
                                                         mod + (int64_t)(2 * i + 1) * 2 * d, ldmod, M, d, ntok, 1e-6f, stream));
             continue;
         }

@@ -48,6 +48,7 @@ constexpr int MI = 4, NI = 11;  // NI: W-side MFMA tiles per wave of the 256 x 3
                                 // as a template parameter: 10 / 11 / 12 -> 320 / 352 / 384 columns per tile
 
 constexpr int EPI_QKNORM_TILED = 4;  // internal: SWIFTK_EPI_QKNORM with the window-tiled store (swiftk_gemm_qkv_tiled)
+constexpr int EPI_NONE_TAIL = 12;     // internal: SWIFTK_EPI_NONE with the LAST ROUND's tiles as two k-halves (swiftk_gemm_tail_split_bf16)
 constexpr int EPI_BIAS_POS_PAIR = 11;  // internal: SWIFTK_EPI_BIAS_POS leaving as the (bf16 hi, 8-bit lo) pair (swiftk_gemm_bias_pos_pair)
 
 // Build-time switches.  SWIFTK_GEMM_INSTR = 1 compiles the timing experiments (tuning key 3: ablation bits, s_memtime
@@ -148,6 +149,7 @@ struct GemmArgs {
     int touch;         // persistent kernel: L2 look-ahead requests on (aligned shapes only: M % 256 == 0, N % tile width == 0)
     int stagger;       // persistent kernel: start-up delay step in 10-ns ticks (workgroup phase p waits p x stagger); 0 = off
     int ksplit;        // persistent kernel: k-ranges per output tile (1 = plain)
+    int tail_from;     // EPI_NONE_TAIL: tiles >= tail_from (in the walk's tile order) run as two k-halves into slabs 0 / 1 (C + c_split)
     int64_t c_split;   // elements between the fp32 slabs of consecutive splits
     int64_t batch_a, batch_w, batch_c;  // one-tile-per-workgroup kernel only: byte steps of A / W / C per blockIdx.y (batched GEMM)
     // QKNORM only: window-tiled output [sample][window][head][q|k|v][256][88] (t_gw = 0: plain row-major C)
@@ -509,8 +511,21 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 #endif
     // work item = (output tile, k-split): with ksplit > 1 (weight gradients: few output tiles, K = all tokens) each
     // split accumulates its k-range into its own fp32 slab C + split*c_split; a reduce kernel sums the slabs
-    const int ksplit = g.ksplit;
-    const int ntiles = ntm * g.ntn * ksplit;
+    // EPI_NONE_TAIL (small batches, ksplit = 1): work items of two sizes -- tiles [0, tail_from) whole, then each later tile as two
+    // k-halves, split s into slab s.  tail_from is a multiple of the grid size and at most half a round of tiles follows it, so the
+    // round-robin walk below hands every workgroup its whole tiles and then at most ONE half: the last round costs half a tile time
+    constexpr bool TAIL = EPI == EPI_NONE_TAIL;
+    const int ksplit = TAIL ? 1 : g.ksplit;
+    const int tail_from = TAIL ? g.tail_from : 0;
+    const int ntiles = TAIL ? 2 * ntm * g.ntn - tail_from : ntm * g.ntn * ksplit;
+    auto tile_of = [&](int item) {
+        if constexpr (TAIL) return item < tail_from ? item : tail_from + ((item - tail_from) >> 1);
+        else return item / ksplit;
+    };
+    auto split_of = [&](int item) {
+        if constexpr (TAIL) return item < tail_from ? 0 : (item - tail_from) & 1;
+        else return item % ksplit;
+    };
     // workgroups with equal blockIdx%8 share an XCD: give each XCD a contiguous run of virtual ids
     int vid;
     {
@@ -537,8 +552,14 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     const int tr2 = min(256 + wv * ((BN - 256 + 7) / 8) + min(lane, (BN - 256 + 7) / 8 - 1), BN - 1);
     int t_m0 = 0, t_n0 = 0;  // origin of the tile the DMA currently feeds (set_sources)
     const int nk_all = g.K / (ROWB / (int)sizeof(T));
-    auto k_begin = [&](int item) { return (int)((int64_t)(item % ksplit) * nk_all / ksplit); };
-    auto k_end = [&](int item) { return (int)((int64_t)(item % ksplit + 1) * nk_all / ksplit); };
+    auto k_begin = [&](int item) {
+        if constexpr (TAIL) return item >= tail_from && ((item - tail_from) & 1) ? nk_all >> 1 : 0;
+        else return (int)((int64_t)(item % ksplit) * nk_all / ksplit);
+    };
+    auto k_end = [&](int item) {
+        if constexpr (TAIL) return item >= tail_from && !((item - tail_from) & 1) ? nk_all >> 1 : nk_all;
+        else return (int)((int64_t)(item % ksplit + 1) * nk_all / ksplit);
+    };
     int tile = vid, kt = k_begin(vid);
     // Row bases of this wave's ten pieces for the tile the DMA currently feeds: computed once per tile and kept in
     // SGPRs, so issuing a piece costs three instructions (M0, nop, load) instead of ~20 scalar address ops -- at
@@ -547,7 +568,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     const char* wbase[6];
     auto set_sources = [&](int t) {
         int tm, tn;
-        it.coords(t / ksplit, tm, tn);
+        it.coords(tile_of(t), tm, tn);
         t_m0 = tm * BM;
         t_n0 = tn * BN;
 #pragma unroll
@@ -583,7 +604,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     auto w1row = [&](int i) { const int n = wv + 8 * i, h = n >= 2 * JB; return h * WT + JA * 16 + (n - 2 * JB * h) * 8; };
     auto set_sources_aw1 = [&](int t) {
         int tm, tn;
-        it.coords(t / ksplit, tm, tn);
+        it.coords(tile_of(t), tm, tn);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             int rb = tm * BM + (wv * 4 + p) * 8;
@@ -600,7 +621,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
     };
     auto set_sources_w0 = [&](int t) {
         int tm, tn;
-        it.coords(t / ksplit, tm, tn);
+        it.coords(tile_of(t), tm, tn);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             int rb = tn * BN + w0row(i);
@@ -1039,7 +1060,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
 #endif
         {
             int tm, tn;
-            it.coords(tile / ksplit, tm, tn);
+            it.coords(tile_of(tile), tm, tn);
             const int m0 = tm * BM, n0 = tn * BN;
             if constexpr (EPI == SWIFTK_EPI_QKNORM || EPI == EPI_QKNORM_TILED)
                 qknorm_tile<NI>(acc, lane, n0 + wn * WT, g.ep0, const_cast<float*>(g.ep1), m0 + wm * 64, g.M, g.N / HD, sizeof(T) == 4 && g.qk_only);
@@ -1049,7 +1070,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel_p(GemmArgs g, int ntm, int gm)
                 asm volatile("" : "+v"(qlane));
                 qknorm_jvp_stats<NI>(acc, qlane, n0 + wn * WT, g.ep0, const_cast<float*>(g.ep1), tm * (BM / 2) + wm * 32, g.N / HD, qf);
             }
-            OutT* C = reinterpret_cast<OutT*>(g.C) + (int64_t)(tile % ksplit) * g.c_split;
+            OutT* C = reinterpret_cast<OutT*>(g.C) + (int64_t)split_of(tile) * g.c_split;
             if constexpr (EPI == SWIFTK_EPI_SWIGLU_JVP) {
                 // FeedForward gate and its tangent (swinv2.py:99-100 under jvp): per 16-token group the primal pre-activations
                 // (optional: the backward pass's saved activation), then silu(gate) * up and its tangent side by side in the
@@ -1706,6 +1727,7 @@ extern "C" int swiftk_set_tuning(int key, int value) {
         case 26: g_x3_normsplit = value; return 0;
         case 27: g_x3_qkonly = value; return 0;
         case 28: g_x3_attnpv = value; return 0;
+        case 29: g_fwd_tail = value; return 0;
         case 25:
             g_zero_memset = value;
             return (value & 4) ? swiftk_zero_check_enable() : 0;
@@ -1742,6 +1764,7 @@ extern "C" int swiftk_get_tuning(int key) {
         case 26: return g_x3_normsplit;
         case 27: return g_x3_qkonly;
         case 28: return g_x3_attnpv;
+        case 29: return g_fwd_tail;
     }
     return SWIFTK_EINVAL;
 }
@@ -1776,8 +1799,10 @@ extern "C" int64_t swiftk_gemm_k_pad(int dtype, int64_t k) {
 static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
                      int64_t K, int dtype, int out_dtype, int epilogue, const float* ep0, const float* ep1, int64_t pos_rows,
                      int ksplit, int64_t c_split, void* stream, const int* tiling = nullptr, float* kscr = nullptr,
-                     int kchunk = 0) {
+                     int kchunk = 0, int64_t* tail_rows_from = nullptr) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || ksplit < 1) return SWIFTK_EINVAL;
+    if (tail_rows_from && (ksplit != 1 || dtype != SWIFTK_BF16 || out_dtype != SWIFTK_BF16 || epilogue != SWIFTK_EPI_NONE || c_split < M * ldc))
+        return SWIFTK_EINVAL;
     if (ksplit > 1 && ((out_dtype != SWIFTK_F32 && !(out_dtype == SWIFTK_BF16 && dtype == SWIFTK_BF16)) || epilogue != SWIFTK_EPI_NONE || c_split < M * ldc))
         return SWIFTK_EINVAL;
     if (epilogue == SWIFTK_EPI_ACCUM && out_dtype != SWIFTK_F32) return SWIFTK_EINVAL;
@@ -1872,11 +1897,41 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, voi
         g.t_gh = tiling[0]; g.t_gw = tiling[1]; g.t_sh = tiling[2]; g.t_sw = tiling[3]; g.t_heads = tiling[4];
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    g.tail_from = 0;
+    if (tail_rows_from) {
+        // The last round of the persistent walk as k-halves (see EPI_NONE_TAIL in the kernel): T tiles on G workgroups with a
+        // remainder r = T % G of at most G / 2 -- the first T - r tiles whole into slab 0, the last r as two halves into slabs 0 / 1.
+        // The caller's norm gets the walk's description (tail[3] = first row of the tile group the first split tile sits in, the first
+        // split tile, the group height): it reads slab 1 exactly under the split tiles; slab 1 is not written anywhere else.
+        const int G = g_persist_wgs, ntm = (int)((M + BM - 1) / BM);
+        const int64_t T = (int64_t)ntm * g.ntn, r = T % G;
+        const int nk_all = (int)(K / tile_k);
+        if (ni != NI || (M & 7) || (N & 7) || ((uintptr_t)C & 15) || (ldc & 7) || (c_split & 7) || g_variant == 0 || !pp_ok(g) || nk_all < 6 ||
+            T <= G || r == 0 || 2 * r > G)
+            return SWIFTK_ESHAPE;
+        g.tail_from = (int)(T - r);
+        const int64_t per = (int64_t)g_group_m * g.ntn, g0 = g.tail_from / per;
+        const int64_t row0 = g0 * g_group_m * BM;
+        tail_rows_from[0] = row0 < M ? row0 : M;
+        tail_rows_from[1] = g.tail_from;
+        tail_rows_from[2] = g_group_m;
+        const int items = (int)(2 * T - g.tail_from);
+        hipLaunchKernelGGL((gemm_kernel_p<bf16_t, bf16_t, EPI_NONE_TAIL, NI, true>), dim3(items < G ? items : G), dim3(NT), 0, st, g, ntm, g_group_m);
+        SWIFTK_CHECK_LAUNCH();
+        return 0;
+    }
     if (dtype == SWIFTK_BF16) {
         if (out_dtype == SWIFTK_BF16) return dispatch_epi<bf16_t, bf16_t>(epilogue, g, st);
         return dispatch_epi<bf16_t, float>(epilogue, g, st);
     }
     return dispatch_epi<float, float>(epilogue, g, st);
+}
+
+extern "C" int swiftk_gemm_tail_split_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* slabs, int64_t ldc,
+                                           int64_t slab_stride, int64_t M, int64_t N, int64_t K, int64_t* tail, void* stream) {
+    if (!tail) return SWIFTK_EINVAL;
+    return gemm_impl(A, lda, W, ldw, slabs, ldc, M, N, K, SWIFTK_BF16, SWIFTK_BF16, SWIFTK_EPI_NONE, nullptr, nullptr, 0, 1, slab_stride,
+                     stream, nullptr, nullptr, 0, tail);
 }
 
 extern "C" int swiftk_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,

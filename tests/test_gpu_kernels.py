@@ -378,6 +378,79 @@ def test_modnorm_residual_pair_from_splitk_slabs(dev, lo_bits):
     assert e_bf < 3e-3 and e_bf < 2.0 * e_one
 
 
+@pytest.mark.parametrize("units,K,ldk", [(3, 1056, 1088), (4, 2816, 2816), (6, 1056, 1088), (4, 1056, 1088)])
+def test_gemm_tail_split_and_halves_norm(dev, units, K, ldk):
+    """Round 6, small batches: wo / w2 with the persistent walk's LAST round as two k-halves (swiftk_gemm_tail_split_bf16) and the
+    packed pair norm that adds the halves (swiftk_modnorm_residual_pair_halves_bf16).  Whole tiles are bit-equal to the plain GEMM and
+    leave slab 1 alone, split tiles sum to the product; the norm reads slab 1 under the split tiles only and equals the one-y kernel
+    on bf16(slab 0 + slab 1) bit for bit; shapes without such a round are refused."""
+    import ctypes
+    from swift_amd import _lib, ops
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    rps, d = 8192, 1056
+    M = units * rps
+    g = torch.Generator(device=dev).manual_seed(units * 1000 + K)
+    a = torch.zeros(M, ldk, dtype=torch.bfloat16, device=dev)
+    a[:, :K] = torch.randn(M, K, generator=g, device=dev).bfloat16()
+    w = torch.zeros(d, ldk, dtype=torch.bfloat16, device=dev)
+    w[:, :K] = (0.03 * torch.randn(d, K, generator=g, device=dev)).bfloat16()
+    slabs = torch.full((2, M, d), float("nan"), dtype=torch.bfloat16, device=dev)
+    tail = (ctypes.c_int64 * 3)(-1, -1, -1)
+    _lib.check(L.swiftk_gemm_tail_split_bf16(a.data_ptr(), ldk, w.data_ptr(), ldk, slabs.data_ptr(), d, M * d, M, d, K, tail, st),
+               "swiftk_gemm_tail_split_bf16")
+    rows_from, tail_from, gm = tail[0], tail[1], tail[2]
+    ntm, ntn = M // 256, 3
+    tiles = ntm * ntn
+    assert tail_from == tiles - tiles % 256 and gm >= 1 and rows_from == (tail_from // (gm * ntn)) * gm * 256 and 0 < rows_from < M
+    # the walk's tile order (groups of gm tile rows, column-major inside a group): which (tile row, tile column) cells are split
+    tm, tn = torch.meshgrid(torch.arange(ntm), torch.arange(ntn), indexing="ij")
+    grp = tm // gm
+    idx = grp * gm * ntn + tn * torch.clamp(ntm - grp * gm, max=gm) + (tm - grp * gm)
+    split = (idx >= tail_from).to(dev)
+    assert int(split.sum()) == tiles % 256 and not bool(split[: rows_from // 256].any())
+    plain = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.swiftk_gemm(a.data_ptr(), ldk, w.data_ptr(), ldk, plain.data_ptr(), d, M, d, K, _lib.BF16, _lib.BF16, _lib.EPI_NONE, None, None, 0, st),
+               "swiftk_gemm")
+    torch.cuda.synchronize()
+    sel = split[:, None, :, None].expand(ntm, 256, ntn, 352)
+    s0, s1, pv = slabs[0].view(ntm, 256, ntn, 352), slabs[1].view(ntm, 256, ntn, 352), plain.view(ntm, 256, ntn, 352)
+    assert torch.equal(s0[~sel], pv[~sel])                     # whole tiles: the same kernel walk, the same sums ...
+    assert bool(torch.isnan(s1[~sel].float()).all())           # ... and slab 1 untouched under them
+    halves = s0[sel].float() + s1[sel].float()
+    assert not torch.isnan(halves).any()
+    e = rel_l2(halves.cpu(), pv[sel].float().cpu())
+    print(f"tail split, {units} units, K {K}: {tiles % 256} of {tiles} tiles as halves (rows from {rows_from}); halves' sum vs whole-K tile {e:.2e}")
+    assert e < 4e-3
+    # the norm on the poisoned slabs (NaN wherever slab 1 does not exist) == the one-y kernel on bf16(slab 0 [+ slab 1])
+    x = torch.randn(M, d, generator=g, device=dev)
+    gam, bet = (1 + 0.1 * torch.randn(d, generator=g, device=dev)), 0.1 * torch.randn(d, generator=g, device=dev)
+    mod = 0.1 * torch.randn(units, 2 * d, generator=g, device=dev)
+    ld = ops.k_pad(torch.bfloat16, d)
+    hi, lo = ops.split_pair(x, ld, 8)
+    hi2, lo2 = hi.clone(), lo.clone()
+    _lib.check(L.swiftk_modnorm_residual_pair_halves_bf16(slabs.data_ptr(), M * d, tail, hi.data_ptr(), ld, lo.data_ptr(), gam.data_ptr(),
+                                                          bet.data_ptr(), mod.data_ptr(), 2 * d, M, d, rps, 1e-6, st), "halves norm")
+    ysum = torch.where(sel, (s0.float() + s1.float()).bfloat16(), s0).reshape(M, d).contiguous()
+    ops.modnorm_residual_pair(ysum, hi2, lo2, gam, bet, mod, rps, d)
+    torch.cuda.synchronize()
+    assert not torch.isnan(ops.pair_value(hi, lo, d)).any()
+    assert torch.equal(hi, hi2) and torch.equal(lo, lo2)
+    # tail = NULL: two halves everywhere (behind swiftk_gemm_splitk_bf16)
+    both = torch.randn(2, M, d, generator=g, device=dev).bfloat16()
+    hi3, lo3 = ops.split_pair(x, ld, 8)
+    hi4, lo4 = hi3.clone(), lo3.clone()
+    _lib.check(L.swiftk_modnorm_residual_pair_halves_bf16(both.data_ptr(), M * d, None, hi3.data_ptr(), ld, lo3.data_ptr(), gam.data_ptr(),
+                                                          bet.data_ptr(), mod.data_ptr(), 2 * d, M, d, rps, 1e-6, st), "halves norm, all rows")
+    ops.modnorm_residual_pair((both[0].float() + both[1].float()).bfloat16(), hi4, lo4, gam, bet, mod, rps, d)
+    assert torch.equal(hi3, hi4) and torch.equal(lo3, lo4)
+    # no such round: two units (192 tiles: one partly filled round), five units (480: a last round of 224 > 128), eight (768 = 3 x 256)
+    for u in (2, 5, 8):
+        Mu = u * rps
+        au, su = torch.zeros(Mu, ldk, dtype=torch.bfloat16, device=dev), torch.empty(2, Mu, d, dtype=torch.bfloat16, device=dev)
+        assert L.swiftk_gemm_tail_split_bf16(au.data_ptr(), ldk, w.data_ptr(), ldk, su.data_ptr(), d, Mu * d, Mu, d, K, tail, st) == -2  # SWIFTK_ESHAPE
+
+
 @pytest.mark.parametrize("rows,cols,inter", [(3168, 1056, 0), (5632, 1056, 2816), (1056, 2816, 0), (276, 1056, 0), (70, 130, 35)])
 def test_cast_pad_t_both_operands(dev, rows, cols, inter):
     """swiftk_cast_pad_t: a weight's forward operand (bf16, zero-padded rows; w1: (gate, up)-interleaved as SWIFTK_EPI_SWIGLU reads

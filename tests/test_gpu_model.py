@@ -91,7 +91,8 @@ def test_forward_vs_reference_golden(dev):
     # bf16 y, what the benchmark runs -- on the same inputs, and the fp32-stream form of the residual (tuning keys 14, 12)
     from swift_amd import _lib
     L = _lib.lib()
-    for key, val in ((14, 0), (12, 1), (12, 0)):
+    # (key 29 = 0: the generic two-slab norm kernel behind the split-K instead of the packed one that adds the halves itself)
+    for key, val in ((14, 0), (12, 1), (12, 0), (29, 0)):
         old = L.swiftk_get_tuning(key)
         L.swiftk_set_tuning(key, val)
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
@@ -100,6 +101,35 @@ def test_forward_vs_reference_golden(dev):
         ev = rel_l2(yv.cpu(), yemu)
         print(f"  tuning {key}:{val}: bf16 engine vs bf16-emulating oracle {ev:.3e}; vs the default form {rel_l2(yv.cpu(), yb.cpu()):.3e}")
         assert ev < BF16_EMU_TOL and not torch.equal(yv, yb)
+
+
+@pytest.mark.parametrize("units", [3, 4, 6])
+def test_forward_small_batch_tail_split(dev, units):
+    """Round 6: at 3 / 4 / 6 units per step wo / w2 leave the persistent walk a last round that is at most half full; the engine runs
+    that round's tiles as two k-halves (swiftk_gemm_tail_split_bf16 + swiftk_modnorm_residual_pair_halves_bf16, tuning key 29 bit 0).
+    Same network, same inputs, with and without: equal up to the halves' extra bf16 rounding; and a step is repeatable."""
+    from swift_amd import _lib
+    L = _lib.lib()
+    net, _ = build(dict(SWIFTB, depth=2), 5, dev)
+    x = det_normal((units, 141, 128, 256), 9, "x").to(dev)
+    t = torch.linspace(0.2, 1.4, units).to(dev)
+    aux = torch.full((units, 1), 0.6).to(dev)
+
+    def run():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return net.model(x, t, auxiliary=aux).float()
+
+    y_tail, y_again = run(), run()
+    old = L.swiftk_get_tuning(29)
+    L.swiftk_set_tuning(29, old & ~1)
+    try:
+        y_plain = run()
+    finally:
+        L.swiftk_set_tuning(29, old)
+    e = rel_l2(y_tail.cpu(), y_plain.cpu())
+    print(f"forward, {units} units, depth 2: last round as k-halves vs whole tiles rel-L2 {e:.3e}")
+    assert torch.isfinite(y_tail).all() and torch.equal(y_tail, y_again)
+    assert e < 1e-2 and not torch.equal(y_tail, y_plain)  # (two bf16 forms of the same network: 5e-3 apart at depth 2; the other path did run)
 
 
 @pytest.mark.parametrize("name,c", [
