@@ -820,6 +820,9 @@ __global__ __launch_bounds__(512) void attn_jvp_bf16_kernel(AttnJvpArgs a) {
                 ds[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, __builtin_bit_cast(bf16x8, dqf[ks]), ds[blk], 0, 0, 0);
                 ds[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dkf, __builtin_bit_cast(bf16x8, qf[ks]), ds[blk], 0, 0, 0);
             }
+            // (no fragment reads of a later key block above this point: left free, hipcc lifts them across the unrolled blocks until the
+            // 256 registers are gone and spills row addresses instead)
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();  // every wave is done with this half's images
         deposit(half == 0 ? JK : JV);
@@ -884,6 +887,7 @@ __global__ __launch_bounds__(512) void attn_jvp_bf16_kernel(AttnJvpArgs a) {
                 u[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, wfs[p]), u[db], 0, 0, 0);
                 tt[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dvf, __builtin_bit_cast(bf16x8, pfs[p]), tt[db], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (half == 0) {
             __syncthreads();
