@@ -711,7 +711,7 @@ def training_leg():
     return out
 
 
-def generate_e2e_leg(members: int = 12, ics: int = 2, steps: int = 12):
+def generate_e2e_leg(members: int = 12, ics: int = 2, steps: int = 60):
     """The disk-included rate of the forecast job: ``python -m swift_amd.generate --synthetic`` as a child
     process -- the CLI a user runs (generate.py:23-43) -- for members x ics units x steps lead steps in ONE batch, once per raw
     output format, into a scratch directory that is removed afterwards.  The figure is the CLI's own clock around
@@ -722,11 +722,22 @@ def generate_e2e_leg(members: int = 12, ics: int = 2, steps: int = 12):
     import subprocess
     import tempfile
 
-    out = {"what": f"swift_amd.generate --synthetic --dtype bf16: {members} members x {ics} ICs x {steps} steps, one batch of {members * ics} "
+    out = {"what": f"swift_amd.generate --synthetic --dtype bf16: {members} members x {ics} ICs x STEPS steps, one batch of {members * ics} "
                    "units, output streamed step by step through a pinned ring; rate = sample-steps / seconds inside rollout_and_save "
                    "(generate.py:48-154), store writes included", "unit": "sample-steps/s"}
     root = os.path.dirname(os.path.abspath(__file__))
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    # the reference's job length (60 lead steps, generate.py:23-43): a 12-step job is over in a second and measures the CLI's start-up
+    # (pinned ring, first launches: ~0.5 s) rather than its rate -- 24 units x 12 steps read 192-239 sample-steps/s where 36 steps read
+    # 294-310 on the same box (profiles/r06zg_generate_e2e_job_length.txt).  The store is 14 GB per format at 60 steps: taken only
+    # where the scratch filesystem has four times that free, else the short job
+    need = 4 * (steps + 1) * members * ics * NV * IMG[0] * IMG[1] * 4
+    try:
+        if shutil.disk_usage(base or tempfile.gettempdir()).free < need:
+            steps = 12
+    except OSError:
+        steps = 12
+    out["what"] = out["what"].replace("STEPS", str(steps))
     for dump in ("numpy", "zarr"):
         d = tempfile.mkdtemp(prefix="swiftk_e2e_", dir=base)
         try:
