@@ -269,18 +269,20 @@ def test_dpm_solver_and_validation_rollout_vs_oracle(dev):
     np.testing.assert_allclose(sep, rsep, rtol=1e-3)
 
 
-def test_hip_graph_step_equals_eager(dev):
-    """RolloutEngine.capture_step: replaying the recorded step advances the state exactly as the eager launches do."""
+@pytest.mark.parametrize("cfg,B", [(SMALLB, 2), (dict(SWIFTB, depth=2), 4)], ids=["smallb-2-units", "full-grid-4-units"])
+def test_hip_graph_step_equals_eager(dev, cfg, B):
+    """RolloutEngine.capture_step: replaying the recorded step advances the state exactly as the eager launches do.  (Four units on
+    the full grid: wo / w2 take the last-round-as-k-halves path, whose walk description travels by value in the launches.)"""
     from swift_amd import ops
     from swift_amd.data.era5 import SyntheticERA5Dataset
     from swift_amd.rollout import RolloutEngine
-    net, _ = build(SMALLB, 9, dev)
-    ds = SyntheticERA5Dataset([f"v{i}" for i in range(69)], ["f0", "f1", "f2"], img_resolution=(64, 64), length=16, seed=9)
+    net, _ = build(cfg, 9, dev)
+    H, W = cfg["img"]
+    ds = SyntheticERA5Dataset([f"v{i}" for i in range(69)], ["f0", "f1", "f2"], img_resolution=(H, W), length=16, seed=9)
     eng = RolloutEngine(net, ds, interval=6, solver="scm", denoise_dtype=torch.bfloat16)
-    B = 2
-    X0 = det_normal((B, 69, 64, 64), 9, "X0").to(dev)
-    forc = det_normal((B, 3, 64, 64), 9, "f").to(dev)
-    zs = [det_normal((B, 69, 64, 64), 9, f"z{i}").to(dev) for i in range(3)]
+    X0 = det_normal((B, 69, H, W), 9, "X0").to(dev)
+    forc = det_normal((B, 3, H, W), 9, "f").to(dev)
+    zs = [det_normal((B, 69, H, W), 9, f"z{i}").to(dev) for i in range(3)]
     mx, sx, st = eng.stats(dev)
     Xe, phys_e = X0.clone(), torch.empty_like(X0)
     for z in zs:
