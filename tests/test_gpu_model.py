@@ -126,6 +126,14 @@ def test_forward_small_batch_tail_split(dev, units):
         y_plain = run()
     finally:
         L.swiftk_set_tuning(29, old)
+    # with the GEMM's ping-pong loop switched off (tuning key 20) the k-half walk does not exist: the engine must fall back to whole
+    # tiles by itself -- and that loop is bit-equal to the ping-pong one, so the result is the whole-tile result
+    L.swiftk_set_tuning(20, 0)
+    try:
+        y_fallback = run()
+    finally:
+        L.swiftk_set_tuning(20, 1)
+    assert torch.equal(y_fallback, y_plain)
     e = rel_l2(y_tail.cpu(), y_plain.cpu())
     print(f"forward, {units} units, depth 2: last round as k-halves vs whole tiles rel-L2 {e:.3e}")
     assert torch.isfinite(y_tail).all() and torch.equal(y_tail, y_again)
