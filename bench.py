@@ -868,8 +868,8 @@ def drift_leg(net, ds, dev, X0, forc, units, nb: int = 2, marks=(1, 10, 60)):
     return out
 
 
-def batch_sweep_leg(net, ds, dev, X0, forc, units, dtype, sizes=(1, 4, 8, 16, 32), steps: int = 6):
-    """the sCM 1-step sampler at {1, 4, 8, 16, 32} units per step (eager launches and, for the
+def batch_sweep_leg(net, ds, dev, X0, forc, units, dtype, sizes=(1, 4, 8, 12, 16, 32), steps: int = 6):
+    """the sCM 1-step sampler at {1, 4, 8, 12, 16, 32} units per step (12 = one initial condition's ensemble; eager launches and, for the
     launch-bound sizes, the whole step replayed as one HIP graph)."""
     import torch
 

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, SWIFTK_MNPK_OCC) void modnorm_pair_packed_kern
                                                                     const float* __restrict__ beta, const float* __restrict__ mod,
                                                                     int64_t ldmod, int64_t M, int64_t rps, float eps, int nt,
                                                                     const bf16_t* __restrict__ y1 = nullptr, int64_t rows2 = 0,
-                                                                    int tail_from = 0, int gm = 8) {
+                                                                    int tail_from = 0, int gm = 8, uint32_t chunk0 = 0) {
     constexpr int D = 8 * NC, NS = (4 * NC + 63) / 64;
     // (measured, 96 units: low part non-temporal 1.465 ms, plain 1.477; hi loads non-temporal 1.555 -- hi stays cached, it is the
     // next GEMM's operand; all forms of this kernel move their bytes at 4.5-4.9 TB/s, the rate a device copy reaches here)
@@ -454,16 +454,17 @@ __global__ __launch_bounds__(256, SWIFTK_MNPK_OCC) void modnorm_pair_packed_kern
     __shared__ __attribute__((aligned(16))) float sP[D], sQ[D];
     // Y2: the two-slab chunks (the last ones) are dealt evenly among the others -- every R-th workgroup takes one -- instead of forming
     // the tail of the launch, where their two request phases would have nothing to hide behind
-    int64_t chunk = blockIdx.x;
+    // (32-bit arithmetic: a 64-bit division is ~100 instructions on this machine, and a workgroup's whole job is 16 rows)
+    uint32_t chunk = blockIdx.x + chunk0;  // (chunk0: the launch covers the rows from 16 chunk0 on)
     if constexpr (Y2) {
-        const int64_t C = M / MN_ROWS, C2 = C - rows2 / MN_ROWS;
-        if (C2 > 0 && C2 < C) {
-            const int64_t R = C / C2, k = chunk / R;
-            if (chunk % R == R - 1 && k < C2) chunk = (C - C2) + k;
+        const uint32_t C = (uint32_t)(M / MN_ROWS), C2 = C - (uint32_t)(rows2 / MN_ROWS);
+        if (C2 > 0 && C2 < C && chunk0 == 0) {
+            const uint32_t R = C / C2, k = chunk / R;
+            if (chunk - k * R == R - 1 && k < C2) chunk = (C - C2) + k;
             else chunk -= k < C2 ? k : C2;
         }
     }
-    const int64_t blk_sample = (chunk * MN_ROWS) / rps;
+    const int64_t blk_sample = Y2 ? (int64_t)((chunk * (uint32_t)MN_ROWS) / (uint32_t)rps) : ((int64_t)chunk * MN_ROWS) / rps;
     {
         const float* mrow = mod + blk_sample * ldmod;
         for (int c = threadIdx.x; c < NC; c += 256) {
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(256, SWIFTK_MNPK_OCC) void modnorm_pair_packed_kern
         }
     }
     __syncthreads();
-    const int64_t r0 = chunk * MN_ROWS + 4 * wv;  // (the launcher guarantees M % 16 == 0)
+    const int64_t r0 = (int64_t)chunk * MN_ROWS + 4 * wv;  // (the launcher guarantees M % 16 == 0)
     if (r0 >= M) return;
     const bf16_t* yb = y + r0 * D;
     uint8_t* lb = xl + r0 * D;
@@ -1300,15 +1301,31 @@ extern "C" int swiftk_modnorm_residual_pair_halves_bf16(const void* y_slabs, int
         ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)mod & 15) || (ldmod % 4))
         return SWIFTK_EALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int cgrid = (int)(M / MN_ROWS);
     const bf16_t* y0 = static_cast<const bf16_t*>(y_slabs);
     bf16_t* hi = static_cast<bf16_t*>(x_hi);
-    if (d == 1056)
-        hipLaunchKernelGGL((modnorm_pair_packed_kernel<132, true>), dim3(cgrid), dim3(256), 0, st, y0, hi, hi, ldh, static_cast<uint8_t*>(x_lo), gamma,
-                           beta, mod, ldmod, M, rows_per_sample, eps, g_modnorm_nt, y0 + slab_stride, rows_from, tail_from, gm);
-    else
-        hipLaunchKernelGGL((modnorm_pair_packed_kernel<160, true>), dim3(cgrid), dim3(256), 0, st, y0, hi, hi, ldh, static_cast<uint8_t*>(x_lo), gamma,
-                           beta, mod, ldmod, M, rows_per_sample, eps, g_modnorm_nt, y0 + slab_stride, rows_from, tail_from, gm);
+    // The rows below rows_from have one y: they go through the one-y kernel (M = rows_from), the others through the two-slab form, which
+    // starts at chunk rows_from / 16.  (One launch of the two-slab form over all rows, its two-slab chunks dealt evenly among the others, was
+    // the first version: that instantiation moves every row 22 % slower than the one-y kernel, second slab or not -- 155.6 against 127.7 us
+    // at twelve units with no row taking a second slab, `tools/halves_norm_bench.py`.)
+    if (rows_from > 0) {
+        const int g1 = (int)(rows_from / MN_ROWS);
+        if (d == 1056)
+            hipLaunchKernelGGL((modnorm_pair_packed_kernel<132>), dim3(g1), dim3(256), 0, st, y0, hi, hi, ldh, static_cast<uint8_t*>(x_lo), gamma, beta, mod,
+                               ldmod, rows_from, rows_per_sample, eps, g_modnorm_nt);
+        else
+            hipLaunchKernelGGL((modnorm_pair_packed_kernel<160>), dim3(g1), dim3(256), 0, st, y0, hi, hi, ldh, static_cast<uint8_t*>(x_lo), gamma, beta, mod,
+                               ldmod, rows_from, rows_per_sample, eps, g_modnorm_nt);
+    }
+    const int cgrid = (int)((M - rows_from) / MN_ROWS);
+    const uint32_t chunk0 = (uint32_t)(rows_from / MN_ROWS);
+    if (cgrid > 0) {
+        if (d == 1056)
+            hipLaunchKernelGGL((modnorm_pair_packed_kernel<132, true>), dim3(cgrid), dim3(256), 0, st, y0, hi, hi, ldh, static_cast<uint8_t*>(x_lo), gamma,
+                               beta, mod, ldmod, M, rows_per_sample, eps, g_modnorm_nt, y0 + slab_stride, rows_from, tail_from, gm, chunk0);
+        else
+            hipLaunchKernelGGL((modnorm_pair_packed_kernel<160, true>), dim3(cgrid), dim3(256), 0, st, y0, hi, hi, ldh, static_cast<uint8_t*>(x_lo), gamma,
+                               beta, mod, ldmod, M, rows_per_sample, eps, g_modnorm_nt, y0 + slab_stride, rows_from, tail_from, gm, chunk0);
+    }
     SWIFTK_CHECK_LAUNCH();
     return 0;
 }
